@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by importing the *reference* (read-only, from
+/root/reference) in the build container.  The reference never travels to the GPU box; only the small
+.npz vectors written here do (inputs + expected outputs -- no reference source).
+
+Recipe: stub the third-party modules the hot path imports but does not need
+(soundfile, wandb, torchaudio, nara_wpe, hydra, omegaconf, plotly, pandas, matplotlib), shim ``torchcde``
+(linear interpolation; absent third-party, parity unpinned), patch ``torch.randn / randn_like / rand`` to
+the deterministic ``NoiseStream`` so sampler runs can be replayed, load configs with the repo's own
+YAML loader, use ``buddy_amd.synth`` seeded weights (the reference default init zeroes half the network).
+
+Usage:  python tests/golden/make_golden.py [--only NAME ...]
+"""
+import argparse
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def _install_stubs():
+    for name in ["soundfile", "wandb", "torchaudio", "nara_wpe", "nara_wpe.wpe", "nara_wpe.utils", "hydra",
+                 "hydra.utils", "omegaconf", "plotly", "plotly.express", "plotly.graph_objects", "pandas",
+                 "matplotlib", "matplotlib.pyplot"]:
+        import importlib.util
+        try:
+            present = importlib.util.find_spec(name) is not None
+        except (ImportError, ValueError):
+            present = False
+        if name not in sys.modules and not present:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    import torch._dynamo  # noqa: F401  (torch.optim imports it lazily; must happen before stubs confuse find_spec)
+    sys.modules["nara_wpe.wpe"].wpe = None
+    sys.modules["nara_wpe.utils"].stft = None
+    sys.modules["nara_wpe.utils"].istft = None
+    cde = types.ModuleType("torchcde")
+
+    def linear_interpolation_coeffs(x):
+        return x
+
+    class LinearInterpolation:
+        def __init__(self, coeffs, t):
+            self.c, self.t = coeffs, t
+
+        def evaluate(self, q):
+            K = self.t.shape[0]
+            idx = (torch.bucketize(q, self.t) - 1).clamp(0, K - 2)
+            t0, t1 = self.t[idx], self.t[idx + 1]
+            frac = ((q - t0) / (t1 - t0)).unsqueeze(-1)
+            return self.c[..., idx, :] + frac * (self.c[..., idx + 1, :] - self.c[..., idx, :])
+
+    cde.linear_interpolation_coeffs = linear_interpolation_coeffs
+    cde.LinearInterpolation = LinearInterpolation
+    sys.modules["torchcde"] = cde
+
+
+_install_stubs()
+
+from buddy_amd.config import compose, load_yaml, AttrDict, to_attrdict  # noqa: E402
+from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir  # noqa: E402
+from oracle.sampler_ref import NoiseStream  # noqa: E402  (only the deterministic noise stream)
+
+
+class patched_noise:
+    """Route torch.randn / randn_like / rand through a NoiseStream inside the reference."""
+
+    def __init__(self, stream):
+        self.s = stream
+
+    def __enter__(self):
+        self.orig = (torch.randn, torch.randn_like, torch.rand)
+        s = self.s
+
+        def randn(*shape, **kw):
+            if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+                shape = tuple(shape[0])
+            return s.randn(shape)
+
+        def randn_like(t, **kw):
+            return s.randn(tuple(t.shape))
+
+        def rand(*shape, **kw):
+            if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+                shape = tuple(shape[0])
+            return s.rand(shape)
+
+        torch.randn, torch.randn_like, torch.rand = randn, randn_like, rand
+        return self
+
+    def __exit__(self, *a):
+        torch.randn, torch.randn_like, torch.rand = self.orig
+
+
+def build_ref_net(nf, n_fft, hop, seed, ch_mult=(1, 2, 2, 2), num_res_blocks=1):
+    from networks.ncsnpp import NCSNppTime
+    cfg = load_yaml(os.path.join(ROOT, "conf/network/ncsnpp.yaml"))
+    cfg.pop("_target_")
+    cfg.update(nf=nf, ch_mult=list(ch_mult), num_res_blocks=num_res_blocks,
+               stft=AttrDict(n_fft=n_fft, hop_length=hop, center=True))
+    net = NCSNppTime(**cfg)
+    sd = synth_state_dict(seed, nf, tuple(ch_mult), num_res_blocks)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return net.eval()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# --------------------------------------------------------------------------------------------------
+def gen_edm_sched():
+    from diff_params.edm import EDM
+    from testing.EulerHeunSampler import EulerHeunSampler
+    out = {}
+    for tester in ["blind_dereverberation_BUDDy", "informed_dereverberation_DPS", "only_unconditional"]:
+        for T in (10, 50, 201):
+            args = compose(tester=tester, overrides=[f"tester.sampling_params.T={T}"])
+            edm = EDM(args.diff_params.type, args.diff_params.sde_hp)
+            s = EulerHeunSampler(torch.nn.Identity(), edm, args)
+            t = s.create_schedule()
+            out[f"{tester}.T{T}.t"] = t
+            out[f"{tester}.T{T}.gamma"] = s.get_gamma(t)
+    args = compose()
+    edm = EDM(args.diff_params.type, args.diff_params.sde_hp)
+    sig = torch.tensor([1e-4, 3e-3, 0.05, 0.5, 7.0])
+    out["sigma"] = sig
+    out["cskip"], out["cout"], out["cin"], out["cnoise"] = edm.cskip(sig), edm.cout(sig), edm.cin(sig), edm.cnoise(sig)
+    save("edm_sched", **out)
+
+
+def _net_fixture(name, nf, n_fft, hop, L, B, seed, with_taps):
+    net = build_ref_net(nf, n_fft, hop, seed)
+    rs = np.random.RandomState(seed + 100)
+    x = torch.from_numpy((0.5 * rs.standard_normal((B, 1, L))).astype(np.float32))
+    cn = torch.from_numpy(rs.uniform(-2.0, 0.3, size=(B,)).astype(np.float32))
+    cot = torch.from_numpy(rs.standard_normal((B, 1, L)).astype(np.float32))
+    x.requires_grad_(True)
+    taps = {}
+    hooks = []
+    if with_taps:
+        from networks.ncsnpp_utils import layerspp
+        for i, mod in enumerate(net.all_modules):
+            if isinstance(mod, (layerspp.ResnetBlockBigGANpp, layerspp.AttnBlockpp)):
+                hooks.append(mod.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(i, o.detach())))
+    y = net(x, cn)
+    g, = torch.autograd.grad(y, x, cot)
+    for h in hooks:
+        h.remove()
+    arrs = dict(x=x.detach(), cnoise=cn, cot=cot, y=y.detach(), vjp=g,
+                meta=np.array([nf, n_fft, hop, L, B, seed]))
+    for i, t in taps.items():
+        arrs[f"tap{i}_mean"] = t.mean()
+        arrs[f"tap{i}_absmax"] = t.abs().max()
+        arrs[f"tap{i}_std"] = t.std()
+    save(name, **arrs)
+
+
+def gen_net_small():
+    _net_fixture("net_small", nf=32, n_fft=126, hop=32, L=4096, B=2, seed=3, with_taps=True)
+
+
+def gen_net_full():
+    _net_fixture("net_full", nf=128, n_fft=510, hop=128, L=16000, B=1, seed=5, with_taps=True)
+
+
+def gen_ops():
+    import utils.reverb_utils as ru
+    from utils.losses import get_loss
+    from testing.operators.reverb import RIROperator
+    from testing.operators.subband_filtering import BlindSubbandFiltering
+    args = compose()
+    op_hp = args.tester.informed_dereverberation.op_hp
+    L = 16000
+    x = torch.from_numpy(synth_clean(0, L))
+    rir = torch.from_numpy(synth_rir(0, taps=3000))
+    out = dict(x=x, rir=rir)
+    # informed operator
+    op = RIROperator(op_hp, time_kernel_size=rir.shape[-1], sample_rate=16000)
+    op.update_params(rir)
+    y = op.degradation(x[None])
+    out["y_rir"] = y
+    out["apply_stft_y"] = torch.view_as_real(op.apply_stft(y))
+    loss = get_loss(args.tester.posterior_sampling.rec_loss, operator=op)
+    xd = (x[None] * 0.9 + 0.01 * torch.from_numpy(synth_clean(1, L))[None]).requires_grad_(True)
+    val = loss(y, op.degradation(xd))
+    out["inf_loss"] = val.detach()
+    out["inf_xd"] = xd.detach()
+    out["inf_loss_grad"] = torch.autograd.grad(val, xd)[0]
+    # DSP utils
+    h = torch.from_numpy(synth_rir(2, taps=1500))
+    out["minphase_in"] = h
+    out["minphase_out"] = ru.minimum_phase_version(h)
+    # blind operator
+    ns = NoiseStream(11)
+    with patched_noise(ns):
+        bop = BlindSubbandFiltering(op_hp, 16000)
+        bop.update_H(use_noise=True)
+    out["blind_A"] = bop.design_filter().detach()
+    out["blind_H"] = torch.view_as_real(bop.H.detach())
+    out["blind_phases"] = bop.params_phases[0].detach()
+    out["blind_deg"] = bop.degradation(x[None]).detach()
+    out["blind_rir"] = bop.get_time_RIR().detach()
+    out["blind_stft_x"] = torch.view_as_real(bop.apply_stft(x[None]))
+    # one gradient of (rec_loss_params + RIR-noise reg) wrt params, as optimize_op forms it
+    ps = args.tester.posterior_sampling
+    lp = get_loss(ps.rec_loss_params, operator=bop)
+    lr = get_loss(ps.RIR_noise_regularization.loss, operator=bop)
+    for p in bop.params + bop.params_phases:
+        p.requires_grad = True
+    bop.update_H()
+    l1 = lp(y, bop.degradation(x[None]))
+    rt = bop.get_time_RIR()
+    n = ns.randn(rt.shape)
+    l2 = lr(rt, (rt + 0.005 * n).detach())
+    gs = torch.autograd.grad(l1 + l2, bop.params + bop.params_phases)
+    out["blind_l_rec"], out["blind_l_reg"] = l1.detach(), l2.detach()
+    out["blind_g_decay"], out["blind_g_weights"], out["blind_g_phases"] = gs
+    # project_params on out-of-range values
+    with torch.no_grad():
+        bop.params[0].copy_(torch.linspace(0.0, 0.8, 25)[None])
+        bop.params[1].copy_(torch.linspace(0.2, 150.0, 25)[None])
+    bop.project_params()
+    out["proj_decay"], out["proj_weights"] = bop.params[0].detach(), bop.params[1].detach()
+    save("ops", **out)
+
+
+def _e2e(name, tester, blind, T, order, overrides=(), L=8192, nf=32, seed=7, utt=0):
+    from diff_params.edm import EDM
+    from testing.EulerHeunSamplerDPS import EulerHeunSamplerDPS
+    from testing.operators.reverb import RIROperator
+    from testing.operators.subband_filtering import BlindSubbandFiltering
+    ov = [f"tester.sampling_params.T={T}", f"tester.sampling_params.order={order}"] + list(overrides)
+    args = compose(tester=tester, overrides=ov)
+    net = build_ref_net(nf, 510, 128, seed)
+    edm = EDM(args.diff_params.type, args.diff_params.sde_hp)
+    sampler = EulerHeunSamplerDPS(net, edm, args)
+    clean = torch.from_numpy(synth_clean(utt, L))
+    rir = torch.from_numpy(synth_rir(utt, taps=2000))
+    op_hp = args.tester.informed_dereverberation.op_hp
+    ns = NoiseStream(1000 + utt)
+    import tqdm as _tq
+    import testing.EulerHeunSamplerDPS as M
+    M.tqdm = lambda it, *a, **k: it
+    with patched_noise(ns):
+        with torch.no_grad():
+            op_ref = RIROperator(op_hp, time_kernel_size=rir.shape[-1], sample_rate=16000)
+            op_ref.update_params(rir)
+            y = op_ref.degradation(clean[None])
+            if blind:
+                op = BlindSubbandFiltering(op_hp, sample_rate=16000)
+                op.update_H(use_noise=True)
+        pred = sampler.predict_conditional(y, op if blind else op_ref, shape=(1, L), blind=blind)
+    arrs = dict(clean=clean, rir=rir, y=y, pred=pred, n_draws=ns.k,
+                meta=np.array([nf, L, T, order, seed, utt, 1000 + utt]))
+    if blind:
+        arrs["est_rir"] = sampler.operator.get_time_RIR().detach()
+        arrs["decay"], arrs["weights"] = op.params[0].detach(), op.params[1].detach()
+        arrs["phases"] = op.params_phases[0].detach()
+    save(name, **arrs)
+
+
+def gen_e2e_informed():
+    _e2e("e2e_informed", "informed_dereverberation_DPS", blind=False, T=4, order=2)
+
+
+def gen_e2e_blind():
+    _e2e("e2e_blind", "blind_dereverberation_BUDDy", blind=True, T=3, order=1,
+         overrides=["tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+                    "tester.posterior_sampling.blind_hp.op_updates_per_step=3"])
+
+
+def gen_uncond():
+    from diff_params.edm import EDM
+    from testing.EulerHeunSampler import EulerHeunSampler
+    import testing.EulerHeunSampler as M
+    M.tqdm = lambda it, *a, **k: it
+    args = compose(tester="only_unconditional", overrides=["tester.sampling_params.T=3"])
+    net = build_ref_net(32, 510, 128, 7)
+    edm = EDM(args.diff_params.type, args.diff_params.sde_hp)
+    s = EulerHeunSampler(net, edm, args)
+    ns = NoiseStream(2000)
+    with patched_noise(ns):
+        x = s.predict_unconditional((2, 8192), "cpu")
+    save("e2e_uncond", pred=x, n_draws=ns.k, meta=np.array([32, 8192, 3, 2, 7, 2000]))
+
+
+GENS = dict(edm_sched=gen_edm_sched, net_small=gen_net_small, net_full=gen_net_full, ops=gen_ops,
+            e2e_informed=gen_e2e_informed, e2e_blind=gen_e2e_blind, e2e_uncond=gen_uncond)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    for k, fn in GENS.items():
+        if a.only is None or k in a.only:
+            print("==", k)
+            fn()
