@@ -1,0 +1,86 @@
+"""ctypes binding of ``libbuddy_hip.so`` (C-ABI in ``include/buddy_hip.h``).
+
+There is NO CPU fallback: importing works anywhere (so configs/host logic can be tested on CPU), but any
+compute call raises ``BuddyHipError`` if the shared library is missing or no GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbuddy_hip.so")
+
+
+class BuddyHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_f32p = C.c_void_p  # raw device / host pointers are passed as integers
+_SIGS = {
+    "buddy_last_error": (C.c_char_p, []),
+    "buddy_version": (C.c_int, []),
+    "buddy_ncsnpp_param_count": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
+    "buddy_ncsnpp_create": (C.c_int, [_f32p, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p)]),
+    "buddy_ncsnpp_destroy": (C.c_int, [C.c_void_p]),
+    "buddy_ncsnpp_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
+    "buddy_ncsnpp_forward": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_ncsnpp_vjp": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_void_p]),
+    "buddy_ncsnpp_tap": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int * 4)]),
+    "buddy_gemm": (C.c_int, [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                             _f32p, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "buddy_conv3x3": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_groupnorm_act": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p]),
+    "buddy_groupnorm_act_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_axpby_rows": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_row_moments": (C.c_int, [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_fir": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+EXPORTED = sorted(_SIGS)
+
+
+def load():
+    """Load the shared library (no GPU needed for loading / symbol checks)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BuddyHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(buddy_amd/csrc/build.sh); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BuddyHipError(f"libbuddy_hip error {rc}: {load().buddy_last_error().decode()}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise BuddyHipError("no HIP device visible: the MI355X path has no CPU fallback")
+    return load()
+
+
+def ptr(t):
+    """device pointer of a contiguous float32 CUDA tensor (or None)."""
+    if t is None:
+        return None
+    import torch
+    assert t.is_cuda and t.is_contiguous(), "expected a contiguous device tensor"
+    assert t.dtype in (torch.float32, torch.float64)
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

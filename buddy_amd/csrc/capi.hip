@@ -1,0 +1,129 @@
+// extern "C" boundary (include/buddy_hip.h) over the C++ graph and kernels.
+#include "../../include/buddy_hip.h"
+#include "common.h"
+#include "net.h"
+
+#include <cstring>
+
+using namespace buddy;
+
+namespace buddy {
+void launch_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, hipStream_t st);
+void launch_row_moments(const float* x, double* out, int B, int L, hipStream_t st);
+void launch_fir(const float* x, const float* h, float* y, int B, int L, int M, int adjoint, hipStream_t st);
+}
+
+static int finish() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return BUDDY_ERR_HIP; }
+  return BUDDY_OK;
+}
+
+static NetCfg mk_cfg(int nf, const int* ch_mult, int nlev, int nrb, int n_fft, int hop) {
+  NetCfg c; std::memset(&c, 0, sizeof(c));
+  c.nf = nf; c.nlev = nlev; c.nrb = nrb; c.n_fft = n_fft; c.hop = hop;
+  for (int i = 0; i < nlev && i < 8; ++i) c.ch_mult[i] = ch_mult[i];
+  return c;
+}
+
+extern "C" {
+
+const char* buddy_last_error(void) { return last_error(); }
+int buddy_version(void) { return 1; }
+
+int buddy_ncsnpp_param_count(int nf, const int* ch_mult, int n_levels, int num_res_blocks, long long* count) {
+  if (!ch_mult || !count || n_levels < 1 || n_levels > 8) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  *count = param_count(mk_cfg(nf, ch_mult, n_levels, num_res_blocks, 510, 128));
+  return BUDDY_OK;
+}
+
+int buddy_ncsnpp_create(const float* host_params, long long n_params, int nf, const int* ch_mult, int n_levels, int num_res_blocks,
+                        int n_fft, int hop, void** handle) {
+  if (!host_params || !ch_mult || !handle || n_levels < 1 || n_levels > 8 || nf % 32 != 0) { set_error("bad arguments (nf must be a multiple of 32)"); return BUDDY_ERR_ARG; }
+  Net* N = nullptr;
+  int rc = net_create(host_params, n_params, mk_cfg(nf, ch_mult, n_levels, num_res_blocks, n_fft, hop), &N);
+  if (rc) return rc;
+  *handle = N;
+  return BUDDY_OK;
+}
+
+int buddy_ncsnpp_destroy(void* handle) { net_destroy((Net*)handle); return BUDDY_OK; }
+
+int buddy_ncsnpp_reserve(void* handle, int B, int L, int with_vjp, long long* bytes) {
+  if (!handle) { set_error("null handle"); return BUDDY_ERR_ARG; }
+  return net_reserve((Net*)handle, B, L, with_vjp, bytes);
+}
+
+int buddy_ncsnpp_forward(void* handle, const float* x, const float* cnoise, const float* cin, const float* cskip, const float* cout, float* y,
+                         int B, int L, int save_for_vjp, void* stream) {
+  if (!handle || !x || !cnoise || !y) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  if ((cin == nullptr) != (cskip == nullptr) || (cin == nullptr) != (cout == nullptr)) { set_error("cin/cskip/cout must be given together"); return BUDDY_ERR_ARG; }
+  return net_forward((Net*)handle, x, cnoise, cin, cskip, cout, y, B, L, save_for_vjp, (hipStream_t)stream);
+}
+
+int buddy_ncsnpp_vjp(void* handle, const float* cot, float* grad_x, void* stream) {
+  if (!handle || !cot || !grad_x) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  return net_vjp((Net*)handle, cot, grad_x, (hipStream_t)stream);
+}
+
+int buddy_ncsnpp_tap(void* handle, int module_idx, const float** ptr, int dims[4]) {
+  if (!handle || !ptr || !dims) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  return net_get_tap((Net*)handle, module_idx, ptr, dims);
+}
+
+int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, int transB, float* C, int ldC, int M, int N, int K, float alpha,
+               const float* bias_n, int accumulate, int batch, long long strideA, long long strideB, long long strideC, void* stream) {
+  if (!A || !Bt || !C || K % 4 || (transA && M % 4) || (transB && N % 4)) { set_error("bad gemm arguments (K, and M/N of k-major operands, must be multiples of 4)"); return BUDDY_ERR_ARG; }
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.A0 = A; p.ldA0 = ldA; p.Cin = K; p.M = M; p.N = N; p.Bt = Bt; p.ldB = ldB; p.C = C; p.ldC = ldC; p.sA = strideA; p.sB = strideB; p.sC = strideC;
+  p.alpha = alpha; p.out_scale = 1.f; p.bias_n = bias_n; p.accumulate = accumulate; p.H = 1; p.W = 1; p.rows_per_batch = 1;
+  launch_igemm(p, 1, transA != 0, transB != 0, batch, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!x || !wt || !y || Cin % 4) { set_error("bad conv arguments"); return BUDDY_ERR_ARG; }
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.A0 = x; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.Bt = wt; p.ldB = 9 * Cin; p.C = y; p.ldC = Cout;
+  p.bias_n = bias; p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
+  launch_igemm(p, 9, false, false, 1, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B, int H, int W, int C,
+                        int G, int mode, int silu, void* stream) {
+  if (!x || !y || !stats || !scratch || C % 4 || (C / G) % 4 || C > 1024) { set_error("bad groupnorm arguments"); return BUDDY_ERR_ARG; }
+  Src2 s; s.p0 = x; s.p1 = nullptr; s.C0 = C; s.ld0 = C; s.ld1 = 0;
+  launch_gn_stats(s, B, H * W, C, G, 1e-6f, (double*)scratch, stats, (hipStream_t)stream);
+  launch_gn_apply(s, stats, gamma, beta, B, H, W, C, G, mode, silu, y, nullptr, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* beta, const float* stats, const float* dy, float* dx, void* scratch,
+                            float* red, int B, int H, int W, int C, int G, int mode, int silu, void* stream) {
+  if (!x || !dy || !dx || !stats || !scratch || !red || C % 4 || (C / G) % 4 || C > 1024) { set_error("bad groupnorm arguments"); return BUDDY_ERR_ARG; }
+  Src2 s; s.p0 = x; s.p1 = nullptr; s.C0 = C; s.ld0 = C; s.ld1 = 0;
+  Dst2 d; d.p0 = dx; d.p1 = nullptr; d.C0 = C; d.ld0 = C; d.ld1 = 0; d.acc0 = 0; d.acc1 = 0;
+  launch_gn_bwd(s, stats, gamma, beta, dy, B, H, W, C, G, mode, silu, nullptr, 0, 0.f, (double*)scratch, red, d, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, void* stream) {
+  if (!x || !a || !out || (y && !c)) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  launch_axpby_rows(x, y, a, c, out, B, L, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_row_moments(const float* x, double* out, int B, int L, void* stream) {
+  if (!x || !out) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  launch_row_moments(x, out, B, L, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_fir(const float* x, const float* h, float* y, int B, int L, int M, int adjoint, void* stream) {
+  if (!x || !h || !y || M < 1) { set_error("bad fir arguments"); return BUDDY_ERR_ARG; }
+  launch_fir(x, h, y, B, L, M, adjoint, (hipStream_t)stream);
+  return finish();
+}
+
+}  // extern "C"

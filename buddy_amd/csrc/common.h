@@ -1,0 +1,78 @@
+// Shared declarations for the gfx950 (MI355X, CDNA4) kernels of the BUDDy sampler path.
+// Layout convention: activations are fp32 "NHWC" [B][H][W][C] with H = STFT frames (time) and W = frequency
+// bins -- i.e. the reference's (B,C,F,T) tensors with the two spatial axes swapped and channels innermost, so
+// the STFT GEMM writes the network input directly and every conv tap is a contiguous C-vector.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+
+#define BUDDY_OK 0
+#define BUDDY_ERR_HIP 1
+#define BUDDY_ERR_ARG 2
+#define BUDDY_ERR_STATE 3
+
+namespace buddy {
+
+// ---- implicit-GEMM (conv3x3 / conv1x1 / plain GEMM) -------------------------------------------------
+// C[m][n] = out_scale * ( alpha * sum_k A[m][k] * Bt[n][k] + bias_n[n] + bias_m[m] + bias_bn[b(m)][n] + res[...] )
+struct IgemmParams {
+  // A operand. TAPS==9: A is an NHWC image, M = B*H*W, K per tap = Cin, optionally split over two sources
+  // along channels (channel c < C0 from A0, else from A1) -- the torch.cat([h, skip]) of the U-Net up path.
+  const float* A0; const float* A1; int C0; int ldA0; int ldA1;
+  int Cin;                 // K per tap (total over both sources); multiple of 4
+  int H, W;                // spatial dims (TAPS==9), also used to derive batch index for bias_bn / res_up
+  int M, N;                // GEMM M (rows/pixels per batch slice) and N
+  const float* Bt; int ldB;  // weights [N][TAPS*Cin] (k contiguous) or, if TRANS_B, [K][N] with ldB
+  float* C; int ldC;
+  long long sA, sB, sC;    // batch strides (blockIdx.z), floats
+  const float* bias_n; const float* bias_m; const float* bias_bn; int ld_bias_bn; int rows_per_batch;
+  const float* res; int ldRes; int res_mode;   // 0 none, 1 same pixel, 2 nearest-upsampled source (H/2 x W/2)
+  float alpha, out_scale; int accumulate;
+};
+void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st);
+
+// ---- small-channel direct convs -----------------------------------------------------------------------
+// Cin == 2 -> Cout (first conv, Combine 1x1, dgrad of the 2-channel pyramid heads)
+void launch_conv_c2in(const float* x, const float* w /*[Cout][taps][2]*/, const float* bias, const float* add, int add_ld,
+                      float* y, int ldY, int B, int H, int W, int Cout, int taps, int accumulate, hipStream_t st);
+// Cin -> 2 (pyramid heads, dgrad of first conv / Combine). up_add: previous pyramid level at (H/2,W/2) added nearest-up.
+void launch_conv_c2out(const float* x, int ldX, const float* w /*[taps][Cin][2]*/, const float* bias, const float* up_add,
+                       float* y, int B, int H, int W, int Cin, int taps, int accumulate, hipStream_t st);
+
+// ---- GroupNorm (+SiLU, + 2x resample) -------------------------------------------------------------------
+struct Src2 { const float* p0; const float* p1; int C0; int ld0; int ld1; };   // channel-concatenated input view
+struct Dst2 { float* p0; float* p1; int C0; int ld0; int ld1; int acc0; int acc1; };
+int  gn_num_chunks(int HW);
+void launch_gn_stats(Src2 x, int B, int HW, int C, int G, float eps, double* partial, float* stats /*[B][G][2]*/, hipStream_t st);
+// mode: 0 same, 1 down (2x2 mean of the activated tensor; pooled_raw gets the 2x2 mean of x itself), 2 up (nearest x2)
+void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float* beta, int B, int H, int W, int C, int G,
+                     int mode, int silu, float* out, float* pooled_raw, hipStream_t st);
+// backward wrt x. da: gradient of the (resampled) activated output. extra: additional gradient added to dx
+// (extra_mode 0 none, 1 same index, 2 quarter of a pooled-resolution tensor), scaled by extra_scale.
+void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C,
+                   int G, int mode, int silu, const float* extra, int extra_mode, float extra_scale, double* partial,
+                   float* red /*[B][G][2]*/, Dst2 dx, hipStream_t st);
+
+// ---- misc elementwise -------------------------------------------------------------------------------------
+void launch_axpy(float* dst, const float* src, float alpha, long long n, int accumulate, hipStream_t st);
+void launch_pool2(const float* src, float* dst, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st); // (H,W)->(H/2,W/2), sum*scale
+void launch_up2_acc(const float* src, float* dst, int B, int Hs, int Ws, int C, float scale, int accumulate, hipStream_t st); // (Hs,Ws)->(2Hs,2Ws)
+void launch_softmax_rows(float* S, int rows, int cols, hipStream_t st);
+void launch_softmax_bwd_rows(const float* P, float* dP /*in: dP, out: dS*/, int rows, int cols, hipStream_t st);
+void launch_linear(const float* x, const float* W, const float* b, float* y, int B, int K, int N, int silu_in, hipStream_t st);
+void launch_fourier(const float* cnoise, const float* Wf, float* out, int B, int nf, hipStream_t st);
+void launch_mix2(const float* x, const float* w /*[2][2]*/, const float* b, float* y, long long npix, int transpose, int accumulate, hipStream_t st);
+
+// ---- STFT / iSTFT glue ------------------------------------------------------------------------------------
+void launch_reflect_pad(const float* x, float* xp, int B, int L, int pad, int Lp, float scale, const float* scale_b, hipStream_t st);
+void launch_ola(const float* frames, int ldF, int Tp, int n_fft, int hop, const float* inv_env, float* y, int B, int L,
+                int pad, const float* xin, const float* cskip_b, const float* cout_b, hipStream_t st);
+void launch_ola_adj(const float* g, int B, int L, int pad, int Tp, int n_fft, int hop, const float* inv_env, const float* cout_b,
+                    float* frames, int ldF, hipStream_t st);
+void launch_unpad_adj(const float* dframes, int ldF, int T, int n_fft, int hop, int B, int L, int pad, float scale,
+                      const float* scale_b, const float* g_out, const float* cskip_b, float* dx, hipStream_t st);
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace buddy

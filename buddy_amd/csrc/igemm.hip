@@ -1,0 +1,203 @@
+// Implicit-GEMM convolution / GEMM on the CDNA4 matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// One kernel family serves every dense contraction of the score network (reference ddpm_conv3x3 layers.py:119-126,
+// ddpm_conv1x1 layers.py:100-106, NIN layers.py:548-557, AttnBlockpp einsums layerspp.py:82-86) and the
+// DFT-as-GEMM STFT/iSTFT (reference ncsnpp.py:473-496; n_fft = 510 is not a power of two).
+//
+// Tiling: 256 threads = 4 wave64 in a 2x2 grid, block tile 128(M) x 128(N) x 32(K); each wave owns 64x64 =
+// 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs).  A/B tiles are staged through LDS as [row][k] with a 36-float
+// row stride: the ds_read_b128 fragment reads (16-lane groups, rows distinct mod 16) are bank-conflict free and
+// the 8-lane ds_write_b128 groups cover one 128-B row each.  The MFMA consumes one f32 per lane for A and B
+// (lane l: row l&31, k-slot l>>5); a float4 fragment read per lane therefore feeds FOUR MFMAs (the two
+// lane-halves take k = g*8+j and g*8+4+j), so a 32-deep K step costs 16 ds_read_b128 per wave for 64 MFMAs
+// (4096 MFMA cycles): the loop is matrix-pipe bound, global loads for the next K step are issued before the
+// MFMA block and land under it.
+#include "common.h"
+
+namespace buddy {
+
+namespace {
+constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = 36, NT = 256;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int TAPS, bool TA, bool TB>
+__global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+  float* As = smem;
+  float* Bs = smem + BM * LDS_LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const long long bz = blockIdx.z;
+  const float* __restrict__ A0 = p.A0 + bz * p.sA;
+  const float* __restrict__ A1 = p.A1 ? p.A1 + bz * p.sA : nullptr;
+  const float* __restrict__ Bt = p.Bt + bz * p.sB;
+  float* __restrict__ C = p.C + bz * p.sC;
+  const int M = p.M, N = p.N, Cin = p.Cin, H = p.H, W = p.W;
+  const int chunks = (Cin + BK - 1) / BK;
+  const int nk = TAPS * chunks;
+
+  // loader coordinates
+  const int lr = tid >> 3, lc4 = tid & 7;     // row-major operands: rows lr + 32 i, float4 column lc4
+  const int tk = tid >> 5, tm4 = tid & 31;    // k-major operands:   k rows tk + 8 i, float4 (4 rows of the tile) tm4
+  int ah[4], aw[4];
+  bool am_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + lr + 32 * i;
+    am_ok[i] = m < M;
+    if (TAPS == 9) { aw[i] = m % W; ah[i] = (m / W) % H; } else { aw[i] = 0; ah[i] = 0; }
+  }
+
+  auto loadA = [&](int kt, float4 (&r)[4]) {
+    if (!TA) {
+      const int tap = (TAPS == 9) ? kt / chunks : 0;
+      const int c0 = (kt - tap * chunks) * BK;
+      const int dy = (TAPS == 9) ? tap / 3 - 1 : 0, dx = (TAPS == 9) ? tap % 3 - 1 : 0;
+      int cc = c0 + lc4 * 4;
+      const bool k_ok = cc < Cin;
+      const float* src = A0; int ld = p.ldA0;
+      if (A1 != nullptr && cc >= p.C0) { src = A1; ld = p.ldA1; cc -= p.C0; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bool v = am_ok[i] && k_ok;
+        if (TAPS == 9) v = v && (unsigned)(ah[i] + dy) < (unsigned)H && (unsigned)(aw[i] + dx) < (unsigned)W;
+        const long long pix = (long long)(m0 + lr + 32 * i) + dy * W + dx;
+        r[i] = v ? ld4(src + pix * ld + cc) : zero4();
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = kt * BK + tk + 8 * i, m = m0 + tm4 * 4;
+        r[i] = (k < Cin && m < M) ? ld4(A0 + (long long)k * p.ldA0 + m) : zero4();
+      }
+    }
+  };
+  auto loadB = [&](int kt, float4 (&r)[4]) {
+    if (!TB) {
+      const int tap = (TAPS == 9) ? kt / chunks : 0;
+      const int c0 = (kt - tap * chunks) * BK;
+      const int cc = c0 + lc4 * 4;
+      const bool k_ok = cc < Cin;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + lr + 32 * i;
+        r[i] = (n < N && k_ok) ? ld4(Bt + (long long)n * p.ldB + tap * Cin + cc) : zero4();
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = kt * BK + tk + 8 * i, n = n0 + tm4 * 4;
+        r[i] = (k < Cin && n < N) ? ld4(Bt + (long long)k * p.ldB + n) : zero4();
+      }
+    }
+  };
+  auto store_tile = [&](float* S, const float4 (&r)[4], bool trans) {
+    if (!trans) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(S + (lr + 32 * i) * LDS_LD + lc4 * 4) = r[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = tk + 8 * i;
+        S[(tm4 * 4 + 0) * LDS_LD + k] = r[i].x;
+        S[(tm4 * 4 + 1) * LDS_LD + k] = r[i].y;
+        S[(tm4 * 4 + 2) * LDS_LD + k] = r[i].z;
+        S[(tm4 * 4 + 3) * LDS_LD + k] = r[i].w;
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 ra[4], rb[4];
+  loadA(0, ra);
+  loadB(0, rb);
+  const float* Af = As + (wm * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+  const float* Bf = Bs + (wn * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile(As, ra, TA);
+    store_tile(Bs, rb, TB);
+    __syncthreads();
+    if (kt + 1 < nk) { loadA(kt + 1, ra); loadB(kt + 1, rb); }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 a0 = *reinterpret_cast<const float4*>(Af + g * 8);
+      const float4 a1 = *reinterpret_cast<const float4*>(Af + 32 * LDS_LD + g * 8);
+      const float4 b0 = *reinterpret_cast<const float4*>(Bf + g * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(Bf + 32 * LDS_LD + g * 8);
+      const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool need_pix = (p.res_mode == 2) || (p.bias_bn != nullptr);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= M) continue;
+      int bidx = 0; long long res_pix = m;
+      if (need_pix) {
+        bidx = m / p.rows_per_batch;
+        if (p.res_mode == 2) {
+          const int w = m % W, h = (m / W) % H;
+          res_pix = ((long long)bidx * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1);
+        }
+      }
+      const float bm = p.bias_m ? p.bias_m[m] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
+        if (n >= N) continue;
+        float v = p.alpha * acc[mt][nt][r] + bm;
+        if (p.bias_n) v += p.bias_n[n];
+        if (p.bias_bn) v += p.bias_bn[(long long)bidx * p.ld_bias_bn + n];
+        if (p.res_mode) v += p.res[res_pix * p.ldRes + n];
+        v *= p.out_scale;
+        float* dst = C + (long long)m * p.ldC + n;
+        if (p.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+}  // namespace
+
+void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st) {
+  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), batch), block(NT);
+  if (taps == 9) {
+    hipLaunchKernelGGL((igemm_kernel<9, false, false>), grid, block, 0, st, p);
+  } else if (!transA && !transB) {
+    hipLaunchKernelGGL((igemm_kernel<1, false, false>), grid, block, 0, st, p);
+  } else if (!transA && transB) {
+    hipLaunchKernelGGL((igemm_kernel<1, false, true>), grid, block, 0, st, p);
+  } else if (transA && !transB) {
+    hipLaunchKernelGGL((igemm_kernel<1, true, false>), grid, block, 0, st, p);
+  } else {
+    hipLaunchKernelGGL((igemm_kernel<1, true, true>), grid, block, 0, st, p);
+  }
+}
+
+}  // namespace buddy

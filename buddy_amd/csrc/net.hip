@@ -1,0 +1,758 @@
+// Host-side graph of the NCSN++ score network (reference networks/ncsnpp.py:281-449 + STFT/iSTFT wrapper :473-506)
+// and its input-VJP, driving the gfx950 kernels of igemm.hip / ops.hip.  One call = one forward (or one VJP) of the
+// whole network for a batch of utterances; activations live in one HBM arena owned by the handle (sized by a dry run).
+// The VJP is a reverse "tape" of closures recorded during the forward (no weight gradients: inference only).
+#include "common.h"
+#include "net.h"
+
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace buddy {
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return BUDDY_ERR_HIP; } } while (0)
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+const char* last_error() { return g_err.c_str(); }
+
+static const float INV_SQRT2 = 0.70710678118654752440f;
+
+// ------------------------------------------------------------------------------------------------ parameter layout
+struct PSpec { std::string name; std::vector<int> shape; long long off; long long numel; };
+
+static long long numel_of(const std::vector<int>& s) { long long n = 1; for (int v : s) n *= v; return n; }
+
+// Same enumeration as buddy_amd/synth.py:module_specs (reference construction order ncsnpp.py:157-274).
+static std::vector<PSpec> build_specs(const NetCfg& c) {
+  std::vector<PSpec> v;
+  long long off = 0;
+  int idx = 0;
+  auto add = [&](const std::string& suffix, std::vector<int> shape) {
+    PSpec s; s.name = "all_modules." + std::to_string(idx) + "." + suffix; s.shape = shape; s.off = off; s.numel = numel_of(shape);
+    off += s.numel; v.push_back(s);
+  };
+  const int nf = c.nf, in_ch = 2;
+  auto resblock = [&](int cin, int cout, bool resample) {
+    add("GroupNorm_0.weight", {cin}); add("GroupNorm_0.bias", {cin});
+    add("Conv_0.weight", {cout, cin, 3, 3}); add("Conv_0.bias", {cout});
+    add("Dense_0.weight", {cout, nf * 4}); add("Dense_0.bias", {cout});
+    add("GroupNorm_1.weight", {cout}); add("GroupNorm_1.bias", {cout});
+    add("Conv_1.weight", {cout, cout, 3, 3}); add("Conv_1.bias", {cout});
+    if (cin != cout || resample) { add("Conv_2.weight", {cout, cin, 1, 1}); add("Conv_2.bias", {cout}); }
+    ++idx;
+  };
+  add("W", {nf}); ++idx;
+  add("weight", {nf * 4, nf * 2}); add("bias", {nf * 4}); ++idx;
+  add("weight", {nf * 4, nf * 4}); add("bias", {nf * 4}); ++idx;
+  add("weight", {nf, in_ch, 3, 3}); add("bias", {nf}); ++idx;
+  std::vector<int> hs_c{nf};
+  int ch = nf;
+  for (int l = 0; l < c.nlev; ++l) {
+    for (int b = 0; b < c.nrb; ++b) { int co = nf * c.ch_mult[l]; resblock(ch, co, false); ch = co; hs_c.push_back(ch); }
+    if (l != c.nlev - 1) {
+      resblock(ch, ch, true);
+      add("Conv_0.weight", {ch, in_ch, 1, 1}); add("Conv_0.bias", {ch}); ++idx;
+      hs_c.push_back(ch);
+    }
+  }
+  resblock(ch, ch, false);
+  add("GroupNorm_0.weight", {ch}); add("GroupNorm_0.bias", {ch});
+  for (int k = 0; k < 4; ++k) { add("NIN_" + std::to_string(k) + ".W", {ch, ch}); add("NIN_" + std::to_string(k) + ".b", {ch}); }
+  ++idx;
+  resblock(ch, ch, false);
+  for (int l = c.nlev - 1; l >= 0; --l) {
+    for (int b = 0; b < c.nrb + 1; ++b) { int co = nf * c.ch_mult[l]; resblock(ch + hs_c.back(), co, false); hs_c.pop_back(); ch = co; }
+    add("weight", {ch}); add("bias", {ch}); ++idx;
+    add("weight", {in_ch, ch, 3, 3}); add("bias", {in_ch}); ++idx;
+    if (l != 0) resblock(ch, ch, true);
+  }
+  PSpec s; s.name = "output_layer.weight"; s.shape = {2, in_ch, 1, 1}; s.off = off; s.numel = 4; off += 4; v.push_back(s);
+  PSpec t; t.name = "output_layer.bias"; t.shape = {2}; t.off = off; t.numel = 2; off += 2; v.push_back(t);
+  return v;
+}
+
+long long param_count(const NetCfg& c) {
+  auto v = build_specs(c);
+  return v.back().off + v.back().numel;
+}
+
+// ------------------------------------------------------------------------------------------------ tensors / arena
+struct Tens {
+  float* p = nullptr; float* g = nullptr; int ginit = 0;
+  int B = 0, H = 0, W = 0, C = 0;
+  long long numel() const { return (long long)B * H * W * C; }
+};
+struct View { Tens* a = nullptr; Tens* b = nullptr; int C() const { return a->C + (b ? b->C : 0); } };
+
+struct Arena {
+  char* base = nullptr; size_t cap = 0, off = 0, peak = 0; bool dry = false; bool overflow = false;
+  void* alloc(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* r = dry ? (void*)(uintptr_t)(0x10000 + off) : (void*)(base + off);
+    off += bytes;
+    if (off > peak) peak = off;
+    if (!dry && off > cap) overflow = true;
+    return r;
+  }
+  float* f(long long n) { return (float*)alloc((size_t)n * 4); }
+};
+
+struct ConvW { int cin = 0, cout = 0, taps = 0; float* wf = nullptr; float* wb = nullptr; float* bias = nullptr; };
+struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
+struct ResW { GNW gn0, gn1; ConvW c0, c1, c2; bool has_c2 = false; int cin = 0, cout = 0, dense_off = 0; };
+struct AttnW { GNW gn; float* Wt[4]; float* Wn[4]; float* b[4]; int C = 0; };
+
+struct Net {
+  NetCfg cfg;
+  int Fb = 0, Kp = 0, pad = 0;
+  std::vector<PSpec> specs;
+  float* dparams = nullptr;    // raw parameters (device)
+  float* dpacked = nullptr;    // packed weights (device)
+  // modules in execution order
+  float* Wf = nullptr; float* lin1_w = nullptr; float* lin1_b = nullptr; float* lin2_w = nullptr; float* lin2_b = nullptr;
+  float* dense_w = nullptr; float* dense_b = nullptr; int dense_total = 0;
+  ConvW conv_in;                       // 2 -> nf (c2in fwd, c2out bwd)
+  std::vector<ResW> res;               // in module order
+  std::vector<ConvW> combine;          // 1x1 2 -> C
+  AttnW attn;
+  std::vector<GNW> pyr_gn; std::vector<ConvW> pyr_conv;   // C -> 2 heads, top level first
+  float* out_w = nullptr; float* out_b = nullptr;
+  float* basisF = nullptr; float* basisI = nullptr;      // [2Fb][Kp], [Kp][2Fb]
+  // per-(B,L) state
+  int B = 0, L = 0, T = 0, Tp = 0, Lp = 0;
+  float* inv_env = nullptr; int env_len = 0; int env_Tp = -1;
+  Arena arena;
+  std::deque<Tens> pool;
+  std::vector<std::function<void()>> tape;
+  std::vector<std::pair<int, Tens*>> taps;
+  double* partial = nullptr; float* red = nullptr;       // reduction scratch
+  bool have_tape = false;
+  hipStream_t st = nullptr;
+  // saved for vjp
+  Tens* spec = nullptr; Tens* pyr0 = nullptr;
+  const float* k_cin = nullptr; const float* k_cskip = nullptr; const float* k_cout = nullptr;
+
+  bool dry() const { return arena.dry; }
+  Tens* mk(int B_, int H, int W, int C, bool grad) {
+    pool.emplace_back();
+    Tens* t = &pool.back();
+    t->B = B_; t->H = H; t->W = W; t->C = C;
+    t->p = arena.f(t->numel());
+    if (grad) t->g = arena.f(t->numel());
+    return t;
+  }
+  float* tmp(long long n) { return arena.f(n); }
+};
+
+// ------------------------------------------------------------------------------------------------ weight packing (host)
+namespace {
+struct Packer {
+  std::vector<float> buf;
+  long long put(const std::vector<float>& v) {
+    long long off = (long long)buf.size();
+    buf.insert(buf.end(), v.begin(), v.end());
+    while (buf.size() % 64) buf.push_back(0.f);
+    return off;
+  }
+};
+
+// conv 3x3 weights are torch OIHW with H = frequency (ky), W = time (kx).  Our spatial axes are swapped
+// (H = time, W = frequency), so tap (dy, dx) of our layout reads W[o][i][ky = dx][kx = dy].
+inline float w3(const float* w, int O, int I, int o, int i, int dy, int dx) { return w[(((long long)o * I + i) * 3 + dx) * 3 + dy]; }
+
+// forward operand Bt[o][(dy*3+dx)*I + i]
+std::vector<float> pack_conv3_fwd(const float* w, int O, int I) {
+  std::vector<float> r((size_t)O * 9 * I);
+  for (int o = 0; o < O; ++o) for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) for (int i = 0; i < I; ++i)
+    r[((size_t)o * 9 + dy * 3 + dx) * I + i] = w3(w, O, I, o, i, dy, dx);
+  return r;
+}
+// data-gradient operand Bt[i][(dy*3+dx)*O + o] = W[o][i][flipped tap]
+std::vector<float> pack_conv3_bwd(const float* w, int O, int I) {
+  std::vector<float> r((size_t)I * 9 * O);
+  for (int i = 0; i < I; ++i) for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) for (int o = 0; o < O; ++o)
+    r[((size_t)i * 9 + dy * 3 + dx) * O + o] = w3(w, O, I, o, i, 2 - dy, 2 - dx);
+  return r;
+}
+std::vector<float> transpose2(const float* w, int R, int Cc) {   // [R][Cc] -> [Cc][R]
+  std::vector<float> r((size_t)R * Cc);
+  for (int i = 0; i < R; ++i) for (int j = 0; j < Cc; ++j) r[(size_t)j * R + i] = w[(size_t)i * Cc + j];
+  return r;
+}
+}  // namespace
+
+static const PSpec* find_spec(const std::vector<PSpec>& v, const std::string& n) {
+  for (auto& s : v) if (s.name == n) return &s;
+  return nullptr;
+}
+
+int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
+  Net* N = new Net();
+  N->cfg = cfg;
+  N->specs = build_specs(cfg);
+  if (n != param_count(cfg)) { set_error("parameter blob size mismatch"); delete N; return BUDDY_ERR_ARG; }
+  if (cfg.n_fft % 2) { set_error("n_fft must be even"); delete N; return BUDDY_ERR_ARG; }
+  N->Fb = cfg.n_fft / 2 + 1;
+  N->Kp = (cfg.n_fft + 3) / 4 * 4;
+  N->pad = cfg.n_fft / 2;
+  if (N->Fb % (1 << (cfg.nlev - 1))) { set_error("frequency bins not divisible by 2^(levels-1)"); delete N; return BUDDY_ERR_ARG; }
+  // device copy of the raw parameters with every tensor start aligned to 256 B (float4 loads on gamma/beta/1x1 weights)
+  std::vector<long long> doff(N->specs.size());
+  {
+    long long o = 0;
+    for (size_t i = 0; i < N->specs.size(); ++i) { doff[i] = o; o += (N->specs[i].numel + 63) / 64 * 64; }
+    std::vector<float> padded((size_t)o, 0.f);
+    for (size_t i = 0; i < N->specs.size(); ++i) std::memcpy(padded.data() + doff[i], hp + N->specs[i].off, (size_t)N->specs[i].numel * 4);
+    HIPCHK(hipMalloc(&N->dparams, (size_t)o * 4));
+    HIPCHK(hipMemcpy(N->dparams, padded.data(), (size_t)o * 4, hipMemcpyHostToDevice));
+  }
+
+  Packer pk;
+  struct Fix { float** dst; long long off; };
+  std::vector<Fix> fixes;
+  auto raw = [&](const std::string& name) -> float* {
+    for (size_t i = 0; i < N->specs.size(); ++i) if (N->specs[i].name == name) return N->dparams + doff[i];
+    return nullptr;
+  };
+  auto host = [&](const std::string& name) -> const float* {
+    const PSpec* s = find_spec(N->specs, name);
+    return s ? hp + s->off : nullptr;
+  };
+  auto packed = [&](float** dst, const std::vector<float>& v) { fixes.push_back({dst, pk.put(v)}); };
+
+  const int nf = cfg.nf;
+  int idx = 0;
+  auto pre = [&]() { return "all_modules." + std::to_string(idx) + "."; };
+  std::vector<float> dense_w_all, dense_b_all;
+  auto load_gn = [&](GNW& g, const std::string& p, int C) { g.gamma = raw(p + ".weight"); g.beta = raw(p + ".bias"); g.C = C; };
+  auto load_conv3 = [&](ConvW& c, const std::string& p, int cin, int cout) {
+    c.cin = cin; c.cout = cout; c.taps = 9; c.bias = raw(p + ".bias");
+    packed(&c.wf, pack_conv3_fwd(host(p + ".weight"), cout, cin));
+    packed(&c.wb, pack_conv3_bwd(host(p + ".weight"), cout, cin));
+  };
+  auto load_res = [&](int cin, int cout, bool resample) {
+    ResW r; r.cin = cin; r.cout = cout;
+    const std::string p = pre();
+    load_gn(r.gn0, p + "GroupNorm_0", cin); load_gn(r.gn1, p + "GroupNorm_1", cout);
+    N->res.push_back(r);
+    ResW& R = N->res.back();
+    load_conv3(R.c0, p + "Conv_0", cin, cout);
+    load_conv3(R.c1, p + "Conv_1", cout, cout);
+    R.dense_off = (int)dense_b_all.size();
+    const float* dw = host(p + "Dense_0.weight"); const float* db = host(p + "Dense_0.bias");
+    dense_w_all.insert(dense_w_all.end(), dw, dw + (size_t)cout * nf * 4);
+    dense_b_all.insert(dense_b_all.end(), db, db + cout);
+    R.has_c2 = (cin != cout) || resample;
+    if (R.has_c2) {
+      R.c2.cin = cin; R.c2.cout = cout; R.c2.taps = 1; R.c2.bias = raw(p + "Conv_2.bias");
+      R.c2.wf = raw(p + "Conv_2.weight");                                  // [cout][cin] already k-contiguous
+      packed(&R.c2.wb, transpose2(host(p + "Conv_2.weight"), cout, cin));  // [cin][cout]
+    }
+    ++idx;
+  };
+  N->res.reserve(64);
+  N->Wf = raw(pre() + "W"); ++idx;
+  N->lin1_w = raw(pre() + "weight"); N->lin1_b = raw(pre() + "bias"); ++idx;
+  N->lin2_w = raw(pre() + "weight"); N->lin2_b = raw(pre() + "bias"); ++idx;
+  {  // input conv 2 -> nf
+    const float* w = host(pre() + "weight");
+    N->conv_in.cin = 2; N->conv_in.cout = nf; N->conv_in.taps = 9; N->conv_in.bias = raw(pre() + "bias");
+    std::vector<float> f((size_t)nf * 18), b((size_t)9 * nf * 2);
+    for (int o = 0; o < nf; ++o) for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) for (int i = 0; i < 2; ++i) {
+      f[((size_t)o * 9 + dy * 3 + dx) * 2 + i] = w3(w, nf, 2, o, i, dy, dx);
+      b[((size_t)(dy * 3 + dx) * nf + o) * 2 + i] = w3(w, nf, 2, o, i, 2 - dy, 2 - dx);
+    }
+    packed(&N->conv_in.wf, f); packed(&N->conv_in.wb, b);
+    ++idx;
+  }
+  std::vector<int> hs_c{nf};
+  int ch = nf;
+  for (int l = 0; l < cfg.nlev; ++l) {
+    for (int b = 0; b < cfg.nrb; ++b) { int co = nf * cfg.ch_mult[l]; load_res(ch, co, false); ch = co; hs_c.push_back(ch); }
+    if (l != cfg.nlev - 1) {
+      load_res(ch, ch, true);
+      ConvW c; c.cin = 2; c.cout = ch; c.taps = 1; c.bias = raw(pre() + "Conv_0.bias");
+      c.wf = raw(pre() + "Conv_0.weight"); c.wb = c.wf;   // [C][2]: both kernels index it the same way for one tap
+      N->combine.push_back(c); ++idx;
+      hs_c.push_back(ch);
+    }
+  }
+  load_res(ch, ch, false);
+  {
+    AttnW& a = N->attn; a.C = ch;
+    const std::string p = pre();
+    load_gn(a.gn, p + "GroupNorm_0", ch);
+    for (int k = 0; k < 4; ++k) {
+      a.Wn[k] = raw(p + "NIN_" + std::to_string(k) + ".W"); a.b[k] = raw(p + "NIN_" + std::to_string(k) + ".b");
+      packed(&a.Wt[k], transpose2(host(p + "NIN_" + std::to_string(k) + ".W"), ch, ch));
+    }
+    ++idx;
+  }
+  load_res(ch, ch, false);
+  N->pyr_gn.resize(cfg.nlev); N->pyr_conv.resize(cfg.nlev);
+  for (int l = cfg.nlev - 1, j = 0; l >= 0; --l, ++j) {
+    for (int b = 0; b < cfg.nrb + 1; ++b) { int co = nf * cfg.ch_mult[l]; load_res(ch + hs_c.back(), co, false); hs_c.pop_back(); ch = co; }
+    load_gn(N->pyr_gn[j], "all_modules." + std::to_string(idx), ch); ++idx;
+    {
+      const float* w = host(pre() + "weight");   // [2][ch][3][3]
+      ConvW& c = N->pyr_conv[j]; c.cin = ch; c.cout = 2; c.taps = 9; c.bias = raw(pre() + "bias");
+      std::vector<float> f((size_t)9 * ch * 2), b((size_t)ch * 18);
+      for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) for (int i = 0; i < ch; ++i) for (int o = 0; o < 2; ++o) {
+        f[((size_t)(dy * 3 + dx) * ch + i) * 2 + o] = w3(w, 2, ch, o, i, dy, dx);
+        b[((size_t)i * 9 + dy * 3 + dx) * 2 + o] = w3(w, 2, ch, o, i, 2 - dy, 2 - dx);
+      }
+      packed(&c.wf, f); packed(&c.wb, b);
+      ++idx;
+    }
+    if (l != 0) load_res(ch, ch, true);
+  }
+  N->out_w = raw("output_layer.weight"); N->out_b = raw("output_layer.bias");
+  N->dense_total = (int)dense_b_all.size();
+  packed(&N->dense_w, dense_w_all); packed(&N->dense_b, dense_b_all);
+
+  // DFT bases with the periodic Hann window folded in (reference ncsnpp.py:464,473-496 via torch.stft/istft).
+  {
+    const int nfft = cfg.n_fft, Fb = N->Fb, Kp = N->Kp;
+    std::vector<float> bf((size_t)2 * Fb * Kp, 0.f), bi((size_t)Kp * 2 * Fb, 0.f);
+    const double PI = 3.14159265358979323846;
+    for (int k = 0; k < nfft; ++k) {
+      const double w = 0.5 - 0.5 * std::cos(2.0 * PI * k / nfft);
+      for (int f = 0; f < Fb; ++f) {
+        const double ang = 2.0 * PI * (double)((long long)f * k % nfft) / nfft;
+        bf[((size_t)f * 2 + 0) * Kp + k] = (float)(w * std::cos(ang));
+        bf[((size_t)f * 2 + 1) * Kp + k] = (float)(-w * std::sin(ang));
+        const double cf = (f == 0 || f == nfft / 2) ? 1.0 : 2.0;
+        bi[(size_t)k * 2 * Fb + f * 2 + 0] = (float)(cf / nfft * std::cos(ang) * w);
+        bi[(size_t)k * 2 * Fb + f * 2 + 1] = (float)(-cf / nfft * std::sin(ang) * w);
+      }
+    }
+    packed(&N->basisF, bf); packed(&N->basisI, bi);
+  }
+  HIPCHK(hipMalloc(&N->dpacked, pk.buf.size() * 4));
+  HIPCHK(hipMemcpy(N->dpacked, pk.buf.data(), pk.buf.size() * 4, hipMemcpyHostToDevice));
+  for (auto& f : fixes) *f.dst = N->dpacked + f.off;
+  *out = N;
+  return BUDDY_OK;
+}
+
+void net_destroy(Net* N) {
+  if (!N) return;
+  if (N->dparams) (void)hipFree(N->dparams);
+  if (N->dpacked) (void)hipFree(N->dpacked);
+  if (N->arena.base) (void)hipFree(N->arena.base);
+  if (N->inv_env) (void)hipFree(N->inv_env);
+  delete N;
+}
+
+// ------------------------------------------------------------------------------------------------ op helpers
+static Src2 src_of(const View& v) {
+  Src2 s; s.p0 = v.a->p; s.p1 = v.b ? v.b->p : nullptr; s.C0 = v.a->C; s.ld0 = v.a->C; s.ld1 = v.b ? v.b->C : 0;
+  return s;
+}
+static Dst2 gdst_of(const View& v) {
+  Dst2 d; d.p0 = v.a->g; d.p1 = v.b ? v.b->g : nullptr; d.C0 = v.a->C; d.ld0 = v.a->C; d.ld1 = v.b ? v.b->C : 0;
+  d.acc0 = v.a->ginit; d.acc1 = v.b ? v.b->ginit : 0;
+  v.a->ginit = 1; if (v.b) v.b->ginit = 1;
+  return d;
+}
+static IgemmParams ig_base() {
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = 1; p.H = 1; p.W = 1;
+  return p;
+}
+static inline int gn_groups(int C) { int g = C / 4; return g < 32 ? g : 32; }
+
+// conv3x3 over an NHWC tensor (single source) -> out
+static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const float* wt, int Cout, const float* bias, const float* bias_bn,
+                  int ld_bn, const float* res, int ldRes, int res_mode, float alpha, float out_scale, float* out) {
+  if (N->dry()) return;
+  IgemmParams p = ig_base();
+  p.A0 = a; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout;
+  p.Bt = wt; p.ldB = 9 * Cin; p.C = out; p.ldC = Cout;
+  p.bias_n = bias; p.bias_bn = bias_bn; p.ld_bias_bn = ld_bn; p.rows_per_batch = H * W;
+  p.res = res; p.ldRes = ldRes; p.res_mode = res_mode; p.alpha = alpha; p.out_scale = out_scale;
+  launch_igemm(p, 9, false, false, 1, N->st);
+}
+// 1x1 conv / per-pixel linear over a (possibly two-source) view
+static void conv1(Net* N, Src2 a, long long M, int Cin, const float* wt, int Cout, const float* bias, float alpha, float* out, int accumulate) {
+  if (N->dry()) return;
+  IgemmParams p = ig_base();
+  p.A0 = a.p0; p.A1 = a.p1; p.C0 = a.C0; p.ldA0 = a.ld0; p.ldA1 = a.ld1; p.Cin = Cin; p.M = (int)M; p.N = Cout;
+  p.Bt = wt; p.ldB = Cin; p.C = out; p.ldC = Cout; p.bias_n = bias; p.alpha = alpha; p.accumulate = accumulate;
+  launch_igemm(p, 1, false, false, 1, N->st);
+}
+static Src2 single(const float* p, int C) { Src2 s; s.p0 = p; s.p1 = nullptr; s.C0 = C; s.ld0 = C; s.ld1 = 0; return s; }
+
+// ------------------------------------------------------------------------------------------------ composite ops
+static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb_all, bool rec) {
+  const int B = x.a->B, H = x.a->H, W = x.a->W, Cin = R.cin, Cout = R.cout;
+  const int Ho = mode == 1 ? H / 2 : (mode == 2 ? H * 2 : H), Wo = mode == 1 ? W / 2 : (mode == 2 ? W * 2 : W);
+  const int G0 = gn_groups(Cin), G1 = gn_groups(Cout);
+  hipStream_t st = N->st;
+  Tens* out = N->mk(B, Ho, Wo, Cout, rec);
+  Tens* h1 = N->mk(B, Ho, Wo, Cout, false);
+  float* stats0 = N->tmp((long long)B * G0 * 2);
+  float* stats1 = N->tmp((long long)B * G1 * 2);
+  const size_t mark = N->arena.off;
+  float* a0 = N->tmp((long long)B * Ho * Wo * Cin);
+  float* xr = (mode == 1) ? N->tmp((long long)B * Ho * Wo * Cin) : nullptr;
+  float* xs = R.has_c2 ? N->tmp((long long)B * (mode == 2 ? H * W : Ho * Wo) * Cout) : nullptr;
+  float* a1 = N->tmp((long long)B * Ho * Wo * Cout);
+  if (!N->dry()) {
+    launch_gn_stats(src_of(x), B, H * W, Cin, G0, 1e-6f, N->partial, stats0, st);
+    launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
+    conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p);
+    launch_gn_stats(single(h1->p, Cout), B, Ho * Wo, Cout, G1, 1e-6f, N->partial, stats1, st);
+    launch_gn_apply(single(h1->p, Cout), stats1, R.gn1.gamma, R.gn1.beta, B, Ho, Wo, Cout, G1, 0, 1, a1, nullptr, st);
+    const float* res; int res_mode = 1;
+    if (R.has_c2) {
+      if (mode == 1) conv1(N, single(xr, Cin), (long long)B * Ho * Wo, Cin, R.c2.wf, Cout, R.c2.bias, 1.f, xs, 0);
+      else conv1(N, src_of(x), (long long)B * H * W, Cin, R.c2.wf, Cout, R.c2.bias, 1.f, xs, 0);
+      res = xs; if (mode == 2) res_mode = 2;
+    } else {
+      res = x.a->p;   // identity skip: single source, same resolution, Cin == Cout
+    }
+    conv3(N, a1, B, Ho, Wo, Cout, R.c1.wf, Cout, R.c1.bias, nullptr, 0, res, Cout, res_mode, 1.f, INV_SQRT2, out->p);
+  }
+  N->arena.off = mark;
+  if (rec) {
+    const ResW* Rp = &R;
+    N->tape.push_back([=]() {
+      Net* n = N; hipStream_t s = n->st;
+      const size_t mk = n->arena.off;
+      const float* dout = out->g;
+      const float* extra; int extra_mode = 1; float extra_scale = 1.f;
+      if (Rp->has_c2) {
+        float* tx;
+        if (mode == 2) {
+          float* pooled = n->tmp((long long)B * H * W * Cout);
+          tx = n->tmp((long long)B * H * W * Cin);
+          if (!n->dry()) {
+            launch_pool2(dout, pooled, B, Ho, Wo, Cout, 1.f, 0, s);
+            conv1(n, single(pooled, Cout), (long long)B * H * W, Cout, Rp->c2.wb, Cin, nullptr, INV_SQRT2, tx, 0);
+          }
+        } else {
+          tx = n->tmp((long long)B * Ho * Wo * Cin);
+          conv1(n, single(dout, Cout), (long long)B * Ho * Wo, Cout, Rp->c2.wb, Cin, nullptr, INV_SQRT2, tx, 0);
+          if (mode == 1) extra_mode = 2;
+        }
+        extra = tx;
+      } else {
+        extra = dout; extra_scale = INV_SQRT2;
+      }
+      float* da1 = n->tmp((long long)B * Ho * Wo * Cout);
+      float* dh1 = n->tmp((long long)B * Ho * Wo * Cout);
+      float* da0 = n->tmp((long long)B * Ho * Wo * Cin);
+      conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1);
+      Dst2 d1; d1.p0 = dh1; d1.p1 = nullptr; d1.C0 = Cout; d1.ld0 = Cout; d1.ld1 = 0; d1.acc0 = 0; d1.acc1 = 0;
+      if (!n->dry())
+        launch_gn_bwd(single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, da1, B, Ho, Wo, Cout, G1, 0, 1, nullptr, 0, 0.f, n->partial,
+                      n->red, d1, s);
+      conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0);
+      Dst2 d0 = gdst_of(x);
+      if (!n->dry())
+        launch_gn_bwd(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0, B, H, W, Cin, G0, mode, 1, extra, extra_mode, extra_scale,
+                      n->partial, n->red, d0, s);
+      n->arena.off = mk;
+    });
+  }
+  return out;
+}
+
+static void gemm_b(Net* N, const float* A, int ldA, long long sA, bool tA, const float* Bt, int ldB, long long sB, bool tB, float* C, int ldC,
+                   long long sC, int M, int Nn, int K, const float* bias_n, const float* bias_m, float alpha, int accumulate, int batch) {
+  if (N->dry()) return;
+  IgemmParams p = ig_base();
+  p.A0 = A; p.ldA0 = ldA; p.sA = sA; p.Bt = Bt; p.ldB = ldB; p.sB = sB; p.C = C; p.ldC = ldC; p.sC = sC;
+  p.M = M; p.N = Nn; p.Cin = K; p.bias_n = bias_n; p.bias_m = bias_m; p.alpha = alpha; p.accumulate = accumulate;
+  launch_igemm(p, 1, tA, tB, batch, N->st);
+}
+
+static Tens* attnblock(Net* N, const AttnW& A, Tens* x, bool rec) {
+  const int B = x->B, H = x->H, W = x->W, C = A.C, T = H * W, G = gn_groups(C);
+  hipStream_t st = N->st;
+  const float scale = 1.f / std::sqrt((float)C);
+  Tens* out = N->mk(B, H, W, C, rec);
+  float* stats = N->tmp((long long)B * G * 2);
+  float* q = N->tmp((long long)B * T * C);
+  float* k = N->tmp((long long)B * T * C);
+  float* vT = N->tmp((long long)B * T * C);
+  float* P = N->tmp((long long)B * T * T);
+  const size_t mark = N->arena.off;
+  float* hn = N->tmp((long long)B * T * C);
+  float* O = N->tmp((long long)B * T * C);
+  if (!N->dry()) {
+    launch_gn_stats(single(x->p, C), B, T, C, G, 1e-6f, N->partial, stats, st);
+    launch_gn_apply(single(x->p, C), stats, A.gn.gamma, A.gn.beta, B, H, W, C, G, 0, 0, hn, nullptr, st);
+    gemm_b(N, hn, C, 0, false, A.Wt[0], C, 0, false, q, C, 0, B * T, C, C, A.b[0], nullptr, 1.f, 0, 1);
+    gemm_b(N, hn, C, 0, false, A.Wt[1], C, 0, false, k, C, 0, B * T, C, C, A.b[1], nullptr, 1.f, 0, 1);
+    gemm_b(N, A.Wt[2], C, 0, false, hn, C, (long long)T * C, false, vT, T, (long long)C * T, C, T, C, nullptr, A.b[2], 1.f, 0, B);
+    gemm_b(N, q, C, (long long)T * C, false, k, C, (long long)T * C, false, P, T, (long long)T * T, T, T, C, nullptr, nullptr, scale, 0, B);
+    launch_softmax_rows(P, B * T, T, st);
+    gemm_b(N, P, T, (long long)T * T, false, vT, T, (long long)C * T, false, O, C, (long long)T * C, T, C, T, nullptr, nullptr, 1.f, 0, B);
+    IgemmParams p = ig_base();
+    p.A0 = O; p.ldA0 = C; p.Cin = C; p.M = B * T; p.N = C; p.Bt = A.Wt[3]; p.ldB = C; p.C = out->p; p.ldC = C; p.bias_n = A.b[3];
+    p.res = x->p; p.ldRes = C; p.res_mode = 1; p.out_scale = INV_SQRT2;
+    launch_igemm(p, 1, false, false, 1, st);
+  }
+  N->arena.off = mark;
+  if (rec) {
+    const AttnW* Ap = &A;
+    N->tape.push_back([=]() {
+      Net* n = N; hipStream_t s = n->st;
+      const size_t mk = n->arena.off;
+      const float* dout = out->g;
+      const long long TC = (long long)T * C, TT = (long long)T * T;
+      float* dO = n->tmp(B * TC); float* dP = n->tmp(B * TT); float* dvT = n->tmp(B * TC);
+      float* dq = n->tmp(B * TC); float* dk = n->tmp(B * TC); float* dhn = n->tmp(B * TC);
+      gemm_b(n, dout, C, 0, false, Ap->Wn[3], C, 0, false, dO, C, 0, B * T, C, C, nullptr, nullptr, INV_SQRT2, 0, 1);
+      gemm_b(n, dO, C, TC, false, vT, T, TC, true, dP, T, TT, T, T, C, nullptr, nullptr, 1.f, 0, B);        // dP = dO V^T
+      gemm_b(n, dO, C, TC, true, P, T, TT, true, dvT, T, TC, C, T, T, nullptr, nullptr, 1.f, 0, B);         // dV^T = dO^T P
+      if (!n->dry()) launch_softmax_bwd_rows(P, dP, B * T, T, s);                                           // dP <- dS
+      gemm_b(n, dP, T, TT, false, k, C, TC, true, dq, C, TC, T, C, T, nullptr, nullptr, scale, 0, B);        // dq = scale dS k
+      gemm_b(n, dP, T, TT, true, q, C, TC, true, dk, C, TC, T, C, T, nullptr, nullptr, scale, 0, B);         // dk = scale dS^T q
+      gemm_b(n, dq, C, 0, false, Ap->Wn[0], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 0, 1);
+      gemm_b(n, dk, C, 0, false, Ap->Wn[1], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);
+      gemm_b(n, dvT, T, TC, true, Ap->Wn[2], C, 0, false, dhn, C, TC, T, C, C, nullptr, nullptr, 1.f, 1, B);
+      View xv; xv.a = x;
+      Dst2 d = gdst_of(xv);
+      if (!n->dry())
+        launch_gn_bwd(single(x->p, C), stats, Ap->gn.gamma, Ap->gn.beta, dhn, B, H, W, C, G, 0, 0, dout, 1, INV_SQRT2, n->partial, n->red, d, s);
+      n->arena.off = mk;
+    });
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------ network forward
+static int ensure_env(Net* N, int Tp) {
+  if (N->env_Tp == Tp) return BUDDY_OK;
+  const int nfft = N->cfg.n_fft, hop = N->cfg.hop;
+  const int len = nfft + hop * (Tp - 1);
+  std::vector<double> env(len, 0.0);
+  const double PI = 3.14159265358979323846;
+  for (int t = 0; t < Tp; ++t)
+    for (int k = 0; k < nfft; ++k) { const double w = 0.5 - 0.5 * std::cos(2.0 * PI * k / nfft); env[t * hop + k] += w * w; }
+  std::vector<float> inv(len);
+  for (int i = 0; i < len; ++i) inv[i] = env[i] > 1e-11 ? (float)(1.0 / (double)(float)env[i]) : 0.f;
+  if (N->inv_env) (void)hipFree(N->inv_env);
+  HIPCHK(hipMalloc(&N->inv_env, (size_t)len * 4));
+  HIPCHK(hipMemcpy(N->inv_env, inv.data(), (size_t)len * 4, hipMemcpyHostToDevice));
+  N->env_len = len; N->env_Tp = Tp;
+  return BUDDY_OK;
+}
+
+static void run_forward(Net* N, const float* x, const float* cnoise, const float* cin_b, const float* cskip_b, const float* cout_b, float* y,
+                        int B, int L, bool rec) {
+  const NetCfg& c = N->cfg;
+  hipStream_t st = N->st;
+  const int nf = c.nf, Fb = N->Fb, Kp = N->Kp, hop = c.hop, nfft = c.n_fft;
+  const int T = 1 + L / hop, Tp = (T + 15) / 16 * 16;
+  const int Lp = (L + nfft + 8 + 3) / 4 * 4;
+  N->B = B; N->L = L; N->T = T; N->Tp = Tp; N->Lp = Lp;
+  N->pool.clear(); N->tape.clear(); N->taps.clear();
+  N->arena.off = 0;
+  N->k_cin = cin_b; N->k_cskip = cskip_b; N->k_cout = cout_b;
+  // reduction scratch: chunks <= 256, C <= 1024
+  N->partial = (double*)N->arena.alloc((size_t)B * 256 * 1024 * 2 * sizeof(double));
+  N->red = N->tmp((long long)B * 32 * 2);
+
+  // STFT as GEMM over the reflect-padded signal
+  float* xp = N->tmp((long long)B * Lp);
+  Tens* spec = N->mk(B, Tp, Fb, 2, rec);
+  N->spec = spec;
+  if (!N->dry()) {
+    launch_reflect_pad(x, xp, B, L, N->pad, Lp, 1.f, cin_b, st);
+    (void)hipMemsetAsync(spec->p, 0, (size_t)spec->numel() * 4, st);
+    gemm_b(N, xp, hop, Lp, false, N->basisF, Kp, 0, false, spec->p, 2 * Fb, (long long)Tp * 2 * Fb, T, 2 * Fb, Kp, nullptr, nullptr, 1.f, 0, B);
+  }
+  // time embedding (reference ncsnpp.py:299-318) and all Dense_0 projections in one launch (layerspp.py:263)
+  float* four = N->tmp((long long)B * 2 * nf);
+  float* t1 = N->tmp((long long)B * 4 * nf);
+  float* temb = N->tmp((long long)B * 4 * nf);
+  float* temb_all = N->tmp((long long)B * N->dense_total);
+  if (!N->dry()) {
+    launch_fourier(cnoise, N->Wf, four, B, nf, st);
+    launch_linear(four, N->lin1_w, N->lin1_b, t1, B, 2 * nf, 4 * nf, 0, st);
+    launch_linear(t1, N->lin2_w, N->lin2_b, temb, B, 4 * nf, 4 * nf, 1, st);
+    launch_linear(temb, N->dense_w, N->dense_b, temb_all, B, 4 * nf, N->dense_total, 1, st);
+  }
+
+  int mi = 3, ri = 0, ci = 0;
+  auto tap = [&](int idx, Tens* t) { N->taps.push_back({idx, t}); };
+  // input conv
+  Tens* h0 = N->mk(B, Tp, Fb, nf, rec);
+  if (!N->dry()) launch_conv_c2in(spec->p, N->conv_in.wf, N->conv_in.bias, nullptr, 0, h0->p, nf, B, Tp, Fb, nf, 9, 0, st);
+  if (rec) N->tape.push_back([=]() {
+    if (N->dry()) { spec->ginit = 1; return; }
+    launch_conv_c2out(h0->g, nf, N->conv_in.wb, nullptr, nullptr, spec->g, B, Tp, Fb, nf, 9, spec->ginit, N->st);
+    spec->ginit = 1;
+  });
+  tap(mi, h0); ++mi;
+  std::vector<Tens*> hs{h0};
+  Tens* pyr_in = spec;
+  for (int l = 0; l < c.nlev; ++l) {
+    for (int b = 0; b < c.nrb; ++b) {
+      View v; v.a = hs.back();
+      Tens* h = resblock(N, N->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi;
+      hs.push_back(h);
+    }
+    if (l != c.nlev - 1) {
+      View v; v.a = hs.back();
+      Tens* h = resblock(N, N->res[ri++], v, 1, temb_all, rec); tap(mi, h); ++mi;
+      Tens* pin = N->mk(B, pyr_in->H / 2, pyr_in->W / 2, 2, rec);
+      Tens* prev = pyr_in;
+      if (!N->dry()) launch_pool2(prev->p, pin->p, B, prev->H, prev->W, 2, 0.25f, 0, st);          // F.avg_pool2d (layerspp.py:156)
+      if (rec) N->tape.push_back([=]() {
+        if (!N->dry()) launch_up2_acc(pin->g, prev->g, B, pin->H, pin->W, 2, 0.25f, prev->ginit, N->st);
+        prev->ginit = 1;
+      });
+      pyr_in = pin;
+      const ConvW& cw = N->combine[ci++];
+      Tens* hc = N->mk(B, h->H, h->W, h->C, rec);
+      if (!N->dry()) launch_conv_c2in(pin->p, cw.wf, cw.bias, h->p, h->C, hc->p, h->C, B, h->H, h->W, h->C, 1, 0, st);   // Combine 'sum'
+      if (rec) { const ConvW* cwp = &cw; N->tape.push_back([=]() {
+        if (!N->dry()) {
+          launch_axpy(h->g, hc->g, 1.f, h->numel(), h->ginit, N->st);
+          launch_conv_c2out(hc->g, h->C, cwp->wb, nullptr, nullptr, pin->g, B, h->H, h->W, h->C, 1, pin->ginit, N->st);
+        }
+        h->ginit = 1; pin->ginit = 1;
+      }); }
+      tap(mi, hc); ++mi;
+      hs.push_back(hc);
+    }
+  }
+  Tens* h = hs.back();
+  { View v; v.a = h; h = resblock(N, N->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi; }
+  h = attnblock(N, N->attn, h, rec); tap(mi, h); ++mi;
+  { View v; v.a = h; h = resblock(N, N->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi; }
+  Tens* pyr = nullptr;
+  for (int l = c.nlev - 1, j = 0; l >= 0; --l, ++j) {
+    for (int b = 0; b < c.nrb + 1; ++b) {
+      View v; v.a = h; v.b = hs.back(); hs.pop_back();
+      h = resblock(N, N->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi;
+    }
+    {  // pyramid head: GroupNorm -> SiLU -> conv3x3 C->2, plus nearest-upsampled previous pyramid (ncsnpp.py:391-412)
+      const GNW& gw = N->pyr_gn[j]; const ConvW& cw = N->pyr_conv[j];
+      const int C = h->C, G = gn_groups(C), Hh = h->H, Ww = h->W;
+      Tens* np = N->mk(B, Hh, Ww, 2, rec);
+      float* stats = N->tmp((long long)B * G * 2);
+      const size_t mark = N->arena.off;
+      float* a = N->tmp(h->numel());
+      Tens* prevp = pyr; Tens* hh = h;
+      if (!N->dry()) {
+        launch_gn_stats(single(h->p, C), B, Hh * Ww, C, G, 1e-6f, N->partial, stats, st);
+        launch_gn_apply(single(h->p, C), stats, gw.gamma, gw.beta, B, Hh, Ww, C, G, 0, 1, a, nullptr, st);
+        launch_conv_c2out(a, C, cw.wf, cw.bias, prevp ? prevp->p : nullptr, np->p, B, Hh, Ww, C, 9, 0, st);
+      }
+      N->arena.off = mark;
+      if (rec) { const GNW* gp = &gw; const ConvW* cp = &cw; N->tape.push_back([=]() {
+        const size_t mk = N->arena.off;
+        float* da = N->tmp(hh->numel());
+        if (!N->dry()) {
+          if (prevp) launch_pool2(np->g, prevp->g, B, Hh, Ww, 2, 1.f, prevp->ginit, N->st);
+          launch_conv_c2in(np->g, cp->wb, nullptr, nullptr, 0, da, C, B, Hh, Ww, C, 9, 0, N->st);
+        }
+        if (prevp) prevp->ginit = 1;
+        View hv; hv.a = hh;
+        Dst2 d = gdst_of(hv);
+        if (!N->dry()) launch_gn_bwd(single(hh->p, C), stats, gp->gamma, gp->beta, da, B, Hh, Ww, C, G, 0, 1, nullptr, 0, 0.f, N->partial, N->red, d, N->st);
+        N->arena.off = mk;
+      }); }
+      pyr = np; mi += 2; tap(mi - 1, pyr);
+    }
+    if (l != 0) { View v; v.a = h; h = resblock(N, N->res[ri++], v, 2, temb_all, rec); tap(mi, h); ++mi; }
+  }
+  N->pyr0 = pyr;
+  // output layer (1x1, 2->2), iSTFT as GEMM + overlap-add with the EDM skip/out scaling folded in
+  float* o2 = N->tmp((long long)B * Tp * Fb * 2);
+  float* frames = N->tmp((long long)B * Tp * Kp);
+  if (!N->dry()) {
+    launch_mix2(pyr->p, N->out_w, N->out_b, o2, (long long)B * Tp * Fb, 0, 0, st);
+    gemm_b(N, o2, 2 * Fb, 0, false, N->basisI, 2 * Fb, 0, false, frames, Kp, 0, B * Tp, Kp, 2 * Fb, nullptr, nullptr, 1.f, 0, 1);
+    launch_ola(frames, Kp, Tp, nfft, hop, N->inv_env, y, B, L, N->pad, cskip_b ? x : nullptr, cskip_b, cout_b, st);
+  }
+  N->have_tape = rec;
+}
+
+static void run_vjp(Net* N, const float* cot, float* gx) {
+  const NetCfg& c = N->cfg;
+  const int B = N->B, L = N->L, T = N->T, Tp = N->Tp, Fb = N->Fb, Kp = N->Kp, hop = c.hop, nfft = c.n_fft;
+  hipStream_t st = N->st;
+  for (auto& t : N->pool) t.ginit = 0;
+  const size_t mark = N->arena.off;
+  float* dframes = N->tmp((long long)B * Tp * Kp);
+  float* do2 = N->tmp((long long)B * Tp * Fb * 2);
+  if (!N->dry()) {
+    launch_ola_adj(cot, B, L, N->pad, Tp, nfft, hop, N->inv_env, N->k_cout, dframes, Kp, st);
+    gemm_b(N, dframes, Kp, 0, false, N->basisI, 2 * Fb, 0, true, do2, 2 * Fb, 0, B * Tp, 2 * Fb, Kp, nullptr, nullptr, 1.f, 0, 1);
+    launch_mix2(do2, N->out_w, nullptr, N->pyr0->g, (long long)B * Tp * Fb, 1, 0, st);
+  }
+  N->pyr0->ginit = 1;
+  for (int i = (int)N->tape.size() - 1; i >= 0; --i) N->tape[i]();
+  float* dfx = N->tmp((long long)B * T * Kp);
+  if (!N->dry()) {
+    gemm_b(N, N->spec->g, 2 * Fb, (long long)Tp * 2 * Fb, false, N->basisF, Kp, 0, true, dfx, Kp, (long long)T * Kp, T, Kp, 2 * Fb, nullptr, nullptr,
+           1.f, 0, B);
+    launch_unpad_adj(dfx, Kp, T, nfft, hop, B, L, N->pad, 1.f, N->k_cin, N->k_cskip ? cot : nullptr, N->k_cskip, gx, st);
+  }
+  N->arena.off = mark;
+}
+
+int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes) {
+  Arena saved = N->arena;
+  N->arena = Arena(); N->arena.dry = true;
+  run_forward(N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, L, with_vjp != 0);
+  if (with_vjp) run_vjp(N, nullptr, nullptr);
+  const size_t need = N->arena.peak + (1 << 20);
+  N->arena = saved;
+  N->pool.clear(); N->tape.clear(); N->taps.clear(); N->have_tape = false;
+  if (bytes) *bytes = (long long)need;
+  if (N->arena.cap < need) {
+    if (N->arena.base) (void)hipFree(N->arena.base);
+    N->arena.base = nullptr; N->arena.cap = 0;
+    HIPCHK(hipMalloc(&N->arena.base, need));
+    N->arena.cap = need;
+  }
+  return BUDDY_OK;
+}
+
+int net_forward(Net* N, const float* x, const float* cnoise, const float* cin_b, const float* cskip_b, const float* cout_b, float* y, int B, int L,
+                int save, hipStream_t st) {
+  if (B < 1 || L < N->cfg.n_fft) { set_error("bad B or L"); return BUDDY_ERR_ARG; }
+  const int T = 1 + L / N->cfg.hop, Tp = (T + 15) / 16 * 16;
+  if (Tp % (1 << (N->cfg.nlev - 1))) { set_error("frames not divisible"); return BUDDY_ERR_ARG; }
+  int rc = net_reserve(N, B, L, save, nullptr);
+  if (rc) return rc;
+  rc = ensure_env(N, Tp);
+  if (rc) return rc;
+  N->st = st;
+  N->arena.dry = false; N->arena.overflow = false;
+  run_forward(N, x, cnoise, cin_b, cskip_b, cout_b, y, B, L, save != 0);
+  if (N->arena.overflow) { set_error("arena overflow"); return BUDDY_ERR_STATE; }
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+
+int net_vjp(Net* N, const float* cot, float* gx, hipStream_t st) {
+  if (!N->have_tape) { set_error("vjp without a saved forward"); return BUDDY_ERR_STATE; }
+  N->st = st;
+  run_vjp(N, cot, gx);
+  if (N->arena.overflow) { set_error("arena overflow"); return BUDDY_ERR_STATE; }
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+
+int net_get_tap(Net* N, int module_idx, const float** p, int dims[4]) {
+  for (auto& t : N->taps)
+    if (t.first == module_idx) { *p = t.second->p; dims[0] = t.second->B; dims[1] = t.second->H; dims[2] = t.second->W; dims[3] = t.second->C; return BUDDY_OK; }
+  set_error("no such tap");
+  return BUDDY_ERR_ARG;
+}
+
+}  // namespace buddy

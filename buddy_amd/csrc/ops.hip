@@ -1,0 +1,599 @@
+// HBM-bound kernels of the score network and STFT glue (gfx950): GroupNorm statistics / apply(+SiLU, +2x resample)
+// and their input-gradients, 2-channel direct convs, pooling, softmax rows, small linears, reflect-pad / overlap-add.
+// All tensors fp32 NHWC (see common.h); every kernel moves float4 per lane along the channel axis (coalesced 16 B/lane).
+#include "common.h"
+
+namespace buddy {
+namespace {
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + expf(-z)); }
+__device__ __forceinline__ float dsilu_f(float z) {
+  const float s = 1.f / (1.f + expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
+__device__ __forceinline__ const float* src_ptr(const Src2& x, long long pix, int c) {
+  return (x.p1 != nullptr && c >= x.C0) ? x.p1 + pix * x.ld1 + (c - x.C0) : x.p0 + pix * x.ld0 + c;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+// gradient of the (resampled) activation arriving at full-resolution pixel (b,h,w), channels c..c+3
+__device__ __forceinline__ float4 da_eff(const float* da, int mode, int b, int h, int w, int H, int W, int C, int c) {
+  if (mode == 0) return ld4(da + (((long long)b * H + h) * W + w) * C + c);
+  if (mode == 1) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    return mul4(ld4(da + (((long long)b * H2 + (h >> 1)) * W2 + (w >> 1)) * C + c), 0.25f);
+  }
+  const int H2 = H << 1, W2 = W << 1;
+  const float* q = da + (((long long)b * H2 + 2 * h) * W2 + 2 * w) * C + c;
+  return add4(add4(ld4(q), ld4(q + C)), add4(ld4(q + (long long)W2 * C), ld4(q + (long long)W2 * C + C)));
+}
+
+// ------------------------------------------------------------------ per-channel two-value reduction over pixels
+// KIND 0: (x, x^2) for the forward statistics.  KIND 1: (dxhat, dxhat*xhat) for the backward.
+struct RedArgs {
+  Src2 x; int B, H, W, C, G; int chunks, ppc;
+  const float* stats; const float* gamma; const float* beta; const float* da; int mode; int silu;
+  double* partial;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const RedArgs a) {
+  __shared__ double red[256 * 8];
+  const int q = a.C >> 2, pl = 256 / q;
+  const int tid = threadIdx.x, quad = tid % q, lp = tid / q;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int HW = a.H * a.W;
+  const int p0 = chunk * a.ppc, p1 = min(HW, p0 + a.ppc);
+  double s[4] = {0, 0, 0, 0}, t[4] = {0, 0, 0, 0};
+  if (lp < pl) {
+    const int c = quad * 4;
+    float mean = 0.f, rstd = 0.f; float4 gm = make_float4(0, 0, 0, 0), bt = gm;
+    if (KIND == 1) {
+      const int g = c / (a.C / a.G);
+      mean = a.stats[((long long)b * a.G + g) * 2]; rstd = a.stats[((long long)b * a.G + g) * 2 + 1];
+      gm = ld4(a.gamma + c); bt = ld4(a.beta + c);
+    }
+    for (int p = p0 + lp; p < p1; p += pl) {
+      const float4 v = ld4(src_ptr(a.x, (long long)b * HW + p, c));
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+      if (KIND == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += (double)xv[j]; t[j] += (double)xv[j] * (double)xv[j]; }
+      } else {
+        const int h = p / a.W, w = p - h * a.W;
+        const float4 d = da_eff(a.da, a.mode, b, h, w, a.H, a.W, a.C, c);
+        const float dv[4] = {d.x, d.y, d.z, d.w};
+        const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[j] - mean) * rstd;
+          const float z = xh * gv[j] + bv[j];
+          const float dxh = dv[j] * (a.silu ? dsilu_f(z) : 1.f) * gv[j];
+          s[j] += (double)dxh; t[j] += (double)dxh * (double)xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = s[j]; red[tid * 8 + 4 + j] = t[j]; }
+  __syncthreads();
+  if (tid < q) {
+    double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int l = 0; l < pl; ++l)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] += red[(l * q + tid) * 8 + j];
+    double* o = a.partial + (((long long)b * a.chunks + chunk) * a.C + tid * 4) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j * 2] = r[j]; o[j * 2 + 1] = r[4 + j]; }
+  }
+}
+
+// one wave per (b, group): combine chunk partials.  KIND 0 -> (mean, rstd); KIND 1 -> (mean dxhat, mean dxhat*xhat)
+template <int KIND>
+__global__ __launch_bounds__(64) void group_finalize_kernel(const double* partial, float* out, int C, int G, int chunks, int HW, float eps) {
+  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int cpg = C / G;
+  double s = 0, t = 0;
+  for (int i = lane; i < chunks * cpg; i += 64) {
+    const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
+    const double* p = partial + (((long long)b * chunks + ch) * C + c) * 2;
+    s += p[0]; t += p[1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); t += __shfl_down(t, off, 64); }
+  if (lane == 0) {
+    const double n = (double)cpg * (double)HW;
+    float* o = out + ((long long)b * G + g) * 2;
+    if (KIND == 0) {
+      const double mean = s / n;
+      double var = t / n - mean * mean;
+      if (var < 0) var = 0;
+      o[0] = (float)mean; o[1] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+      o[0] = (float)(s / n); o[1] = (float)(t / n);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ GroupNorm apply (+SiLU) with optional 2x resample
+__global__ __launch_bounds__(256) void gn_apply_kernel(Src2 x, const float* stats, const float* gamma, const float* beta, int B, int H,
+                                                       int W, int C, int G, int mode, int silu, float* out, float* pooled_raw) {
+  const int q = C >> 2, cpg = C / G;
+  const int Ho = (mode == 1) ? H >> 1 : H, Wo = (mode == 1) ? W >> 1 : W;   // iteration space (mode 2 iterates inputs)
+  const long long total = (long long)B * Ho * Wo * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int quad = (int)(idx % q); long long pix = idx / q;
+    const int w = (int)(pix % Wo); pix /= Wo; const int h = (int)(pix % Ho); const int b = (int)(pix / Ho);
+    const int c = quad * 4, g = c / cpg;
+    const float mean = stats[((long long)b * G + g) * 2], rstd = stats[((long long)b * G + g) * 2 + 1];
+    const float4 gm = ld4(gamma + c), bt = ld4(beta + c);
+    auto act = [&](float4 v) {
+      float4 z = make_float4((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y,
+                             (v.z - mean) * rstd * gm.z + bt.z, (v.w - mean) * rstd * gm.w + bt.w);
+      if (silu) z = make_float4(silu_f(z.x), silu_f(z.y), silu_f(z.z), silu_f(z.w));
+      return z;
+    };
+    if (mode == 0) {
+      const long long p = ((long long)b * H + h) * W + w;
+      st4(out + p * C + c, act(ld4(src_ptr(x, p, c))));
+    } else if (mode == 1) {
+      const long long p = ((long long)b * H + 2 * h) * W + 2 * w;
+      const float4 v0 = ld4(src_ptr(x, p, c)), v1 = ld4(src_ptr(x, p + 1, c)), v2 = ld4(src_ptr(x, p + W, c)), v3 = ld4(src_ptr(x, p + W + 1, c));
+      const long long po = ((long long)b * Ho + h) * Wo + w;
+      st4(out + po * C + c, mul4(add4(add4(act(v0), act(v1)), add4(act(v2), act(v3))), 0.25f));
+      if (pooled_raw) st4(pooled_raw + po * C + c, mul4(add4(add4(v0, v1), add4(v2, v3)), 0.25f));
+    } else {
+      const long long p = ((long long)b * H + h) * W + w;
+      const float4 a = act(ld4(src_ptr(x, p, c)));
+      const int W2 = W << 1;
+      float* o = out + ((((long long)b * (H << 1)) + 2 * h) * W2 + 2 * w) * C + c;
+      st4(o, a); st4(o + C, a); st4(o + (long long)W2 * C, a); st4(o + (long long)W2 * C + C, a);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da,
+                                                           int B, int H, int W, int C, int G, int mode, int silu, const float* extra,
+                                                           int extra_mode, float extra_scale, const float* red, Dst2 dx) {
+  const int q = C >> 2, cpg = C / G;
+  const long long total = (long long)B * H * W * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int quad = (int)(idx % q); long long pix = idx / q;
+    const long long p = pix;
+    const int w = (int)(pix % W); pix /= W; const int h = (int)(pix % H); const int b = (int)(pix / H);
+    const int c = quad * 4, g = c / cpg;
+    const float mean = stats[((long long)b * G + g) * 2], rstd = stats[((long long)b * G + g) * 2 + 1];
+    const float m1 = red[((long long)b * G + g) * 2], m2 = red[((long long)b * G + g) * 2 + 1];
+    const float4 gm = ld4(gamma + c), bt = ld4(beta + c);
+    const float4 v = ld4(src_ptr(x, p, c));
+    const float4 d = da_eff(da, mode, b, h, w, H, W, C, c);
+    const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
+    const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (xv[j] - mean) * rstd;
+      const float z = xh * gv[j] + bv[j];
+      const float dxh = dv[j] * (silu ? dsilu_f(z) : 1.f) * gv[j];
+      r[j] = rstd * (dxh - m1 - xh * m2);
+    }
+    if (extra_mode == 1) {
+      const float4 e = ld4(extra + p * C + c);
+      r[0] += extra_scale * e.x; r[1] += extra_scale * e.y; r[2] += extra_scale * e.z; r[3] += extra_scale * e.w;
+    } else if (extra_mode == 2) {
+      const float4 e = ld4(extra + ((((long long)b * (H >> 1)) + (h >> 1)) * (W >> 1) + (w >> 1)) * C + c);
+      const float s = 0.25f * extra_scale;
+      r[0] += s * e.x; r[1] += s * e.y; r[2] += s * e.z; r[3] += s * e.w;
+    }
+    float* o; int acc;
+    if (dx.p1 != nullptr && c >= dx.C0) { o = dx.p1 + p * dx.ld1 + (c - dx.C0); acc = dx.acc1; }
+    else { o = dx.p0 + p * dx.ld0 + c; acc = dx.acc0; }
+    float4 res = make_float4(r[0], r[1], r[2], r[3]);
+    if (acc) res = add4(res, ld4(o));
+    st4(o, res);
+  }
+}
+
+// ------------------------------------------------------------------ elementwise helpers
+__global__ __launch_bounds__(256) void axpy_kernel(float* dst, const float* src, float alpha, long long n4, int accumulate) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 v = mul4(ld4(src + i * 4), alpha);
+    if (accumulate) v = add4(v, ld4(dst + i * 4));
+    st4(dst + i * 4, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void pool2_kernel(const float* src, float* dst, int B, int H, int W, int C, float scale, int accumulate) {
+  const int q = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)B * Ho * Wo * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int quad = (int)(idx % q); long long pix = idx / q;
+    const int w = (int)(pix % Wo); pix /= Wo; const int h = (int)(pix % Ho); const int b = (int)(pix / Ho);
+    const float* s = src + ((((long long)b * H) + 2 * h) * W + 2 * w) * C + quad * 4;
+    float4 v = mul4(add4(add4(ld4(s), ld4(s + C)), add4(ld4(s + (long long)W * C), ld4(s + (long long)W * C + C))), scale);
+    float* o = dst + idx * 4;
+    if (accumulate) v = add4(v, ld4(o));
+    st4(o, v);
+  }
+}
+
+// C == 2 variant (input pyramid): float2 per pixel
+__global__ __launch_bounds__(256) void pool2_c2_kernel(const float* src, float* dst, int B, int H, int W, float scale, int accumulate) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)B * Ho * Wo;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    long long pix = idx;
+    const int w = (int)(pix % Wo); pix /= Wo; const int h = (int)(pix % Ho); const int b = (int)(pix / Ho);
+    const float2* s = reinterpret_cast<const float2*>(src) + (((long long)b * H) + 2 * h) * W + 2 * w;
+    const float2 a = s[0], b1 = s[1], c = s[W], d = s[W + 1];
+    float2 v = make_float2(((a.x + b1.x) + (c.x + d.x)) * scale, ((a.y + b1.y) + (c.y + d.y)) * scale);
+    float2* o = reinterpret_cast<float2*>(dst) + idx;
+    if (accumulate) { v.x += o->x; v.y += o->y; }
+    *o = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void up2_acc_kernel(const float* src, float* dst, int B, int Hs, int Ws, int C, float scale, int accumulate) {
+  const int cv = C >> 1;   // float2 granularity so that C == 2 works too
+  const int H = Hs << 1, W = Ws << 1;
+  const long long total = (long long)B * H * W * cv;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cc = (int)(idx % cv); long long pix = idx / cv;
+    const int w = (int)(pix % W); pix /= W; const int h = (int)(pix % H); const int b = (int)(pix / H);
+    const float2 s = *reinterpret_cast<const float2*>(src + ((((long long)b * Hs) + (h >> 1)) * Ws + (w >> 1)) * C + cc * 2);
+    float2* o = reinterpret_cast<float2*>(dst + idx * 2);
+    float2 v = make_float2(s.x * scale, s.y * scale);
+    if (accumulate) { v.x += o->x; v.y += o->y; }
+    *o = v;
+  }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, int rows, int cols) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float* r = S + (long long)row * cols;
+  float m = -INFINITY;
+  for (int j = lane; j < cols; j += 64) m = fmaxf(m, r[j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  float s = 0.f;
+  for (int j = lane; j < cols; j += 64) { const float e = expf(r[j] - m); r[j] = e; s += e; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float inv = 1.f / s;
+  for (int j = lane; j < cols; j += 64) r[j] *= inv;
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* P, float* dP, int rows, int cols) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* p = P + (long long)row * cols;
+  float* d = dP + (long long)row * cols;
+  float s = 0.f;
+  for (int j = lane; j < cols; j += 64) s += p[j] * d[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  for (int j = lane; j < cols; j += 64) d[j] = p[j] * (d[j] - s);
+}
+
+// y[b][n] = sum_k act(x[b][k]) W[n][k] + bias[n]; one wave per output
+__global__ __launch_bounds__(256) void linear_kernel(const float* x, const float* Wt, const float* bias, float* y, int B, int K, int N, int silu_in) {
+  const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= (long long)B * N) return;
+  const int b = (int)(o / N), n = (int)(o % N);
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    float v = x[(long long)b * K + k];
+    if (silu_in) v = silu_f(v);
+    s += v * Wt[(long long)n * K + k];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) y[o] = s + (bias ? bias[n] : 0.f);
+}
+
+__global__ void fourier_kernel(const float* cnoise, const float* Wf, float* out, int B, int nf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nf) return;
+  const int b = i / nf, j = i % nf;
+  const float pr = cnoise[b] * Wf[j] * 2.f * 3.14159265358979323846f;   // reference layerspp.py:40 (fp32 product order)
+  out[(long long)b * 2 * nf + j] = sinf(pr);
+  out[(long long)b * 2 * nf + nf + j] = cosf(pr);
+}
+
+__global__ __launch_bounds__(256) void mix2_kernel(const float* x, const float* w, const float* b, float* y, long long npix, int transpose, int accumulate) {
+  const float w00 = w[0], w01 = w[1], w10 = w[2], w11 = w[3];
+  const float b0 = b ? b[0] : 0.f, b1 = b ? b[1] : 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+    const float2 v = reinterpret_cast<const float2*>(x)[i];
+    float2 o;
+    if (!transpose) { o.x = w00 * v.x + w01 * v.y + b0; o.y = w10 * v.x + w11 * v.y + b1; }
+    else { o.x = w00 * v.x + w10 * v.y; o.y = w01 * v.x + w11 * v.y; }
+    float2* d = reinterpret_cast<float2*>(y) + i;
+    if (accumulate) { o.x += d->x; o.y += d->y; }
+    *d = o;
+  }
+}
+
+// ------------------------------------------------------------------ 2-channel direct convs
+// x [B][H][W][2] -> y [.., Cout]; w [Cout][TAPS][2]; thread = (pixel, 4 output channels)
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_c2in_kernel(const float* x, const float* w, const float* bias, const float* add, int add_ld,
+                                                        float* y, int ldY, int B, int H, int W, int Cout, int accumulate) {
+  const int q = Cout >> 2;
+  const long long total = (long long)B * H * W * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int quad = (int)(idx % q); long long pix = idx / q;
+    const long long p = pix;
+    const int wq = (int)(pix % W); pix /= W; const int h = (int)(pix % H);
+    const int c = quad * 4;
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = bias ? bias[c + j] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int dy = (TAPS == 9) ? t / 3 - 1 : 0, dx = (TAPS == 9) ? t % 3 - 1 : 0;
+      if ((unsigned)(h + dy) >= (unsigned)H || (unsigned)(wq + dx) >= (unsigned)W) continue;
+      const float2 v = reinterpret_cast<const float2*>(x)[p + dy * W + dx];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float2 ww = *reinterpret_cast<const float2*>(w + ((long long)(c + j) * TAPS + t) * 2);
+        acc[j] += ww.x * v.x + ww.y * v.y;
+      }
+    }
+    float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (add) r = add4(r, ld4(add + p * add_ld + c));
+    float* o = y + p * ldY + c;
+    if (accumulate) r = add4(r, ld4(o));
+    st4(o, r);
+  }
+}
+
+// x [B][H][W][Cin] (ldX) -> y [B][H][W][2]; w [TAPS][Cin][2]; LPP = Cin/4 lanes cooperate on one pixel
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_c2out_kernel(const float* x, int ldX, const float* w, const float* bias, const float* up_add,
+                                                         float* y, int B, int H, int W, int Cin, int accumulate) {
+  const int lpp = Cin >> 2, ppb = 256 / lpp;
+  const int tid = threadIdx.x, sub = tid % lpp, slot = tid / lpp;
+  const int c = sub * 4;
+  float wr[TAPS][8];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wr[t][j] = w[((long long)t * Cin + c) * 2 + j];
+  const long long npix = (long long)B * H * W;
+  const long long ngroups = (npix + ppb - 1) / ppb;
+  for (long long gidx = blockIdx.x; gidx < ngroups; gidx += gridDim.x) {
+    const long long p = gidx * ppb + slot;
+    float s0 = 0.f, s1 = 0.f;
+    int b = 0, h = 0, wq = 0;
+    if (p < npix) {
+      long long pix = p;
+      wq = (int)(pix % W); pix /= W; h = (int)(pix % H); b = (int)(pix / H);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int dy = (TAPS == 9) ? t / 3 - 1 : 0, dx = (TAPS == 9) ? t % 3 - 1 : 0;
+        if ((unsigned)(h + dy) >= (unsigned)H || (unsigned)(wq + dx) >= (unsigned)W) continue;
+        const float4 v = ld4(x + (p + dy * W + dx) * ldX + c);
+        s0 += v.x * wr[t][0] + v.y * wr[t][2] + v.z * wr[t][4] + v.w * wr[t][6];
+        s1 += v.x * wr[t][1] + v.y * wr[t][3] + v.z * wr[t][5] + v.w * wr[t][7];
+      }
+    }
+    for (int off = lpp >> 1; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+    if (sub == 0 && p < npix) {
+      if (bias) { s0 += bias[0]; s1 += bias[1]; }
+      if (up_add) {
+        const float2 u = reinterpret_cast<const float2*>(up_add)[(((long long)b * (H >> 1)) + (h >> 1)) * (W >> 1) + (wq >> 1)];
+        s0 += u.x; s1 += u.y;
+      }
+      float2* o = reinterpret_cast<float2*>(y) + p;
+      if (accumulate) { s0 += o->x; s1 += o->y; }
+      *o = make_float2(s0, s1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ STFT glue
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* x, float* xp, int B, int L, int pad, int Lp, float scale, const float* scale_b) {
+  const long long total = (long long)B * Lp;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int b = (int)(idx / Lp), j = (int)(idx % Lp);
+    float v = 0.f;
+    if (j < L + 2 * pad) {
+      int i = j - pad;
+      if (i < 0) i = -i;
+      if (i >= L) i = 2 * (L - 1) - i;
+      v = x[(long long)b * L + i] * scale * (scale_b ? scale_b[b] : 1.f);
+    }
+    xp[idx] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void ola_kernel(const float* frames, int ldF, int Tp, int n_fft, int hop, const float* inv_env, float* y, int B,
+                                                  int L, int pad, const float* xin, const float* cskip_b, const float* cout_b) {
+  const long long total = (long long)B * L;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int b = (int)(idx / L), s = (int)(idx % L);
+    const int j = s + pad;
+    int t0 = (j - n_fft + hop) / hop; if (t0 < 0) t0 = 0;     // ceil((j - n_fft + 1)/hop) for j-n_fft+1 > 0
+    int t1 = j / hop; if (t1 > Tp - 1) t1 = Tp - 1;
+    float acc = 0.f;
+    for (int t = t0; t <= t1; ++t) {
+      const int n = j - t * hop;
+      if (n >= 0 && n < n_fft) acc += frames[((long long)b * Tp + t) * ldF + n];
+    }
+    acc *= inv_env[j];
+    if (xin) acc = cskip_b[b] * xin[idx] + cout_b[b] * acc;
+    y[idx] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void ola_adj_kernel(const float* g, int B, int L, int pad, int Tp, int n_fft, int hop, const float* inv_env,
+                                                      const float* cout_b, float* frames, int ldF) {
+  const long long total = (long long)B * Tp * ldF;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int n = (int)(idx % ldF); const long long bt = idx / ldF;
+    const int t = (int)(bt % Tp), b = (int)(bt / Tp);
+    float v = 0.f;
+    if (n < n_fft) {
+      const int j = t * hop + n, s = j - pad;
+      if (s >= 0 && s < L) v = g[(long long)b * L + s] * inv_env[j] * (cout_b ? cout_b[b] : 1.f);
+    }
+    frames[idx] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void unpad_adj_kernel(const float* dframes, int ldF, int T, int n_fft, int hop, int B, int L, int pad, float scale,
+                                                        const float* scale_b, const float* g_out, const float* cskip_b, float* dx) {
+  const long long total = (long long)B * L;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int b = (int)(idx / L), s = (int)(idx % L);
+    auto U = [&](int j) {
+      int t0 = (j - n_fft + hop) / hop; if (t0 < 0) t0 = 0;
+      int t1 = j / hop; if (t1 > T - 1) t1 = T - 1;
+      float a = 0.f;
+      for (int t = t0; t <= t1; ++t) {
+        const int n = j - t * hop;
+        if (n >= 0 && n < n_fft) a += dframes[((long long)b * T + t) * ldF + n];
+      }
+      return a;
+    };
+    float v = U(s + pad);
+    if (s >= 1 && s <= pad) v += U(pad - s);
+    if (s >= L - 1 - pad && s <= L - 2) v += U(pad + 2 * (L - 1) - s);
+    v *= scale * (scale_b ? scale_b[b] : 1.f);
+    if (g_out) v += cskip_b[b] * g_out[idx];
+    dx[idx] = v;
+  }
+}
+
+inline int grid_for(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+// ================================================================== launchers
+int gn_num_chunks(int HW) {
+  int c = HW / 64;
+  if (c < 1) c = 1;
+  if (c > 256) c = 256;
+  return c;
+}
+
+static RedArgs make_red(Src2 x, int B, int H, int W, int C, int G, double* partial) {
+  RedArgs a{};
+  a.x = x; a.B = B; a.H = H; a.W = W; a.C = C; a.G = G;
+  a.chunks = gn_num_chunks(H * W);
+  a.ppc = (H * W + a.chunks - 1) / a.chunks;
+  a.partial = partial;
+  return a;
+}
+
+void launch_gn_stats(Src2 x, int B, int HW, int C, int G, float eps, double* partial, float* stats, hipStream_t st) {
+  RedArgs a = make_red(x, B, 1, HW, C, G, partial);
+  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(a.chunks, B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(group_finalize_kernel<0>, dim3(G, B), dim3(64), 0, st, (const double*)partial, stats, C, G, a.chunks, HW, eps);
+}
+
+void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float* beta, int B, int H, int W, int C, int G, int mode, int silu,
+                     float* out, float* pooled_raw, hipStream_t st) {
+  const long long total = (long long)B * (mode == 1 ? (H / 2) * (W / 2) : H * W) * (C / 4);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, B, H, W, C, G, mode, silu, out, pooled_raw);
+}
+
+void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G, int mode,
+                   int silu, const float* extra, int extra_mode, float extra_scale, double* partial, float* red, Dst2 dx, hipStream_t st) {
+  RedArgs a = make_red(x, B, H, W, C, G, partial);
+  a.stats = stats; a.gamma = gamma; a.beta = beta; a.da = da; a.mode = mode; a.silu = silu;
+  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(a.chunks, B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(group_finalize_kernel<1>, dim3(G, B), dim3(64), 0, st, (const double*)partial, red, C, G, a.chunks, H * W, 0.f);
+  const long long total = (long long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, da, B, H, W, C, G, mode, silu, extra,
+                     extra_mode, extra_scale, (const float*)red, dx);
+}
+
+void launch_axpy(float* dst, const float* src, float alpha, long long n, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, dst, src, alpha, n / 4, accumulate);
+}
+
+void launch_pool2(const float* src, float* dst, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st) {
+  if (C == 2) {
+    hipLaunchKernelGGL(pool2_c2_kernel, dim3(grid_for((long long)B * (H / 2) * (W / 2))), dim3(256), 0, st, src, dst, B, H, W, scale, accumulate);
+  } else {
+    hipLaunchKernelGGL(pool2_kernel, dim3(grid_for((long long)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, st, src, dst, B, H, W, C, scale, accumulate);
+  }
+}
+
+void launch_up2_acc(const float* src, float* dst, int B, int Hs, int Ws, int C, float scale, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(up2_acc_kernel, dim3(grid_for((long long)B * Hs * Ws * 4 * (C / 2))), dim3(256), 0, st, src, dst, B, Hs, Ws, C, scale, accumulate);
+}
+
+void launch_softmax_rows(float* S, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, S, rows, cols);
+}
+
+void launch_softmax_bwd_rows(const float* P, float* dP, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, P, dP, rows, cols);
+}
+
+void launch_linear(const float* x, const float* W, const float* b, float* y, int B, int K, int N, int silu_in, hipStream_t st) {
+  hipLaunchKernelGGL(linear_kernel, dim3(cdiv((long long)B * N, 4)), dim3(256), 0, st, x, W, b, y, B, K, N, silu_in);
+}
+
+void launch_fourier(const float* cnoise, const float* Wf, float* out, int B, int nf, hipStream_t st) {
+  hipLaunchKernelGGL(fourier_kernel, dim3(cdiv(B * nf, 256)), dim3(256), 0, st, cnoise, Wf, out, B, nf);
+}
+
+void launch_mix2(const float* x, const float* w, const float* b, float* y, long long npix, int transpose, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(mix2_kernel, dim3(grid_for(npix)), dim3(256), 0, st, x, w, b, y, npix, transpose, accumulate);
+}
+
+void launch_conv_c2in(const float* x, const float* w, const float* bias, const float* add, int add_ld, float* y, int ldY, int B, int H, int W,
+                      int Cout, int taps, int accumulate, hipStream_t st) {
+  const long long total = (long long)B * H * W * (Cout / 4);
+  if (taps == 9)
+    hipLaunchKernelGGL(conv_c2in_kernel<9>, dim3(grid_for(total)), dim3(256), 0, st, x, w, bias, add, add_ld, y, ldY, B, H, W, Cout, accumulate);
+  else
+    hipLaunchKernelGGL(conv_c2in_kernel<1>, dim3(grid_for(total)), dim3(256), 0, st, x, w, bias, add, add_ld, y, ldY, B, H, W, Cout, accumulate);
+}
+
+void launch_conv_c2out(const float* x, int ldX, const float* w, const float* bias, const float* up_add, float* y, int B, int H, int W, int Cin,
+                       int taps, int accumulate, hipStream_t st) {
+  const int ppb = 256 / (Cin / 4);
+  long long groups = ((long long)B * H * W + ppb - 1) / ppb;
+  int grid = (int)(groups < 256 * 8 ? groups : 256 * 8);
+  if (taps == 9)
+    hipLaunchKernelGGL(conv_c2out_kernel<9>, dim3(grid), dim3(256), 0, st, x, ldX, w, bias, up_add, y, B, H, W, Cin, accumulate);
+  else
+    hipLaunchKernelGGL(conv_c2out_kernel<1>, dim3(grid), dim3(256), 0, st, x, ldX, w, bias, up_add, y, B, H, W, Cin, accumulate);
+}
+
+void launch_reflect_pad(const float* x, float* xp, int B, int L, int pad, int Lp, float scale, const float* scale_b, hipStream_t st) {
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3(grid_for((long long)B * Lp)), dim3(256), 0, st, x, xp, B, L, pad, Lp, scale, scale_b);
+}
+
+void launch_ola(const float* frames, int ldF, int Tp, int n_fft, int hop, const float* inv_env, float* y, int B, int L, int pad, const float* xin,
+                const float* cskip_b, const float* cout_b, hipStream_t st) {
+  hipLaunchKernelGGL(ola_kernel, dim3(grid_for((long long)B * L)), dim3(256), 0, st, frames, ldF, Tp, n_fft, hop, inv_env, y, B, L, pad, xin, cskip_b, cout_b);
+}
+
+void launch_ola_adj(const float* g, int B, int L, int pad, int Tp, int n_fft, int hop, const float* inv_env, const float* cout_b, float* frames,
+                    int ldF, hipStream_t st) {
+  hipLaunchKernelGGL(ola_adj_kernel, dim3(grid_for((long long)B * Tp * ldF)), dim3(256), 0, st, g, B, L, pad, Tp, n_fft, hop, inv_env, cout_b, frames, ldF);
+}
+
+void launch_unpad_adj(const float* dframes, int ldF, int T, int n_fft, int hop, int B, int L, int pad, float scale, const float* scale_b,
+                      const float* g_out, const float* cskip_b, float* dx, hipStream_t st) {
+  hipLaunchKernelGGL(unpad_adj_kernel, dim3(grid_for((long long)B * L)), dim3(256), 0, st, dframes, ldF, T, n_fft, hop, B, L, pad, scale, scale_b, g_out, cskip_b, dx);
+}
+
+}  // namespace buddy

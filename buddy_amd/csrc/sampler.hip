@@ -1,0 +1,87 @@
+// Sampler-side kernels (gfx950): per-utterance (row) elementwise / reductions and the time-domain RIR operator.
+#include "common.h"
+
+namespace buddy {
+namespace {
+
+__global__ __launch_bounds__(256) void axpby_rows_kernel(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L) {
+  const long long total = (long long)B * L;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / L);
+    float v = a[b] * x[i];
+    if (y) v += c[b] * y[i];
+    out[i] = v;
+  }
+}
+
+// one block per row; double accumulation (the reference's y.std(), torch.norm run in fp32 with pairwise summation --
+// double keeps us within fp32 round-off of either order)
+__global__ __launch_bounds__(256) void row_moments_kernel(const float* x, double* out, int L) {
+  __shared__ double s1[256], s2[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* r = x + (long long)b * L;
+  double a = 0, q = 0;
+  for (int i = tid; i < L; i += 256) { const double v = r[i]; a += v; q += v * v; }
+  s1[tid] = a; s2[tid] = q;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { s1[tid] += s1[tid + off]; s2[tid] += s2[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) { out[b * 2] = s1[0]; out[b * 2 + 1] = s2[0]; }
+}
+
+// Direct-form FIR, 1024 outputs per block, taps staged through LDS in tiles of 1024.
+//   forward: y[n] = sum_m h[m] x[n - m]        adjoint: y[n] = sum_m h[m] x[n + m]
+constexpr int FIR_OUT = 1024, FIR_TAPS = 1024;
+template <bool ADJ>
+__global__ __launch_bounds__(256) void fir_kernel(const float* x, const float* h, float* y, int L, int M) {
+  __shared__ float hs[FIR_TAPS];
+  __shared__ float xs[FIR_OUT + FIR_TAPS];
+  const int b = blockIdx.y, n0 = blockIdx.x * FIR_OUT, tid = threadIdx.x;
+  const float* xr = x + (long long)b * L;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int m0 = 0; m0 < M; m0 += FIR_TAPS) {
+    __syncthreads();
+    for (int i = tid; i < FIR_TAPS; i += 256) hs[i] = (m0 + i < M) ? h[m0 + i] : 0.f;
+    // window of x needed: forward covers indices [n0 - m0 - (TAPS-1), n0 - m0 + OUT), adjoint [n0 + m0, n0 + m0 + OUT + TAPS - 1)
+    const int base = ADJ ? (n0 + m0) : (n0 - m0 - (FIR_TAPS - 1));
+    for (int i = tid; i < FIR_OUT + FIR_TAPS; i += 256) {
+      const int g = base + i;
+      xs[i] = (g >= 0 && g < L) ? xr[g] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int m = 0; m < FIR_TAPS; ++m) {
+      const float hv = hs[m];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int o = tid + 256 * j;
+        const int idx = ADJ ? (o + m) : (o - m + FIR_TAPS - 1);
+        acc[j] += hv * xs[idx];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + tid + 256 * j;
+    if (n < L) y[(long long)b * L + n] = acc[j];
+  }
+}
+
+}  // namespace
+
+void launch_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, hipStream_t st) {
+  long long g = ((long long)B * L + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(axpby_rows_kernel, dim3((int)g), dim3(256), 0, st, x, y, a, c, out, B, L);
+}
+void launch_row_moments(const float* x, double* out, int B, int L, hipStream_t st) {
+  hipLaunchKernelGGL(row_moments_kernel, dim3(B), dim3(256), 0, st, x, out, L);
+}
+void launch_fir(const float* x, const float* h, float* y, int B, int L, int M, int adjoint, hipStream_t st) {
+  dim3 grid(cdiv(L, FIR_OUT), B);
+  if (adjoint) hipLaunchKernelGGL(fir_kernel<true>, grid, dim3(256), 0, st, x, h, y, L, M);
+  else hipLaunchKernelGGL(fir_kernel<false>, grid, dim3(256), 0, st, x, h, y, L, M);
+}
+
+}  // namespace buddy

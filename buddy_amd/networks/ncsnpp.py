@@ -1,0 +1,196 @@
+"""``NCSNppTime`` -- the reference's score-network plug point (``networks.ncsnpp.NCSNppTime``,
+reference ``networks/ncsnpp.py:455-506``) backed by the hand-written gfx950 network in ``libbuddy_hip.so``.
+
+Same surface as the reference class: constructor kwargs = ``conf/network/ncsnpp.yaml`` keys (incl. nested
+``stft:{n_fft,hop_length,center}``), ``nn.Module`` protocol with the reference ``state_dict`` key names
+(``all_modules.N.*``, ``output_layer.*``), ``forward(x:(B,1,L) f32, time_cond:(B,) f32) -> (B,1,L)``,
+differentiable w.r.t. ``x`` (the input-VJP runs in HIP; no weight gradients -- inference only).
+Only the shipped architecture family is supported (biggan resblocks, input_skip/sum, output_skip, fir=False, one
+bottleneck attention); anything else raises ``NotImplementedError`` at construction.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..synth import module_specs
+
+
+class _Bag(nn.Module):
+    """parameter container; gives nested state-dict names without any compute."""
+
+
+def _variance_scaling_uniform(shape, scale, in_axis, out_axis):
+    # default_init: variance_scaling(scale, 'fan_avg', 'uniform') -- reference layers.py:54-91
+    scale = 1e-10 if scale == 0 else scale
+    rf = np.prod(shape) / shape[in_axis] / shape[out_axis]
+    fan_in, fan_out = shape[in_axis] * rf, shape[out_axis] * rf
+    var = scale / ((fan_in + fan_out) / 2)
+    return (torch.rand(*shape) * 2.0 - 1.0) * np.sqrt(3 * var)
+
+
+class _NetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cnoise, scal, net):
+        B, L = x.shape
+        lib = _lib.require_gpu()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        save = 1 if ctx.needs_input_grad[0] else 0
+        cin = cskip = cout = None
+        if scal is not None:
+            cin, cskip, cout = (s.contiguous() for s in scal)
+        _lib.check(lib.buddy_ncsnpp_forward(net._get_handle(), _lib.ptr(x), _lib.ptr(cnoise.contiguous()), _lib.ptr(cin),
+                                            _lib.ptr(cskip), _lib.ptr(cout), _lib.ptr(y), B, L, save, _lib.stream_ptr()))
+        net._fwd_id += 1
+        ctx.net, ctx.fwd_id = net, net._fwd_id
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        net = ctx.net
+        if ctx.fwd_id != net._fwd_id:
+            raise _lib.BuddyHipError("backward through a stale NCSNppTime forward: the handle keeps one tape (call "
+                                     "backward before the next forward)")
+        g = g.contiguous()
+        gx = torch.empty_like(g)
+        _lib.check(_lib.load().buddy_ncsnpp_vjp(net._get_handle(), _lib.ptr(g), _lib.ptr(gx), _lib.stream_ptr()))
+        return gx, None, None, None
+
+
+class NCSNppTime(nn.Module):
+    def __init__(self, stft=None, nonlinearity="swish", nf=128, ch_mult=(1, 2, 2, 2), num_res_blocks=1,
+                 attn_resolutions=(0,), resamp_with_conv=True, time_conditional=True, fir=False,
+                 fir_kernel=(1, 3, 3, 1), skip_rescale=True, resblock_type="biggan", progressive="output_skip",
+                 progressive_input="input_skip", progressive_combine="sum", init_scale=0.0, fourier_scale=16,
+                 image_size=256, embedding_type="fourier", input_channels=2, spatial_channels=1, dropout=0.0,
+                 centered=True, discriminative=False, **kwargs):
+        super().__init__()
+        assert stft is not None, "stft must be provided"          # reference ncsnpp.py:459
+        unsupported = []
+        if nonlinearity != "swish": unsupported.append("nonlinearity")
+        if fir: unsupported.append("fir=True")
+        if not skip_rescale: unsupported.append("skip_rescale=False")
+        if str(resblock_type).lower() != "biggan": unsupported.append("resblock_type")
+        if str(progressive).lower() != "output_skip": unsupported.append("progressive")
+        if str(progressive_input).lower() != "input_skip": unsupported.append("progressive_input")
+        if str(progressive_combine).lower() != "sum": unsupported.append("progressive_combine")
+        if str(embedding_type).lower() != "fourier": unsupported.append("embedding_type")
+        if input_channels != 2 or spatial_channels != 1: unsupported.append("channels")
+        if not time_conditional or discriminative or not centered or dropout not in (0, 0.0):
+            unsupported.append("time_conditional/discriminative/centered/dropout")
+        res = [image_size // (2 ** i) for i in range(len(ch_mult))]
+        if any(r in tuple(attn_resolutions) for r in res): unsupported.append("attn_resolutions")
+        if nf % 32: unsupported.append("nf % 32")
+        if unsupported:
+            raise NotImplementedError("NCSNppTime (MI355X): unsupported options: " + ", ".join(unsupported))
+        get = (lambda k: stft[k]) if isinstance(stft, dict) else (lambda k: getattr(stft, k))
+        self.stft_kwargs = stft
+        self.n_fft, self.hop_length = int(get("n_fft")), int(get("hop_length"))
+        assert bool(get("center")), "center=False not supported"
+        self.nf, self.ch_mult, self.num_res_blocks = int(nf), tuple(int(c) for c in ch_mult), int(num_res_blocks)
+        self._specs = module_specs(self.nf, self.ch_mult, self.num_res_blocks)
+        # parameter containers under the reference names
+        n_mod = 1 + max(int(n.split(".")[1]) for n, *_ in self._specs if n.startswith("all_modules."))
+        self.all_modules = nn.ModuleList([_Bag() for _ in range(n_mod)])
+        self.output_layer = _Bag()
+        for name, shape, kind, _ in self._specs:
+            parts = name.split(".")
+            node = self
+            for p in parts[:-1]:
+                if p.isdigit():
+                    node = node[int(p)]
+                else:
+                    if not hasattr(node, p):
+                        setattr(node, p, _Bag())
+                    node = getattr(node, p)
+            node.register_parameter(parts[-1], nn.Parameter(self._init(name, shape, kind, init_scale, fourier_scale),
+                                                            requires_grad=False))
+        self._handle = None
+        self._fwd_id = 0
+
+    @staticmethod
+    def _init(name, shape, kind, init_scale, fourier_scale):
+        if kind == "fourier":
+            return torch.randn(*shape) * fourier_scale                      # layerspp.py:37
+        if kind in ("b", "beta"):
+            return torch.zeros(*shape)
+        if kind == "gamma":
+            return torch.ones(*shape)
+        leaf = name.split(".")[-2] if name.count(".") >= 2 else ""
+        scaled = leaf in ("Conv_1", "NIN_3") or (len(shape) == 4 and shape[0] == 2 and shape[2] == 3)
+        if name.endswith(".W"):                                             # NIN (in, out): layers.py:551
+            return _variance_scaling_uniform(shape, init_scale if scaled else 0.1, 0, 1)
+        if name.startswith("output_layer"):
+            return _variance_scaling_uniform(shape, 1.0, 1, 0)
+        return _variance_scaling_uniform(shape, init_scale if scaled else 1.0, 1, 0)
+
+    # ---- handle management ---------------------------------------------------------------------------
+    def _flat_params(self):
+        sd = self.state_dict()
+        return np.concatenate([sd[n].detach().float().cpu().numpy().ravel() for n, *_ in self._specs]).astype(np.float32)
+
+    def _drop_handle(self):
+        if getattr(self, "_handle", None) is not None:
+            _lib.load().buddy_ncsnpp_destroy(self._handle)
+        self._handle = None
+
+    def _get_handle(self):
+        if self._handle is None:
+            lib = _lib.require_gpu()
+            blob = np.ascontiguousarray(self._flat_params())
+            cm = (C.c_int * len(self.ch_mult))(*self.ch_mult)
+            h = C.c_void_p()
+            _lib.check(lib.buddy_ncsnpp_create(blob.ctypes.data, blob.size, self.nf, cm, len(self.ch_mult),
+                                               self.num_res_blocks, self.n_fft, self.hop_length, C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._drop_handle()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._drop_handle()
+        return r
+
+    def __del__(self):
+        try:
+            self._drop_handle()
+        except Exception:
+            pass
+
+    def arena_bytes(self, B, L, with_vjp=True):
+        n = C.c_longlong()
+        _lib.check(_lib.require_gpu().buddy_ncsnpp_reserve(self._get_handle(), B, L, int(with_vjp), C.byref(n)))
+        return n.value
+
+    # ---- compute -------------------------------------------------------------------------------------
+    def forward(self, x, time_cond=None):
+        """x: (B,1,L) (reference signature) or (B,L); time_cond: (B,) = c_noise."""
+        squeeze = x.dim() == 3
+        x2 = x[:, 0] if squeeze else x
+        y = _NetFn.apply(x2.float(), time_cond.float().reshape(-1), None, self)
+        return y[:, None] if squeeze else y
+
+    def denoise_fused(self, x, cnoise, cin, cskip, cout):
+        """EDM denoiser with the preconditioning scalars folded into the STFT / overlap-add kernels:
+        cskip[b]*x + cout[b]*net(cin[b]*x, cnoise[b]) (reference diff_params/shared.py:98-120).  x: (B,L); rest (B,)."""
+        return _NetFn.apply(x.float(), cnoise.float(), (cin.float(), cskip.float(), cout.float()), self)
+
+    def tap(self, module_idx):
+        """(B, frames, bins, C) copy of all_modules[module_idx]'s output from the last forward (parity tests)."""
+        p = C.c_void_p()
+        dims = (C.c_int * 4)()
+        _lib.check(_lib.load().buddy_ncsnpp_tap(self._get_handle(), module_idx, C.byref(p), C.byref(dims)))
+        n = int(np.prod(list(dims)))
+        out = torch.empty(tuple(dims), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(out.data_ptr()), p, C.c_size_t(n * 4), C.c_int(3))
+        return out

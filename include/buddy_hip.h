@@ -1,0 +1,81 @@
+/* C-ABI of libbuddy_hip.so -- the MI355X (gfx950) drop-in boundary for the reverse-diffusion dereverberation
+ * sampler path of sp-uhh/buddy.
+ *
+ * The reference has no FFI boundary on this path: its plug points are Python classes resolved from Hydra
+ * `_target_` strings.  This library sits *under* those classes: the Python side
+ * (buddy_amd/) keeps the reference's class/constructor/method surface and calls these entry points with raw
+ * device pointers (plain pointers and sizes, no torch types).  Each entry point names the reference interface it
+ * replaces.  All functions return 0 on success, non-zero on error (text via buddy_last_error()); `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  All tensors are fp32, device-resident, contiguous.
+ */
+#ifndef BUDDY_HIP_H
+#define BUDDY_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* buddy_last_error(void);
+int buddy_version(void);
+
+/* ---- score network: replaces networks/ncsnpp.py NCSNppTime (ctor :458-464, forward :498-506) and the torch.autograd
+ * backward through it that EulerHeunSamplerDPS.get_likelihood_score needs (testing/EulerHeunSamplerDPS.py:61-69). ---- */
+
+/* number of fp32 parameters for an architecture = size of the flat blob `buddy_ncsnpp_create` expects: every tensor of
+ * NCSNppTime.state_dict() (names all_modules.N.*, output_layer.*; reference networks/ncsnpp.py:157-274) concatenated in
+ * module-construction order (GroupNorm_0.{weight,bias}, Conv_0.{weight,bias}, Dense_0.{weight,bias}, GroupNorm_1.*,
+ * Conv_1.*, [Conv_2.*]) -- buddy_amd/synth.py:module_specs is the Python mirror of that order. */
+int buddy_ncsnpp_param_count(int nf, const int* ch_mult, int n_levels, int num_res_blocks, long long* count);
+
+/* build a network handle from a HOST blob (weights are repacked for the MFMA kernels and uploaded once).
+ * n_fft / hop: conf/network/ncsnpp.yaml:2-5 (510 / 128). */
+int buddy_ncsnpp_create(const float* host_params, long long n_params, int nf, const int* ch_mult, int n_levels,
+                        int num_res_blocks, int n_fft, int hop, void** handle);
+int buddy_ncsnpp_destroy(void* handle);
+
+/* size the activation arena for batch B, length L samples (done implicitly by forward; exposed to report bytes). */
+int buddy_ncsnpp_reserve(void* handle, int B, int L, int with_vjp, long long* bytes);
+
+/* y = cskip[b]*x + cout[b]*net(cin[b]*x, cnoise[b])  if cin/cskip/cout are non-NULL (EDM denoiser,
+ * reference diff_params/shared.py:98-120), else y = net(x, cnoise) (NCSNppTime.forward).
+ * x, y: [B][L]; cnoise, cin, cskip, cout: [B].  save_for_vjp != 0 keeps activations for buddy_ncsnpp_vjp. */
+int buddy_ncsnpp_forward(void* handle, const float* x, const float* cnoise, const float* cin, const float* cskip,
+                         const float* cout, float* y, int B, int L, int save_for_vjp, void* stream);
+
+/* grad_x = (d y / d x)^T cot for the last forward issued with save_for_vjp (includes the EDM scalars if they were given). */
+int buddy_ncsnpp_vjp(void* handle, const float* cot, float* grad_x, void* stream);
+
+/* debugging / per-module parity: device pointer + NHWC dims ([B][frames][bins][C]) of the output of all_modules[idx]. */
+int buddy_ncsnpp_tap(void* handle, int module_idx, const float** ptr, int dims[4]);
+
+/* ---- unit-level kernels (the pieces the network is made of; used by the parity tests) ---- */
+/* C[b] = alpha * op(A[b]) op(Bt[b])^T (+ bias_n), row-major; transX = operand stored k-major. replaces torch.einsum/bmm
+ * in AttnBlockpp (networks/ncsnpp_utils/layerspp.py:82-86) and NIN (layers.py:548-557). */
+int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, int transB, float* C, int ldC, int M, int N,
+               int K, float alpha, const float* bias_n, int accumulate, int batch, long long strideA, long long strideB,
+               long long strideC, void* stream);
+/* NHWC 3x3 stride-1 pad-1 conv, packed weights wt[Cout][9*Cin] (tap-major, channel-minor); replaces ddpm_conv3x3
+ * (networks/ncsnpp_utils/layers.py:119-126). */
+int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
+                  void* stream);
+/* GroupNorm(G, C, eps=1e-6) [+SiLU] [+2x down(mode 1)/up(mode 2)] forward; replaces nn.GroupNorm + nn.SiLU +
+ * naive_{up,down}sample_2d (layerspp.py:243-258). stats: [B][G][2] out; scratch: >= B*256*C*16 bytes. */
+int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B,
+                        int H, int W, int C, int G, int mode, int silu, void* stream);
+/* input-gradient of the above given dy (at the resampled resolution). red: [B][G][2] scratch. */
+int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* beta, const float* stats, const float* dy, float* dx,
+                            void* scratch, float* red, int B, int H, int W, int C, int G, int mode, int silu, void* stream);
+
+/* ---- sampler elementwise / reductions (replace the tensor expressions of testing/EulerHeunSampler.py:41-72,
+ * testing/EulerHeunSamplerDPS.py:61-69,115-157, diff_params/edm.py:83-96), per-utterance (row) semantics ---- */
+/* out[b][i] = a[b]*x[b][i] + c[b]*y[b][i] (y may be NULL) */
+int buddy_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, void* stream);
+/* per-row sum and sum of squares in double precision: out[b] = {sum, sumsq} */
+int buddy_row_moments(const float* x, double* out, int B, int L, void* stream);
+/* time-domain FIR (direct form) y[b][n] = sum_m h[m] x[b][n-m], n < L: replaces utils/reverb_utils.py:25-61 fast_apply_RIR
+ * (same linear convolution, no FFT); adjoint != 0 computes the correlation (its transpose) for the VJP. */
+int buddy_fir(const float* x, const float* h, float* y, int B, int L, int M, int adjoint, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,151 @@
+"""GPU parity tests for the unit kernels behind the C-ABI (libbuddy_hip.so) against plain torch fp32 references
+of the same op.  Tolerances: fp32 MFMA accumulates exactly like an fmaf chain, so differences to torch are pure
+summation-order round-off: rel-to-absmax 2e-5 for K <= 4608 contractions, 1e-5 for normalisation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from buddy_amd import _lib
+    return _lib.require_gpu()
+
+
+def P(t):
+    return None if t is None else t.data_ptr()
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K,batch", [(256, 128, 64, 1), (200, 72, 132, 3), (2048, 2048, 256, 2)])
+def test_gemm(lib, tA, tB, M, N, K, batch):
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + tA * 2 + tB)
+    A = torch.randn(batch, M, K, generator=g).cuda()
+    Bm = torch.randn(batch, N, K, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    As = A.transpose(1, 2).contiguous() if tA else A
+    Bs = Bm.transpose(1, 2).contiguous() if tB else Bm
+    Cc = torch.full((batch, M, N), 7.0, device="cuda")
+    ref = 0.5 * torch.einsum("bmk,bnk->bmn", A.double(), Bm.double()).float() + bias
+    _lib.check(lib.buddy_gemm(P(As), M if tA else K, tA, P(Bs), N if tB else K, tB, P(Cc), N, M, N, K, 0.5, P(bias), 0, batch,
+                              M * K, N * K, M * N, S()))
+    torch.cuda.synchronize()
+    assert rel(Cc, ref) < 2e-5
+    # accumulate
+    _lib.check(lib.buddy_gemm(P(As), M if tA else K, tA, P(Bs), N if tB else K, tB, P(Cc), N, M, N, K, 0.5, None, 1, batch,
+                              M * K, N * K, M * N, S()))
+    torch.cuda.synchronize()
+    assert rel(Cc, 2 * ref - bias) < 2e-5
+
+
+def test_gemm_asymmetric_layout(lib):
+    """A = I against an asymmetric B catches a transposed C write (guide rule: always A=I with asymmetric B)."""
+    from buddy_amd import _lib
+    n = 128
+    A = torch.eye(n, device="cuda")
+    Bm = (torch.arange(n * n, device="cuda", dtype=torch.float32).reshape(n, n) % 97) + 0.25 * torch.arange(n, device="cuda")[:, None]
+    Cc = torch.empty(n, n, device="cuda")
+    _lib.check(lib.buddy_gemm(P(A), n, 0, P(Bm), n, 0, P(Cc), n, n, n, n, 1.0, None, 0, 1, 0, 0, 0, S()))
+    torch.cuda.synchronize()
+    assert torch.equal(Cc, Bm.t().contiguous())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 16, 24, 32, 64), (2, 33, 20, 96, 32), (1, 64, 128, 256, 128), (1, 8, 8, 384, 256)])
+def test_conv3x3(lib, B, H, W, Cin, Cout):
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin)).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()        # [o][(ky*3+kx)*Cin + i]; here H is "our H"
+    y = torch.empty(B, H, W, Cout, device="cuda")
+    _lib.check(lib.buddy_conv3x3(P(x_nhwc), P(wt), P(b), P(y), B, H, W, Cin, Cout, S()))
+    torch.cuda.synchronize()
+    assert rel(y.permute(0, 3, 1, 2), ref) < 2e-5
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("C,silu", [(32, 1), (96, 1), (128, 0), (384, 1), (512, 1)])
+def test_groupnorm_act_fwd_bwd(lib, mode, C, silu):
+    from buddy_amd import _lib
+    B, H, W = 2, 16, 24
+    G = min(C // 4, 32)
+    g = torch.Generator(device="cpu").manual_seed(C + mode)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).cuda().double().requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.2 * torch.randn(C, generator=g)).cuda()
+    z = F.group_norm(x, G, gamma.double(), beta.double(), eps=1e-6)
+    if silu:
+        z = F.silu(z)
+    if mode == 1:
+        z = z.reshape(B, C, H // 2, 2, W // 2, 2).mean(dim=(3, 5))
+    elif mode == 2:
+        z = z.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    dy = torch.randn(z.shape, generator=g).cuda()
+    gx_ref, = torch.autograd.grad(z, x, dy.double())
+    x_nhwc = x.detach().float().permute(0, 2, 3, 1).contiguous()
+    Ho, Wo = z.shape[2], z.shape[3]
+    y = torch.empty(B, Ho, Wo, C, device="cuda")
+    stats = torch.empty(B, G, 2, device="cuda")
+    red = torch.empty(B, G, 2, device="cuda")
+    scratch = torch.empty(B * 256 * C * 4, device="cuda")
+    _lib.check(lib.buddy_groupnorm_act(P(x_nhwc), P(gamma), P(beta), P(y), P(stats), P(scratch), B, H, W, C, G, mode, silu, S()))
+    torch.cuda.synchronize()
+    assert rel(y.permute(0, 3, 1, 2), z.detach().float()) < 1e-5
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous()
+    dx = torch.empty(B, H, W, C, device="cuda")
+    _lib.check(lib.buddy_groupnorm_act_bwd(P(x_nhwc), P(gamma), P(beta), P(stats), P(dy_nhwc), P(dx), P(scratch), P(red), B, H, W, C, G,
+                                           mode, silu, S()))
+    torch.cuda.synchronize()
+    assert rel(dx.permute(0, 3, 1, 2), gx_ref.float()) < 2e-5
+
+
+@pytest.mark.parametrize("L,M", [(4096, 100), (16000, 3000), (5000, 1024)])
+def test_fir_and_adjoint(lib, L, M):
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(L + M)
+    x = torch.randn(2, L, generator=g).cuda()
+    h = (torch.randn(M, generator=g) * torch.exp(-torch.arange(M) / (M / 5))).cuda()
+    y = torch.empty_like(x)
+    _lib.check(lib.buddy_fir(P(x), P(h), P(y), 2, L, M, 0, S()))
+    ref = F.conv1d(F.pad(x.double()[:, None], (M - 1, 0)), h.double().flip(0)[None, None])[:, 0].float()
+    torch.cuda.synchronize()
+    assert rel(y, ref) < 1e-5
+    gy = torch.randn(2, L, generator=g).cuda()
+    gx = torch.empty_like(x)
+    _lib.check(lib.buddy_fir(P(gy), P(h), P(gx), 2, L, M, 1, S()))
+    torch.cuda.synchronize()
+    # <y, gy> == <x, gx>
+    lhs, rhs = float((ref.double() * gy.double()).sum()), float((x.double() * gx.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
+def test_row_ops(lib):
+    from buddy_amd import _lib
+    x = torch.randn(3, 5001, device="cuda")
+    y = torch.randn(3, 5001, device="cuda")
+    a = torch.tensor([0.5, -1.0, 2.0], device="cuda")
+    c = torch.tensor([1.5, 0.25, -3.0], device="cuda")
+    out = torch.empty_like(x)
+    _lib.check(lib.buddy_axpby_rows(P(x), P(y), P(a), P(c), P(out), 3, 5001, S()))
+    mom = torch.empty(3, 2, device="cuda", dtype=torch.float64)
+    _lib.check(lib.buddy_row_moments(P(x), P(mom), 3, 5001, S()))
+    torch.cuda.synchronize()
+    assert rel(out, a[:, None] * x + c[:, None] * y) < 1e-6
+    assert rel(mom[:, 0], x.double().sum(1)) < 1e-9 and rel(mom[:, 1], (x.double() ** 2).sum(1)) < 1e-9
