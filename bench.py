@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X reverse-diffusion dereverberation sampler (BASELINE.json metric).
+
+A "step" = ONE diffusion step of the blind Euler-Heun DPS sampler (order 1: stochastic churn, one score-network
+forward + input-VJP through the hand-written HIP NCSN++, 10 operator Adam updates, likelihood score, Euler update;
+reference testing/EulerHeunSamplerDPS.py:115-157) over one batch of B=8 synthetic 4 s @ 16 kHz utterances per GPU --
+BASELINE.json configs[1] ("Batch=8 4 s@16 kHz synthetic STFT, 50-step EulerHeun blind sampler, NCSN++ HIP on 1 MI355X").
+value = utterance-diffusion-steps per second over ALL ranks = n_gpus * B * K / max-over-ranks(elapsed).
+
+Launch: `python bench.py` (1 GPU) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(one process per GPU; utterances sharded across ranks, no collective inside the loop, ONE all_gather of the outputs
+at the end of the run, outside the timed region and reported as gather_ms).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+U_FWD = 1.2501e12   # algorithmic FLOPs of one score-network forward for a 4 s utterance (measured with
+                    # torch.utils.flop_counter on the reference); forward + input-VJP = 2 * U_FWD
+PEAK_FP32_MFMA = 157.3   # TFLOP/s, MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+
+
+def build_stack(args_ns, device, B, rank):
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
+    from buddy_amd.testing.tester import Tester
+    ov = [f"tester.sampling_params.T={args_ns.T}", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled"]
+    args = compose(tester="blind_dereverberation_BUDDy", overrides=ov)
+    net = instantiate(args.network)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(0, args.network.nf).items()})
+    net = net.to(device).eval()
+    edm = instantiate(args.diff_params)
+    tester = Tester(args, net, edm, test_set=None, device=device, in_training=True)
+    L = args_ns.length
+    items = [(synth_clean(rank * B + u, L), synth_rir(rank * B + u, 8000), f"utt{rank * B + u}.wav") for u in range(B)]
+    torch.manual_seed(1234 + rank)
+    seg, y, op, _ = tester.prepare_batch(items, blind=True)
+    return args, net, edm, tester, seg, y, op
+
+
+class StepRunner:
+    """Drives the sampler one diffusion step at a time (what predict() does in its loop)."""
+
+    def __init__(self, tester, y, op, device):
+        s = tester.sampler
+        from buddy_amd.utils.losses import get_loss
+        ps = s.args.tester.posterior_sampling
+        s.operator, s.y = op, y
+        s.rec_loss = get_loss(ps.rec_loss, operator=op)
+        s.rec_loss_params = get_loss(ps.rec_loss_params, operator=op)
+        s.optimizer_operator = torch.optim.Adam(op.params + op.params_phases, lr=ps.blind_hp.lr_op, weight_decay=ps.blind_hp.weight_decay,
+                                                betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
+        s.RIR_noise_regularization_loss = get_loss(ps.RIR_noise_regularization.loss, operator=op)
+        self.s = s
+        self.t = s.create_schedule().to(device)
+        self.gamma = s.get_gamma(self.t).to(device)
+        self.x = s.initialize_x(tuple(y.shape), device, self.t)
+        self.i = 0
+        self.x_den = None
+
+    def step(self):
+        s = self.s
+        if self.i >= s.T - 1:           # stay inside the schedule (the last step has t_{i+1} = 0): restart the trajectory
+            self.i = 0
+        self.x, self.x_den = s.step(self.x, self.t[self.i], self.t[self.i + 1], self.gamma[self.i], blind=True)
+        self.i += 1
+
+
+def cpu_baseline(length, n_threads):
+    """The CPU oracle (oracle/, reference-faithful restatement, torch fp32) on the host cores: ONE blind DPS step
+    (order 1, 10 operator updates) for ONE 4 s utterance -- the same unit of work as the GPU metric."""
+    from buddy_amd.config import compose
+    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
+    from oracle import ncsnpp_ref, operators_ref as O, sampler_ref as S
+    torch.set_num_threads(n_threads)
+    args = compose(tester="blind_dereverberation_BUDDy", overrides=["tester.sampling_params.T=50",
+                                                                     "tester.posterior_sampling.warm_initialization.mode=reverb_scaled"])
+    P = ncsnpp_ref.to_torch(synth_state_dict(0, 128))
+    net = lambda x, cn: ncsnpp_ref.ncsnpp_time(P, x, cn, 510, 128)
+    ns = S.NoiseStream(1)
+    smp = S.EulerHeunDPSRef(net, S.EDMRef(args.diff_params.sde_hp), args, ns)
+    op_hp = args.tester.informed_dereverberation.op_hp
+    clean, rir = torch.from_numpy(synth_clean(0, length)), torch.from_numpy(synth_rir(0, 8000))
+    op_ref = O.RIROperatorRef(op_hp)
+    op_ref.update_params(rir)
+    y = op_ref.degradation(clean[None])
+    op = O.BlindSubbandFilteringRef(op_hp, 16000, ns)
+    op.update_H(use_noise=True, noise=ns)
+    hp = args.tester.posterior_sampling.blind_hp
+    smp.operator, smp.y = op, y
+    smp.rec_loss = O.get_loss_ref(args.tester.posterior_sampling.rec_loss, op)
+    smp.rec_loss_params = O.get_loss_ref(args.tester.posterior_sampling.rec_loss_params, op)
+    smp.optim = torch.optim.Adam(op.params + op.params_phases, lr=hp.lr_op, weight_decay=hp.weight_decay, betas=(hp.beta1, hp.beta2))
+    smp.rir_reg_loss = O.get_loss_ref(args.tester.posterior_sampling.RIR_noise_regularization.loss, op)
+    t = S.create_schedule(smp.sde_hp, smp.T)
+    gamma = S.get_gamma(t, smp.sp)
+    x = smp.initialize_x(y.shape, t)
+    n_steps = 4
+    t0 = time.time()
+    for i in range(n_steps):
+        x, _ = smp.step(x, t[i], t[i + 1], gamma[i], True)
+    dt = time.time() - t0
+    return {"value": n_steps / dt, "unit": "utterance-steps/s", "cores": n_threads, "kind": "port",
+            "sample": f"{n_steps} blind DPS steps (order 1, 10 operator updates each) of ONE 4 s utterance, oracle/ torch fp32 on "
+                      f"{n_threads} host threads ({dt:.1f} s)"}
+
+
+def run_cpu_baseline(length):
+    """CPU leg in a child process (no GPU context, bounded by a hard timeout so the bench always finishes in minutes)."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 32)     # oneDNN/OpenMP stop scaling (and can crawl) far beyond this on big hosts
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(threads), "--length", str(length)],
+                             capture_output=True, text=True, timeout=240, env=env)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # report honestly instead of hanging the bench
+        return {"value": None, "unit": "utterance-steps/s", "cores": threads, "kind": "port", "sample": f"CPU leg failed/timed out: {type(e).__name__}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
+    ap.add_argument("--length", type=int, default=64000)
+    ap.add_argument("--T", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="THREADS", help="internal: run only the CPU leg and print its JSON")
+    a = ap.parse_args()
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(a.length, a.cpu_baseline_only)))
+        return
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the sampler path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    from buddy_amd import _lib
+    lib = _lib.require_gpu()
+    B = a.batch
+    log(f"building stack: B={B}/GPU, L={a.length}, world={world}")
+    args, net, edm, tester, seg, y, op = build_stack(a, device, B, rank)
+    run = StepRunner(tester, y, op, device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("stack ready; warmup")
+    for _ in range(a.warmup):
+        run.step()
+        log("warmup step done")
+    barrier()
+    log("timed region")
+    lib.buddy_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.buddy_prof_enable(0)
+    log(f"timed region done: {elapsed:.3f} s")
+    ms = (C.c_double * 2)(); fl = (C.c_double * 2)(); ln = (C.c_longlong * 2)()
+    _lib.check(lib.buddy_prof_collect(ms, fl, ln))
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    # end-of-run gather of the (B_local, L) outputs: the only collective on this path (RCCL over xGMI)
+    gather_ms = 0.0
+    out = run.x_den.contiguous()
+    if dist is not None:
+        torch.cuda.synchronize(); tg = time.perf_counter()
+        bufs = [torch.empty_like(out) for _ in range(world)]
+        dist.all_gather(bufs, out)
+        torch.cuda.synchronize(); gather_ms = (time.perf_counter() - tg) * 1e3
+        assert torch.isfinite(torch.stack(bufs)).all()
+    assert torch.isfinite(out).all(), "sampler diverged"
+
+    if rank == 0:
+        n_utt_steps = world * B * a.steps
+        conv_tf = fl[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+        res = {
+            "metric": "diffusion steps/sec (4 s@16 kHz utterance, blind Euler-Heun DPS, order 1, 10 operator updates/step)",
+            "value": n_utt_steps / elapsed, "unit": "utterance-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seeded clean/RIR/weights; random-init NCSN++ 27.7 M params)",
+            "config": {"workload": f"blind DPS sampler step, B={B} utterances/GPU x {a.length} samples (4 s@16 kHz), T={a.T}-step schedule, "
+                                   f"NCSN++ nf=128 STFT 510/128 (BASELINE.json configs[1])",
+                       "batch_per_gpu": B, "length": a.length, "T": a.T, "order": 1, "op_updates_per_step": 10,
+                       "parallelism": f"utterance-sharded x{world}"},
+            "score_evals_per_s": n_utt_steps / elapsed,   # order 1: one forward+VJP evaluation per utterance-step
+            "network_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
+            "gather_ms": gather_ms,
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<9,false,false> (3x3 conv, implicit GEMM, fp32 MFMA 32x32x2)",
+                         "achieved": conv_tf, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": conv_tf / PEAK_FP32_MFMA,
+                         "traffic": None, "launches": int(ln[0]), "avg_launch_ms": ms[0] / max(1, ln[0]),
+                         "kernel_time_share_of_step": ms[0] * 1e-3 / elapsed,
+                         "other_matrix_kernels": {"tflops": fl[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0, "ms": ms[1], "launches": int(ln[1])}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            log("cpu baseline (oracle on host cores)")
+            res["cpu_baseline"] = run_cpu_baseline(a.length)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

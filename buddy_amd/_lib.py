@@ -30,6 +30,9 @@ _SIGS = {
     "buddy_ncsnpp_forward": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_ncsnpp_vjp": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_void_p]),
     "buddy_ncsnpp_tap": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int * 4)]),
+    "buddy_prof_enable": (C.c_int, [C.c_int]),
+    "buddy_prof_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "buddy_copy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "buddy_gemm": (C.c_int, [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                              _f32p, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_void_p]),
     "buddy_conv3x3": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -39,7 +42,7 @@ _SIGS = {
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_axpby_rows": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_void_p]),
     "buddy_row_moments": (C.c_int, [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "buddy_fir": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_fir": (C.c_int, [_f32p, _f32p, C.c_longlong, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 EXPORTED = sorted(_SIGS)
 
@@ -51,6 +54,8 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise BuddyHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(buddy_amd/csrc/build.sh); there is no CPU fallback")
+        import torch  # noqa: F401  -- FIRST: torch ships its own libamdhip64 (same SONAME); loading ours before it would put two
+        #                       HIP runtimes in the process ("no ROCm-capable device is detected" from the second one)
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)

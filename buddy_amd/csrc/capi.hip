@@ -10,7 +10,7 @@ using namespace buddy;
 namespace buddy {
 void launch_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, hipStream_t st);
 void launch_row_moments(const float* x, double* out, int B, int L, hipStream_t st);
-void launch_fir(const float* x, const float* h, float* y, int B, int L, int M, int adjoint, hipStream_t st);
+void launch_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, hipStream_t st);
 }
 
 static int finish() {
@@ -71,6 +71,20 @@ int buddy_ncsnpp_tap(void* handle, int module_idx, const float** ptr, int dims[4
   return net_get_tap((Net*)handle, module_idx, ptr, dims);
 }
 
+int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream) {
+  if (!dst || !src || bytes < 0) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  hipError_t e = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error(std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); return BUDDY_ERR_HIP; }
+  return BUDDY_OK;
+}
+
+int buddy_prof_enable(int on) { igemm_prof_enable(on); return BUDDY_OK; }
+int buddy_prof_collect(double* ms, double* flops, long long* launches) {
+  if (!ms || !flops || !launches) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  if (igemm_prof_collect(ms, flops, launches)) { set_error("event timing failed"); return BUDDY_ERR_HIP; }
+  return BUDDY_OK;
+}
+
 int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, int transB, float* C, int ldC, int M, int N, int K, float alpha,
                const float* bias_n, int accumulate, int batch, long long strideA, long long strideB, long long strideC, void* stream) {
   if (!A || !Bt || !C || K % 4 || (transA && M % 4) || (transB && N % 4)) { set_error("bad gemm arguments (K, and M/N of k-major operands, must be multiples of 4)"); return BUDDY_ERR_ARG; }
@@ -120,9 +134,9 @@ int buddy_row_moments(const float* x, double* out, int B, int L, void* stream) {
   return finish();
 }
 
-int buddy_fir(const float* x, const float* h, float* y, int B, int L, int M, int adjoint, void* stream) {
+int buddy_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, void* stream) {
   if (!x || !h || !y || M < 1) { set_error("bad fir arguments"); return BUDDY_ERR_ARG; }
-  launch_fir(x, h, y, B, L, M, adjoint, (hipStream_t)stream);
+  launch_fir(x, h, h_stride, y, B, L, M, adjoint, (hipStream_t)stream);
   return finish();
 }
 

@@ -31,6 +31,8 @@ struct IgemmParams {
   float alpha, out_scale; int accumulate;
 };
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st);
+void igemm_prof_enable(int on);
+int igemm_prof_collect(double ms[2], double flops[2], long long launches[2]);
 
 // ---- small-channel direct convs -----------------------------------------------------------------------
 // Cin == 2 -> Cout (first conv, Combine 1x1, dgrad of the 2-channel pyramid heads)

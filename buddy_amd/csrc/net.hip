@@ -557,7 +557,18 @@ static void run_forward(Net* N, const float* x, const float* cnoise, const float
   N->B = B; N->L = L; N->T = T; N->Tp = Tp; N->Lp = Lp;
   N->pool.clear(); N->tape.clear(); N->taps.clear();
   N->arena.off = 0;
-  N->k_cin = cin_b; N->k_cskip = cskip_b; N->k_cout = cout_b;
+  // the EDM scalars are needed again by the VJP: keep private copies (the caller's buffers may be gone by then)
+  N->k_cin = N->k_cskip = N->k_cout = nullptr;
+  if (cin_b) {
+    float* sc = N->tmp(3 * (long long)B);
+    if (!N->dry()) {
+      (void)hipMemcpyAsync(sc, cin_b, (size_t)B * 4, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(sc + B, cskip_b, (size_t)B * 4, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(sc + 2 * B, cout_b, (size_t)B * 4, hipMemcpyDeviceToDevice, st);
+    }
+    N->k_cin = sc; N->k_cskip = sc + B; N->k_cout = sc + 2 * B;
+    cin_b = N->k_cin; cskip_b = N->k_cskip; cout_b = N->k_cout;
+  }
   // reduction scratch: chunks <= 256, C <= 1024
   N->partial = (double*)N->arena.alloc((size_t)B * 256 * 1024 * 2 * sizeof(double));
   N->red = N->tmp((long long)B * 32 * 2);

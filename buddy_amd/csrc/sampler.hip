@@ -35,11 +35,12 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* x, double
 //   forward: y[n] = sum_m h[m] x[n - m]        adjoint: y[n] = sum_m h[m] x[n + m]
 constexpr int FIR_OUT = 1024, FIR_TAPS = 1024;
 template <bool ADJ>
-__global__ __launch_bounds__(256) void fir_kernel(const float* x, const float* h, float* y, int L, int M) {
+__global__ __launch_bounds__(256) void fir_kernel(const float* x, const float* hbase, long long h_stride, float* y, int L, int M) {
   __shared__ float hs[FIR_TAPS];
   __shared__ float xs[FIR_OUT + FIR_TAPS];
   const int b = blockIdx.y, n0 = blockIdx.x * FIR_OUT, tid = threadIdx.x;
   const float* xr = x + (long long)b * L;
+  const float* h = hbase + (long long)b * h_stride;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int m0 = 0; m0 < M; m0 += FIR_TAPS) {
     __syncthreads();
@@ -78,10 +79,10 @@ void launch_axpby_rows(const float* x, const float* y, const float* a, const flo
 void launch_row_moments(const float* x, double* out, int B, int L, hipStream_t st) {
   hipLaunchKernelGGL(row_moments_kernel, dim3(B), dim3(256), 0, st, x, out, L);
 }
-void launch_fir(const float* x, const float* h, float* y, int B, int L, int M, int adjoint, hipStream_t st) {
+void launch_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, hipStream_t st) {
   dim3 grid(cdiv(L, FIR_OUT), B);
-  if (adjoint) hipLaunchKernelGGL(fir_kernel<true>, grid, dim3(256), 0, st, x, h, y, L, M);
-  else hipLaunchKernelGGL(fir_kernel<false>, grid, dim3(256), 0, st, x, h, y, L, M);
+  if (adjoint) hipLaunchKernelGGL(fir_kernel<true>, grid, dim3(256), 0, st, x, h, h_stride, y, L, M);
+  else hipLaunchKernelGGL(fir_kernel<false>, grid, dim3(256), 0, st, x, h, h_stride, y, L, M);
 }
 
 }  // namespace buddy

@@ -1,0 +1,1 @@
+from .edm import EDM  # noqa: F401

@@ -191,6 +191,6 @@ class NCSNppTime(nn.Module):
         _lib.check(_lib.load().buddy_ncsnpp_tap(self._get_handle(), module_idx, C.byref(p), C.byref(dims)))
         n = int(np.prod(list(dims)))
         out = torch.empty(tuple(dims), dtype=torch.float32, device="cuda")
+        _lib.check(_lib.load().buddy_copy_d2d(out.data_ptr(), p, n * 4, _lib.stream_ptr()))
         torch.cuda.synchronize()
-        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(out.data_ptr()), p, C.c_size_t(n * 4), C.c_int(3))
         return out

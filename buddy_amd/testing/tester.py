@@ -1,0 +1,179 @@
+"""Test harness -- same surface as reference ``testing/tester.py:21-236`` (``Tester(args, network, diff_params, test_set,
+device, in_training)``, ``load_checkpoint``, ``load_latest_checkpoint``, ``do_test``), plus ``batch_size`` /
+rank sharding for utterance-batch data parallelism (utterance u -> rank u mod world; one gather at the end)."""
+from __future__ import annotations
+
+import copy
+import os
+import re
+from datetime import date
+from glob import glob
+
+import numpy as np
+import torch
+from scipy.io import wavfile
+
+from ..instantiate import instantiate
+from .operators.reverb import RIROperator
+from .operators.subband_filtering import BlindSubbandFiltering
+
+
+def write_audio_file(x, sr, string, path="tmp"):
+    """float32 wav writer (reference utils/log.py write_audio_file: <path>/<string>.wav)."""
+    os.makedirs(path, exist_ok=True)
+    p = os.path.join(path, string + ".wav")
+    a = torch.as_tensor(x).detach().flatten().float().cpu().numpy()
+    wavfile.write(p, sr, a.astype(np.float32))
+    return p
+
+
+class Tester:
+    def __init__(self, args, network, diff_params, test_set=None, device=None, in_training=False, batch_size=1, rank=0, world_size=1):
+        self.args = args
+        self.network = network
+        self.diff_params = copy.copy(diff_params)
+        self.device = device
+        self.test_set = test_set
+        self.in_training = in_training
+        self.batch_size, self.rank, self.world_size = batch_size, rank, world_size
+        self.sampler = instantiate(args.tester.sampler, self.network, self.diff_params, self.args)
+        self.paths = {}
+        self.results = []
+
+    # ---- checkpoints (reference :34-98): the EMA weights are what gets loaded ------------------------------------
+    def load_checkpoint(self, path):
+        state_dict = torch.load(path, map_location="cpu", weights_only=False)
+        self.it = state_dict.get("it", 0) if isinstance(state_dict, dict) else 0
+        for key in ("ema", "network", "model"):
+            if isinstance(state_dict, dict) and key in state_dict:
+                try:
+                    self.network.load_state_dict(state_dict[key])
+                    return True
+                except Exception as e:  # try next key, like the reference's fallback chain (training_utils.py:6-178)
+                    print(f"load_checkpoint: key '{key}' failed: {e}")
+        self.network.load_state_dict(state_dict)
+        return True
+
+    def load_latest_checkpoint(self):
+        try:
+            name = f"{self.args.model_dir}/{self.args.exp.exp_name}-*.pt"
+            rx = re.compile(f"{self.args.exp.exp_name}-(\\d*)\\.pt")
+            ids = [int(rx.search(w).groups()[0]) for w in glob(name)]
+            cid = max(ids)
+            return self.load_checkpoint(f"{self.args.model_dir}/{self.args.exp.exp_name}-{cid}.pt")
+        except (FileNotFoundError, ValueError):
+            raise ValueError("No checkpoint found")
+
+    # ---- unconditional ---------------------------------------------------------------------------------------------
+    def sample_unconditional(self, mode):
+        unc = self.args.tester.unconditional
+        audio_len = self.args.exp.audio_len if "audio_len" not in unc.keys() else unc.audio_len
+        preds = self.sampler.predict_unconditional([unc.num_samples, audio_len], self.device)
+        if not self.in_training:
+            for i in range(len(preds)):
+                write_audio_file(preds[i], self.args.exp.sample_rate, f"unconditional_{i}", path=self.paths["unconditional"])
+        return preds
+
+    # ---- dereverberation (reference :123-163) ----------------------------------------------------------------------
+    def prepare_batch(self, items, blind, noise=None):
+        """clean/RIR pairs -> (seg, y, operator) for one batch of equal-length utterances."""
+        sf = self.args.tester.posterior_sampling.warm_initialization.scaling_factor
+        op_hp = self.args.tester.informed_dereverberation.op_hp
+        segs, rirs = [], []
+        for original, rir, _ in items:
+            seg = torch.from_numpy(np.asarray(original)).float().to(self.device)
+            segs.append(sf * seg / seg.std())       # normalised with the warm-init scaling factor (reference :135, appendix B.13)
+            rirs.append(torch.as_tensor(np.asarray(rir), dtype=torch.float32))
+        seg = torch.stack(segs)
+        with torch.no_grad():
+            operator_ref = RIROperator(op_hp, time_kernel_size=max(r.shape[-1] for r in rirs), sample_rate=self.args.exp.sample_rate, device=self.device)
+            operator_ref.update_params(rirs if len(rirs) > 1 else rirs[0])
+            y = operator_ref.degradation(seg)
+            operator = operator_ref
+            if blind:
+                assert self.args.tester.blind_dereverberation.operator == "subband_filtering"
+                operator = BlindSubbandFiltering(op_hp, sample_rate=self.args.exp.sample_rate, num_utts=len(items), noise=noise, device=self.device)
+                operator.update_H(use_noise=True)
+        return seg, y, operator, rirs
+
+    def test_dereverberation(self, mode, blind=False):
+        if self.test_set is None or len(self.test_set) == 0:
+            print("No test set specified / no samples found")
+            return
+        mine = [i for i in range(len(self.test_set)) if i % self.world_size == self.rank]
+        sr = self.args.exp.sample_rate
+        for s in range(0, len(mine), self.batch_size):
+            idx = mine[s:s + self.batch_size]
+            items = [self.test_set[i] for i in idx]
+            groups = {}
+            for it in items:                      # only equal-length utterances share a batch
+                groups.setdefault(len(it[0]), []).append(it)
+            for L, grp in groups.items():
+                seg, y, operator, rirs = self.prepare_batch(grp, blind)
+                pred = self.sampler.predict_conditional(y, operator, shape=(len(grp), L), blind=blind)
+                est = self.sampler.operator.get_time_RIR().detach().cpu() if blind else None
+                for b, (_, _, filename) in enumerate(grp):
+                    name = os.path.basename(filename)[:-4]
+                    self.results.append((name, pred[b].detach().cpu()))
+                    if self.in_training or not self.paths:
+                        continue
+                    write_audio_file(seg[b], sr, name, path=self.paths[mode + "original"])
+                    write_audio_file(y[b], sr, name, path=self.paths[mode + "degraded"])
+                    p = write_audio_file(pred[b], sr, name, path=self.paths[mode + "reconstructed"])
+                    write_audio_file(rirs[b], sr, name, path=self.paths[mode + "true_rir"])
+                    if blind:
+                        write_audio_file(est[b] if est.dim() == 2 else est, sr, name, path=self.paths[mode + "estimated_rir"])
+                    print(p)
+
+    def prepare_directories(self, mode, unconditional=False, blind=False):
+        today = date.today()
+        self.paths = {}
+        if "overriden_name" in self.args.tester.keys() and self.args.tester.overriden_name is not None:
+            self.path_sampling = os.path.join(self.args.model_dir, self.args.tester.overriden_name)
+        else:
+            self.path_sampling = os.path.join(self.args.model_dir, "test" + today.strftime("%d_%m_%Y"))
+        self.paths[mode] = os.path.join(self.path_sampling, mode, self.args.exp.exp_name)
+        os.makedirs(self.paths[mode], exist_ok=True)
+        if not unconditional:
+            subs = ["original", "degraded", "reconstructed"]
+            if "dereverberation" in mode:
+                subs.append("true_rir")
+                if mode == "blind_dereverberation":
+                    subs.append("estimated_rir")
+            for s in subs:
+                self.paths[mode + s] = os.path.join(self.paths[mode], s)
+                os.makedirs(self.paths[mode + s], exist_ok=True)
+
+    def save_experiment_args(self, mode):
+        import yaml
+        with open(os.path.join(self.paths[mode], ".argv"), "w") as f:
+            yaml.safe_dump(_plain(self.args), f)
+
+    def do_test(self, it=0):
+        self.it = it
+        for m in self.args.tester.modes:
+            if m == "unconditional":
+                if not self.in_training:
+                    self.prepare_directories(m, unconditional=True)
+                    self.save_experiment_args(m)
+                return self.sample_unconditional(m)
+            elif m == "informed_dereverberation":
+                if not self.in_training:
+                    self.prepare_directories(m)
+                    self.save_experiment_args(m)
+                self.test_dereverberation(m)
+            elif m == "blind_dereverberation":
+                if not self.in_training:
+                    self.prepare_directories(m)
+                    self.save_experiment_args(m)
+                self.test_dereverberation(m, blind=True)
+            else:
+                print("Warning: unknown mode: ", m)
+
+
+def _plain(o):
+    if isinstance(o, dict):
+        return {k: _plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_plain(v) for v in o]
+    return o

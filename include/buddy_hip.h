@@ -47,6 +47,16 @@ int buddy_ncsnpp_vjp(void* handle, const float* cot, float* grad_x, void* stream
 /* debugging / per-module parity: device pointer + NHWC dims ([B][frames][bins][C]) of the output of all_modules[idx]. */
 int buddy_ncsnpp_tap(void* handle, int module_idx, const float** ptr, int dims[4]);
 
+/* device-to-device copy on `stream` (used to read taps without touching another HIP runtime handle) */
+int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream);
+
+/* ---- measurement: time every matrix-core (igemm) launch with HIP events on its own launch stream.  collect() waits for
+ * the recorded events and returns, per class (index 0: 3x3 convolutions, index 1: 1x1 convs / attention / DFT GEMMs),
+ * the summed kernel time [ms], the algorithmic FLOPs (2*M*N*K, zero padding counted like torch's flop counter) and
+ * the number of launches since the last collect. ---- */
+int buddy_prof_enable(int on);
+int buddy_prof_collect(double* ms /*[2]*/, double* flops /*[2]*/, long long* launches /*[2]*/);
+
 /* ---- unit-level kernels (the pieces the network is made of; used by the parity tests) ---- */
 /* C[b] = alpha * op(A[b]) op(Bt[b])^T (+ bias_n), row-major; transX = operand stored k-major. replaces torch.einsum/bmm
  * in AttnBlockpp (networks/ncsnpp_utils/layerspp.py:82-86) and NIN (layers.py:548-557). */
@@ -71,9 +81,10 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
 int buddy_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, void* stream);
 /* per-row sum and sum of squares in double precision: out[b] = {sum, sumsq} */
 int buddy_row_moments(const float* x, double* out, int B, int L, void* stream);
-/* time-domain FIR (direct form) y[b][n] = sum_m h[m] x[b][n-m], n < L: replaces utils/reverb_utils.py:25-61 fast_apply_RIR
- * (same linear convolution, no FFT); adjoint != 0 computes the correlation (its transpose) for the VJP. */
-int buddy_fir(const float* x, const float* h, float* y, int B, int L, int M, int adjoint, void* stream);
+/* time-domain FIR (direct form) y[b][n] = sum_m h_b[m] x[b][n-m], n < L, h_b = h + b*h_stride (h_stride 0 = shared RIR):
+ * replaces utils/reverb_utils.py:25-61 fast_apply_RIR (same linear convolution, no FFT); adjoint != 0 computes the
+ * correlation (its transpose) for the VJP. */
+int buddy_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, void* stream);
 
 #ifdef __cplusplus
 }

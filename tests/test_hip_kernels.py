@@ -123,13 +123,13 @@ def test_fir_and_adjoint(lib, L, M):
     x = torch.randn(2, L, generator=g).cuda()
     h = (torch.randn(M, generator=g) * torch.exp(-torch.arange(M) / (M / 5))).cuda()
     y = torch.empty_like(x)
-    _lib.check(lib.buddy_fir(P(x), P(h), P(y), 2, L, M, 0, S()))
+    _lib.check(lib.buddy_fir(P(x), P(h), 0, P(y), 2, L, M, 0, S()))
     ref = F.conv1d(F.pad(x.double()[:, None], (M - 1, 0)), h.double().flip(0)[None, None])[:, 0].float()
     torch.cuda.synchronize()
     assert rel(y, ref) < 1e-5
     gy = torch.randn(2, L, generator=g).cuda()
     gx = torch.empty_like(x)
-    _lib.check(lib.buddy_fir(P(gy), P(h), P(gx), 2, L, M, 1, S()))
+    _lib.check(lib.buddy_fir(P(gy), P(h), 0, P(gx), 2, L, M, 1, S()))
     torch.cuda.synchronize()
     # <y, gy> == <x, gx>
     lhs, rhs = float((ref.double() * gy.double()).sum()), float((x.double() * gx.double()).sum())

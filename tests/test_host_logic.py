@@ -1,0 +1,184 @@
+"""CPU tests of the host-side mirror of the reference interfaces (no GPU compute): config idioms, C-ABI symbols,
+schedule / gamma / EDM scalars, the batched blind operator and the batched DPS sampler logic (with a small stand-in
+score function so that no HIP kernel is needed) against golden fixtures and the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from buddy_amd.config import compose, to_attrdict
+from buddy_amd.instantiate import instantiate, resolve
+
+torch.set_num_threads(8)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / (np.abs(b).max() + 1e-30)
+
+
+def test_config_access_idioms():
+    args = compose(overrides=["tester.sampling_params.T=50", "+gpu=0"])
+    assert args.tester.sampling_params.T == 50 and args.gpu == 0
+    assert "checkpoint" in args.tester.keys() and args.tester.checkpoint is None
+    assert args.tester.posterior_sampling.rec_loss.get("freq_weighting", None) is None
+    assert not hasattr(args.tester.posterior_sampling.rec_loss, "loss_1")
+    assert args.tester.sampling_params.sde_hp.sigma_min == 1e-4
+    assert to_attrdict({"a": "1e-5"}).a == 1e-5
+
+
+def test_library_exports_declared_symbols():
+    from buddy_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "buddy_hip.h")).read()
+    declared = set(re.findall(r"\b(buddy_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTED), declared ^ set(_lib.EXPORTED)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.buddy_version() >= 1
+    cm = (ctypes.c_int * 4)(1, 2, 2, 2)
+    n = ctypes.c_longlong()
+    assert lib.buddy_ncsnpp_param_count(128, cm, 4, 1, ctypes.byref(n)) == 0 and n.value == 27736590
+
+
+def test_no_cpu_fallback():
+    from buddy_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.BuddyHipError):
+        _lib.require_gpu()
+    net = instantiate(compose().network)
+    with pytest.raises(_lib.BuddyHipError):
+        net(torch.zeros(1, 1, 4096), torch.zeros(1))
+
+
+def test_targets_resolve_and_state_dict_names():
+    args = compose()
+    assert resolve(args.tester.sampler["_target_"]).__name__ == "EulerHeunSamplerDPS"
+    net = instantiate(compose().network)
+    from buddy_amd.synth import module_specs
+    assert [k for k in net.state_dict().keys()] == [n for n, *_ in module_specs()]
+    edm = instantiate(args.diff_params)
+    assert edm.sigma_data == 0.05
+
+
+def test_schedule_gamma_edm_scalars(golden):
+    g = golden("edm_sched")
+    for tester in ["blind_dereverberation_BUDDy", "informed_dereverberation_DPS", "only_unconditional"]:
+        for T in (10, 50, 201):
+            args = compose(tester=tester, overrides=[f"tester.sampling_params.T={T}"])
+            edm = instantiate(args.diff_params)
+            s = instantiate(args.tester.sampler, torch.nn.Identity(), edm, args)
+            t = s.create_schedule()
+            assert np.allclose(t.numpy(), g[f"{tester}.T{T}.t"], rtol=1e-6, atol=0)
+            assert np.allclose(s.get_gamma(t).numpy(), g[f"{tester}.T{T}.gamma"], rtol=1e-6, atol=0)
+    edm = instantiate(compose().diff_params)
+    sig = torch.from_numpy(g["sigma"])
+    for k in ["cskip", "cout", "cin", "cnoise"]:
+        assert np.allclose(getattr(edm, k)(sig).numpy(), g[k], rtol=1e-6)
+
+
+def test_blind_operator_vs_golden_and_batching(golden):
+    from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering
+    from buddy_amd.utils.losses import get_loss
+    from oracle.sampler_ref import NoiseStream
+    g = golden("ops")
+    args = compose()
+    op_hp = args.tester.informed_dereverberation.op_hp
+    x = torch.from_numpy(g["x"])
+    # U = 2: utterance 0 replays the golden stream, utterance 1 another stream
+    ns = [NoiseStream(11), NoiseStream(12)]
+    bop = BlindSubbandFiltering(op_hp, 16000, num_utts=2, noise=ns, device="cpu")
+    bop.update_H(use_noise=True)
+    assert rel(bop.design_filter()[0], g["blind_A"]) < 1e-5
+    assert rel(torch.view_as_real(bop.H[0].detach()), g["blind_H"]) < 1e-4
+    xx = torch.stack([x, 0.5 * x.flip(0)])
+    assert rel(bop.degradation(xx)[0], g["blind_deg"]) < 1e-4
+    assert rel(bop.get_time_RIR()[0], g["blind_rir"]) < 1e-4
+    assert rel(torch.view_as_real(bop.apply_stft(xx))[0], g["blind_stft_x"]) < 1e-5
+    ps = args.tester.posterior_sampling
+    lp, lr = get_loss(ps.rec_loss_params, bop), get_loss(ps.RIR_noise_regularization.loss, bop)
+    y = torch.stack([torch.from_numpy(g["y_rir"])[0], torch.from_numpy(g["y_rir"])[0].flip(0)])
+    for p in bop.params + bop.params_phases:
+        p.requires_grad = True
+    bop.update_H()
+    l1 = lp(y, bop.degradation(xx), per_utt=True)
+    rt = bop.get_time_RIR()
+    n = bop._randn(rt.shape[1:])
+    l2 = lr(rt, (rt + 0.005 * n).detach(), per_utt=True)
+    gs = torch.autograd.grad((l1 + l2).sum(), bop.params + bop.params_phases)
+    assert abs(float(l1[0]) - float(g["blind_l_rec"])) < 1e-4 * abs(float(g["blind_l_rec"]))
+    assert abs(float(l2[0]) - float(g["blind_l_reg"])) < 1e-4 * abs(float(g["blind_l_reg"]))
+    assert rel(gs[0][0], g["blind_g_decay"]) < 2e-3
+    assert rel(gs[1][0], g["blind_g_weights"]) < 2e-3
+    assert rel(gs[2][0], g["blind_g_phases"]) < 2e-3
+    with torch.no_grad():
+        bop.params[0].copy_(torch.linspace(0.0, 0.8, 25)[None, None].expand(2, 1, 25))
+        bop.params[1].copy_(torch.linspace(0.2, 150.0, 25)[None, None].expand(2, 1, 25))
+    bop.project_params()
+    assert np.array_equal(bop.params[0][0].detach().numpy(), g["proj_decay"])
+    assert np.array_equal(bop.params[1][1].detach().numpy(), g["proj_weights"])
+
+
+class _ToyNet(torch.nn.Module):
+    """differentiable stand-in score network (B,1,L),(B,) -> (B,1,L) used on BOTH sides of the sampler-logic test."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.k = torch.nn.Parameter(0.3 * torch.randn(1, 1, 31, generator=g), requires_grad=False)
+
+    def forward(self, x, cn):
+        h = torch.nn.functional.conv1d(x, self.k, padding=15)
+        return torch.tanh(h) * (1.0 + 0.1 * cn.view(-1, 1, 1))
+
+
+def test_batched_blind_dps_equals_oracle_per_utterance():
+    """Row b of the batched sampler == the oracle's (reference-faithful) B=1 run of utterance b."""
+    from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering
+    from oracle import operators_ref as O, sampler_ref as S
+    ov = ["tester.sampling_params.T=3", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+          "tester.posterior_sampling.blind_hp.op_updates_per_step=2"]
+    args = compose(overrides=ov)
+    op_hp = args.tester.informed_dereverberation.op_hp
+    net = _ToyNet()
+    L, U = 8192, 2
+    rs = np.random.RandomState(0)
+    y = torch.from_numpy((0.05 * rs.standard_normal((U, L))).astype(np.float32))
+    # product, batched
+    ns = [S.NoiseStream(50 + u) for u in range(U)]
+    edm = instantiate(args.diff_params)
+    smp = instantiate(args.tester.sampler, net, edm, args)
+    smp.noise = ns
+    op = BlindSubbandFiltering(op_hp, 16000, num_utts=U, noise=ns, device="cpu")
+    op.update_H(use_noise=True)
+    pred = smp.predict_conditional(y, op, shape=(U, L), blind=True)
+    est = smp.operator.get_time_RIR()
+    for u in range(U):
+        nsr = S.NoiseStream(50 + u)
+        ref = S.EulerHeunDPSRef(net, S.EDMRef(args.diff_params.sde_hp), args, nsr)
+        opr = O.BlindSubbandFilteringRef(op_hp, 16000, nsr)
+        opr.update_H(use_noise=True, noise=nsr)
+        pr = ref.predict_conditional(y[u:u + 1], opr, shape=(1, L), blind=True)
+        assert nsr.k == ns[u].k
+        assert rel(pred[u], pr[0]) < 2e-4
+        assert rel(op.params[0][u], opr.params[0].detach()) < 1e-4
+        assert rel(est[u], opr.get_time_RIR().detach()) < 2e-3
+
+
+def test_unconditional_sampler_equals_oracle():
+    from oracle import sampler_ref as S
+    args = compose(tester="only_unconditional", overrides=["tester.sampling_params.T=4"])
+    net = _ToyNet()
+    edm = instantiate(args.diff_params)
+    smp = instantiate(args.tester.sampler, net, edm, args)
+    smp.noise = [S.NoiseStream(7)]
+    x = smp.predict_unconditional((1, 4096), "cpu")
+    ref = S.EulerHeunRef(net, S.EDMRef(args.diff_params.sde_hp), args, S.NoiseStream(7))
+    xr = ref.predict_unconditional((1, 4096))
+    assert rel(x, xr) < 1e-5
