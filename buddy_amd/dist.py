@@ -1,0 +1,46 @@
+"""Utterance-batch data parallelism: one process per GPU, utterance u -> rank u mod world, no communication inside the
+sampling loop, ONE all_gather of the outputs at the end (RCCL over xGMI on the GPU box; gloo in the CPU tests).
+New capability -- the reference is single-process."""
+from __future__ import annotations
+
+import os
+
+import torch
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init(backend=None, device=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    import torch.distributed as dist
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return rank, local_rank, world
+
+
+def shard_indices(n_items, rank, world):
+    return [i for i in range(n_items) if i % world == rank]
+
+
+def gather_rows(local, n_items, rank, world):
+    """local: (n_local, L) rows of the utterances in ``shard_indices(n_items, rank, world)`` order.
+    Returns the (n_items, L) tensor in utterance order on every rank (one all_gather; ragged shards are padded)."""
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    per = (n_items + world - 1) // world
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad.contiguous())
+    out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = shard_indices(n_items, r, world)
+        out[idx] = bufs[r][: len(idx)]
+    return out

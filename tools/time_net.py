@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from tests.test_hip_network import build
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
