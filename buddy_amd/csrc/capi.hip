@@ -10,6 +10,7 @@ using namespace buddy;
 namespace buddy {
 void launch_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, hipStream_t st);
 void launch_row_moments(const float* x, double* out, int B, int L, hipStream_t st);
+void launch_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st);
 void launch_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, hipStream_t st);
 }
 
@@ -76,6 +77,12 @@ int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream) {
   hipError_t e = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
   if (e != hipSuccess) { set_error(std::string("hipMemcpyAsync: ") + hipGetErrorString(e)); return BUDDY_ERR_HIP; }
   return BUDDY_OK;
+}
+
+int buddy_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, void* stream) {
+  if (!seed || !out || !clk) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  launch_mfma_ubench(seed, out, blocks, iters, clk, (hipStream_t)stream);
+  return finish();
 }
 
 int buddy_prof_enable(int on) { igemm_prof_enable(on); return BUDDY_OK; }

@@ -11,9 +11,11 @@
 // (lane l: row l&31, k-slot l>>5); a float4 fragment read per lane therefore feeds FOUR MFMAs (the two
 // lane-halves take k = g*8+j and g*8+4+j), so a 32-deep K step costs 16 ds_read_b128 per wave for 64 MFMAs
 // (4096 MFMA cycles): the loop is matrix-pipe bound, global loads for the next K step are issued before the
-// MFMA block and land under it.
+// first quarter of the MFMA block and land under the rest.  K order is channel-chunk outer / tap inner and the tile order is
+// XCD-aware, so the nine shifted reads of a 3x3 conv hit the same L2 (HBM FETCH 9.7 GB -> 1.1 GB per 1.07 GB input).
 #include "common.h"
 #include <vector>
+#include <cstdlib>
 
 namespace buddy {
 
@@ -24,15 +26,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int TAPS, bool TA, bool TB>
+template <int TAPS, bool TA, bool TB, int V = 2>
 __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+  constexpr int NBUF = (V >= 4) ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LDS_LD];
   float* As = smem;
   float* Bs = smem + BM * LDS_LD;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: hardware places block b on XCD b % 8 (each XCD has its own 4 MiB L2).  Give every XCD a
+  // contiguous range of logical tiles, N-tiles of one M-tile adjacent, so the 3x3 halo rows and the A tile shared by the
+  // N-tiles are re-read from the same L2 instead of 8 different ones (bijective remap, any grid size).
+  const int nNt = (p.N + BN - 1) / BN;
+  int lid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int m0 = (lid / nNt) * BM, n0 = (lid % nNt) * BN;
   const long long bz = blockIdx.z;
   const float* __restrict__ A0 = p.A0 + bz * p.sA;
   const float* __restrict__ A1 = p.A1 ? p.A1 + bz * p.sA : nullptr;
@@ -56,8 +69,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
 
   auto loadA = [&](int kt, float4 (&r)[4]) {
     if (!TA) {
-      const int tap = (TAPS == 9) ? kt / chunks : 0;
-      const int c0 = (kt - tap * chunks) * BK;
+      // K order: channel chunk outer, tap inner -- the 9 shifted reads of one 32-channel slab are back to back (L2 reuse)
+      const int tap = (TAPS == 9) ? kt % 9 : 0;
+      const int c0 = ((TAPS == 9) ? kt / 9 : kt) * BK;
       const int dy = (TAPS == 9) ? tap / 3 - 1 : 0, dx = (TAPS == 9) ? tap % 3 - 1 : 0;
       int cc = c0 + lc4 * 4;
       const bool k_ok = cc < Cin;
@@ -80,8 +94,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
   };
   auto loadB = [&](int kt, float4 (&r)[4]) {
     if (!TB) {
-      const int tap = (TAPS == 9) ? kt / chunks : 0;
-      const int c0 = (kt - tap * chunks) * BK;
+      const int tap = (TAPS == 9) ? kt % 9 : 0;
+      const int c0 = ((TAPS == 9) ? kt / 9 : kt) * BK;
       const int cc = c0 + lc4 * 4;
       const bool k_ok = cc < Cin;
 #pragma unroll
@@ -127,28 +141,57 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
   const float* Af = As + (wm * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
   const float* Bf = Bs + (wn * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
 
-  for (int kt = 0; kt < nk; ++kt) {
+  auto mfma_group = [&](const float* Afp, const float* Bfp, int g) {
+    const float4 a0 = *reinterpret_cast<const float4*>(Afp + g * 8);
+    const float4 a1 = *reinterpret_cast<const float4*>(Afp + 32 * LDS_LD + g * 8);
+    const float4 b0 = *reinterpret_cast<const float4*>(Bfp + g * 8);
+    const float4 b1 = *reinterpret_cast<const float4*>(Bfp + 32 * LDS_LD + g * 8);
+    const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+    const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+    }
+  };
+
+  if (V < 4) {
+    for (int kt = 0; kt < nk; ++kt) {
+      store_tile(As, ra, TA);
+      store_tile(Bs, rb, TB);
+      __syncthreads();
+      if (V == 0 && kt + 1 < nk) { loadA(kt + 1, ra); loadB(kt + 1, rb); }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (V == 2 && g == 1 && kt + 1 < nk) { loadA(kt + 1, ra); loadB(kt + 1, rb); }
+        if (V == 3 && g == 1 && kt + 1 < nk) loadA(kt + 1, ra);
+        if (V == 3 && g == 2 && kt + 1 < nk) loadB(kt + 1, rb);
+        mfma_group(Af, Bf, g);
+      }
+      __syncthreads();
+    }
+  } else {
+    // double-buffered LDS: one barrier per K step
+    constexpr int BUFSZ = (BM + BN) * LDS_LD;
     store_tile(As, ra, TA);
     store_tile(Bs, rb, TB);
     __syncthreads();
-    if (kt + 1 < nk) { loadA(kt + 1, ra); loadB(kt + 1, rb); }
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = (kt & 1) * BUFSZ, nxt = BUFSZ - cur;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 a0 = *reinterpret_cast<const float4*>(Af + g * 8);
-      const float4 a1 = *reinterpret_cast<const float4*>(Af + 32 * LDS_LD + g * 8);
-      const float4 b0 = *reinterpret_cast<const float4*>(Bf + g * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(Bf + 32 * LDS_LD + g * 8);
-      const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) {
+        if (g == 1 && kt + 1 < nk) loadA(kt + 1, ra);
+        if (g == 2 && kt + 1 < nk) loadB(kt + 1, rb);
+        mfma_group(Af + cur, Bf + cur, g);
       }
+      if (kt + 1 < nk) {
+        store_tile(As + nxt, ra, TA);
+        store_tile(Bs + nxt, rb, TB);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -209,7 +252,7 @@ int igemm_prof_collect(double ms[2], double flops[2], long long launches[2]) {
 }
 
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st) {
-  dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), batch), block(NT);
+  dim3 grid(cdiv(p.N, BN) * cdiv(p.M, BM), 1, batch), block(NT);
   ProfRec rec{};
   if (g_prof_on) {
     (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
@@ -217,8 +260,13 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
     (void)hipEventRecord(rec.e0, st);
   }
   struct Fin { ProfRec& r; hipStream_t s; ~Fin() { if (g_prof_on) { (void)hipEventRecord(r.e1, s); g_prof.push_back(r); } } } fin{rec, st};
+  // V: 0 = next-tile global loads issued before the MFMA block, 2 = after its first quarter (default; +4 % measured,
+  // profiles/README.md), 4 = double-buffered LDS, one barrier per K step (slower: 2 blocks/CU).  A/B switch for the 3x3 kernel:
+  static const int variant = getenv("BUDDY_IGEMM_VARIANT") ? atoi(getenv("BUDDY_IGEMM_VARIANT")) : 2;
   if (taps == 9) {
-    hipLaunchKernelGGL((igemm_kernel<9, false, false>), grid, block, 0, st, p);
+    if (variant == 0) hipLaunchKernelGGL((igemm_kernel<9, false, false, 0>), grid, block, 0, st, p);
+    else if (variant == 4) hipLaunchKernelGGL((igemm_kernel<9, false, false, 4>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<9, false, false, 2>), grid, block, 0, st, p);
   } else if (!transA && !transB) {
     hipLaunchKernelGGL((igemm_kernel<1, false, false>), grid, block, 0, st, p);
   } else if (!transA && transB) {

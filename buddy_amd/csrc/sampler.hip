@@ -86,3 +86,33 @@ void launch_fir(const float* x, const float* h, long long h_stride, float* y, in
 }
 
 }  // namespace buddy
+
+// ---- calibration micro-benchmark: pure fp32 MFMA issue rate (no memory traffic), to read the matrix-core peak the chip
+// actually sustains at its power-managed clock on random operands (MI355X_MICROARCH.md: DVFS give-back) ----
+namespace buddy {
+namespace {
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mfma_ubench_kernel(const float* seed, float* out, int iters, unsigned long long* clk) {
+  const int tid = threadIdx.x;
+  float a0 = seed[tid], a1 = seed[tid + 256], b0 = seed[tid + 512], b1 = seed[tid + 768];
+  f32x16_t c00, c01, c10, c11;
+  for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+  const unsigned long long t0 = clock64(), w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+    c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c00, 0, 0, 0);
+    c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c01, 0, 0, 0);
+    c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c10, 0, 0, 0);
+    c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c11, 0, 0, 0);
+    a0 = -a0; b1 = -b1;     // keep operands toggling without growing the accumulators
+  }
+  const unsigned long long t1 = clock64(), w1 = wall_clock64();
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += c00[r] + c01[r] + c10[r] + c11[r];
+  out[blockIdx.x * 256 + tid] = s;
+  if (blockIdx.x == 0 && tid == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
+}  // namespace
+void launch_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_ubench_kernel, dim3(blocks), dim3(256), 0, st, seed, out, iters, clk);
+}
+}  // namespace buddy

@@ -57,6 +57,11 @@ int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream);
 int buddy_prof_enable(int on);
 int buddy_prof_collect(double* ms /*[2]*/, double* flops /*[2]*/, long long* launches /*[2]*/);
 
+/* calibration: `blocks` workgroups x 4 waves issue 4*iters fp32 MFMAs (32x32x2) each on operands from seed[1024] with no
+ * memory traffic; out[blocks*256] keeps the result live; clk[0] = shader clocks, clk[1] = 100 MHz wall ticks of block 0.
+ * FLOPs = blocks * 4 waves * 4 * iters * 4096. */
+int buddy_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, void* stream);
+
 /* ---- unit-level kernels (the pieces the network is made of; used by the parity tests) ---- */
 /* C[b] = alpha * op(A[b]) op(Bt[b])^T (+ bias_n), row-major; transX = operand stored k-major. replaces torch.einsum/bmm
  * in AttnBlockpp (networks/ncsnpp_utils/layerspp.py:82-86) and NIN (layers.py:548-557). */
