@@ -41,6 +41,7 @@ def build_stack(args_ns, device, B, rank):
     net = net.to(device).eval()
     edm = instantiate(args.diff_params)
     tester = Tester(args, net, edm, test_set=None, device=device, in_training=True)
+    tester.blind_backend = None if args_ns.operator == "hip" else "torch"
     L = args_ns.length
     items = [(synth_clean(rank * B + u, L), synth_rir(rank * B + u, 8000), f"utt{rank * B + u}.wav") for u in range(B)]
     torch.manual_seed(1234 + rank)
@@ -57,10 +58,14 @@ class StepRunner:
         ps = s.args.tester.posterior_sampling
         s.operator, s.y = op, y
         s.rec_loss = get_loss(ps.rec_loss, operator=op)
-        s.rec_loss_params = get_loss(ps.rec_loss_params, operator=op)
-        s.optimizer_operator = torch.optim.Adam(op.params + op.params_phases, lr=ps.blind_hp.lr_op, weight_decay=ps.blind_hp.weight_decay,
-                                                betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
-        s.RIR_noise_regularization_loss = get_loss(ps.RIR_noise_regularization.loss, operator=op)
+        s._hip_op = hasattr(op, "hip_optimize")
+        if s._hip_op:
+            op.hip_bind(y, ps)
+        else:
+            s.rec_loss_params = get_loss(ps.rec_loss_params, operator=op)
+            s.optimizer_operator = torch.optim.Adam(op.params + op.params_phases, lr=ps.blind_hp.lr_op, weight_decay=ps.blind_hp.weight_decay,
+                                                    betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
+            s.RIR_noise_regularization_loss = get_loss(ps.RIR_noise_regularization.loss, operator=op)
         self.s = s
         self.t = s.create_schedule().to(device)
         self.gamma = s.get_gamma(self.t).to(device)
@@ -138,6 +143,7 @@ def main():
     ap.add_argument("--length", type=int, default=64000)
     ap.add_argument("--T", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--operator", default="hip", choices=["hip", "torch"], help="blind operator backend (torch = interim torch-op path)")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="THREADS", help="internal: run only the CPU leg and print its JSON")
     a = ap.parse_args()
     if a.cpu_baseline_only:

@@ -43,6 +43,20 @@ _SIGS = {
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_axpby_rows": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_void_p]),
     "buddy_row_moments": (C.c_int, [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_blindop_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "buddy_blindop_destroy": (C.c_int, [C.c_void_p]),
+    "buddy_blindop_set_params": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_int, C.c_void_p]),
+    "buddy_blindop_get_params": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p]),
+    "buddy_blindop_update_H": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
+    "buddy_blindop_get_H": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
+    "buddy_blindop_set_y": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
+    "buddy_blindop_degrade": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_void_p]),
+    "buddy_blindop_time_rir": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
+    "buddy_blindop_rec_loss_grad": (C.c_int, [C.c_void_p, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),
+    "buddy_blindop_param_grads": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),
+    "buddy_blindop_optimize": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                         C.c_float, C.c_void_p]),
     "buddy_fir": (C.c_int, [_f32p, _f32p, C.c_longlong, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 EXPORTED = sorted(_SIGS)

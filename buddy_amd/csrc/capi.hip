@@ -147,4 +147,47 @@ int buddy_fir(const float* x, const float* h, long long h_stride, float* y, int 
   return finish();
 }
 
+
+// ---- blind operator ----
+int buddy_blindop_create(int U, int L, int Nf, int E, int num_knots, const float* knots, int sample_rate, float comp, float min_decay,
+                         float max_decay, float w_lo, float w_hi, int clamp_decay, int long_second, void** handle) {
+  if (!knots || !handle || U < 1 || L < 1024 || num_knots > 64) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  BlindOpCfg c; std::memset(&c, 0, sizeof(c));
+  c.n_fft = 1024; c.win = 512; c.hop = 128; c.Nf = Nf; c.E = E; c.num_knots = num_knots; c.sample_rate = sample_rate; c.comp = comp;
+  for (int i = 0; i < num_knots; ++i) c.knots[i] = knots[i];
+  c.min_decay = min_decay; c.max_decay = max_decay; c.w_lo = w_lo; c.w_hi = w_hi; c.clamp_decay = clamp_decay; c.long2nd = long_second;
+  BlindOp* o = nullptr;
+  int rc = blindop_create(c, U, L, &o);
+  if (rc) return rc;
+  *handle = o;
+  return BUDDY_OK;
+}
+int buddy_blindop_destroy(void* h) { blindop_destroy((BlindOp*)h); return BUDDY_OK; }
+#define BOP_CHECK(h) if (!(h)) { set_error("null handle"); return BUDDY_ERR_ARG; }
+int buddy_blindop_set_params(void* h, const float* decay, const float* weights, const float* phases, int reset_adam, void* stream) {
+  BOP_CHECK(h); return blindop_set_params((BlindOp*)h, decay, weights, phases, reset_adam, (hipStream_t)stream);
+}
+int buddy_blindop_get_params(void* h, float* decay, float* weights, float* phases, void* stream) {
+  BOP_CHECK(h); return blindop_get_params((BlindOp*)h, decay, weights, phases, (hipStream_t)stream);
+}
+int buddy_blindop_update_H(void* h, const float* noise, void* stream) { BOP_CHECK(h); return blindop_update_H((BlindOp*)h, noise, (hipStream_t)stream); }
+int buddy_blindop_get_H(void* h, float* out, void* stream) { BOP_CHECK(h); if (!out) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_get_H((BlindOp*)h, out, (hipStream_t)stream); }
+int buddy_blindop_set_y(void* h, const float* y, void* stream) { BOP_CHECK(h); if (!y) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_set_y((BlindOp*)h, y, (hipStream_t)stream); }
+int buddy_blindop_degrade(void* h, const float* x, float* y, void* stream) { BOP_CHECK(h); if (!x || !y) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_degrade((BlindOp*)h, x, y, (hipStream_t)stream); }
+int buddy_blindop_time_rir(void* h, float* out, void* stream) { BOP_CHECK(h); if (!out) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_time_rir((BlindOp*)h, out, (hipStream_t)stream); }
+int buddy_blindop_rec_loss_grad(void* h, const float* x_den, float weight, float* loss, float* g_x, void* stream) {
+  BOP_CHECK(h); if (!x_den || !loss) { set_error("null"); return BUDDY_ERR_ARG; }
+  return blindop_rec_loss_grad((BlindOp*)h, x_den, weight, loss, g_x, (hipStream_t)stream);
+}
+int buddy_blindop_param_grads(void* h, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, float* g_decay, float* g_weights,
+                              float* g_phases, float* losses, void* stream) {
+  BOP_CHECK(h); if (!x_den) { set_error("null"); return BUDDY_ERR_ARG; }
+  return blindop_param_grads((BlindOp*)h, x_den, noise, t_op, w_rec, w_reg, g_decay, g_weights, g_phases, losses, (hipStream_t)stream);
+}
+int buddy_blindop_optimize(void* h, const float* x_den, const float* noise, float t_op, int n_iters, float w_rec, float w_reg, float lr, float beta1,
+                           float beta2, float weight_decay, void* stream) {
+  BOP_CHECK(h); if (!x_den || n_iters < 0) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  return blindop_optimize((BlindOp*)h, x_den, noise, t_op, n_iters, w_rec, w_reg, lr, beta1, beta2, weight_decay, (hipStream_t)stream);
+}
+
 }  // extern "C"

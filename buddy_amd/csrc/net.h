@@ -19,4 +19,29 @@ int net_forward(Net* N, const float* x, const float* cnoise, const float* cin_b,
 int net_vjp(Net* N, const float* cot, float* gx, hipStream_t st);
 int net_get_tap(Net* N, int module_idx, const float** p, int dims[4]);
 
+
+// ---- blind subband-filtering operator (operator.hip) ----
+struct BlindOpCfg {
+  int n_fft, win, hop, Nf, E, num_knots, sample_rate;
+  float knots[64];
+  float comp;                       // compression exponent of the spectral loss
+  float min_decay, max_decay, w_lo, w_hi;
+  int clamp_decay, long2nd;
+};
+struct BlindOp;
+int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out);
+void blindop_destroy(BlindOp* o);
+int blindop_set_params(BlindOp* o, const float* decay, const float* wts, const float* phases_ref, int reset_adam, hipStream_t st);
+int blindop_get_params(BlindOp* o, float* decay, float* wts, float* phases_ref, hipStream_t st);
+int blindop_update_H(BlindOp* o, const float* noise, hipStream_t st);
+int blindop_get_H(BlindOp* o, float* out, hipStream_t st);
+int blindop_set_y(BlindOp* o, const float* y, hipStream_t st);
+int blindop_degrade(BlindOp* o, const float* x, float* y, hipStream_t st);
+int blindop_time_rir(BlindOp* o, float* out, hipStream_t st);
+int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* loss, float* g_x, hipStream_t st);
+int blindop_param_grads(BlindOp* o, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, float* g_decay, float* g_wts,
+                        float* g_phases_ref, float* losses, hipStream_t st);
+int blindop_optimize(BlindOp* o, const float* x_den, const float* noise, float t_op, int n_iters, float w_rec, float w_reg, float lr, float b1,
+                     float b2, float wd, hipStream_t st);
+
 }  // namespace buddy

@@ -1,0 +1,792 @@
+// Blind subband-filtering reverb operator on gfx950: batched over U utterances, hand-written forward AND analytic
+// backward (no autograd), one C-ABI call per optimize_op (reference testing/EulerHeunSamplerDPS.py:71-113) and one per
+// likelihood evaluation (:61-69).  Restates reference testing/operators/subband_filtering.py (SubbandFiltering :8-136,
+// BlindSubbandFiltering :142-351), utils/reverb_utils.py:3-23 (hilbert / minimum_phase_version), utils/losses.py:59-64
+// (l2_comp_stft_summean) and torch.optim.Adam for the shipped op_hp (fix_EQ_extremes, single exponential per band set
+// E >= 1, minimum_phase, fix_direct_path, clamp_decay, enforce_long_decay_in_second_exponential).
+//
+// Layouts: spectrograms [U][T][LDS_=1028] floats = 513 interleaved complex bins + 2 zero pad floats (16-B aligned rows,
+// K % 4 == 0 for the MFMA GEMMs); subband filters are frame-major [U][Nf][1028] so that the filter IS a spectrogram of the
+// RIR (cons() = iSTFT -> minimum phase -> STFT needs no transposes).  STFT/iSTFT (n_fft 1024, hann(512) zero-padded, hop
+// 128) run as DFT-GEMMs on the fp32 MFMA kernel (K = 512: the window support); the 25856-point FFTs of the minimum-phase
+// projection are two-stage Cooley-Tukey (101 x 256) direct kernels.
+#include "common.h"
+#include "net.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace buddy {
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return BUDDY_ERR_HIP; } } while (0)
+
+namespace {
+constexpr int FB = 513, LDSP = 1028, NFFT = 1024, WIN = 512, HOP = 128;
+constexpr int N2 = 25856, F1 = 101, F2 = 256;     // N2 = F1 * F2
+constexpr double PI = 3.14159265358979323846;
+
+// ------------------------------------------------------------------ small kernels
+__global__ __launch_bounds__(256) void pad_const_kernel(const float* s, float* sp, int U, int Ls, int P, int Lpad, const float* add, float add_scale) {
+  const long long total = (long long)U * Lpad;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int u = (int)(i / Lpad), j = (int)(i % Lpad) - P;
+    float v = 0.f;
+    if (j >= 0 && j < Ls) { v = s[(long long)u * Ls + j]; if (add) v += add_scale * add[(long long)u * Ls + j]; }
+    sp[i] = v;
+  }
+}
+
+// Y[u][t][f] = sum_k H[u][k][f] * X[u][t + 1 - k][f]   (reference subband_filtering :67-74, one pre-impulse frame)
+__global__ __launch_bounds__(256) void fir_kernel_sb(const float* X, long long xs, const float* H, float* Y, int U, int T, int Nf) {
+  const long long total = (long long)U * T * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB); const int t = (int)((i / FB) % T); const int u = (int)(i / ((long long)FB * T));
+    const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs);
+    const float2* Hu = reinterpret_cast<const float2*>(H + (long long)u * Nf * LDSP);
+    float ar = 0.f, ai = 0.f;
+    for (int k = 0; k < Nf; ++k) {
+      const int tt = t + 1 - k;
+      if (tt < 0) break;
+      if (tt >= T) continue;
+      const float2 h = Hu[(long long)k * (LDSP / 2) + f], x = Xu[(long long)tt * (LDSP / 2) + f];
+      ar += h.x * x.x - h.y * x.y; ai += h.x * x.y + h.y * x.x;
+    }
+    reinterpret_cast<float2*>(Y + ((long long)u * T + t) * LDSP)[f] = make_float2(ar, ai);
+  }
+}
+// GX[u][t'][f] = sum_k conj(H[k]) * GY[t' - 1 + k]
+__global__ __launch_bounds__(256) void fir_adjx_kernel(const float* GY, const float* H, float* GX, int U, int T, int Nf) {
+  const long long total = (long long)U * T * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB); const int t = (int)((i / FB) % T); const int u = (int)(i / ((long long)FB * T));
+    const float2* Gu = reinterpret_cast<const float2*>(GY + (long long)u * T * LDSP);
+    const float2* Hu = reinterpret_cast<const float2*>(H + (long long)u * Nf * LDSP);
+    float ar = 0.f, ai = 0.f;
+    for (int k = 0; k < Nf; ++k) {
+      const int tt = t - 1 + k;
+      if (tt < 0) continue;
+      if (tt >= T) break;
+      const float2 h = Hu[(long long)k * (LDSP / 2) + f], g = Gu[(long long)tt * (LDSP / 2) + f];
+      ar += h.x * g.x + h.y * g.y; ai += h.x * g.y - h.y * g.x;
+    }
+    reinterpret_cast<float2*>(GX + ((long long)u * T + t) * LDSP)[f] = make_float2(ar, ai);
+  }
+}
+// GH[u][k][f] (+)= sum_t conj(X[t + 1 - k]) * GY[t]
+__global__ __launch_bounds__(256) void fir_gradh_kernel(const float* X, long long xs, const float* GY, float* GH, int U, int T, int Nf, int accumulate) {
+  const long long total = (long long)U * Nf * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB); const int k = (int)((i / FB) % Nf); const int u = (int)(i / ((long long)FB * Nf));
+    const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs);
+    const float2* Gu = reinterpret_cast<const float2*>(GY + (long long)u * T * LDSP);
+    float ar = 0.f, ai = 0.f;
+    const int t0 = k > 0 ? k - 1 : 0;
+    for (int t = t0; t < T; ++t) {
+      const int tt = t + 1 - k;
+      if (tt >= T) break;
+      const float2 x = Xu[(long long)tt * (LDSP / 2) + f], g = Gu[(long long)t * (LDSP / 2) + f];
+      ar += x.x * g.x + x.y * g.y; ai += x.x * g.y - x.y * g.x;
+    }
+    float2* o = reinterpret_cast<float2*>(GH + ((long long)u * Nf + k) * LDSP) + f;
+    if (accumulate) { ar += o->x; ai += o->y; }
+    *o = make_float2(ar, ai);
+  }
+}
+
+// compressed spectrum: Xc = (|X| + 1e-8)^p * exp(j angle X)   (reference losses.py:59-64)
+__device__ __forceinline__ float2 compress(float2 x, float p) {
+  const float r = sqrtf(x.x * x.x + x.y * x.y);
+  if (r == 0.f) return make_float2(powf(1e-8f, p), 0.f);      // angle(0) = 0
+  const float rho = powf(r + 1e-8f, p) / r;
+  return make_float2(x.x * rho, x.y * rho);
+}
+__global__ __launch_bounds__(256) void compress_kernel(const float* X, float* Xc, long long rows, float p) {
+  const long long total = rows * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / FB; const int f = (int)(i % FB);
+    reinterpret_cast<float2*>(Xc + r * LDSP)[f] = compress(reinterpret_cast<const float2*>(X + r * LDSP)[f], p);
+  }
+}
+// loss_u = kappa * sum_{t,f} |Rc - comp(Xh)|^2 ;  G = d loss / d Xh (as dRe + j dIm).  partial sums per block (deterministic).
+__global__ __launch_bounds__(256) void comp_loss_kernel(const float* Rc, const float* Xh, float* G, double* partial, int T, float kappa, float p) {
+  __shared__ double red[256];
+  const int u = blockIdx.y;
+  const long long total = (long long)T * FB;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long t = i / FB; const int f = (int)(i % FB);
+    const long long row = ((long long)u * T + t) * LDSP;
+    const float2 x = reinterpret_cast<const float2*>(Xh + row)[f], rc = reinterpret_cast<const float2*>(Rc + row)[f];
+    const float r = sqrtf(x.x * x.x + x.y * x.y);
+    float2 g = make_float2(0.f, 0.f);
+    float2 xc;
+    if (r == 0.f) {
+      xc = make_float2(powf(1e-8f, p), 0.f);
+    } else {
+      const float cr = x.x / r, ci = x.y / r;               // e^{j theta}
+      const float rho = powf(r + 1e-8f, p);
+      xc = make_float2(rho * cr, rho * ci);
+      const float dr = xc.x - rc.x, di = xc.y - rc.y;       // D = Xc_hat - Rc
+      const float a = dr * cr + di * ci;                    // Re(conj(D) e^{j theta})
+      const float b = dr * ci - di * cr;                    // Im(conj(D) e^{j theta})
+      const float gr = 2.f * kappa * a * p * powf(r + 1e-8f, p - 1.f);
+      const float gt = -2.f * kappa * rho * b / r;          // (1/r) dL/dtheta
+      g = make_float2(gr * cr - gt * ci, gr * ci + gt * cr);
+    }
+    const float dr = xc.x - rc.x, di = xc.y - rc.y;
+    acc += (double)(dr * dr + di * di);
+    if (G) reinterpret_cast<float2*>(G + row)[f] = g;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) partial[(long long)u * gridDim.x + blockIdx.x] = red[0];
+}
+__global__ void loss_finalize_kernel(const double* partial, int nblk, float kappa, float* loss, int accumulate) {
+  const int u = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += partial[(long long)u * nblk + i];
+  const float v = (float)(s * (double)kappa);
+  loss[u] = accumulate ? loss[u] + v : v;
+}
+
+// ---- filter design (reference :212-251) ----
+struct DesignTabs { const int* idx; const float* frac; const float* corr; const float* dpm; };   // per-bin knot index / fraction; OLA corr[Nf]; dpm[Nf][FB]
+// dm[u][n][j], j = 0..K-1 knots (rows 0 and K-1 are zero): sum_e w[e][j-1] * exp(decay[e][j-1])^(-n)
+__global__ void design_dm_kernel(const float* decay, const float* wts, float* logdm, float* dmv, int U, int E, int NB, int Nf) {
+  const int K = NB + 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= U * Nf * K) return;
+  const int j = i % K, n = (i / K) % Nf, u = i / (K * Nf);
+  float v = 0.f;
+  if (j >= 1 && j <= NB)
+    for (int e = 0; e < E; ++e) v += wts[((long long)u * E + e) * NB + j - 1] * powf(expf(decay[((long long)u * E + e) * NB + j - 1]), -(float)n);
+  dmv[i] = v;
+  logdm[i] = logf(v + 1e-6f);
+}
+__global__ __launch_bounds__(256) void design_A_kernel(const float* logdm, DesignTabs tb, float* A, float* Apre, int U, int K, int Nf) {
+  const long long total = (long long)U * Nf * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB), n = (int)((i / FB) % Nf), u = (int)(i / ((long long)FB * Nf));
+    const float* l = logdm + ((long long)u * Nf + n) * K;
+    const int j = tb.idx[f];
+    const float v0 = l[j], v1 = l[j + 1];
+    const float e = expf(v0 + tb.frac[f] * (v1 - v0));
+    Apre[i] = e;
+    A[i] = (e + 1e-6f) / tb.corr[n] + tb.dpm[(long long)n * FB + f];
+  }
+}
+// H0 frames: Fin[u][k+1][f] = A[u][k][f] * exp(j phi[u][k][f]); rows 0 and Nf+1 stay zero
+__global__ __launch_bounds__(256) void h0_kernel(const float* A, const float* phi, float* Fin, int U, int Nf) {
+  const long long total = (long long)U * Nf * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB), k = (int)((i / FB) % Nf), u = (int)(i / ((long long)FB * Nf));
+    float s, c; sincosf(phi[i], &s, &c);
+    reinterpret_cast<float2*>(Fin + ((long long)u * (Nf + 2) + k + 1) * LDSP)[f] = make_float2(A[i] * c, A[i] * s);
+  }
+}
+// gA, gphi from G_Fin (rows 1..Nf)
+__global__ __launch_bounds__(256) void h0_bwd_kernel(const float* GFin, const float* A, const float* phi, float* gA, float* gphi, int U, int Nf) {
+  const long long total = (long long)U * Nf * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB), k = (int)((i / FB) % Nf), u = (int)(i / ((long long)FB * Nf));
+    const float2 g = reinterpret_cast<const float2*>(GFin + ((long long)u * (Nf + 2) + k + 1) * LDSP)[f];
+    float s, c; sincosf(phi[i], &s, &c);
+    gA[i] = g.x * c + g.y * s;
+    gphi[i] = A[i] * (-g.x * s + g.y * c);
+  }
+}
+// g_logdm[u][n][j] = sum_f [idx(f) == j] (1 - frac) gi + [idx(f) + 1 == j] frac gi,  gi = gA / corr[n] * Apre
+__global__ void design_bwd_knots_kernel(const float* gA, const float* Apre, DesignTabs tb, const float* dmv, float* gdm, int U, int K, int Nf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= U * Nf * K) return;
+  const int j = i % K, n = (i / K) % Nf, u = i / (K * Nf);
+  const float* g = gA + ((long long)u * Nf + n) * FB;
+  const float* ap = Apre + ((long long)u * Nf + n) * FB;
+  float acc = 0.f;
+  for (int f = 0; f < FB; ++f) {
+    const int id = tb.idx[f];
+    if (id == j) acc += (1.f - tb.frac[f]) * g[f] * ap[f];
+    else if (id + 1 == j) acc += tb.frac[f] * g[f] * ap[f];
+  }
+  gdm[i] = acc / tb.corr[n] / (dmv[i] + 1e-6f);      // d/d dm of log(dm + 1e-6)
+}
+__global__ void design_bwd_params_kernel(const float* gdm, const float* decay, const float* wts, float* gdecay, float* gw, int U, int E, int NB, int Nf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= U * E * NB) return;
+  const int b = i % NB, u = i / (E * NB);
+  const int K = NB + 2;
+  const float base = expf(decay[i]), w = wts[i];
+  float gd = 0.f, gwv = 0.f;
+  for (int n = 0; n < Nf; ++n) {
+    const float pw = powf(base, -(float)n);
+    const float g = gdm[((long long)u * Nf + n) * K + b + 1];
+    gwv += g * pw;
+    gd += g * w * (-(float)n) * pw;
+  }
+  gdecay[i] = gd; gw[i] = gwv;
+}
+
+// ---- 25856-point complex FFT, two stages (N2 = 101 * 256): n = 256 n1 + n2, k = k1 + 101 k2 ----
+// stage 1: Y1[u][n2][k1] = tw(n2 k1) * sum_{n1} x[256 n1 + n2] W101^(n1 k1)
+__global__ __launch_bounds__(256) void fft_stage1_kernel(const float2* x, float2* y1, const float2* w101, const float2* twN, int sign) {
+  __shared__ float2 W[F1];
+  for (int i = threadIdx.x; i < F1; i += 256) W[i] = w101[i];
+  __syncthreads();
+  const int u = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F2 * F1) return;
+  const int k1 = i % F1, n2 = i / F1;
+  const float2* xu = x + (long long)u * N2;
+  float ar = 0.f, ai = 0.f;
+  int idx = 0;
+  for (int n1 = 0; n1 < F1; ++n1) {
+    const float2 v = xu[F2 * n1 + n2];
+    const float wr = W[idx].x, wi = sign * W[idx].y;
+    ar += v.x * wr - v.y * wi; ai += v.x * wi + v.y * wr;
+    idx += k1; if (idx >= F1) idx -= F1;
+  }
+  const float2 t = twN[(long long)n2 * F1 + k1];
+  const float tr = t.x, ti = sign * t.y;
+  y1[(long long)u * N2 + i] = make_float2(ar * tr - ai * ti, ar * ti + ai * tr);
+}
+// stage 2: X[k1 + 101 k2] = scale * sum_{n2} Y1[n2][k1] W256^(n2 k2)
+__global__ __launch_bounds__(256) void fft_stage2_kernel(const float2* y1, float2* X, const float2* w256, int sign, float scale) {
+  __shared__ float2 W[F2];
+  for (int i = threadIdx.x; i < F2; i += 256) W[i] = w256[i];
+  __syncthreads();
+  const int u = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N2) return;
+  const int k1 = i % F1, k2 = i / F1;
+  const float2* yu = y1 + (long long)u * N2;
+  float ar = 0.f, ai = 0.f;
+  int idx = 0;
+  for (int n2 = 0; n2 < F2; ++n2) {
+    const float2 v = yu[n2 * F1 + k1];
+    const float wr = W[idx].x, wi = sign * W[idx].y;
+    ar += v.x * wr - v.y * wi; ai += v.x * wi + v.y * wr;
+    idx = (idx + k2) & (F2 - 1);
+  }
+  X[(long long)u * N2 + k1 + F1 * k2] = make_float2(ar * scale, ai * scale);
+}
+
+// ---- minimum-phase projection glue (reference reverb_utils.py:9-23) ----
+__global__ __launch_bounds__(256) void mp_pack_kernel(const float* h0, int Lh, float2* hp, int U) {      // hp = [h0, zeros] as complex
+  const long long total = (long long)U * N2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int u = (int)(i / N2), n = (int)(i % N2);
+    hp[i] = make_float2(n < Lh ? h0[(long long)u * Lh + n] : 0.f, 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void mp_logabs_kernel(const float2* Hf, float* M, float2* Lg, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const float2 h = Hf[i];
+    const float m = sqrtf(h.x * h.x + h.y * h.y);
+    M[i] = m;
+    Lg[i] = make_float2(logf(m + 1e-8f), 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void mp_window_kernel(float2* F, long long total) {     // hilbert window: 2 on the first half, 0 on the second
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i % N2);
+    const float w = n < N2 / 2 ? 2.f : 0.f;
+    F[i].x *= w; F[i].y *= w;
+  }
+}
+__global__ __launch_bounds__(256) void mp_phase_kernel(const float2* hil, const float* M, float* phim, float2* Z, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const float ph = -hil[i].y;
+    phim[i] = ph;
+    float s, c; sincosf(ph, &s, &c);
+    Z[i] = make_float2(M[i] * c, M[i] * s);
+  }
+}
+__global__ __launch_bounds__(256) void mp_out_kernel(const float2* o, float* hm, int Lm, int U, float first) {   // hm = Re(o)[:Lm], hm[0] = first
+  const long long total = (long long)U * Lm;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int u = (int)(i / Lm), n = (int)(i % Lm);
+    hm[i] = n == 0 ? first : o[(long long)u * N2 + n].x;
+  }
+}
+// backward glue
+__global__ __launch_bounds__(256) void mpb_pack_kernel(const float* ghm, int Lm, float2* gp, int U) {     // g padded, g[0] = 0 (hm[0] is a constant)
+  const long long total = (long long)U * N2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int u = (int)(i / N2), n = (int)(i % N2);
+    gp[i] = make_float2((n > 0 && n < Lm) ? ghm[(long long)u * Lm + n] : 0.f, 0.f);
+  }
+}
+// GZ = FFT(g)/N2 ; gM = Re(conj(GZ) e^{j phi}), gphi = -M Im(conj(GZ) e^{j phi})
+__global__ __launch_bounds__(256) void mpb_z_kernel(const float2* GZ, const float* M, const float* phim, float* gM, float2* gphi_c, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    float s, c; sincosf(phim[i], &s, &c);
+    const float2 g = GZ[i];
+    const float a = g.x * c + g.y * s;         // Re(conj(G) e^{j phi})
+    const float b = g.x * s - g.y * c;         // Im(conj(G) e^{j phi})
+    gM[i] = a;
+    gphi_c[i] = make_float2(-M[i] * b, 0.f);
+  }
+}
+// gLg = Im(IFFT(win FFT(gphi))) ; gM += gLg / (M + 1e-8) ; GH = gM * Hf / |Hf|
+__global__ __launch_bounds__(256) void mpb_h_kernel(const float2* hil, const float* M, const float* gM, const float2* Hf, float2* GH, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const float m = M[i];
+    const float g = gM[i] + hil[i].y / (m + 1e-8f);
+    const float2 h = Hf[i];
+    GH[i] = m > 0.f ? make_float2(g * h.x / m, g * h.y / m) : make_float2(0.f, 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void mpb_out_kernel(const float2* o, float* gh0, int Lh, int U) {   // g_h0 = Re(N2 * IFFT(GH))[:Lh] (o already scaled)
+  const long long total = (long long)U * Lh;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int u = (int)(i / Lh), n = (int)(i % Lh);
+    gh0[i] = o[(long long)u * N2 + n].x;
+  }
+}
+
+// ---- Adam (torch.optim.Adam single-tensor arithmetic: lerp, addcmul, addcdiv) + projection ----
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2_sqrt) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float gi = g[i];
+    if (wd != 0.f) gi += wd * p[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+  }
+}
+__global__ void project_kernel(float* decay, float* wts, int U, int E, int NB, float dmin, float dmax, float wlo, float whi, int clamp_decay, int long2nd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= U * NB) return;
+  const int b = i % NB, u = i / NB;
+  float d0 = 0.f, w0 = 0.f;
+  for (int e = 0; e < E; ++e) {
+    float* d = decay + ((long long)u * E + e) * NB + b;
+    float* w = wts + ((long long)u * E + e) * NB + b;
+    if (clamp_decay) {
+      float hi = dmax;
+      if (e > 0 && long2nd) hi = fminf(d0 / 1.01f, dmax);
+      *d = fminf(fmaxf(*d, dmin), hi);
+      if (e == 0) d0 = *d;
+    }
+    if (e == 0) { *w = fminf(fmaxf(*w, wlo), whi); w0 = *w; }
+    else *w = fminf(fmaxf(*w, wlo), w0);
+  }
+}
+// reference layout (U, F, Nf) <-> frame-major (U, Nf, F)
+__global__ __launch_bounds__(256) void transpose_fk_kernel(const float* src, float* dst, int U, int Nf, int to_frame_major) {
+  const long long total = (long long)U * Nf * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB), k = (int)((i / FB) % Nf), u = (int)(i / ((long long)FB * Nf));
+    const long long a = ((long long)u * FB + f) * Nf + k;       // reference index
+    if (to_frame_major) dst[i] = src[a]; else dst[a] = src[i];
+  }
+}
+__global__ __launch_bounds__(256) void angle_kernel(const float* H, float* phi, int U, int Nf) {
+  const long long total = (long long)U * Nf * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB); const long long r = i / FB;
+    const float2 h = reinterpret_cast<const float2*>(H + r * LDSP)[f];
+    phi[i] = atan2f(h.y, h.x);
+  }
+}
+__global__ __launch_bounds__(256) void unit_phase_kernel(const float* Nz, float* phi, int U, int Nf) {   // phi = angle(N[:, 1:]) frame k <- noise frame k+1
+  const long long total = (long long)U * Nf * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB), k = (int)((i / FB) % Nf), u = (int)(i / ((long long)FB * Nf));
+    const float2 h = reinterpret_cast<const float2*>(Nz + ((long long)u * (Nf + 1) + k + 1) * LDSP)[f];
+    phi[i] = atan2f(h.y, h.x);
+  }
+}
+__global__ __launch_bounds__(256) void copy_h_kernel(const float* H, float* out, int U, int Nf) {   // frame-major padded -> reference (U,F,Nf,2)
+  const long long total = (long long)U * Nf * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB), k = (int)((i / FB) % Nf), u = (int)(i / ((long long)FB * Nf));
+    const float2 h = reinterpret_cast<const float2*>(H + ((long long)u * Nf + k) * LDSP)[f];
+    reinterpret_cast<float2*>(out)[((long long)u * FB + f) * Nf + k] = h;
+  }
+}
+
+inline int gridf(long long total) { long long g = (total + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1; return (int)g; }
+}  // namespace
+
+// =================================================================== host-side operator object
+struct BlindOp {
+  BlindOpCfg c;
+  int U = 0, L = 0, T = 0, Td = 0, Lr = 0, Lh = 0, Lm = 0, E = 0, NB = 0, K = 0, Nf = 0;
+  hipStream_t st = nullptr;
+  std::vector<void*> allocs;
+  // tables
+  float *Bf = nullptr, *Bi = nullptr, *ones = nullptr, *env_T = nullptr, *env_d = nullptr, *env_c = nullptr;
+  float norm = 1.f;
+  int* idx = nullptr; float *frac = nullptr, *corr = nullptr, *dpm = nullptr;
+  float2 *w101 = nullptr, *w256 = nullptr, *twN = nullptr;
+  // parameters + Adam state
+  float *decay = nullptr, *wts = nullptr, *phi = nullptr;
+  float *m_d = nullptr, *v_d = nullptr, *m_w = nullptr, *v_w = nullptr, *m_p = nullptr, *v_p = nullptr;
+  int adam_step = 0;
+  // state
+  float *H = nullptr, *Yc = nullptr, *Xdelta = nullptr;
+  // work buffers
+  float *sp = nullptr, *frames = nullptr, *X1 = nullptr, *X2 = nullptr, *X3 = nullptr, *Ybuf = nullptr, *sig1 = nullptr, *sig2 = nullptr;
+  float *A = nullptr, *Apre = nullptr, *logdm = nullptr, *dmv = nullptr, *gdm = nullptr, *Fin = nullptr, *GFin = nullptr, *GH = nullptr;
+  float *gA = nullptr, *gphi = nullptr, *gdecay = nullptr, *gw = nullptr, *h0 = nullptr, *hm = nullptr, *ghm = nullptr, *gh0 = nullptr;
+  float2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr, *Hf = nullptr;
+  float *Mabs = nullptr, *phim = nullptr, *gM = nullptr;
+  double* partial = nullptr; float* losses = nullptr;
+  float *rir = nullptr, *Rc = nullptr;
+
+  template <typename Tp> int dalloc(Tp** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(Tp)) != hipSuccess) return 1;
+    if (hipMemset(q, 0, n * sizeof(Tp)) != hipSuccess) return 1;
+    allocs.push_back(q); *p = (Tp*)q;
+    return 0;
+  }
+  ~BlindOp() { for (void* q : allocs) (void)hipFree(q); }
+
+  // ---- primitive routines (all batched over U, on stream st) ----
+  void gemm(const float* Am, int ldA, long long sA, const float* Bt, int ldB, bool tB, float* C, int ldC, long long sC, int M, int N, int Kk, float alpha, int batch) {
+    IgemmParams p; std::memset(&p, 0, sizeof(p));
+    p.A0 = Am; p.ldA0 = ldA; p.sA = sA; p.Bt = Bt; p.ldB = ldB; p.C = C; p.ldC = ldC; p.sC = sC; p.M = M; p.N = N; p.Cin = Kk;
+    p.alpha = alpha; p.out_scale = 1.f; p.H = 1; p.W = 1; p.rows_per_batch = 1;
+    launch_igemm(p, 1, false, tB, batch, st);
+  }
+  // X[u][t][:] = scale * STFT frames of s (frame t starts at sample 128 t - P), Tn frames
+  void stft(const float* s, int Ls, int P, int Tn, float scale, float* X, const float* add = nullptr, float add_scale = 0.f) {
+    const int Lpad = ((Tn - 1) * HOP + WIN + 3) / 4 * 4;
+    hipLaunchKernelGGL(pad_const_kernel, dim3(gridf((long long)U * Lpad)), dim3(256), 0, st, s, sp, U, Ls, P, Lpad, add, add_scale);
+    gemm(sp, HOP, Lpad, Bf, WIN, false, X, LDSP, (long long)Tn * LDSP, Tn, LDSP, WIN, scale, U);
+  }
+  // y[u][s] = sum_t frames_t[s + Q - 128 t] * inv_env[s + Q],  frames = scale * iDFT(Y) * window
+  void istft(const float* Y, int Tn, int Q, const float* inv_env, int Ls, float scale, float* y) {
+    gemm(Y, LDSP, 0, Bi, LDSP, false, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
+    launch_ola(frames, WIN, Tn, WIN, HOP, inv_env, y, U, Ls, Q, nullptr, nullptr, nullptr, st);
+  }
+  // adjoint of stft: g_s from G_X
+  void stft_adj(const float* GX, int Ls, int P, int Tn, float scale, float* gs) {
+    gemm(GX, LDSP, 0, Bf, WIN, true, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
+    launch_ola(frames, WIN, Tn, WIN, HOP, ones, gs, U, Ls, P, nullptr, nullptr, nullptr, st);
+  }
+  // adjoint of istft: G_Y from g_y
+  void istft_adj(const float* gy, int Tn, int Q, const float* inv_env, int Ls, float scale, float* GY) {
+    launch_ola_adj(gy, U, Ls, Q, Tn, WIN, HOP, inv_env, nullptr, frames, WIN, st);
+    gemm(frames, WIN, 0, Bi, LDSP, true, GY, LDSP, 0, U * Tn, LDSP, WIN, scale, 1);
+  }
+  void fft(const float2* x, float2* tmp, float2* X, int sign, float scale) {
+    hipLaunchKernelGGL(fft_stage1_kernel, dim3(cdiv(N2, 256), U), dim3(256), 0, st, x, tmp, (const float2*)w101, (const float2*)twN, sign);
+    hipLaunchKernelGGL(fft_stage2_kernel, dim3(cdiv(N2, 256), U), dim3(256), 0, st, (const float2*)tmp, X, (const float2*)w256, sign, scale);
+  }
+  DesignTabs tabs() const { DesignTabs t; t.idx = idx; t.frac = frac; t.corr = corr; t.dpm = dpm; return t; }
+
+  void design() {
+    hipLaunchKernelGGL(design_dm_kernel, dim3(cdiv(U * Nf * K, 256)), dim3(256), 0, st, (const float*)decay, (const float*)wts, logdm, dmv, U, E, NB, Nf);
+    hipLaunchKernelGGL(design_A_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)logdm, tabs(), A, Apre, U, K, Nf);
+  }
+  // H = cons(A * exp(j phi))   (reference :333-351)
+  void cons_forward() {
+    hipLaunchKernelGGL(h0_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)A, (const float*)phi, Fin, U, Nf);
+    istft(Fin, Nf + 2, WIN, env_c, Lh, 1.f, h0);
+    const long long tot = (long long)U * N2;
+    hipLaunchKernelGGL(mp_pack_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float*)h0, Lh, c1, U);
+    fft(c1, c2, Hf, -1, 1.f);
+    hipLaunchKernelGGL(mp_logabs_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)Hf, Mabs, c1, tot);
+    fft(c1, c2, c3, -1, 1.f);
+    hipLaunchKernelGGL(mp_window_kernel, dim3(gridf(tot)), dim3(256), 0, st, c3, tot);
+    fft(c3, c2, c1, +1, 1.f / N2);
+    hipLaunchKernelGGL(mp_phase_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)c1, (const float*)Mabs, phim, c3, tot);
+    fft(c3, c2, c1, +1, 1.f / N2);
+    hipLaunchKernelGGL(mp_out_kernel, dim3(gridf((long long)U * Lm)), dim3(256), 0, st, (const float2*)c1, hm, Lm, U, (float)(WIN / (HOP * 2.0)));
+    stft(hm, Lm, WIN - HOP, Nf, 1.f, H);          // frames 1..Nf of the centred STFT: frame k starts at 128 (k+1) - 512
+  }
+  // G_Fin from G_H
+  void cons_backward(const float* GHin) {
+    stft_adj(GHin, Lm, WIN - HOP, Nf, 1.f, ghm);
+    const long long tot = (long long)U * N2;
+    hipLaunchKernelGGL(mpb_pack_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float*)ghm, Lm, c1, U);
+    fft(c1, c2, c3, -1, 1.f / N2);                                   // GZ
+    hipLaunchKernelGGL(mpb_z_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)c3, (const float*)Mabs, (const float*)phim, gM, c1, tot);
+    fft(c1, c2, c3, -1, 1.f);
+    hipLaunchKernelGGL(mp_window_kernel, dim3(gridf(tot)), dim3(256), 0, st, c3, tot);
+    fft(c3, c2, c1, +1, 1.f / N2);                                   // hilbert(g_phi)
+    hipLaunchKernelGGL(mpb_h_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)c1, (const float*)Mabs, (const float*)gM, (const float2*)Hf, c3, tot);
+    fft(c3, c2, c1, +1, 1.f);                                        // N2 * IFFT(GH)
+    hipLaunchKernelGGL(mpb_out_kernel, dim3(gridf((long long)U * Lh)), dim3(256), 0, st, (const float2*)c1, gh0, Lh, U);
+    istft_adj(gh0, Nf + 2, WIN, env_c, Lh, 1.f, GFin);
+  }
+  void update_H() { design(); cons_forward(); }
+  void fir(const float* X, long long xs, int Tn, float* Y) {
+    hipLaunchKernelGGL(fir_kernel_sb, dim3(gridf((long long)U * Tn * FB)), dim3(256), 0, st, X, xs, (const float*)H, Y, U, Tn, Nf);
+  }
+  // loss_u (+)= kappa * sum |Rc - comp(Xh)|^2, G optional
+  void comp_loss(const float* Rcx, const float* Xh, float* G, int Tn, float weight, float* out, int accumulate) {
+    const float kappa = weight / (float)Tn;
+    const int nblk = 64;
+    hipLaunchKernelGGL(comp_loss_kernel, dim3(nblk, U), dim3(256), 0, st, Rcx, Xh, G, partial, Tn, kappa, c.comp);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(U), dim3(32), 0, st, (const double*)partial, nblk, kappa, out, accumulate);
+  }
+  void degrade(const float* x, float* y) {
+    stft(x, L, WIN, T, 1.f / norm, X1);
+    fir(X1, (long long)T * LDSP, T, Ybuf);
+    istft(Ybuf, T, WIN + WIN / 2, env_T, L, norm, y);
+  }
+  void time_rir(float* out) {
+    fir(Xdelta, 0, Td, Ybuf);
+    istft(Ybuf, Td, WIN + WIN / 2, env_d, Lr, norm, out);
+  }
+};
+
+static void host_tables(BlindOp* o, std::vector<float>& Bf, std::vector<float>& Bi, std::vector<float>& w, double& norm2) {
+  Bf.assign((size_t)LDSP * WIN, 0.f); Bi.assign((size_t)WIN * LDSP, 0.f); w.resize(WIN);
+  norm2 = 0;
+  for (int n = 0; n < WIN; ++n) { const double v = 0.5 - 0.5 * std::cos(2.0 * PI * n / WIN); w[n] = (float)v; norm2 += (double)(float)v * (double)(float)v; }
+  for (int f = 0; f < FB; ++f)
+    for (int n = 0; n < WIN; ++n) {
+      const double ang = 2.0 * PI * (double)(((long long)f * n) % NFFT) / NFFT;
+      Bf[((size_t)f * 2 + 0) * WIN + n] = (float)(w[n] * std::cos(ang));
+      Bf[((size_t)f * 2 + 1) * WIN + n] = (float)(-w[n] * std::sin(ang));
+      const double cf = (f == 0 || f == NFFT / 2) ? 1.0 : 2.0;
+      Bi[(size_t)n * LDSP + f * 2 + 0] = (float)(cf / NFFT * std::cos(ang) * w[n]);
+      Bi[(size_t)n * LDSP + f * 2 + 1] = (float)(-cf / NFFT * std::sin(ang) * w[n]);
+    }
+}
+static std::vector<float> inv_env_of(const std::vector<float>& w, int Tn) {
+  std::vector<double> e((size_t)(Tn - 1) * HOP + NFFT, 0.0);
+  for (int t = 0; t < Tn; ++t) for (int n = 0; n < WIN; ++n) e[(size_t)t * HOP + n] += (double)w[n] * (double)w[n];
+  std::vector<float> r(e.size());
+  for (size_t i = 0; i < e.size(); ++i) r[i] = e[i] > 1e-11 ? (float)(1.0 / (double)(float)e[i]) : 0.f;
+  return r;
+}
+#define UP(dst, vec) do { if (o->dalloc(&o->dst, (vec).size())) { set_error("hipMalloc failed"); delete o; return BUDDY_ERR_HIP; } \
+  if (hipMemcpy(o->dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); delete o; return BUDDY_ERR_HIP; } } while (0)
+#define DA(dst, n) do { if (o->dalloc(&o->dst, (size_t)(n))) { set_error("hipMalloc failed"); delete o; return BUDDY_ERR_HIP; } } while (0)
+
+int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
+  if (cfg.n_fft != NFFT || cfg.win != WIN || cfg.hop != HOP) { set_error("operator STFT must be 1024/512/128"); return BUDDY_ERR_ARG; }
+  if (cfg.num_knots < 3 || cfg.num_knots > 64 || cfg.Nf < 4 || cfg.E < 1) { set_error("bad operator config"); return BUDDY_ERR_ARG; }
+  BlindOp* o = new BlindOp();
+  o->c = cfg; o->U = U; o->L = L; o->Nf = cfg.Nf; o->E = cfg.E; o->K = cfg.num_knots; o->NB = cfg.num_knots - 2;
+  o->T = 1 + (L + WIN) / HOP;
+  o->Lh = HOP * cfg.Nf; o->Lm = o->Lh + HOP; o->Lr = o->Lh + 1024; o->Td = 1 + (o->Lr + WIN) / HOP;
+  if (2 * o->Lm != N2) { set_error("Nf must be 100 (25856-point minimum-phase FFT)"); delete o; return BUDDY_ERR_ARG; }
+  std::vector<float> Bf, Bi, w; double norm2;
+  host_tables(o, Bf, Bi, w, norm2);
+  o->norm = (float)std::sqrt((double)(float)norm2);
+  UP(Bf, Bf); UP(Bi, Bi);
+  std::vector<float> eT = inv_env_of(w, o->T), ed = inv_env_of(w, o->Td), ec = inv_env_of(w, cfg.Nf + 2);
+  UP(env_T, eT); UP(env_d, ed); UP(env_c, ec);
+  std::vector<float> ones((size_t)((o->T > o->Td ? o->T : o->Td) + 8) * HOP + NFFT, 1.f); UP(ones, ones);
+  // interpolation tables (torchcde LinearInterpolation semantics: bucketize(q, knots) - 1, clamped)
+  std::vector<int> idx(FB); std::vector<float> frac(FB);
+  for (int f = 0; f < FB; ++f) {
+    const float q = (float)f * (float)cfg.sample_rate / (float)NFFT;      // rfftfreq
+    int b = 0;
+    while (b < o->K && cfg.knots[b] < q) ++b;                              // bucketize (right = False): first index with knot >= q
+    int i0 = b - 1; if (i0 < 0) i0 = 0; if (i0 > o->K - 2) i0 = o->K - 2;
+    idx[f] = i0; frac[f] = (q - cfg.knots[i0]) / (cfg.knots[i0 + 1] - cfg.knots[i0]);
+  }
+  UP(idx, idx); UP(frac, frac);
+  std::vector<float> corr(cfg.Nf, 1.f);
+  { const int Kc = WIN / HOP - 1; double ws = 0; for (int n = 0; n < WIN; ++n) ws += w[n];
+    for (int k = 0; k < Kc; ++k) { double s = 0; for (int n = (Kc - k) * HOP; n < WIN; ++n) s += w[n]; corr[k] = (float)((float)ws / (float)s); } }
+  UP(corr, corr);
+  // FFT twiddles (double precision tables)
+  std::vector<float2> w101(F1), w256(F2), tw((size_t)F2 * F1);
+  for (int i = 0; i < F1; ++i) w101[i] = make_float2((float)std::cos(2 * PI * i / F1), (float)(std::sin(2 * PI * i / F1)));
+  for (int i = 0; i < F2; ++i) w256[i] = make_float2((float)std::cos(2 * PI * i / F2), (float)(std::sin(2 * PI * i / F2)));
+  for (int n2 = 0; n2 < F2; ++n2) for (int k1 = 0; k1 < F1; ++k1) {
+    const double a = 2 * PI * (double)((long long)n2 * k1) / N2;
+    tw[(size_t)n2 * F1 + k1] = make_float2((float)std::cos(a), (float)(std::sin(a)));
+  }
+  UP(w101, w101); UP(w256, w256); UP(twN, tw);
+  const int U_ = U, Nf = cfg.Nf, Td = o->Td;
+  const int T = o->T > Td ? o->T : Td;            // work buffers hold either the signal (T frames) or the time-RIR (Td frames)
+  const int Lmax = L > o->Lr ? L : o->Lr;
+  const size_t specT = (size_t)U_ * T * LDSP + 8, specH = (size_t)U_ * (Nf + 2) * LDSP + 8;
+  DA(decay, U_ * o->E * o->NB); DA(wts, U_ * o->E * o->NB); DA(phi, (size_t)U_ * Nf * FB);
+  DA(m_d, U_ * o->E * o->NB); DA(v_d, U_ * o->E * o->NB); DA(m_w, U_ * o->E * o->NB); DA(v_w, U_ * o->E * o->NB);
+  DA(m_p, (size_t)U_ * Nf * FB); DA(v_p, (size_t)U_ * Nf * FB);
+  DA(H, specH); DA(Yc, specT); DA(Xdelta, (size_t)Td * LDSP + 8);
+  DA(sp, (size_t)U_ * ((size_t)(T + 4) * HOP + NFFT)); DA(frames, (size_t)U_ * (T + 2) * WIN);
+  DA(X1, specT); DA(X2, specT); DA(X3, specT); DA(Ybuf, specT); DA(sig1, (size_t)U_ * (Lmax + 8)); DA(sig2, (size_t)U_ * (Lmax + 8));
+  DA(A, (size_t)U_ * Nf * FB); DA(Apre, (size_t)U_ * Nf * FB); DA(logdm, U_ * Nf * o->K); DA(dmv, U_ * Nf * o->K); DA(gdm, U_ * Nf * o->K);
+  DA(Fin, specH); DA(GFin, specH); DA(GH, specH); DA(gA, (size_t)U_ * Nf * FB); DA(gphi, (size_t)U_ * Nf * FB);
+  DA(gdecay, U_ * o->E * o->NB); DA(gw, U_ * o->E * o->NB);
+  DA(h0, (size_t)U_ * o->Lh); DA(hm, (size_t)U_ * o->Lm); DA(ghm, (size_t)U_ * o->Lm); DA(gh0, (size_t)U_ * o->Lh);
+  DA(c1, (size_t)U_ * N2); DA(c2, (size_t)U_ * N2); DA(c3, (size_t)U_ * N2); DA(Hf, (size_t)U_ * N2);
+  DA(Mabs, (size_t)U_ * N2); DA(phim, (size_t)U_ * N2); DA(gM, (size_t)U_ * N2);
+  DA(partial, (size_t)U_ * 64); DA(losses, (size_t)U_ * 4);
+  DA(rir, (size_t)U_ * o->Lr); DA(Rc, (size_t)U_ * Td * LDSP + 8);
+  DA(dpm, (size_t)Nf * FB);
+  // direct-path magnitude correction |STFT(2 delta)|[:, 1:] (reference :201-205) and STFT of the unit impulse, computed on device
+  {
+    const int saveU = o->U; o->U = 1; o->st = nullptr;
+    std::vector<float> imp((size_t)o->Lr, 0.f);
+    imp[0] = (float)(WIN / (HOP * 2.0));
+    float* tmp_sig = o->rir;              // reuse as staging (Lr floats per utterance)
+    HIPCHK(hipMemcpy(tmp_sig, imp.data(), (size_t)o->Lh * 4, hipMemcpyHostToDevice));
+    // raw centred STFT of h (length Lh): frame t starts at 128 t - 512; columns 1..Nf
+    o->stft(tmp_sig, o->Lh, WIN - HOP, Nf, 1.f, o->GH);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> hs((size_t)Nf * LDSP);
+    HIPCHK(hipMemcpy(hs.data(), o->GH, hs.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> dpm((size_t)Nf * FB);
+    for (int k = 0; k < Nf; ++k) for (int f = 0; f < FB; ++f) {
+      const float re = hs[(size_t)k * LDSP + 2 * f], im = hs[(size_t)k * LDSP + 2 * f + 1];
+      dpm[(size_t)k * FB + f] = std::sqrt(re * re + im * im);
+    }
+    HIPCHK(hipMemcpy(o->dpm, dpm.data(), dpm.size() * 4, hipMemcpyHostToDevice));
+    imp[0] = 1.f;
+    HIPCHK(hipMemcpy(tmp_sig, imp.data(), (size_t)o->Lr * 4, hipMemcpyHostToDevice));
+    o->stft(tmp_sig, o->Lr, WIN, Td, 1.f / o->norm, o->Xdelta);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(o->GH, 0, specH * 4));
+    o->U = saveU;
+  }
+  *out = o;
+  return BUDDY_OK;
+}
+void blindop_destroy(BlindOp* o) { delete o; }
+
+int blindop_set_params(BlindOp* o, const float* decay, const float* wts, const float* phases_ref, int reset_adam, hipStream_t st) {
+  o->st = st;
+  const size_t nb = (size_t)o->U * o->E * o->NB * 4;
+  if (decay) HIPCHK(hipMemcpyAsync(o->decay, decay, nb, hipMemcpyDeviceToDevice, st));
+  if (wts) HIPCHK(hipMemcpyAsync(o->wts, wts, nb, hipMemcpyDeviceToDevice, st));
+  if (phases_ref) hipLaunchKernelGGL(transpose_fk_kernel, dim3(gridf((long long)o->U * o->Nf * FB)), dim3(256), 0, st, phases_ref, o->phi, o->U, o->Nf, 1);
+  if (reset_adam) {
+    o->adam_step = 0;
+    HIPCHK(hipMemsetAsync(o->m_d, 0, nb, st)); HIPCHK(hipMemsetAsync(o->v_d, 0, nb, st));
+    HIPCHK(hipMemsetAsync(o->m_w, 0, nb, st)); HIPCHK(hipMemsetAsync(o->v_w, 0, nb, st));
+    const size_t np = (size_t)o->U * o->Nf * FB * 4;
+    HIPCHK(hipMemsetAsync(o->m_p, 0, np, st)); HIPCHK(hipMemsetAsync(o->v_p, 0, np, st));
+  }
+  return BUDDY_OK;
+}
+int blindop_get_params(BlindOp* o, float* decay, float* wts, float* phases_ref, hipStream_t st) {
+  o->st = st;
+  const size_t nb = (size_t)o->U * o->E * o->NB * 4;
+  if (decay) HIPCHK(hipMemcpyAsync(decay, o->decay, nb, hipMemcpyDeviceToDevice, st));
+  if (wts) HIPCHK(hipMemcpyAsync(wts, o->wts, nb, hipMemcpyDeviceToDevice, st));
+  if (phases_ref) hipLaunchKernelGGL(transpose_fk_kernel, dim3(gridf((long long)o->U * o->Nf * FB)), dim3(256), 0, st, (const float*)o->phi, phases_ref, o->U, o->Nf, 0);
+  return BUDDY_OK;
+}
+// H from the current parameters; with noise (U, Nf*128 samples): phases := angle(STFT(noise)/norm)[:, 1:], then phases := angle(H)
+int blindop_update_H(BlindOp* o, const float* noise, hipStream_t st) {
+  o->st = st;
+  if (noise) {
+    o->stft(noise, o->Lh, WIN, o->Nf + 1, 1.f / o->norm, o->X1);     // centred frames 0..Nf; we need 1..Nf
+    hipLaunchKernelGGL(unit_phase_kernel, dim3(gridf((long long)o->U * o->Nf * FB)), dim3(256), 0, st, (const float*)o->X1, o->phi, o->U, o->Nf);
+  }
+  o->update_H();
+  if (noise) hipLaunchKernelGGL(angle_kernel, dim3(gridf((long long)o->U * o->Nf * FB)), dim3(256), 0, st, (const float*)o->H, o->phi, o->U, o->Nf);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+int blindop_get_H(BlindOp* o, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(copy_h_kernel, dim3(gridf((long long)o->U * o->Nf * FB)), dim3(256), 0, st, (const float*)o->H, out, o->U, o->Nf);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+int blindop_set_y(BlindOp* o, const float* y, hipStream_t st) {
+  o->st = st;
+  o->stft(y, o->L, WIN, o->T, 1.f / o->norm, o->X1);
+  hipLaunchKernelGGL(compress_kernel, dim3(gridf((long long)o->U * o->T * FB)), dim3(256), 0, st, (const float*)o->X1, o->Yc, (long long)o->U * o->T, o->c.comp);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+int blindop_degrade(BlindOp* o, const float* x, float* y, hipStream_t st) { o->st = st; o->degrade(x, y); HIPCHK(hipGetLastError()); return BUDDY_OK; }
+int blindop_time_rir(BlindOp* o, float* out, hipStream_t st) { o->st = st; o->time_rir(out); HIPCHK(hipGetLastError()); return BUDDY_OK; }
+
+// likelihood: loss_u = w_rec * l2_comp_stft_summean(y, degrade(x_den)), g = d sum_u loss_u / d x_den  (uses the CURRENT H)
+int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* loss, float* g_x, hipStream_t st) {
+  o->st = st;
+  const int U = o->U, T = o->T, L = o->L;
+  o->stft(x_den, L, WIN, T, 1.f / o->norm, o->X1);
+  o->fir(o->X1, (long long)T * LDSP, T, o->Ybuf);
+  o->istft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, o->norm, o->sig1);
+  o->stft(o->sig1, L, WIN, T, 1.f / o->norm, o->X2);
+  o->comp_loss(o->Yc, o->X2, g_x ? o->X3 : nullptr, T, weight, loss, 0);
+  if (g_x) {
+    o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, o->sig2);
+    o->istft_adj(o->sig2, T, WIN + WIN / 2, o->env_T, L, o->norm, o->X2);
+    hipLaunchKernelGGL(fir_adjx_kernel, dim3(gridf((long long)U * T * FB)), dim3(256), 0, st, (const float*)o->X2, (const float*)o->H, o->X3, U, T, o->Nf);
+    o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, g_x);
+  }
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+
+// one gradient evaluation of  rec_loss_params(y, degrade(x_den)) + reg(rir, rir + t_op * noise)  w.r.t. (decay, weights, phases);
+// H is rebuilt from the parameters first (update_H at the top of each optimize_op iteration, reference :83)
+static int param_grads(BlindOp* o, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, bool have_Xd) {
+  const int U = o->U, T = o->T, Td = o->Td, L = o->L, Nf = o->Nf;
+  hipStream_t st = o->st;
+  o->update_H();
+  if (!have_Xd) o->stft(x_den, L, WIN, T, 1.f / o->norm, o->X1);          // X1 = STFT(x_den) stays valid across the iterations
+  // reconstruction term
+  o->fir(o->X1, (long long)T * LDSP, T, o->Ybuf);
+  o->istft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, o->norm, o->sig1);
+  o->stft(o->sig1, L, WIN, T, 1.f / o->norm, o->X2);
+  o->comp_loss(o->Yc, o->X2, o->X3, T, w_rec, o->losses, 0);
+  o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, o->sig2);
+  o->istft_adj(o->sig2, T, WIN + WIN / 2, o->env_T, L, o->norm, o->X2);
+  hipLaunchKernelGGL(fir_gradh_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->X1, (long long)T * LDSP, (const float*)o->X2, o->GH, U, T, Nf, 0);
+  // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach())
+  if (noise) {
+    o->time_rir(o->rir);                                                     // Ybuf = FIR(Xdelta, H) consumed inside
+    o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X3, noise, t_op);      // STFT(rir + t n)
+    hipLaunchKernelGGL(compress_kernel, dim3(gridf((long long)U * Td * FB)), dim3(256), 0, st, (const float*)o->X3, o->Rc, (long long)U * Td, o->c.comp);
+    o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X2);
+    o->comp_loss(o->Rc, o->X2, o->X3, Td, w_reg, o->losses + U, 0);
+    o->stft_adj(o->X3, o->Lr, WIN, Td, 1.f / o->norm, o->sig2);
+    o->istft_adj(o->sig2, Td, WIN + WIN / 2, o->env_d, o->Lr, o->norm, o->X2);
+    hipLaunchKernelGGL(fir_gradh_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->Xdelta, 0LL, (const float*)o->X2, o->GH, U, Td, Nf, 1);
+  }
+  o->cons_backward(o->GH);
+  hipLaunchKernelGGL(h0_bwd_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->GFin, (const float*)o->A, (const float*)o->phi, o->gA, o->gphi, U, Nf);
+  hipLaunchKernelGGL(design_bwd_knots_kernel, dim3(cdiv(U * Nf * o->K, 256)), dim3(256), 0, st, (const float*)o->gA, (const float*)o->Apre, o->tabs(), (const float*)o->dmv, o->gdm, U, o->K, Nf);
+  hipLaunchKernelGGL(design_bwd_params_kernel, dim3(cdiv(U * o->E * o->NB, 256)), dim3(256), 0, st, (const float*)o->gdm, (const float*)o->decay, (const float*)o->wts, o->gdecay, o->gw, U, o->E, o->NB, Nf);
+  return BUDDY_OK;
+}
+
+int blindop_param_grads(BlindOp* o, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, float* g_decay, float* g_wts,
+                        float* g_phases_ref, float* losses, hipStream_t st) {
+  o->st = st;
+  param_grads(o, x_den, noise, t_op, w_rec, w_reg, false);
+  const size_t nb = (size_t)o->U * o->E * o->NB * 4;
+  if (g_decay) HIPCHK(hipMemcpyAsync(g_decay, o->gdecay, nb, hipMemcpyDeviceToDevice, st));
+  if (g_wts) HIPCHK(hipMemcpyAsync(g_wts, o->gw, nb, hipMemcpyDeviceToDevice, st));
+  if (g_phases_ref) hipLaunchKernelGGL(transpose_fk_kernel, dim3(gridf((long long)o->U * o->Nf * FB)), dim3(256), 0, st, (const float*)o->gphi, g_phases_ref, o->U, o->Nf, 0);
+  if (losses) HIPCHK(hipMemcpyAsync(losses, o->losses, (size_t)o->U * 2 * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+
+// n_iters iterations of optimize_op (reference :71-113): update_H, losses, backward, Adam step on [decay, weights, phases], projection.
+// noise: (n_iters, U, Lr) standard normal draws for the RIR regulariser (NULL disables it).
+int blindop_optimize(BlindOp* o, const float* x_den, const float* noise, float t_op, int n_iters, float w_rec, float w_reg, float lr, float b1,
+                     float b2, float wd, hipStream_t st) {
+  o->st = st;
+  const int U = o->U;
+  const long long nb = (long long)U * o->E * o->NB, np = (long long)U * o->Nf * FB;
+  for (int it = 0; it < n_iters; ++it) {
+    param_grads(o, x_den, noise ? noise + (long long)it * U * o->Lr : nullptr, t_op, w_rec, w_reg, it > 0);
+    o->adam_step += 1;
+    const float bc1 = 1.f - std::pow(b1, (float)o->adam_step), bc2s = std::sqrt(1.f - std::pow(b2, (float)o->adam_step));
+    hipLaunchKernelGGL(adam_kernel, dim3(gridf(nb)), dim3(256), 0, st, o->decay, (const float*)o->gdecay, o->m_d, o->v_d, nb, lr, b1, b2, 1e-8f, wd, bc1, bc2s);
+    hipLaunchKernelGGL(adam_kernel, dim3(gridf(nb)), dim3(256), 0, st, o->wts, (const float*)o->gw, o->m_w, o->v_w, nb, lr, b1, b2, 1e-8f, wd, bc1, bc2s);
+    hipLaunchKernelGGL(adam_kernel, dim3(gridf(np)), dim3(256), 0, st, o->phi, (const float*)o->gphi, o->m_p, o->v_p, np, lr, b1, b2, 1e-8f, wd, bc1, bc2s);
+    hipLaunchKernelGGL(project_kernel, dim3(cdiv(U * o->NB, 256)), dim3(256), 0, st, o->decay, o->wts, U, o->E, o->NB, o->c.min_decay, o->c.max_decay,
+                       o->c.w_lo, o->c.w_hi, o->c.clamp_decay, o->c.long2nd);
+  }
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+
+}  // namespace buddy

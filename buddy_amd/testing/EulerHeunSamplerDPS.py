@@ -22,6 +22,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
     def __init__(self, model, diff_params, args):
         super().__init__(model, diff_params, args)
         self.zeta = self.args.tester.posterior_sampling.zeta
+        self._hip_op = False
 
     def initialize_x(self, shape, device, schedule):
         wi = self.args.tester.posterior_sampling.warm_initialization
@@ -35,13 +36,18 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         raise NotImplementedError
 
     def get_likelihood_score(self, x_den, x, t):
-        y_hat = self.operator.degradation(x_den, mode="waveform")
-        rec = self.rec_loss(self.y, y_hat)                        # sum over utterances: gradients decouple per row
+        if self._hip_op:
+            rec = self.operator.hip_rec_loss(x_den)               # fused HIP loss + analytic d/dx_den; autograd continues into the net VJP
+        else:
+            y_hat = self.operator.degradation(x_den, mode="waveform")
+            rec = self.rec_loss(self.y, y_hat)                    # sum over utterances: gradients decouple per row
         rec_grads = torch.autograd.grad(outputs=rec, inputs=x)[0]
         normguide = torch.linalg.vector_norm(rec_grads, dim=-1, keepdim=True) / (self.args.exp.audio_len ** 0.5)
         return self.zeta / (normguide + 1e-8) * rec_grads, rec
 
     def optimize_op(self, x_den, t):
+        if self._hip_op:
+            return self.operator.hip_optimize(x_den, t)           # the whole loop below as one library call (buddy_blindop_optimize)
         ps = self.args.tester.posterior_sampling
         for _ in range(ps.blind_hp.op_updates_per_step):
             for p in self.operator.params:
@@ -117,7 +123,10 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         self.operator = operator
         self.y = y
         self.rec_loss = get_loss(ps.rec_loss, operator=self.operator)
-        if blind:
+        self._hip_op = bool(blind and hasattr(operator, "hip_optimize"))
+        if self._hip_op:
+            operator.hip_bind(y, ps)
+        elif blind:
             self.rec_loss_params = get_loss(ps.rec_loss_params, operator=self.operator)
             self.optimizer_operator = torch.optim.Adam(self.operator.params + self.operator.params_phases, lr=ps.blind_hp.lr_op,
                                                        weight_decay=ps.blind_hp.weight_decay, betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))

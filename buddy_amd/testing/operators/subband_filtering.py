@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from ... import _lib
 from ...utils import reverb_utils
 from .shared import Operator
 from ._stft import OperatorSTFT
@@ -96,10 +97,41 @@ class SubbandFiltering(Operator, OperatorSTFT):
         assert self.H.shape[-2] == self.n_fft // 2 + 1 and self.H.shape[-1] == self.Nf
 
 
+class _HipRecLoss(torch.autograd.Function):
+    """sum_u weight * l2_comp_stft_summean(y_u, degrade(x_den_u)) with the analytic gradient from the HIP operator."""
+
+    @staticmethod
+    def forward(ctx, x_den, op, weight):
+        lib = _lib.require_gpu()
+        x = x_den.contiguous().float()
+        loss = torch.empty(op.U, device=x.device)
+        g = torch.empty_like(x)
+        _lib.check(lib.buddy_blindop_rec_loss_grad(op._h, _lib.ptr(x), float(weight), _lib.ptr(loss), _lib.ptr(g), _lib.stream_ptr()))
+        ctx.save_for_backward(g)
+        op.last_rec_per_utt = loss
+        return loss.sum()
+
+    @staticmethod
+    def backward(ctx, gout):
+        g, = ctx.saved_tensors
+        return gout * g, None, None
+
+
 class BlindSubbandFiltering(SubbandFiltering):
-    def __init__(self, op_hp, sample_rate, magnitude_distance=True, H_cplx=False, num_utts=1, noise=None, device=None):
+    def __new__(cls, op_hp, sample_rate, *a, backend=None, length=None, device=None, **k):
+        if cls is BlindSubbandFiltering:
+            dev = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+            use_hip = (backend == "hip") or (backend is None and length is not None and str(dev).startswith("cuda"))
+            if use_hip:
+                return super().__new__(BlindSubbandFilteringHIP)
+        return super().__new__(cls)
+
+    def __init__(self, op_hp, sample_rate, magnitude_distance=True, H_cplx=False, num_utts=1, noise=None, device=None, backend=None,
+                 length=None):
         """``num_utts``: utterances handled by this operator object (per-utterance parameters).  ``noise``: optional list
-        of per-utterance noise sources with ``rand(shape)`` / ``randn(shape)`` (parity runs); default torch RNG."""
+        of per-utterance noise sources with ``rand(shape)`` / ``randn(shape)`` (parity runs); default torch RNG.
+        ``length`` (signal length in samples) + a CUDA device selects the hand-written HIP backend
+        (``BlindSubbandFilteringHIP``); ``backend="torch"`` forces this torch-op implementation."""
         super().__init__(op_hp, sample_rate, device=device)
         self.U = int(num_utts)
         self.noise = noise
@@ -260,3 +292,155 @@ class BlindSubbandFiltering(SubbandFiltering):
             h = torch.cat([first, h[..., 1:]], dim=-1)
         X_rec = self.stft(h)[..., 1:-1]
         return X_rec[..., :L]
+
+
+class BlindSubbandFilteringHIP(BlindSubbandFiltering):
+    """Same interface, hand-written HIP backend (``buddy_blindop_*`` in ``include/buddy_hip.h``): parameters, Adam state, the
+    filter H and every intermediate live on the device inside the library handle; forward and analytic backward of
+    design_filter -> cons (iSTFT, minimum phase, STFT) -> subband FIR -> iSTFT -> STFT -> compressed-spectrum loss run as fused
+    kernels, a whole ``optimize_op`` (reference EulerHeunSamplerDPS.py:71-113) is ONE library call."""
+
+    def __init__(self, op_hp, sample_rate, magnitude_distance=True, H_cplx=False, num_utts=1, noise=None, device=None, backend=None,
+                 length=None):
+        SubbandFiltering.__init__(self, op_hp, sample_rate, device=device)
+        import ctypes as C
+        assert length is not None, "the HIP backend needs the signal length"
+        assert op_hp.fix_EQ_extremes and op_hp.minimum_phase and op_hp.fix_direct_path and not op_hp.strictly_decreasing_decay
+        self.U, self.noise, self.length = int(num_utts), noise, int(length)
+        self.Amin, self.Amax = op_hp.Amin, op_hp.Amax
+        knots = [float(f) for f in op_hp.EQ_freqs]
+        self.num_bands = len(knots) - 2
+        if op_hp.init_single_value:
+            t60 = [self.num_bands * [float(t)] for t in op_hp.init_params.T60_breakpoints]
+            wts = [self.num_bands * [float(w)] for w in op_hp.init_params.multiexp_weighting]
+        else:
+            t60, wts = op_hp.init_params.T60_breakpoints, op_hp.init_params.multiexp_weighting
+        frame_rate = self.sample_rate / op_hp.hop
+        decay = 6.908 / (torch.tensor(t60, dtype=torch.float32) * frame_rate)
+        self.num_exponentials = decay.shape[0]
+        self.max_decay = 6.908 / (op_hp.T60min * frame_rate)
+        self.min_decay = 6.908 / (op_hp.T60max * frame_rate)
+        self.comp = None              # compression exponent fixed at hip_bind (losses) -- default of the shipped configs
+        lib = _lib.require_gpu()
+        h = C.c_void_p()
+        kn = (C.c_float * len(knots))(*knots)
+        _lib.check(lib.buddy_blindop_create(self.U, self.length, int(op_hp.Nf), int(self.num_exponentials), len(knots), kn, int(sample_rate),
+                                            float(0.667), float(self.min_decay), float(self.max_decay), float(10 ** (self.Amin / 20)),
+                                            float(10 ** (self.Amax / 20)), int(bool(op_hp.clamp_decay)),
+                                            int(bool(op_hp.enforce_long_decay_in_second_exponential)), C.byref(h)))
+        self._h = h
+        self._comp_created = 0.667
+        d0 = decay.unsqueeze(0).repeat(self.U, 1, 1).to(self.device).contiguous()
+        w0 = torch.tensor(wts, dtype=torch.float32).unsqueeze(0).repeat(self.U, 1, 1).to(self.device).contiguous()
+        with torch.no_grad():
+            ph = (self._rand((self.n_fft // 2 + 1, self.Nf)) * 2 * np.pi - np.pi).contiguous()
+        _lib.check(lib.buddy_blindop_set_params(self._h, _lib.ptr(d0), _lib.ptr(w0), _lib.ptr(ph), 1, _lib.stream_ptr()))
+        self.last_rec_per_utt = None
+        if op_hp.init_phases == "random_coherent":
+            self.update_H(use_noise=True)
+        elif op_hp.init_phases == "random":
+            self.update_H()
+        else:
+            raise NotImplementedError("This is not implemented yet")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None:
+                _lib.load().buddy_blindop_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- state views (fresh device copies in the reference layout) ----
+    def _get(self):
+        E, NB, F = self.num_exponentials, self.num_bands, self.n_fft // 2 + 1
+        d = torch.empty(self.U, E, NB, device=self.device); w = torch.empty_like(d)
+        p = torch.empty(self.U, F, self.Nf, device=self.device)
+        _lib.check(_lib.load().buddy_blindop_get_params(self._h, _lib.ptr(d), _lib.ptr(w), _lib.ptr(p), _lib.stream_ptr()))
+        return d, w, p
+
+    @property
+    def params(self):
+        d, w, _ = self._get()
+        return [d, w]
+
+    @property
+    def params_phases(self):
+        return [self._get()[2]]
+
+    @property
+    def H(self):
+        out = torch.empty(self.U, self.n_fft // 2 + 1, self.Nf, 2, device=self.device)
+        _lib.check(_lib.load().buddy_blindop_get_H(self._h, _lib.ptr(out), _lib.stream_ptr()))
+        return torch.view_as_complex(out)
+
+    @H.setter
+    def H(self, v):
+        if v is not None:
+            raise NotImplementedError("H is owned by the HIP operator")
+
+    def set_params(self, decay=None, weights=None, phases=None, reset_adam=False):
+        c = lambda t: None if t is None else t.to(self.device).float().contiguous()
+        d, w, p = c(decay), c(weights), c(phases)
+        _lib.check(_lib.load().buddy_blindop_set_params(self._h, _lib.ptr(d), _lib.ptr(w), _lib.ptr(p), int(reset_adam), _lib.stream_ptr()))
+
+    def update_H(self, rir=None, H=None, use_noise=False, noise=None, phases=None):
+        if rir is not None or H is not None:
+            raise NotImplementedError("informed H is the torch SubbandFiltering operator")
+        if phases is not None:
+            self.set_params(phases=phases)
+        n = None
+        if use_noise:
+            n = (noise if noise is not None else self._randn((self.length_rir,))).to(self.device).float().contiguous()
+        _lib.check(_lib.load().buddy_blindop_update_H(self._h, _lib.ptr(n), _lib.stream_ptr()))
+
+    def project_params(self):
+        pass    # done inside buddy_blindop_optimize after every Adam step
+
+    def degradation(self, x, mode="waveform", H=None, detach_operator=False):
+        assert mode == "waveform" and H is None
+        squeeze = x.dim() == 1
+        xx = (x.unsqueeze(0) if squeeze else x).contiguous().float()
+        y = torch.empty_like(xx)
+        _lib.check(_lib.load().buddy_blindop_degrade(self._h, _lib.ptr(xx), _lib.ptr(y), _lib.stream_ptr()))
+        return y.squeeze(0) if squeeze else y
+
+    def get_time_RIR(self, excitation=None, H=None):
+        assert excitation is None and H is None
+        out = torch.empty(self.U, self.length_rir + 1024, device=self.device)
+        _lib.check(_lib.load().buddy_blindop_time_rir(self._h, _lib.ptr(out), _lib.stream_ptr()))
+        return out.squeeze(0) if self.U == 1 else out
+
+    # ---- sampler fast paths ----
+    def hip_bind(self, y, ps):
+        """cache comp(STFT(y)); read loss weights / compression from the posterior_sampling config"""
+        for l in (ps.rec_loss, ps.rec_loss_params, ps.RIR_noise_regularization.loss):
+            assert l.name == "l2_comp_stft_summean" and abs(l.compression_factor - self._comp_created) < 1e-9, \
+                "HIP operator supports l2_comp_stft_summean with compression_factor 0.667"
+        self.w_rec = float(ps.rec_loss.get("weight", 1.0))
+        self.w_rec_params = float(ps.rec_loss_params.get("weight", 1.0))
+        self.w_reg = float(ps.RIR_noise_regularization.loss.get("weight", 1.0)) if ps.RIR_noise_regularization.use else None
+        self.reg = ps.RIR_noise_regularization
+        self.hp = ps.blind_hp
+        yy = y.contiguous().float()
+        _lib.check(_lib.load().buddy_blindop_set_y(self._h, _lib.ptr(yy), _lib.stream_ptr()))
+        self.set_params(reset_adam=True)          # fresh Adam state, like constructing torch.optim.Adam in predict_conditional
+
+    def hip_rec_loss(self, x_den):
+        return _HipRecLoss.apply(x_den, self, self.w_rec)
+
+    def hip_optimize(self, x_den, t):
+        n_it = int(self.hp.op_updates_per_step)
+        noise = None
+        if self.w_reg is not None:
+            Lr = self.length_rir + 1024
+            if self.noise is None:
+                noise = torch.randn(n_it, self.U, Lr).to(self.device)
+            else:
+                noise = torch.stack([torch.stack([n.randn((Lr,)) for n in self.noise]) for _ in range(n_it)]).to(self.device)
+            noise = noise.contiguous()
+        t_op = max(min(float(t), self.reg.crop_sigma_max), self.reg.crop_sigma_min)
+        xd = x_den.contiguous().float()
+        _lib.check(_lib.load().buddy_blindop_optimize(self._h, _lib.ptr(xd), _lib.ptr(noise), float(t_op), n_it, self.w_rec_params,
+                                                      float(self.w_reg or 0.0), float(self.hp.lr_op), float(self.hp.beta1), float(self.hp.beta2),
+                                                      float(self.hp.weight_decay), _lib.stream_ptr()))

@@ -39,6 +39,7 @@ class Tester:
         self.sampler = instantiate(args.tester.sampler, self.network, self.diff_params, self.args)
         self.paths = {}
         self.results = []
+        self.blind_backend = None      # None: HIP operator on a GPU; "torch" forces the torch-op implementation
 
     # ---- checkpoints (reference :34-98): the EMA weights are what gets loaded ------------------------------------
     def load_checkpoint(self, path):
@@ -92,7 +93,8 @@ class Tester:
             operator = operator_ref
             if blind:
                 assert self.args.tester.blind_dereverberation.operator == "subband_filtering"
-                operator = BlindSubbandFiltering(op_hp, sample_rate=self.args.exp.sample_rate, num_utts=len(items), noise=noise, device=self.device)
+                operator = BlindSubbandFiltering(op_hp, sample_rate=self.args.exp.sample_rate, num_utts=len(items), noise=noise, device=self.device,
+                                                 length=seg.shape[-1], backend=self.blind_backend)
                 operator.update_H(use_noise=True)
         return seg, y, operator, rirs
 

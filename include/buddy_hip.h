@@ -91,6 +91,32 @@ int buddy_row_moments(const float* x, double* out, int B, int L, void* stream);
  * correlation (its transpose) for the VJP. */
 int buddy_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, void* stream);
 
+/* ---- blind subband-filtering reverb operator, batched over U utterances; replaces testing/operators/subband_filtering.py
+ * (BlindSubbandFiltering :142-351 incl. SubbandFiltering :8-136), utils/reverb_utils.py:3-23, utils/losses.py:59-64 and the
+ * torch.optim.Adam loop of EulerHeunSamplerDPS.optimize_op (testing/EulerHeunSamplerDPS.py:71-113) with hand-written
+ * forward + analytic backward kernels.  STFT is fixed to NFFT 1024 / win 512 / hop 128 (conf/tester/*.yaml op_hp).
+ * Tensor shapes follow the reference: decay/weights (U,E,bands), phases (U,513,Nf), H (U,513,Nf) complex64 interleaved. ---- */
+int buddy_blindop_create(int U, int L, int Nf, int E, int num_knots, const float* knots_hz /*host*/, int sample_rate, float compression,
+                         float min_decay, float max_decay, float w_lo, float w_hi, int clamp_decay, int long_second, void** handle);
+int buddy_blindop_destroy(void* handle);
+int buddy_blindop_set_params(void* handle, const float* decay, const float* weights, const float* phases, int reset_adam, void* stream);
+int buddy_blindop_get_params(void* handle, float* decay, float* weights, float* phases, void* stream);
+/* update_H (:253-285): H = cons(A exp(j phases)); noise != NULL (U, 128*Nf samples) = use_noise=True (phases := angle(H)). */
+int buddy_blindop_update_H(void* handle, const float* noise, void* stream);
+int buddy_blindop_get_H(void* handle, float* H_out, void* stream);
+int buddy_blindop_set_y(void* handle, const float* y /*(U,L)*/, void* stream);            /* caches comp(STFT(y)) for the losses */
+int buddy_blindop_degrade(void* handle, const float* x, float* y, void* stream);           /* degradation (:82-101) with the current H */
+int buddy_blindop_time_rir(void* handle, float* rir /*(U, 128*Nf+1024)*/, void* stream);   /* get_time_RIR (:103-113) */
+/* loss[u] = weight * l2_comp_stft_summean(y_u, degrade(x_den_u)); g_x = d sum_u loss / d x_den (NULL to skip) */
+int buddy_blindop_rec_loss_grad(void* handle, const float* x_den, float weight, float* loss, float* g_x, void* stream);
+/* one gradient evaluation of optimize_op's objective (H rebuilt from the parameters first); losses = [rec (U), reg (U)] */
+int buddy_blindop_param_grads(void* handle, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, float* g_decay,
+                              float* g_weights, float* g_phases, float* losses, void* stream);
+/* n_iters iterations of optimize_op: update_H, rec + RIR-noise losses, backward, Adam on [decay, weights, phases], projection.
+ * noise: (n_iters, U, 128*Nf+1024) N(0,1) draws (NULL = no regulariser) */
+int buddy_blindop_optimize(void* handle, const float* x_den, const float* noise, float t_op, int n_iters, float w_rec, float w_reg, float lr,
+                           float beta1, float beta2, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,7 @@ def test_library_exports_declared_symbols():
     from buddy_amd import _lib
     lib = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "buddy_hip.h")).read()
-    declared = set(re.findall(r"\b(buddy_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(buddy_[A-Za-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.EXPORTED), declared ^ set(_lib.EXPORTED)
     for name in declared:
         assert hasattr(lib, name)
