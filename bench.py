@@ -194,8 +194,8 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.buddy_prof_enable(0)
     log(f"timed region done: {elapsed:.3f} s")
-    ms = (C.c_double * 2)(); fl = (C.c_double * 2)(); ln = (C.c_longlong * 2)()
-    _lib.check(lib.buddy_prof_collect(ms, fl, ln))
+    ms = (C.c_double * 2)(); fl = (C.c_double * 2)(); ln = (C.c_longlong * 2)(); by = (C.c_double * 2)()
+    _lib.check(lib.buddy_prof_collect(ms, fl, ln, by))
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -215,13 +215,20 @@ def main():
     if rank == 0:
         n_utt_steps = world * B * a.steps
         conv_tf = fl[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this same command
+        # (tools/pmc_summary.py -> profiles/*_conv_traffic_pmc.json); counters cannot be read from inside the process
+        traffic, traffic_src = None, None
+        tp = os.path.join(ROOT, "profiles", "r01b_conv_traffic_pmc.json")
+        if os.path.exists(tp) and B == 8 and a.length == 64000:
+            traffic = json.load(open(tp))["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01b_conv_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH x2 gfx950 correction)"
         res = {
-            "metric": "diffusion steps/sec (4 s@16 kHz utterance, blind Euler-Heun DPS, order 1, 10 operator updates/step)",
+            "metric": f"diffusion steps/sec ({a.length / 16000:g} s@16 kHz utterance, blind Euler-Heun DPS, order 1, 10 operator updates/step)",
             "value": n_utt_steps / elapsed, "unit": "utterance-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seeded clean/RIR/weights; random-init NCSN++ 27.7 M params)",
-            "config": {"workload": f"blind DPS sampler step, B={B} utterances/GPU x {a.length} samples (4 s@16 kHz), T={a.T}-step schedule, "
-                                   f"NCSN++ nf=128 STFT 510/128 (BASELINE.json configs[1])",
+            "config": {"workload": f"blind DPS sampler step, B={B} utterances/GPU x {a.length} samples ({a.length / 16000:g} s@16 kHz), T={a.T}-step schedule, "
+                                   f"NCSN++ nf=128 STFT 510/128" + (" (BASELINE.json configs[1])" if (B == 8 and a.length == 64000) else ""),
                        "batch_per_gpu": B, "length": a.length, "T": a.T, "order": 1, "op_updates_per_step": 10,
                        "parallelism": f"utterance-sharded x{world}"},
             "score_evals_per_s": n_utt_steps / elapsed,   # order 1: one forward+VJP evaluation per utterance-step
@@ -229,7 +236,8 @@ def main():
             "gather_ms": gather_ms,
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel<9,false,false> (3x3 conv, implicit GEMM, fp32 MFMA 32x32x2)",
                          "achieved": conv_tf, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": conv_tf / PEAK_FP32_MFMA,
-                         "traffic": None, "launches": int(ln[0]), "avg_launch_ms": ms[0] / max(1, ln[0]),
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by[0] / max(1, ln[0]),
+                         "launches": int(ln[0]), "avg_launch_ms": ms[0] / max(1, ln[0]),
                          "kernel_time_share_of_step": ms[0] * 1e-3 / elapsed,
                          "other_matrix_kernels": {"tflops": fl[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0, "ms": ms[1], "launches": int(ln[1])}},
         }

@@ -86,9 +86,9 @@ int buddy_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsi
 }
 
 int buddy_prof_enable(int on) { igemm_prof_enable(on); return BUDDY_OK; }
-int buddy_prof_collect(double* ms, double* flops, long long* launches) {
-  if (!ms || !flops || !launches) { set_error("null argument"); return BUDDY_ERR_ARG; }
-  if (igemm_prof_collect(ms, flops, launches)) { set_error("event timing failed"); return BUDDY_ERR_HIP; }
+int buddy_prof_collect(double* ms, double* flops, long long* launches, double* bytes) {
+  if (!ms || !flops || !launches || !bytes) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  if (igemm_prof_collect(ms, flops, launches, bytes)) { set_error("event timing failed"); return BUDDY_ERR_HIP; }
   return BUDDY_OK;
 }
 

@@ -32,7 +32,7 @@ struct IgemmParams {
 };
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st);
 void igemm_prof_enable(int on);
-int igemm_prof_collect(double ms[2], double flops[2], long long launches[2]);
+int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], double bytes[2]);
 
 // ---- small-channel direct convs -----------------------------------------------------------------------
 // Cin == 2 -> Cout (first conv, Combine 1x1, dgrad of the 2-channel pyramid heads)

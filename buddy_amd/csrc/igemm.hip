@@ -231,20 +231,20 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
 
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg) ----
 namespace {
-struct ProfRec { hipEvent_t e0, e1; double flops; int taps; };
+struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int taps; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }
 void igemm_prof_enable(int on) { g_prof_on = on != 0; }
 // sums elapsed time / algorithmic flops / launches per class (class 0: 3x3 convs, class 1: everything else) and clears
-int igemm_prof_collect(double ms[2], double flops[2], long long launches[2]) {
-  for (int c = 0; c < 2; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; }
+int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], double bytes[2]) {
+  for (int c = 0; c < 2; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; bytes[c] = 0; }
   for (auto& r : g_prof) {
     if (hipEventSynchronize(r.e1) != hipSuccess) return 1;
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return 1;
     const int c = r.taps == 9 ? 0 : 1;
-    ms[c] += t; flops[c] += r.flops; launches[c] += 1;
+    ms[c] += t; flops[c] += r.flops; launches[c] += 1; bytes[c] += r.bytes;
     (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
   g_prof.clear();
@@ -257,6 +257,8 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
   if (g_prof_on) {
     (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
     rec.flops = 2.0 * (double)p.M * (double)p.N * (double)p.Cin * (double)taps * (double)batch; rec.taps = taps;
+    // algorithmic bytes: read A once, read the weights once, write C once (+ residual read once if fused)
+    rec.bytes = 4.0 * (double)batch * ((double)p.M * p.Cin + (double)p.N * p.Cin * taps + (double)p.M * p.N * (p.res_mode ? 2.0 : 1.0));
     (void)hipEventRecord(rec.e0, st);
   }
   struct Fin { ProfRec& r; hipStream_t s; ~Fin() { if (g_prof_on) { (void)hipEventRecord(r.e1, s); g_prof.push_back(r); } } } fin{rec, st};

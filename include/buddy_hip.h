@@ -53,9 +53,9 @@ int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream);
 /* ---- measurement: time every matrix-core (igemm) launch with HIP events on its own launch stream.  collect() waits for
  * the recorded events and returns, per class (index 0: 3x3 convolutions, index 1: 1x1 convs / attention / DFT GEMMs),
  * the summed kernel time [ms], the algorithmic FLOPs (2*M*N*K, zero padding counted like torch's flop counter) and
- * the number of launches since the last collect. ---- */
+ * the number of launches since the last collect, and the algorithmic bytes (A once + weights once + C once). ---- */
 int buddy_prof_enable(int on);
-int buddy_prof_collect(double* ms /*[2]*/, double* flops /*[2]*/, long long* launches /*[2]*/);
+int buddy_prof_collect(double* ms /*[2]*/, double* flops /*[2]*/, long long* launches /*[2]*/, double* bytes /*[2]*/);
 
 /* calibration: `blocks` workgroups x 4 waves issue 4*iters fp32 MFMAs (32x32x2) each on operands from seed[1024] with no
  * memory traffic; out[blocks*256] keeps the result live; clk[0] = shader clocks, clk[1] = 100 MHz wall ticks of block 0.

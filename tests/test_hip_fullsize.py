@@ -1,0 +1,125 @@
+"""GPU tests at BASELINE.json's full size (NCSN++ nf=128, 4 s @ 16 kHz = 64 000 samples): direct parity against the CPU oracle
+for one utterance, and size-independent properties (adjoint identity <J v, w> = <v, J^T w> by central differences, linearity of the
+VJP, bit-exact batch independence, per-utterance magnitude constraint of the sampler)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+L = 64000
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def net():
+    from tests.test_hip_network import build
+    return build(128, 510, 128, 0)
+
+
+def test_fullsize_forward_vjp_vs_oracle(net):
+    from oracle import ncsnpp_ref
+    from buddy_amd.synth import synth_state_dict
+    torch.set_num_threads(32)
+    P = ncsnpp_ref.to_torch(synth_state_dict(0, 128))
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy((0.4 * rs.standard_normal((1, L))).astype(np.float32))
+    cot = torch.from_numpy(rs.standard_normal((1, L)).astype(np.float32))
+    cn = torch.tensor([-0.6])
+    xr = x.clone().requires_grad_(True)
+    yr = ncsnpp_ref.ncsnpp_time(P, xr, cn, 510, 128)
+    gr, = torch.autograd.grad(yr, xr, cot)
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg, cn.cuda())
+    g, = torch.autograd.grad(y, xg, cot.cuda())
+    assert rel(y, yr) < 5e-4
+    assert rel(g, gr) < 5e-4
+
+
+def test_fullsize_adjoint_identity_and_linearity(net):
+    rs = np.random.RandomState(6)
+    B = 2
+    x = torch.from_numpy((0.3 * rs.standard_normal((B, L))).astype(np.float32)).cuda()
+    v = torch.from_numpy(rs.standard_normal((B, L)).astype(np.float32)).cuda()
+    w1 = torch.from_numpy(rs.standard_normal((B, L)).astype(np.float32)).cuda()
+    w2 = torch.from_numpy(rs.standard_normal((B, L)).astype(np.float32)).cuda()
+    cn = torch.tensor([-0.4, -1.1]).cuda()
+
+    def vjp(w):
+        xg = x.clone().requires_grad_(True)
+        y = net(xg, cn)
+        return torch.autograd.grad(y, xg, w)[0]
+
+    g1, g2, g12 = vjp(w1), vjp(w2), vjp(0.5 * w1 + w2)
+    assert rel(g12, 0.5 * g1 + g2) < 1e-5                         # linear in the cotangent
+    eps = 1e-2
+    with torch.no_grad():
+        jv = (net(x + eps * v, cn).double() - net(x - eps * v, cn).double()) / (2 * eps)
+    lhs = (jv * w1.double()).sum(dim=1)
+    rhs = (v.double() * g1.double()).sum(dim=1)
+    assert float(((lhs - rhs).abs() / rhs.abs()).max()) < 2e-2      # central difference of a fp32 network: O(eps^2) + round-off/eps
+    # rows are independent and bit-identical to B=1 calls
+    with torch.no_grad():
+        yb = net(x, cn)
+        y0 = net(x[:1], cn[:1])
+    assert torch.equal(yb[:1], y0)
+
+
+def test_fullsize_blind_sampler_two_steps_vs_oracle(net):
+    """Two blind DPS steps at full size: utterance 0 of a B=2 batch against the oracle's B=1 run (same noise draws)."""
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
+    from buddy_amd.testing.tester import Tester
+    from buddy_amd.utils.metrics import si_sdr
+    from oracle import ncsnpp_ref, operators_ref as O, sampler_ref as S
+    ov = ["tester.sampling_params.T=50", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+          "tester.posterior_sampling.blind_hp.op_updates_per_step=3"]
+    args = compose(overrides=ov)
+    edm = instantiate(args.diff_params)
+    items = [(synth_clean(u, L), synth_rir(u, 4000), f"u{u}.wav") for u in range(2)]
+    t = Tester(args, net, edm, test_set=None, device="cuda", in_training=True)
+    ns = [S.NoiseStream(70 + u) for u in range(2)]
+    t.sampler.noise = ns
+    seg, y, op, _ = t.prepare_batch(items, blind=True, noise=ns)
+    smp = t.sampler
+    smp.operator, smp.y = op, y
+    from buddy_amd.utils.losses import get_loss
+    smp.rec_loss = get_loss(args.tester.posterior_sampling.rec_loss, operator=op)
+    smp._hip_op = hasattr(op, "hip_optimize")
+    assert smp._hip_op
+    op.hip_bind(y, args.tester.posterior_sampling)
+    sched = smp.create_schedule().cuda(); gam = smp.get_gamma(sched).cuda()
+    x = smp.initialize_x(tuple(y.shape), "cuda", sched)
+    for i in range(2):
+        x, x_den = smp.step(x, sched[i], sched[i + 1], gam[i], blind=True)
+    assert torch.isfinite(x).all() and torch.isfinite(x_den).all()
+    assert float((x_den.std(dim=1) - 0.05).abs().max()) < 1e-5          # constraint_speech_magnitude per utterance
+    # oracle, utterance 0
+    torch.set_num_threads(32)
+    P = ncsnpp_ref.to_torch(synth_state_dict(0, 128))
+    onet = lambda z, cn: ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
+    nr = S.NoiseStream(70)
+    ref = S.EulerHeunDPSRef(onet, S.EDMRef(args.diff_params.sde_hp), args, nr)
+    op_hp = args.tester.informed_dereverberation.op_hp
+    oo = O.RIROperatorRef(op_hp); oo.update_params(torch.from_numpy(items[0][1]))
+    c0 = torch.from_numpy(items[0][0]); c0 = 0.05 * c0 / c0.std()
+    y0 = oo.degradation(c0[None])
+    assert rel(y[:1], y0) < 1e-4
+    bo = O.BlindSubbandFilteringRef(op_hp, 16000, nr); bo.update_H(use_noise=True, noise=nr)
+    ref.operator, ref.y = bo, y0
+    ps = args.tester.posterior_sampling
+    ref.rec_loss = O.get_loss_ref(ps.rec_loss, bo); ref.rec_loss_params = O.get_loss_ref(ps.rec_loss_params, bo)
+    ref.rir_reg_loss = O.get_loss_ref(ps.RIR_noise_regularization.loss, bo)
+    ref.optim = torch.optim.Adam(bo.params + bo.params_phases, lr=ps.blind_hp.lr_op, betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
+    ts = S.create_schedule(ref.sde_hp, ref.T); gm = S.get_gamma(ts, ref.sp)
+    xr = ref.initialize_x(y0.shape, ts)
+    for i in range(2):
+        xr, xdr = ref.step(xr, ts[i], ts[i + 1], gm[i], True)
+    assert nr.k == ns[0].k
+    s = float(si_sdr(x_den[:1].cpu(), xdr))
+    assert s > 40.0, f"SI-SDR(build; oracle) = {s:.1f} dB"
+    assert rel(x_den[:1], xdr) < 1e-2
