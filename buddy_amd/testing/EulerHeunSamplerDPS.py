@@ -31,8 +31,12 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         if wi.mode == "reverb_scaled":
             return wi.scaling_factor * self.y.clone() / _row_std(self.y) + schedule[0] * self._randn(shape, device)
         if wi.mode == "wpe_scaled":
-            raise NotImplementedError("wpe_scaled warm start needs nara_wpe (third-party, absent offline): SURVEY.md 8(f) 'next'; "
-                                      "use warm_initialization.mode=reverb_scaled or none")
+            from ..utils.wpe import wpe_dereverb    # nara_wpe restated (third-party, parity unpinned)
+            x_pred = wpe_dereverb(self.y, taps=wi.wpe.taps, delay=wi.wpe.delay, iterations=wi.wpe.iterations)
+            if x_pred.shape[-1] < self.y.shape[-1]:
+                x_pred = torch.nn.functional.pad(x_pred, (0, self.y.shape[-1] - x_pred.shape[-1]))
+            x_pred = wi.scaling_factor * x_pred / _row_std(x_pred)
+            return x_pred + schedule[0] * self._randn(shape, device)
         raise NotImplementedError
 
     def get_likelihood_score(self, x_den, x, t):

@@ -182,3 +182,31 @@ def test_unconditional_sampler_equals_oracle():
     ref = S.EulerHeunRef(net, S.EDMRef(args.diff_params.sde_hp), args, S.NoiseStream(7))
     xr = ref.predict_unconditional((1, 4096))
     assert rel(x, xr) < 1e-5
+
+
+def test_wpe_restated_roundtrip_and_dereverb():
+    """nara_wpe restatement (parity unpinned): STFT/iSTFT round trip is exact and WPE removes late reverberation of a bursty source."""
+    from buddy_amd.utils import wpe
+    rs = np.random.RandomState(0)
+    n = 16000
+    env = (np.sin(2 * np.pi * 3 * np.arange(n) / 16000) > 0.6).astype(np.float64)
+    x = torch.from_numpy(rs.standard_normal(n) * env)
+    X = wpe.stft(x[None])
+    assert float((wpe.istft(X)[0, :n] - x).abs().max()) < 1e-12
+    h = torch.from_numpy(np.exp(-np.arange(4000) / 700.0) * rs.standard_normal(4000)); h[0] = 1.0
+    y = torch.nn.functional.conv1d(torch.nn.functional.pad(x[None, None], (3999, 0)), h.flip(0)[None, None])[0]
+    z = wpe.wpe_dereverb(y.float(), taps=50, delay=2, iterations=5).double()
+    gap = torch.from_numpy(env[:z.shape[-1]] == 0)
+    assert z.shape[-1] == n and torch.isfinite(z).all()
+    assert float((z[0, gap] ** 2).mean()) < 0.5 * float((y[0, :n][gap] ** 2).mean())     # reverberant tail in the pauses at least halved
+
+
+def test_cli_parser_matches_reference_command_line():
+    import test as cli
+    groups, ov = cli.parse(["--config-name=conf_VCTK.yaml", "tester=blind_dereverberation_BUDDy", "tester.checkpoint=x.pt",
+                            "tester.sampling_params.T=201", "model_dir=experiments/run", "+gpu=0", "dset=vctk_16k_4s_test-benchmark",
+                            "dset.test.path=audio_examples", "dset.test.num_examples=2"])
+    assert groups == {"tester": "blind_dereverberation_BUDDy"}
+    args = compose(tester=groups["tester"], overrides=ov)
+    assert args.tester.sampling_params.T == 201 and args.gpu == 0 and args.dset.test.path == "audio_examples"
+    assert args.tester.checkpoint == "x.pt" and args.model_dir == "experiments/run"
