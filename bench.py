@@ -194,8 +194,8 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.buddy_prof_enable(0)
     log(f"timed region done: {elapsed:.3f} s")
-    ms = (C.c_double * 2)(); fl = (C.c_double * 2)(); ln = (C.c_longlong * 2)(); by = (C.c_double * 2)()
-    _lib.check(lib.buddy_prof_collect(ms, fl, ln, by))
+    ms = (C.c_double * 2)(); fl = (C.c_double * 2)(); ln = (C.c_longlong * 2)(); by = (C.c_double * 2)(); xf = (C.c_double * 2)()
+    _lib.check(lib.buddy_prof_collect(ms, fl, ln, by, xf))
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -234,8 +234,13 @@ def main():
             "score_evals_per_s": n_utt_steps / elapsed,   # order 1: one forward+VJP evaluation per utterance-step
             "network_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
             "gather_ms": gather_ms,
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<9,false,false> (3x3 conv, implicit GEMM, fp32 MFMA 32x32x2)",
+            "roofline": {"bound": "mfma", "kernel": "3x3 convolutions: wino3_kernel (fused Winograd F(2x2,3x3), fp32 MFMA 16x16x4) where the shape allows, "
+                                                     "else igemm_kernel<9> (direct implicit GEMM, fp32 MFMA 32x32x2)",
                          "achieved": conv_tf, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": conv_tf / PEAK_FP32_MFMA,
+                         "achieved_note": "ALGORITHMIC flops of the direct 3x3 convolution (2*M*N*9*Cin) / kernel time; Winograd executes 4/9 of them, "
+                                          "so frac can exceed 1 -- executed_tflops / peak is the matrix-pipe utilisation",
+                         "executed_tflops": xf[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0,
+                         "executed_frac": (xf[0] / (ms[0] * 1e-3) / 1e12 / PEAK_FP32_MFMA) if ms[0] > 0 else 0.0,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by[0] / max(1, ln[0]),
                          "launches": int(ln[0]), "avg_launch_ms": ms[0] / max(1, ln[0]),
                          "kernel_time_share_of_step": ms[0] * 1e-3 / elapsed,

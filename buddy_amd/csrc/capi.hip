@@ -86,9 +86,9 @@ int buddy_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsi
 }
 
 int buddy_prof_enable(int on) { igemm_prof_enable(on); return BUDDY_OK; }
-int buddy_prof_collect(double* ms, double* flops, long long* launches, double* bytes) {
-  if (!ms || !flops || !launches || !bytes) { set_error("null argument"); return BUDDY_ERR_ARG; }
-  if (igemm_prof_collect(ms, flops, launches, bytes)) { set_error("event timing failed"); return BUDDY_ERR_HIP; }
+int buddy_prof_collect(double* ms, double* flops, long long* launches, double* bytes, double* exec_flops) {
+  if (!ms || !flops || !launches || !bytes || !exec_flops) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  if (igemm_prof_collect(ms, flops, launches, bytes, exec_flops)) { set_error("event timing failed"); return BUDDY_ERR_HIP; }
   return BUDDY_OK;
 }
 
@@ -108,6 +108,24 @@ int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, 
   p.A0 = x; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.Bt = wt; p.ldB = 9 * Cin; p.C = y; p.ldC = Cout;
   p.bias_n = bias; p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
   launch_igemm(p, 9, false, false, 1, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_winograd_transform_weights(const float* wt_host, int Cout, int Cin, float* U_host) {
+  if (!wt_host || !U_host || Cin % 16) { set_error("bad arguments (Cin must be a multiple of 16)"); return BUDDY_ERR_ARG; }
+  wino_transform_weights(wt_host, Cout, Cin, U_host);
+  return BUDDY_OK;
+}
+
+int buddy_conv3x3_winograd(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!x || !U || !y) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.A0 = x; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = y; p.ldC = Cout;
+  p.bias_n = bias; p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
+  if (!wino_supported(p)) { set_error("shape not supported by the Winograd kernel (H, W even; Cin % 16; Cout % 32)"); return BUDDY_ERR_ARG; }
+  igemm_prof_record(p, 9, 1, (hipStream_t)stream, true);
+  launch_wino(p, U, (hipStream_t)stream);
+  igemm_prof_record(p, 9, 1, (hipStream_t)stream, false);
   return finish();
 }
 

@@ -31,8 +31,13 @@ struct IgemmParams {
   float alpha, out_scale; int accumulate;
 };
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st);
+// Winograd F(2x2,3x3) variant of the 3x3 conv (wino.hip): same IgemmParams, pre-transformed weights U[Cin/16][16][Cout][16]
+bool wino_supported(const IgemmParams& p);
+void launch_wino(const IgemmParams& p, const float* Uw, hipStream_t st);
+void wino_transform_weights(const float* wt_host, int Cout, int Cin, float* U_host);
+void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin);
 void igemm_prof_enable(int on);
-int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], double bytes[2]);
+int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], double bytes[2], double exec_flops[2]);
 
 // ---- small-channel direct convs -----------------------------------------------------------------------
 // Cin == 2 -> Cout (first conv, Combine 1x1, dgrad of the 2-channel pyramid heads)

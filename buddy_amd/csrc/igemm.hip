@@ -231,24 +231,40 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
 
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg) ----
 namespace {
-struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int taps; };
+struct ProfRec { hipEvent_t e0, e1; double flops, bytes, exec_flops; int taps; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }
 void igemm_prof_enable(int on) { g_prof_on = on != 0; }
 // sums elapsed time / algorithmic flops / launches per class (class 0: 3x3 convs, class 1: everything else) and clears
-int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], double bytes[2]) {
-  for (int c = 0; c < 2; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; bytes[c] = 0; }
+int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], double bytes[2], double exec_flops[2]) {
+  for (int c = 0; c < 2; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; bytes[c] = 0; exec_flops[c] = 0; }
   for (auto& r : g_prof) {
     if (hipEventSynchronize(r.e1) != hipSuccess) return 1;
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return 1;
     const int c = r.taps == 9 ? 0 : 1;
-    ms[c] += t; flops[c] += r.flops; launches[c] += 1; bytes[c] += r.bytes;
+    ms[c] += t; flops[c] += r.flops; launches[c] += 1; bytes[c] += r.bytes; exec_flops[c] += r.exec_flops;
     (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
   g_prof.clear();
   return 0;
+}
+
+static ProfRec g_cur;
+void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin) {
+  if (!g_prof_on) return;
+  if (begin) {
+    // called for the Winograd launches: algorithmic flops are those of the direct 3x3 conv, executed MACs are 16/36 of them
+    (void)hipEventCreate(&g_cur.e0); (void)hipEventCreate(&g_cur.e1);
+    g_cur.flops = 2.0 * (double)p.M * (double)p.N * (double)p.Cin * (double)taps * (double)batch; g_cur.taps = taps;
+    g_cur.exec_flops = g_cur.flops * 4.0 / 9.0;
+    g_cur.bytes = 4.0 * (double)batch * ((double)p.M * p.Cin + (double)p.N * p.Cin * taps + (double)p.M * p.N * (p.res_mode ? 2.0 : 1.0));
+    (void)hipEventRecord(g_cur.e0, st);
+  } else {
+    (void)hipEventRecord(g_cur.e1, st);
+    g_prof.push_back(g_cur);
+  }
 }
 
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st) {
@@ -256,7 +272,7 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
   ProfRec rec{};
   if (g_prof_on) {
     (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
-    rec.flops = 2.0 * (double)p.M * (double)p.N * (double)p.Cin * (double)taps * (double)batch; rec.taps = taps;
+    rec.flops = 2.0 * (double)p.M * (double)p.N * (double)p.Cin * (double)taps * (double)batch; rec.taps = taps; rec.exec_flops = rec.flops;
     // algorithmic bytes: read A once, read the weights once, write C once (+ residual read once if fused)
     rec.bytes = 4.0 * (double)batch * ((double)p.M * p.Cin + (double)p.N * p.Cin * taps + (double)p.M * p.N * (p.res_mode ? 2.0 : 1.0));
     (void)hipEventRecord(rec.e0, st);

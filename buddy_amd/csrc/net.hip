@@ -6,6 +6,7 @@
 #include "net.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -102,7 +103,8 @@ struct Arena {
   float* f(long long n) { return (float*)alloc((size_t)n * 4); }
 };
 
-struct ConvW { int cin = 0, cout = 0, taps = 0; float* wf = nullptr; float* wb = nullptr; float* bias = nullptr; };
+struct ConvW { int cin = 0, cout = 0, taps = 0; float* wf = nullptr; float* wb = nullptr; float* bias = nullptr;
+               float* uf = nullptr; float* ub = nullptr; };   // uf/ub: Winograd-domain weights (forward / data-gradient)
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResW { GNW gn0, gn1; ConvW c0, c1, c2; bool has_c2 = false; int cin = 0, cout = 0, dense_off = 0; };
 struct AttnW { GNW gn; float* Wt[4]; float* Wn[4]; float* b[4]; int C = 0; };
@@ -232,8 +234,14 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   auto load_gn = [&](GNW& g, const std::string& p, int C) { g.gamma = raw(p + ".weight"); g.beta = raw(p + ".bias"); g.C = C; };
   auto load_conv3 = [&](ConvW& c, const std::string& p, int cin, int cout) {
     c.cin = cin; c.cout = cout; c.taps = 9; c.bias = raw(p + ".bias");
-    packed(&c.wf, pack_conv3_fwd(host(p + ".weight"), cout, cin));
-    packed(&c.wb, pack_conv3_bwd(host(p + ".weight"), cout, cin));
+    std::vector<float> wfv = pack_conv3_fwd(host(p + ".weight"), cout, cin), wbv = pack_conv3_bwd(host(p + ".weight"), cout, cin);
+    packed(&c.wf, wfv);
+    packed(&c.wb, wbv);
+    if (cin % 8 == 0 && cout % 8 == 0) {     // Winograd F(2x2,3x3) operands U = G g G^T for both directions (wino.hip)
+      std::vector<float> u((size_t)16 * cin * cout);
+      wino_transform_weights(wfv.data(), cout, cin, u.data()); packed(&c.uf, u);
+      wino_transform_weights(wbv.data(), cin, cout, u.data()); packed(&c.ub, u);
+    }
   };
   auto load_res = [&](int cin, int cout, bool resample) {
     ResW r; r.cin = cin; r.cout = cout;
@@ -369,14 +377,21 @@ static inline int gn_groups(int C) { int g = C / 4; return g < 32 ? g : 32; }
 
 // conv3x3 over an NHWC tensor (single source) -> out
 static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const float* wt, int Cout, const float* bias, const float* bias_bn,
-                  int ld_bn, const float* res, int ldRes, int res_mode, float alpha, float out_scale, float* out) {
+                  int ld_bn, const float* res, int ldRes, int res_mode, float alpha, float out_scale, float* out, const float* U = nullptr) {
   if (N->dry()) return;
+  static const bool use_wino = !(getenv("BUDDY_CONV") && std::string(getenv("BUDDY_CONV")) == "direct");
   IgemmParams p = ig_base();
   p.A0 = a; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout;
   p.Bt = wt; p.ldB = 9 * Cin; p.C = out; p.ldC = Cout;
   p.bias_n = bias; p.bias_bn = bias_bn; p.ld_bias_bn = ld_bn; p.rows_per_batch = H * W;
   p.res = res; p.ldRes = ldRes; p.res_mode = res_mode; p.alpha = alpha; p.out_scale = out_scale;
-  launch_igemm(p, 9, false, false, 1, N->st);
+  if (use_wino && U != nullptr && wino_supported(p)) {
+    igemm_prof_record(p, 9, 1, N->st, true);
+    launch_wino(p, U, N->st);
+    igemm_prof_record(p, 9, 1, N->st, false);
+  } else {
+    launch_igemm(p, 9, false, false, 1, N->st);
+  }
 }
 // 1x1 conv / per-pixel linear over a (possibly two-source) view
 static void conv1(Net* N, Src2 a, long long M, int Cin, const float* wt, int Cout, const float* bias, float alpha, float* out, int accumulate) {
@@ -406,7 +421,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
   if (!N->dry()) {
     launch_gn_stats(src_of(x), B, H * W, Cin, G0, 1e-6f, N->partial, stats0, st);
     launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
-    conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p);
+    conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p, R.c0.uf);
     launch_gn_stats(single(h1->p, Cout), B, Ho * Wo, Cout, G1, 1e-6f, N->partial, stats1, st);
     launch_gn_apply(single(h1->p, Cout), stats1, R.gn1.gamma, R.gn1.beta, B, Ho, Wo, Cout, G1, 0, 1, a1, nullptr, st);
     const float* res; int res_mode = 1;
@@ -417,7 +432,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
     } else {
       res = x.a->p;   // identity skip: single source, same resolution, Cin == Cout
     }
-    conv3(N, a1, B, Ho, Wo, Cout, R.c1.wf, Cout, R.c1.bias, nullptr, 0, res, Cout, res_mode, 1.f, INV_SQRT2, out->p);
+    conv3(N, a1, B, Ho, Wo, Cout, R.c1.wf, Cout, R.c1.bias, nullptr, 0, res, Cout, res_mode, 1.f, INV_SQRT2, out->p, R.c1.uf);
   }
   N->arena.off = mark;
   if (rec) {
@@ -448,12 +463,12 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       float* da1 = n->tmp((long long)B * Ho * Wo * Cout);
       float* dh1 = n->tmp((long long)B * Ho * Wo * Cout);
       float* da0 = n->tmp((long long)B * Ho * Wo * Cin);
-      conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1);
+      conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub);
       Dst2 d1; d1.p0 = dh1; d1.p1 = nullptr; d1.C0 = Cout; d1.ld0 = Cout; d1.ld1 = 0; d1.acc0 = 0; d1.acc1 = 0;
       if (!n->dry())
         launch_gn_bwd(single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, da1, B, Ho, Wo, Cout, G1, 0, 1, nullptr, 0, 0.f, n->partial,
                       n->red, d1, s);
-      conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0);
+      conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub);
       Dst2 d0 = gdst_of(x);
       if (!n->dry())
         launch_gn_bwd(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0, B, H, W, Cin, G0, mode, 1, extra, extra_mode, extra_scale,

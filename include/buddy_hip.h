@@ -55,7 +55,8 @@ int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream);
  * the summed kernel time [ms], the algorithmic FLOPs (2*M*N*K, zero padding counted like torch's flop counter) and
  * the number of launches since the last collect, and the algorithmic bytes (A once + weights once + C once). ---- */
 int buddy_prof_enable(int on);
-int buddy_prof_collect(double* ms /*[2]*/, double* flops /*[2]*/, long long* launches /*[2]*/, double* bytes /*[2]*/);
+int buddy_prof_collect(double* ms /*[2]*/, double* flops /*[2]*/, long long* launches /*[2]*/, double* bytes /*[2]*/,
+                       double* executed_flops /*[2]: = flops except for Winograd launches (4/9 of the direct-conv flops)*/);
 
 /* calibration: `blocks` workgroups x 4 waves issue 4*iters fp32 MFMAs (32x32x2) each on operands from seed[1024] with no
  * memory traffic; out[blocks*256] keeps the result live; clk[0] = shader clocks, clk[1] = 100 MHz wall ticks of block 0.
@@ -72,6 +73,11 @@ int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, in
  * (networks/ncsnpp_utils/layers.py:119-126). */
 int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                   void* stream);
+/* the same convolution through the fused Winograd F(2x2,3x3) kernel (4*Cin instead of 9*Cin MACs per output, fp32):
+ * transform_weights (host -> host): wt[Cout][9*Cin] -> U[Cin/16][16][Cout][16]; conv takes U on the device. */
+int buddy_winograd_transform_weights(const float* wt_host, int Cout, int Cin, float* U_host);
+int buddy_conv3x3_winograd(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
+                           void* stream);
 /* GroupNorm(G, C, eps=1e-6) [+SiLU] [+2x down(mode 1)/up(mode 2)] forward; replaces nn.GroupNorm + nn.SiLU +
  * naive_{up,down}sample_2d (layerspp.py:243-258). stats: [B][G][2] out; scratch: >= B*256*C*16 bytes. */
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B,

@@ -80,6 +80,26 @@ def test_conv3x3(lib, B, H, W, Cin, Cout):
     assert rel(y.permute(0, 3, 1, 2), ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 16, 32, 32, 64), (2, 40, 64, 96, 32), (1, 64, 128, 256, 128), (3, 8, 32, 384, 256)])
+def test_conv3x3_winograd(lib, B, H, W, Cin, Cout):
+    """Fused Winograd F(2x2,3x3): same tolerance class as the direct kernel (fp32, different summation order)."""
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin + Cout + 1)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = F.conv2d(x.double(), w.cuda().double(), b.double(), padding=1).float()
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().numpy()
+    U = np.empty(16 * Cin * Cout, dtype=np.float32)
+    _lib.check(lib.buddy_winograd_transform_weights(wt.ctypes.data, Cout, Cin, U.ctypes.data))
+    Ud = torch.from_numpy(U).cuda()
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    y = torch.empty(B, H, W, Cout, device="cuda")
+    _lib.check(lib.buddy_conv3x3_winograd(P(x_nhwc), P(Ud), P(b), P(y), B, H, W, Cin, Cout, S()))
+    torch.cuda.synchronize()
+    assert rel(y.permute(0, 3, 1, 2), ref) < 2e-5
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("C,silu", [(32, 1), (96, 1), (128, 0), (384, 1), (512, 1)])
 def test_groupnorm_act_fwd_bwd(lib, mode, C, silu):

@@ -32,9 +32,27 @@ def conv(B, H, W, Cin, Cout, reps=5):
     fl = 2.0 * B * H * W * Cout * 9 * Cin
     print(f"conv3x3 B{B} {H}x{W} {Cin:3d}->{Cout:3d}: {dt*1e3:8.3f} ms  {fl/dt/1e12:6.1f} TFLOP/s")
 
+def conv_wino(B, H, W, Cin, Cout, reps=5):
+    import numpy as np
+    x = torch.randn(B, H, W, Cin, device="cuda"); w = (torch.randn(Cout, 9 * Cin) / (9 * Cin) ** 0.5).numpy()
+    U = np.empty(16 * Cin * Cout, dtype=np.float32)
+    _lib.check(lib.buddy_winograd_transform_weights(w.ctypes.data, Cout, Cin, U.ctypes.data))
+    Ud = torch.from_numpy(U).cuda()
+    b = torch.randn(Cout, device="cuda"); y = torch.empty(B, H, W, Cout, device="cuda")
+    for _ in range(2):
+        _lib.check(lib.buddy_conv3x3_winograd(x.data_ptr(), Ud.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, S()))
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps):
+        _lib.check(lib.buddy_conv3x3_winograd(x.data_ptr(), Ud.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, S()))
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
+    fl = 2.0 * B * H * W * Cout * 9 * Cin
+    print(f"winograd B{B} {H}x{W} {Cin:3d}->{Cout:3d}: {dt*1e3:8.3f} ms  {fl/dt/1e12:6.1f} TFLOP/s (direct-conv algorithmic flops; executed {fl*4/9/dt/1e12:5.1f})")
+
+
 if __name__ == "__main__":
     for m in ["zero", "const", "rand"]:
         ubench(m)
     for shp in [(8, 512, 256, 256, 256), (8, 512, 256, 128, 128), (8, 512, 256, 384, 128), (8, 256, 128, 512, 256), (8, 128, 64, 256, 256),
                 (8, 64, 32, 512, 256), (1, 512, 256, 256, 256), (1, 64, 32, 512, 256)]:
         conv(*shp)
+        conv_wino(*shp)
