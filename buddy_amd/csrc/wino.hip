@@ -231,15 +231,14 @@ void launch_wino(const IgemmParams& p, const float* Uw, hipStream_t st) {
   const int B = p.M / (p.H * p.W);
   const int TH = p.H / 2, TW = p.W / 2;
   static const int abl = getenv("BUDDY_WINO_ABL") ? atoi(getenv("BUDDY_WINO_ABL")) : 0;     // timing ablations (wrong results): 1 no MFMA, 2 no patch reads, 3 no DMA
-  static const int geo = getenv("BUDDY_WINO_GEO") ? atoi(getenv("BUDDY_WINO_GEO")) : 83;    // 83: 8 waves x 3 buffers, 82: 8 x 2, 42: 4 waves x 2 buffers
+  static const int geo = getenv("BUDDY_WINO_GEO") ? atoi(getenv("BUDDY_WINO_GEO")) : 42;    // 42: 4-wave workgroups, 2 per CU (default, fastest); 82: 8-wave workgroups
   const float* z = g_zero_page;
   if (TH % 8 == 0 && geo / 10 == 8) {
     const int grid = B * (TH / 8) * (TW / BTX) * (p.N / WN);
-    if (abl == 1) hipLaunchKernelGGL((wino3_kernel<1, 8, 3>), dim3(grid), dim3(512), 0, st, p, Uw, z);
-    else if (abl == 2) hipLaunchKernelGGL((wino3_kernel<2, 8, 3>), dim3(grid), dim3(512), 0, st, p, Uw, z);
-    else if (abl == 3) hipLaunchKernelGGL((wino3_kernel<3, 8, 3>), dim3(grid), dim3(512), 0, st, p, Uw, z);
-    else if (geo == 82) hipLaunchKernelGGL((wino3_kernel<0, 8, 2>), dim3(grid), dim3(512), 0, st, p, Uw, z);
-    else hipLaunchKernelGGL((wino3_kernel<0, 8, 3>), dim3(grid), dim3(512), 0, st, p, Uw, z);
+    if (abl == 1) hipLaunchKernelGGL((wino3_kernel<1, 8, 2>), dim3(grid), dim3(512), 0, st, p, Uw, z);
+    else if (abl == 2) hipLaunchKernelGGL((wino3_kernel<2, 8, 2>), dim3(grid), dim3(512), 0, st, p, Uw, z);
+    else if (abl == 3) hipLaunchKernelGGL((wino3_kernel<3, 8, 2>), dim3(grid), dim3(512), 0, st, p, Uw, z);
+    else hipLaunchKernelGGL((wino3_kernel<0, 8, 2>), dim3(grid), dim3(512), 0, st, p, Uw, z);
   } else {
     const int grid = B * (TH / 4) * (TW / BTX) * (p.N / WN);
     hipLaunchKernelGGL((wino3_kernel<0, 4, 2>), dim3(grid), dim3(256), 0, st, p, Uw, z);
