@@ -10,6 +10,9 @@ using namespace buddy;
 namespace buddy {
 void launch_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, hipStream_t st);
 void launch_row_moments(const float* x, double* out, int B, int L, hipStream_t st);
+void launch_perturb(const float* x, const float* eps, float scale, float* out, long long n, hipStream_t st);
+void launch_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* den_scale_b, const float* base, const float* d_prev,
+                       float t, float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, hipStream_t st);
 void launch_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st);
 void launch_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, hipStream_t st);
 }
@@ -150,6 +153,19 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
 int buddy_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, void* stream) {
   if (!x || !a || !out || (y && !c)) { set_error("null argument"); return BUDDY_ERR_ARG; }
   launch_axpby_rows(x, y, a, c, out, B, L, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_perturb(const float* x, const float* eps, float scale, float* out, long long n, void* stream) {
+  if (!x || !eps || !out) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  launch_perturb(x, eps, scale, out, n, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* den_scale, const float* base, const float* d_prev, float t,
+                     float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, void* stream) {
+  if (!x_hat || !x_den || !base || !out || t <= 0.f) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  launch_dps_update(x_hat, x_den, lh, den_scale, base, d_prev, t, dt, w_prev, w_cur, out, d_out, x_den_out, B, L, (hipStream_t)stream);
   return finish();
 }
 

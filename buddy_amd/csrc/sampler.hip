@@ -14,6 +14,34 @@ __global__ __launch_bounds__(256) void axpby_rows_kernel(const float* x, const f
   }
 }
 
+// x_hat[b][i] = x[b][i] + sqrt(t_hat^2 - t^2) * eps[b][i]      (reference EulerHeunSampler.py:41-45)
+__global__ __launch_bounds__(256) void perturb_kernel(const float* x, const float* eps, float scale, float* out, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = x[i] + scale * eps[i];
+}
+// Euler(-Heun) update with the likelihood term (reference EulerHeunSamplerDPS.py:128-157, diff_params/edm.py:83-96):
+//   x_den' = x_den * (speech_scaling / std_b) if rescale            (per utterance b)
+//   d      = -t * (x_den' - x_hat) / t^2 + lh                         (ODE integrand + likelihood score)
+//   out    = base + dt * (w_prev * d_prev + w_cur * d)                (Euler: base = x_hat, w_prev = 0, w_cur = 1; Heun: 0.5 / 0.5)
+// also writes d (for the Heun corrector) and the rescaled x_den'.
+__global__ __launch_bounds__(256) void dps_update_kernel(const float* x_hat, const float* x_den, const float* lh, const float* den_scale_b,
+                                                         const float* base, const float* d_prev, float t, float dt, float w_prev, float w_cur,
+                                                         float* out, float* d_out, float* x_den_out, int B, int L) {
+  const long long n = (long long)B * L;
+  const float inv_t = 1.f / t;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / L);
+    const float xd = x_den[i] * (den_scale_b ? den_scale_b[b] : 1.f);
+    const float score = (xd - x_hat[i]) * inv_t * inv_t;
+    float d = -t * score;
+    if (lh) d += lh[i];
+    float acc = w_cur * d;
+    if (d_prev) acc += w_prev * d_prev[i];
+    out[i] = base[i] + dt * acc;
+    if (d_out) d_out[i] = d;
+    if (x_den_out) x_den_out[i] = xd;
+  }
+}
+
 // one block per row; double accumulation (the reference's y.std(), torch.norm run in fp32 with pairwise summation --
 // double keeps us within fp32 round-off of either order)
 __global__ __launch_bounds__(256) void row_moments_kernel(const float* x, double* out, int L) {
@@ -75,6 +103,16 @@ __global__ __launch_bounds__(256) void fir_kernel(const float* x, const float* h
 void launch_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, hipStream_t st) {
   long long g = ((long long)B * L + 255) / 256; if (g > 4096) g = 4096;
   hipLaunchKernelGGL(axpby_rows_kernel, dim3((int)g), dim3(256), 0, st, x, y, a, c, out, B, L);
+}
+void launch_perturb(const float* x, const float* eps, float scale, float* out, long long n, hipStream_t st) {
+  long long g = (n + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(perturb_kernel, dim3((int)g), dim3(256), 0, st, x, eps, scale, out, n);
+}
+void launch_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* den_scale_b, const float* base, const float* d_prev,
+                       float t, float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, hipStream_t st) {
+  long long g = ((long long)B * L + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(dps_update_kernel, dim3((int)g), dim3(256), 0, st, x_hat, x_den, lh, den_scale_b, base, d_prev, t, dt, w_prev, w_cur, out, d_out,
+                     x_den_out, B, L);
 }
 void launch_row_moments(const float* x, double* out, int B, int L, hipStream_t st) {
   hipLaunchKernelGGL(row_moments_kernel, dim3(B), dim3(256), 0, st, x, out, L);

@@ -23,6 +23,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         super().__init__(model, diff_params, args)
         self.zeta = self.args.tester.posterior_sampling.zeta
         self._hip_op = False
+        self.use_hip_update = True      # fused elementwise tail on the GPU (False: torch expressions, as on the CPU)
 
     def initialize_x(self, shape, device, schedule):
         wi = self.args.tester.posterior_sampling.warm_initialization
@@ -97,7 +98,36 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         score = self.Tweedie2score(x_den, x_in, t)
         return self.diff_params._ode_integrand(x_in, t, score) + lh_score, x_den
 
+    def _eval_parts(self, x_in, t, blind):
+        """network + operator part of one guided evaluation: (likelihood score, raw Tweedie estimate), both detached."""
+        x_in.requires_grad = True
+        x_den = self.get_Tweedie_estimate(x_in, t)
+        if blind:
+            self.optimize_op(x_den.clone().detach(), t)
+        lh_score, _ = self.get_likelihood_score(x_den, x_in, t)
+        x_in.detach_()
+        return lh_score.detach(), x_den.detach()
+
+    def _step_hip(self, x_i, t_i, t_iplus1, gamma_i, blind):
+        """same arithmetic as step() with the elementwise tail fused into HIP kernels (buddy_perturb / buddy_dps_update)."""
+        from . import _hipops
+        csm = self.args.tester.posterior_sampling.constraint_speech_magnitude
+        x_hat, t_hat = self.stochastic_timestep(x_i, t_i, gamma_i)
+        lh, x_den = self._eval_parts(x_hat, t_hat, blind)
+        scale = (csm.speech_scaling / _hipops.row_std(x_den)).reshape(-1) if csm.use else None
+        dt = float(t_iplus1 - t_hat)
+        if t_iplus1 != 0 and self.order == 2:
+            x_prime, d1, _ = _hipops.dps_update(x_hat, x_den, lh, scale, x_hat, None, float(t_hat), dt, 0.0, 1.0, want_d=True)
+            lh2, x_den2 = self._eval_parts(x_prime, t_iplus1, blind)
+            scale2 = (csm.speech_scaling / _hipops.row_std(x_den2)).reshape(-1) if csm.use else None
+            x_next, _, x_den_out = _hipops.dps_update(x_prime, x_den2, lh2, scale2, x_hat, d1, float(t_iplus1), dt, 0.5, 0.5)
+        else:
+            x_next, _, x_den_out = _hipops.dps_update(x_hat, x_den, lh, scale, x_hat, None, float(t_hat), dt, 0.0, 1.0)
+        return x_next, x_den_out
+
     def step(self, x_i, t_i, t_iplus1, gamma_i, blind=False):
+        if x_i.is_cuda and x_i.dim() == 2 and self.use_hip_update:
+            return self._step_hip(x_i, t_i, t_iplus1, gamma_i, blind)
         x_hat, t_hat = self.stochastic_timestep(x_i, t_i, gamma_i)
         ode_integrand, x_den = self._guided_eval(x_hat, t_hat, blind)
         dt = t_iplus1 - t_hat

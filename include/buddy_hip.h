@@ -90,6 +90,13 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
  * testing/EulerHeunSamplerDPS.py:61-69,115-157, diff_params/edm.py:83-96), per-utterance (row) semantics ---- */
 /* out[b][i] = a[b]*x[b][i] + c[b]*y[b][i] (y may be NULL) */
 int buddy_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, void* stream);
+/* stochastic churn: out = x + scale * eps (EulerHeunSampler.py:41-45, scale = sqrt(t_hat^2 - t^2)) */
+int buddy_perturb(const float* x, const float* eps, float scale, float* out, long long n, void* stream);
+/* fused Euler / Heun update of the DPS sampler (EulerHeunSamplerDPS.py:128-157, edm.py:83-96), per-utterance rows:
+ *   x_den' = x_den * den_scale[b] (NULL = 1);  d = -t * (x_den' - x_hat) / t^2 + lh (NULL = 0);
+ *   out = base + dt * (w_prev * d_prev (NULL = 0) + w_cur * d);   d_out / x_den_out optional. */
+int buddy_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* den_scale, const float* base, const float* d_prev,
+                     float t, float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, void* stream);
 /* per-row sum and sum of squares in double precision: out[b] = {sum, sumsq} */
 int buddy_row_moments(const float* x, double* out, int B, int L, void* stream);
 /* time-domain FIR (direct form) y[b][n] = sum_m h_b[m] x[b][n-m], n < L, h_b = h + b*h_stride (h_stride 0 = shared RIR):

@@ -15,5 +15,6 @@ pinned against outputs of the reference itself (fixtures under ``tests/golden/``
 tests/golden vectors of its own.  Two third-party pieces are absent from
 ``/root/reference`` and restated from their API semantics -- parity for these two is UNPINNED:
 ``torchcde`` (unpinned in reference ``requirements.txt:17``; linear interpolation in
-``operators_ref.linear_interp``) and ``nara_wpe`` (WPE warm start; not restated).
+``operators_ref.linear_interp``) and ``nara_wpe`` (WPE warm start; the product restates it in ``buddy_amd/utils/wpe.py``, the
+oracle does not, so ``wpe_scaled`` runs have no oracle counterpart -- see DESIGN.md).
 """
