@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--length", type=int, default=64000)
     ap.add_argument("--T", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
     ap.add_argument("--operator", default="hip", choices=["hip", "torch"], help="blind operator backend (torch = interim torch-op path)")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="THREADS", help="internal: run only the CPU leg and print its JSON")
     a = ap.parse_args()
@@ -155,13 +156,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sampler path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # == local_rank on a real node; lets 2 gloo ranks share one GPU in smoke tests
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = device if a.backend == "nccl" else torch.device("cpu")
 
     def log(msg):
         if rank == 0:
@@ -196,7 +202,7 @@ def main():
     log(f"timed region done: {elapsed:.3f} s")
     ms = (C.c_double * 2)(); fl = (C.c_double * 2)(); ln = (C.c_longlong * 2)(); by = (C.c_double * 2)(); xf = (C.c_double * 2)()
     _lib.check(lib.buddy_prof_collect(ms, fl, ln, by, xf))
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    el = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -206,8 +212,9 @@ def main():
     out = run.x_den.contiguous()
     if dist is not None:
         torch.cuda.synchronize(); tg = time.perf_counter()
-        bufs = [torch.empty_like(out) for _ in range(world)]
-        dist.all_gather(bufs, out)
+        out_c = out.to(coll_dev)
+        bufs = [torch.empty_like(out_c) for _ in range(world)]
+        dist.all_gather(bufs, out_c)
         torch.cuda.synchronize(); gather_ms = (time.perf_counter() - tg) * 1e3
         assert torch.isfinite(torch.stack(bufs)).all()
     assert torch.isfinite(out).all(), "sampler diverged"

@@ -435,7 +435,7 @@ class BlindSubbandFilteringHIP(BlindSubbandFiltering):
         if self.w_reg is not None:
             Lr = self.length_rir + 1024
             if self.noise is None:
-                noise = torch.randn(n_it, self.U, Lr).to(self.device)
+                noise = torch.randn(n_it, self.U, Lr, device=self.device)      # the reference draws this one on the device too (randn_like(rir_time))
             else:
                 noise = torch.stack([torch.stack([n.randn((Lr,)) for n in self.noise]) for _ in range(n_it)]).to(self.device)
             noise = noise.contiguous()
