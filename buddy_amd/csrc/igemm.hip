@@ -14,6 +14,7 @@
 // first quarter of the MFMA block and land under the rest.  K order is channel-chunk outer / tap inner and the tile order is
 // XCD-aware, so the nine shifted reads of a 3x3 conv hit the same L2 (HBM FETCH 9.7 GB -> 1.1 GB per 1.07 GB input).
 #include "common.h"
+#include <cstdio>
 #include <vector>
 #include <cstdlib>
 
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
 
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg) ----
 namespace {
-struct ProfRec { hipEvent_t e0, e1; double flops, bytes, exec_flops; int taps; };
+struct ProfRec { hipEvent_t e0, e1; double flops, bytes, exec_flops; int taps; int M, N, K, batch, kind; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }
@@ -244,6 +245,9 @@ int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], dou
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return 1;
     const int c = r.taps == 9 ? 0 : 1;
+    static FILE* dump = getenv("BUDDY_PROF_DUMP") ? fopen(getenv("BUDDY_PROF_DUMP"), "w") : nullptr;   // per-launch shapes for tools/gemm_shapes.py
+    if (dump) setvbuf(dump, nullptr, _IOLBF, 0);
+    if (dump) fprintf(dump, "%d %d %d %d %d %d %.6f\n", r.kind, r.taps, r.M, r.N, r.K, r.batch, t);
     ms[c] += t; flops[c] += r.flops; launches[c] += 1; bytes[c] += r.bytes; exec_flops[c] += r.exec_flops;
     (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
@@ -259,6 +263,7 @@ void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st
     (void)hipEventCreate(&g_cur.e0); (void)hipEventCreate(&g_cur.e1);
     g_cur.flops = 2.0 * (double)p.M * (double)p.N * (double)p.Cin * (double)taps * (double)batch; g_cur.taps = taps;
     g_cur.exec_flops = g_cur.flops * 4.0 / 9.0;
+    g_cur.M = p.M; g_cur.N = p.N; g_cur.K = p.Cin; g_cur.batch = batch; g_cur.kind = 9;
     g_cur.bytes = 4.0 * (double)batch * ((double)p.M * p.Cin + (double)p.N * p.Cin * taps + (double)p.M * p.N * (p.res_mode ? 2.0 : 1.0));
     (void)hipEventRecord(g_cur.e0, st);
   } else {
@@ -273,6 +278,7 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
   if (g_prof_on) {
     (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
     rec.flops = 2.0 * (double)p.M * (double)p.N * (double)p.Cin * (double)taps * (double)batch; rec.taps = taps; rec.exec_flops = rec.flops;
+    rec.M = p.M; rec.N = p.N; rec.K = p.Cin; rec.batch = batch; rec.kind = (transA ? 2 : 0) + (transB ? 1 : 0);
     // algorithmic bytes: read A once, read the weights once, write C once (+ residual read once if fused)
     rec.bytes = 4.0 * (double)batch * ((double)p.M * p.Cin + (double)p.N * p.Cin * taps + (double)p.M * p.N * (p.res_mode ? 2.0 : 1.0));
     (void)hipEventRecord(rec.e0, st);
