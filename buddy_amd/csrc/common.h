@@ -29,6 +29,7 @@ struct IgemmParams {
   const float* bias_n; const float* bias_m; const float* bias_bn; int ld_bias_bn; int rows_per_batch;
   const float* res; int ldRes; int res_mode;   // 0 none, 1 same pixel, 2 nearest-upsampled source (H/2 x W/2)
   float alpha, out_scale; int accumulate;
+  int wide_epi;            // set by launch_igemm: full-width aligned tile -> LDS-staged float4 epilogue
 };
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st);
 // Winograd F(2x2,3x3) variant of the 3x3 conv (wino.hip): same IgemmParams, pre-transformed weights U[Cin/16][16][Cout][16]

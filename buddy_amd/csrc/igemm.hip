@@ -15,6 +15,7 @@
 // XCD-aware, so the nine shifted reads of a 3x3 conv hit the same L2 (HBM FETCH 9.7 GB -> 1.1 GB per 1.07 GB input).
 #include "common.h"
 #include <cstdio>
+#include <cstdint>
 #include <vector>
 #include <cstdlib>
 
@@ -151,10 +152,12 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
     const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+      // operands swapped (weights first): the accumulator tile is C^T, i.e. a lane holds pixel m = lane&31 and FOUR CONSECUTIVE
+      // output channels per register quad -- the epilogue moves 16-byte vectors.  Products and k order are unchanged (bit-identical).
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0[j], av0[j], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1[j], av0[j], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0[j], av1[j], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1[j], av1[j], acc[1][1], 0, 0, 0);
     }
   };
 
@@ -195,26 +198,77 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
     }
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // epilogue.  Accumulator layout (transposed tile): m = lane&31, n = (r&3) + 8*(r>>2) + 4*(lane>>5) within a 32x32 tile.
   const bool need_pix = (p.res_mode == 2) || (p.bias_bn != nullptr);
+  if (p.wide_epi) {
+    // Full-width N tile, 16-byte-aligned rows: stage the tile through LDS 64 rows at a time (the A/B buffers are free now) and
+    // write whole 512-byte output rows with float4 stores; bias / residual reads are float4 too.
+    constexpr int SLD = BN + 4;
+    float* S = smem;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h) __syncthreads();
+      if (wm == h) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(S + (mt * 32 + (lane & 31)) * SLD + wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5)) =
+                  make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+      }
+      __syncthreads();
+      const int c4 = (tid & 31) * 4, n = n0 + c4;
+      float4 bn4 = zero4();
+      if (p.bias_n) bn4 = ld4(p.bias_n + n);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = (tid >> 5) + 8 * i;
+        const int m = m0 + h * 64 + row;
+        if (m >= M) continue;
+        float4 v = *reinterpret_cast<const float4*>(S + row * SLD + c4);
+        int bidx = 0; long long res_pix = m;
+        if (need_pix) {
+          bidx = m / p.rows_per_batch;
+          if (p.res_mode == 2) {
+            const int w = m % W, hh = (m / W) % H;
+            res_pix = ((long long)bidx * (H >> 1) + (hh >> 1)) * (W >> 1) + (w >> 1);
+          }
+        }
+        // same operation order per element as the scalar path: alpha*acc + bias_m, + bias_n, + bias_bn, + res, * out_scale, + C
+        v.x = p.alpha * v.x; v.y = p.alpha * v.y; v.z = p.alpha * v.z; v.w = p.alpha * v.w;
+        if (p.bias_m) { const float bm = p.bias_m[m]; v.x += bm; v.y += bm; v.z += bm; v.w += bm; }
+        if (p.bias_n) { v.x += bn4.x; v.y += bn4.y; v.z += bn4.z; v.w += bn4.w; }
+        if (p.bias_bn) { const float4 t = ld4(p.bias_bn + (long long)bidx * p.ld_bias_bn + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (p.res_mode) { const float4 t = ld4(p.res + res_pix * p.ldRes + n); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        v.x *= p.out_scale; v.y *= p.out_scale; v.z *= p.out_scale; v.w *= p.out_scale;
+        float* dst = C + (long long)m * p.ldC + n;
+        if (p.accumulate) { const float4 t = ld4(dst); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        *reinterpret_cast<float4*>(dst) = v;
+      }
+    }
+    return;
+  }
+  // generic path (ragged N, unaligned rows): scalar stores
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m >= M) continue;
-      int bidx = 0; long long res_pix = m;
-      if (need_pix) {
-        bidx = m / p.rows_per_batch;
-        if (p.res_mode == 2) {
-          const int w = m % W, h = (m / W) % H;
-          res_pix = ((long long)bidx * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1);
-        }
+    const int m = m0 + wm * 64 + mt * 32 + (lane & 31);
+    if (m >= M) continue;
+    int bidx = 0; long long res_pix = m;
+    if (need_pix) {
+      bidx = m / p.rows_per_batch;
+      if (p.res_mode == 2) {
+        const int w = m % W, h = (m / W) % H;
+        res_pix = ((long long)bidx * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1);
       }
-      const float bm = p.bias_m ? p.bias_m[m] : 0.f;
+    }
+    const float bm = p.bias_m ? p.bias_m[m] : 0.f;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + wn * 64 + nt * 32 + (lane & 31);
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (n >= N) continue;
         float v = p.alpha * acc[mt][nt][r] + bm;
         if (p.bias_n) v += p.bias_n[n];
@@ -274,6 +328,16 @@ void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st
 
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st) {
   dim3 grid(cdiv(p.N, BN) * cdiv(p.M, BM), 1, batch), block(NT);
+  IgemmParams pw = p;
+  {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    bool wide = (p.N % BN == 0) && (p.ldC % 4 == 0) && al16(p.C) && (p.sC % 4 == 0);
+    if (p.bias_n) wide = wide && al16(p.bias_n);
+    if (p.bias_bn) wide = wide && al16(p.bias_bn) && (p.ld_bias_bn % 4 == 0);
+    if (p.res_mode) wide = wide && al16(p.res) && (p.ldRes % 4 == 0);
+    static const bool force_scalar = getenv("BUDDY_IGEMM_EPI") && atoi(getenv("BUDDY_IGEMM_EPI")) == 0;   // A/B switch
+    pw.wide_epi = (wide && !force_scalar) ? 1 : 0;
+  }
   ProfRec rec{};
   if (g_prof_on) {
     (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
@@ -288,17 +352,17 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
   // profiles/README.md), 4 = double-buffered LDS, one barrier per K step (slower: 2 blocks/CU).  A/B switch for the 3x3 kernel:
   static const int variant = getenv("BUDDY_IGEMM_VARIANT") ? atoi(getenv("BUDDY_IGEMM_VARIANT")) : 2;
   if (taps == 9) {
-    if (variant == 0) hipLaunchKernelGGL((igemm_kernel<9, false, false, 0>), grid, block, 0, st, p);
-    else if (variant == 4) hipLaunchKernelGGL((igemm_kernel<9, false, false, 4>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<9, false, false, 2>), grid, block, 0, st, p);
+    if (variant == 0) hipLaunchKernelGGL((igemm_kernel<9, false, false, 0>), grid, block, 0, st, pw);
+    else if (variant == 4) hipLaunchKernelGGL((igemm_kernel<9, false, false, 4>), grid, block, 0, st, pw);
+    else hipLaunchKernelGGL((igemm_kernel<9, false, false, 2>), grid, block, 0, st, pw);
   } else if (!transA && !transB) {
-    hipLaunchKernelGGL((igemm_kernel<1, false, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<1, false, false>), grid, block, 0, st, pw);
   } else if (!transA && transB) {
-    hipLaunchKernelGGL((igemm_kernel<1, false, true>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<1, false, true>), grid, block, 0, st, pw);
   } else if (transA && !transB) {
-    hipLaunchKernelGGL((igemm_kernel<1, true, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<1, true, false>), grid, block, 0, st, pw);
   } else {
-    hipLaunchKernelGGL((igemm_kernel<1, true, true>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((igemm_kernel<1, true, true>), grid, block, 0, st, pw);
   }
 }
 

@@ -354,6 +354,42 @@ __global__ __launch_bounds__(256) void conv_c2in_kernel(const float* x, const fl
   }
 }
 
+// Same op for Cout/4 dividing 256: a thread keeps its channel quad for the whole grid-stride loop, so its TAPS x 4 x 2 weights live
+// in registers (the generic kernel re-loads them per pixel: 36 weight loads per 16-byte store).
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_c2in_reg_kernel(const float* x, const float* w, const float* bias, const float* add, int add_ld,
+                                                            float* y, int ldY, int B, int H, int W, int Cout, int accumulate) {
+  const int q = Cout >> 2;
+  const int quad = threadIdx.x % q, c = quad * 4;
+  float2 wr[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[t][j] = *reinterpret_cast<const float2*>(w + ((long long)(c + j) * TAPS + t) * 2);
+  float b4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b4[j] = bias ? bias[c + j] : 0.f;
+  const int ppb = 256 / q;                                  // pixels per block iteration
+  const long long npix = (long long)B * H * W;
+  for (long long p = (long long)blockIdx.x * ppb + threadIdx.x / q; p < npix; p += (long long)gridDim.x * ppb) {
+    const int wq = (int)(p % W); const int h = (int)((p / W) % H);
+    float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int dy = (TAPS == 9) ? t / 3 - 1 : 0, dx = (TAPS == 9) ? t % 3 - 1 : 0;
+      if ((unsigned)(h + dy) >= (unsigned)H || (unsigned)(wq + dx) >= (unsigned)W) continue;
+      const float2 v = reinterpret_cast<const float2*>(x)[p + dy * W + dx];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += wr[t][j].x * v.x + wr[t][j].y * v.y;
+    }
+    float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (add) r = add4(r, ld4(add + p * add_ld + c));
+    float* o = y + p * ldY + c;
+    if (accumulate) r = add4(r, ld4(o));
+    st4(o, r);
+  }
+}
+
 // x [B][H][W][Cin] (ldX) -> y [B][H][W][2]; w [TAPS][Cin][2]; LPP = Cin/4 lanes cooperate on one pixel
 template <int TAPS>
 __global__ __launch_bounds__(256) void conv_c2out_kernel(const float* x, int ldX, const float* w, const float* bias, const float* up_add,
@@ -560,6 +596,16 @@ void launch_mix2(const float* x, const float* w, const float* b, float* y, long 
 void launch_conv_c2in(const float* x, const float* w, const float* bias, const float* add, int add_ld, float* y, int ldY, int B, int H, int W,
                       int Cout, int taps, int accumulate, hipStream_t st) {
   const long long total = (long long)B * H * W * (Cout / 4);
+  if (Cout % 4 == 0 && 256 % (Cout / 4) == 0) {
+    const int ppb = 256 / (Cout / 4);
+    long long g = ((long long)B * H * W + ppb - 1) / ppb;
+    if (g > 256 * 8) g = 256 * 8;
+    if (taps == 9)
+      hipLaunchKernelGGL(conv_c2in_reg_kernel<9>, dim3((int)g), dim3(256), 0, st, x, w, bias, add, add_ld, y, ldY, B, H, W, Cout, accumulate);
+    else
+      hipLaunchKernelGGL(conv_c2in_reg_kernel<1>, dim3((int)g), dim3(256), 0, st, x, w, bias, add, add_ld, y, ldY, B, H, W, Cout, accumulate);
+    return;
+  }
   if (taps == 9)
     hipLaunchKernelGGL(conv_c2in_kernel<9>, dim3(grid_for(total)), dim3(256), 0, st, x, w, bias, add, add_ld, y, ldY, B, H, W, Cout, accumulate);
   else

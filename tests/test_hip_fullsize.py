@@ -39,6 +39,28 @@ def test_fullsize_forward_vjp_vs_oracle(net):
     assert rel(g, gr) < 5e-4
 
 
+def test_longform_forward_vjp_vs_oracle(net):
+    """Maximum documented size (BASELINE.json configs[4]: 30 s = 480 000 samples, 3 751 -> 3 760 frames, 15 040 attention tokens;
+    the lowest level falls back to the direct 3x3 kernel because its 470 rows are not a multiple of 8)."""
+    from oracle import ncsnpp_ref
+    from buddy_amd.synth import synth_state_dict
+    torch.set_num_threads(32)
+    LL = 480000
+    P = ncsnpp_ref.to_torch(synth_state_dict(0, 128))
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy((0.4 * rs.standard_normal((1, LL))).astype(np.float32))
+    cot = torch.from_numpy(rs.standard_normal((1, LL)).astype(np.float32))
+    cn = torch.tensor([-0.6])
+    xr = x.clone().requires_grad_(True)
+    yr = ncsnpp_ref.ncsnpp_time(P, xr, cn, 510, 128)
+    gr, = torch.autograd.grad(yr, xr, cot)
+    xg = x.cuda().requires_grad_(True)
+    y = net(xg, cn.cuda())
+    g, = torch.autograd.grad(y, xg, cot.cuda())
+    assert rel(y, yr) < 5e-4
+    assert rel(g, gr) < 5e-4
+
+
 def test_fullsize_adjoint_identity_and_linearity(net):
     rs = np.random.RandomState(6)
     B = 2
