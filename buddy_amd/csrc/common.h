@@ -38,6 +38,7 @@ void launch_wino(const IgemmParams& p, const float* Uw, hipStream_t st);
 void wino_transform_weights(const float* wt_host, int Cout, int Cin, float* U_host);
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin);
 void igemm_prof_enable(int on);
+bool igemm_prof_enabled();
 int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], double bytes[2], double exec_flops[2]);
 
 // ---- small-channel direct convs -----------------------------------------------------------------------

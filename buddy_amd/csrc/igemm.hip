@@ -291,6 +291,7 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }
 void igemm_prof_enable(int on) { g_prof_on = on != 0; }
+bool igemm_prof_enabled() { return g_prof_on; }
 // sums elapsed time / algorithmic flops / launches per class (class 0: 3x3 convs, class 1: everything else) and clears
 int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], double bytes[2], double exec_flops[2]) {
   for (int c = 0; c < 2; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; bytes[c] = 0; exec_flops[c] = 0; }

@@ -27,7 +27,9 @@ constexpr int N2 = 25856, F1 = 101, F2 = 256;     // N2 = F1 * F2
 constexpr double PI = 3.14159265358979323846;
 
 // ------------------------------------------------------------------ small kernels
-__global__ __launch_bounds__(256) void pad_const_kernel(const float* s, float* sp, int U, int Ls, int P, int Lpad, const float* add, float add_scale) {
+__global__ __launch_bounds__(256) void pad_const_kernel(const float* s, float* sp, int U, int Ls, int P, int Lpad, const float* add, float add_scale,
+                                                        const float* add_scale_dev) {
+  if (add_scale_dev) add_scale = *add_scale_dev;          // captured-graph mode: the scalar lives in device memory
   const long long total = (long long)U * Lpad;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int u = (int)(i / Lpad), j = (int)(i % Lpad) - P;
@@ -349,7 +351,8 @@ __global__ __launch_bounds__(256) void mpb_out_kernel(const float2* o, float* gh
 
 // ---- Adam (torch.optim.Adam single-tensor arithmetic: lerp, addcmul, addcdiv) + projection ----
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
-                                                   float wd, float bc1, float bc2_sqrt) {
+                                                   float wd, float bc1, float bc2_sqrt, const int* step_dev, const float2* bc_tab) {
+  if (step_dev) { const float2 bc = bc_tab[*step_dev]; bc1 = bc.x; bc2_sqrt = bc.y; }   // captured-graph mode: bias corrections by table
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float gi = g[i];
     if (wd != 0.f) gi += wd * p[i];
@@ -360,6 +363,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     p[i] = p[i] - (lr / bc1) * (mi / denom);
   }
 }
+__global__ void set_scalar_kernel(float* dst, float v) { *dst = v; }
+__global__ void step_inc_kernel(int* step) { *step += 1; }
 __global__ void project_kernel(float* decay, float* wts, int U, int E, int NB, float dmin, float dmax, float wlo, float whi, int clamp_decay, int long2nd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= U * NB) return;
@@ -430,6 +435,11 @@ struct BlindOp {
   float *decay = nullptr, *wts = nullptr, *phi = nullptr;
   float *m_d = nullptr, *v_d = nullptr, *m_w = nullptr, *v_w = nullptr, *m_p = nullptr, *v_p = nullptr;
   int adam_step = 0;
+  // captured optimize_op graph (launch-bound loop: ~72 small kernels per Adam iteration): per-call inputs live at fixed device addresses
+  static constexpr int MAXSTEP = 65536;
+  int* d_step = nullptr; float* d_scal = nullptr; float2* bc_tab = nullptr; float tab_b1 = -1.f, tab_b2 = -1.f;
+  float *xden_buf = nullptr, *noise_buf = nullptr; int noise_iters = 0;
+  hipStream_t cap_stream = nullptr; hipGraphExec_t gexec = nullptr; int g_iters = -1; float g_hp[7] = {0, 0, 0, 0, 0, 0, 0};
   // state
   float *H = nullptr, *Yc = nullptr, *Xdelta = nullptr;
   // work buffers
@@ -448,7 +458,11 @@ struct BlindOp {
     allocs.push_back(q); *p = (Tp*)q;
     return 0;
   }
-  ~BlindOp() { for (void* q : allocs) (void)hipFree(q); }
+  ~BlindOp() {
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    for (void* q : allocs) (void)hipFree(q);
+  }
 
   // ---- primitive routines (all batched over U, on stream st) ----
   void gemm(const float* Am, int ldA, long long sA, const float* Bt, int ldB, bool tB, float* C, int ldC, long long sC, int M, int N, int Kk, float alpha, int batch) {
@@ -458,9 +472,9 @@ struct BlindOp {
     launch_igemm(p, 1, false, tB, batch, st);
   }
   // X[u][t][:] = scale * STFT frames of s (frame t starts at sample 128 t - P), Tn frames
-  void stft(const float* s, int Ls, int P, int Tn, float scale, float* X, const float* add = nullptr, float add_scale = 0.f) {
+  void stft(const float* s, int Ls, int P, int Tn, float scale, float* X, const float* add = nullptr, float add_scale = 0.f, const float* add_scale_dev = nullptr) {
     const int Lpad = ((Tn - 1) * HOP + WIN + 3) / 4 * 4;
-    hipLaunchKernelGGL(pad_const_kernel, dim3(gridf((long long)U * Lpad)), dim3(256), 0, st, s, sp, U, Ls, P, Lpad, add, add_scale);
+    hipLaunchKernelGGL(pad_const_kernel, dim3(gridf((long long)U * Lpad)), dim3(256), 0, st, s, sp, U, Ls, P, Lpad, add, add_scale, add_scale_dev);
     gemm(sp, HOP, Lpad, Bf, WIN, false, X, LDSP, (long long)Tn * LDSP, Tn, LDSP, WIN, scale, U);
   }
   // y[u][s] = sum_t frames_t[s + Q - 128 t] * inv_env[s + Q],  frames = scale * iDFT(Y) * window
@@ -623,6 +637,7 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
   DA(partial, (size_t)U_ * 64); DA(losses, (size_t)U_ * 4);
   DA(rir, (size_t)U_ * o->Lr); DA(Rc, (size_t)U_ * Td * LDSP + 8);
   DA(dpm, (size_t)Nf * FB);
+  DA(d_step, 4); DA(d_scal, 4); DA(bc_tab, BlindOp::MAXSTEP); DA(xden_buf, (size_t)U_ * L);
   // direct-path magnitude correction |STFT(2 delta)|[:, 1:] (reference :201-205) and STFT of the unit impulse, computed on device
   {
     const int saveU = o->U; o->U = 1; o->st = nullptr;
@@ -661,6 +676,7 @@ int blindop_set_params(BlindOp* o, const float* decay, const float* wts, const f
   if (phases_ref) hipLaunchKernelGGL(transpose_fk_kernel, dim3(gridf((long long)o->U * o->Nf * FB)), dim3(256), 0, st, phases_ref, o->phi, o->U, o->Nf, 1);
   if (reset_adam) {
     o->adam_step = 0;
+    HIPCHK(hipMemsetAsync(o->d_step, 0, 4, st));
     HIPCHK(hipMemsetAsync(o->m_d, 0, nb, st)); HIPCHK(hipMemsetAsync(o->v_d, 0, nb, st));
     HIPCHK(hipMemsetAsync(o->m_w, 0, nb, st)); HIPCHK(hipMemsetAsync(o->v_w, 0, nb, st));
     const size_t np = (size_t)o->U * o->Nf * FB * 4;
@@ -724,7 +740,7 @@ int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* l
 
 // one gradient evaluation of  rec_loss_params(y, degrade(x_den)) + reg(rir, rir + t_op * noise)  w.r.t. (decay, weights, phases);
 // H is rebuilt from the parameters first (update_H at the top of each optimize_op iteration, reference :83)
-static int param_grads(BlindOp* o, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, bool have_Xd) {
+static int param_grads(BlindOp* o, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, bool have_Xd, const float* t_op_dev = nullptr) {
   const int U = o->U, T = o->T, Td = o->Td, L = o->L, Nf = o->Nf;
   hipStream_t st = o->st;
   o->update_H();
@@ -740,7 +756,7 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
   // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach())
   if (noise) {
     o->time_rir(o->rir);                                                     // Ybuf = FIR(Xdelta, H) consumed inside
-    o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X3, noise, t_op);      // STFT(rir + t n)
+    o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X3, noise, t_op, t_op_dev);      // STFT(rir + t n)
     hipLaunchKernelGGL(compress_kernel, dim3(gridf((long long)U * Td * FB)), dim3(256), 0, st, (const float*)o->X3, o->Rc, (long long)U * Td, o->c.comp);
     o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X2);
     o->comp_loss(o->Rc, o->X2, o->X3, Td, w_reg, o->losses + U, 0);
@@ -768,24 +784,78 @@ int blindop_param_grads(BlindOp* o, const float* x_den, const float* noise, floa
   return BUDDY_OK;
 }
 
+// One Adam iteration of optimize_op; dev = captured-graph mode (step counter, bias corrections and t_op read from device memory).
+static void optimize_iteration(BlindOp* o, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, float lr, float b1, float b2,
+                               float wd, bool have_Xd, bool dev) {
+  const int U = o->U;
+  hipStream_t st = o->st;
+  const long long nb = (long long)U * o->E * o->NB, np = (long long)U * o->Nf * FB;
+  param_grads(o, x_den, noise, t_op, w_rec, w_reg, have_Xd, dev ? o->d_scal : nullptr);
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, o->d_step);
+  o->adam_step += 1;
+  const float bc1 = 1.f - std::pow(b1, (float)o->adam_step), bc2s = std::sqrt(1.f - std::pow(b2, (float)o->adam_step));
+  const int* sd = dev ? o->d_step : nullptr;
+  hipLaunchKernelGGL(adam_kernel, dim3(gridf(nb)), dim3(256), 0, st, o->decay, (const float*)o->gdecay, o->m_d, o->v_d, nb, lr, b1, b2, 1e-8f, wd, bc1, bc2s, sd, (const float2*)o->bc_tab);
+  hipLaunchKernelGGL(adam_kernel, dim3(gridf(nb)), dim3(256), 0, st, o->wts, (const float*)o->gw, o->m_w, o->v_w, nb, lr, b1, b2, 1e-8f, wd, bc1, bc2s, sd, (const float2*)o->bc_tab);
+  hipLaunchKernelGGL(adam_kernel, dim3(gridf(np)), dim3(256), 0, st, o->phi, (const float*)o->gphi, o->m_p, o->v_p, np, lr, b1, b2, 1e-8f, wd, bc1, bc2s, sd, (const float2*)o->bc_tab);
+  hipLaunchKernelGGL(project_kernel, dim3(cdiv(U * o->NB, 256)), dim3(256), 0, st, o->decay, o->wts, U, o->E, o->NB, o->c.min_decay, o->c.max_decay,
+                     o->c.w_lo, o->c.w_hi, o->c.clamp_decay, o->c.long2nd);
+}
+
 // n_iters iterations of optimize_op (reference :71-113): update_H, losses, backward, Adam step on [decay, weights, phases], projection.
 // noise: (n_iters, U, Lr) standard normal draws for the RIR regulariser (NULL disables it).
+// The loop is ~72 small launches per iteration and launch-bound, so it is captured ONCE into a hipGraph (on a private stream; the
+// caller's stream may be the legacy default stream, which cannot capture) and replayed on the caller's stream every sampler step;
+// the per-call inputs (x_den, noise, t_op) are first copied to fixed device buffers.  BUDDY_OP_GRAPH=0 keeps the eager launches.
 int blindop_optimize(BlindOp* o, const float* x_den, const float* noise, float t_op, int n_iters, float w_rec, float w_reg, float lr, float b1,
                      float b2, float wd, hipStream_t st) {
   o->st = st;
   const int U = o->U;
-  const long long nb = (long long)U * o->E * o->NB, np = (long long)U * o->Nf * FB;
-  for (int it = 0; it < n_iters; ++it) {
-    param_grads(o, x_den, noise ? noise + (long long)it * U * o->Lr : nullptr, t_op, w_rec, w_reg, it > 0);
-    o->adam_step += 1;
-    const float bc1 = 1.f - std::pow(b1, (float)o->adam_step), bc2s = std::sqrt(1.f - std::pow(b2, (float)o->adam_step));
-    hipLaunchKernelGGL(adam_kernel, dim3(gridf(nb)), dim3(256), 0, st, o->decay, (const float*)o->gdecay, o->m_d, o->v_d, nb, lr, b1, b2, 1e-8f, wd, bc1, bc2s);
-    hipLaunchKernelGGL(adam_kernel, dim3(gridf(nb)), dim3(256), 0, st, o->wts, (const float*)o->gw, o->m_w, o->v_w, nb, lr, b1, b2, 1e-8f, wd, bc1, bc2s);
-    hipLaunchKernelGGL(adam_kernel, dim3(gridf(np)), dim3(256), 0, st, o->phi, (const float*)o->gphi, o->m_p, o->v_p, np, lr, b1, b2, 1e-8f, wd, bc1, bc2s);
-    hipLaunchKernelGGL(project_kernel, dim3(cdiv(U * o->NB, 256)), dim3(256), 0, st, o->decay, o->wts, U, o->E, o->NB, o->c.min_decay, o->c.max_decay,
-                       o->c.w_lo, o->c.w_hi, o->c.clamp_decay, o->c.long2nd);
+  static const bool want_graph = !(getenv("BUDDY_OP_GRAPH") && atoi(getenv("BUDDY_OP_GRAPH")) == 0);
+  const bool use_graph = want_graph && n_iters > 0 && o->adam_step + n_iters < BlindOp::MAXSTEP;
+  if (!use_graph) {
+    for (int it = 0; it < n_iters; ++it)
+      optimize_iteration(o, x_den, noise ? noise + (long long)it * U * o->Lr : nullptr, t_op, w_rec, w_reg, lr, b1, b2, wd, it > 0, false);
+    HIPCHK(hipGetLastError());
+    return BUDDY_OK;
   }
-  HIPCHK(hipGetLastError());
+  if (o->tab_b1 != b1 || o->tab_b2 != b2) {               // bias-correction table, same host arithmetic as the eager path
+    std::vector<float2> tab(BlindOp::MAXSTEP);
+    for (int k = 0; k < BlindOp::MAXSTEP; ++k) tab[k] = make_float2(1.f - std::pow(b1, (float)k), std::sqrt(1.f - std::pow(b2, (float)k)));
+    HIPCHK(hipMemcpy(o->bc_tab, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    o->tab_b1 = b1; o->tab_b2 = b2;
+  }
+  if (noise && o->noise_iters < n_iters) {
+    if (o->dalloc(&o->noise_buf, (size_t)n_iters * U * o->Lr)) { return BUDDY_ERR_HIP; }
+    o->noise_iters = n_iters;
+    if (o->gexec) { (void)hipGraphExecDestroy(o->gexec); o->gexec = nullptr; }
+  }
+  HIPCHK(hipMemcpyAsync(o->xden_buf, x_den, (size_t)U * o->L * 4, hipMemcpyDeviceToDevice, st));
+  if (noise) HIPCHK(hipMemcpyAsync(o->noise_buf, noise, (size_t)n_iters * U * o->Lr * 4, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, o->d_scal, t_op);
+  const float hp[7] = {w_rec, w_reg, lr, b1, b2, wd, noise ? 1.f : 0.f};
+  if (!o->gexec || o->g_iters != n_iters || std::memcmp(hp, o->g_hp, sizeof(hp)) != 0) {
+    if (o->gexec) { (void)hipGraphExecDestroy(o->gexec); o->gexec = nullptr; }
+    if (!o->cap_stream) HIPCHK(hipStreamCreateWithFlags(&o->cap_stream, hipStreamNonBlocking));
+    const bool prof = igemm_prof_enabled();
+    igemm_prof_enable(0);                                // no event records inside the captured region
+    const int step0 = o->adam_step;
+    HIPCHK(hipStreamBeginCapture(o->cap_stream, hipStreamCaptureModeThreadLocal));
+    o->st = o->cap_stream;
+    for (int it = 0; it < n_iters; ++it)
+      optimize_iteration(o, o->xden_buf, noise ? o->noise_buf + (long long)it * U * o->Lr : nullptr, t_op, w_rec, w_reg, lr, b1, b2, wd, it > 0, true);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(o->cap_stream, &graph);
+    o->st = st; o->adam_step = step0;
+    igemm_prof_enable(prof ? 1 : 0);
+    if (ce != hipSuccess || !graph) { set_error(std::string("optimize_op graph capture failed: ") + hipGetErrorString(ce)); return BUDDY_ERR_HIP; }
+    const hipError_t ie = hipGraphInstantiate(&o->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) { o->gexec = nullptr; set_error(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(ie)); return BUDDY_ERR_HIP; }
+    o->g_iters = n_iters; std::memcpy(o->g_hp, hp, sizeof(hp));
+  }
+  HIPCHK(hipGraphLaunch(o->gexec, st));
+  o->adam_step += n_iters;
   return BUDDY_OK;
 }
 

@@ -107,7 +107,7 @@ int buddy_fir(const float* x, const float* h, long long h_stride, float* y, int 
 /* ---- blind subband-filtering reverb operator, batched over U utterances; replaces testing/operators/subband_filtering.py
  * (BlindSubbandFiltering :142-351 incl. SubbandFiltering :8-136), utils/reverb_utils.py:3-23, utils/losses.py:59-64 and the
  * torch.optim.Adam loop of EulerHeunSamplerDPS.optimize_op (testing/EulerHeunSamplerDPS.py:71-113) with hand-written
- * forward + analytic backward kernels.  STFT is fixed to NFFT 1024 / win 512 / hop 128 (conf/tester/*.yaml op_hp).
+ * forward + analytic backward kernels.  STFT is fixed to NFFT 1024 / win 512 / hop 128 (op_hp of the conf/tester yaml files).
  * Tensor shapes follow the reference: decay/weights (U,E,bands), phases (U,513,Nf), H (U,513,Nf) complex64 interleaved. ---- */
 int buddy_blindop_create(int U, int L, int Nf, int E, int num_knots, const float* knots_hz /*host*/, int sample_rate, float compression,
                          float min_decay, float max_decay, float w_lo, float w_hi, int clamp_decay, int long_second, void** handle);
