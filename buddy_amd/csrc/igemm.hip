@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
   // epilogue.  Accumulator layout (transposed tile): m = lane&31, n = (r&3) + 8*(r>>2) + 4*(lane>>5) within a 32x32 tile.
   const bool need_pix = (p.res_mode == 2) || (p.bias_bn != nullptr);
   if (p.wide_epi) {
-    // Full-width N tile, 16-byte-aligned rows: stage the tile through LDS 64 rows at a time (the A/B buffers are free now) and
+    // 16-byte-aligned rows, N a multiple of 4: stage the tile through LDS 64 rows at a time (the A/B buffers are free now) and
     // write whole 512-byte output rows with float4 stores; bias / residual reads are float4 too.
     constexpr int SLD = BN + 4;
     float* S = smem;
@@ -220,13 +220,14 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
       }
       __syncthreads();
       const int c4 = (tid & 31) * 4, n = n0 + c4;
+      const bool n_ok = n < N;
       float4 bn4 = zero4();
-      if (p.bias_n) bn4 = ld4(p.bias_n + n);
+      if (p.bias_n && n_ok) bn4 = ld4(p.bias_n + n);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = (tid >> 5) + 8 * i;
         const int m = m0 + h * 64 + row;
-        if (m >= M) continue;
+        if (m >= M || !n_ok) continue;
         float4 v = *reinterpret_cast<const float4*>(S + row * SLD + c4);
         int bidx = 0; long long res_pix = m;
         if (need_pix) {
@@ -332,7 +333,7 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
   IgemmParams pw = p;
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    bool wide = (p.N % BN == 0) && (p.ldC % 4 == 0) && al16(p.C) && (p.sC % 4 == 0);
+    bool wide = (p.N % 4 == 0) && (p.ldC % 4 == 0) && al16(p.C) && (p.sC % 4 == 0);    // a float4 of columns is all inside or all outside N
     if (p.bias_n) wide = wide && al16(p.bias_n);
     if (p.bias_bn) wide = wide && al16(p.bias_bn) && (p.ld_bias_bn % 4 == 0);
     if (p.res_mode) wide = wide && al16(p.res) && (p.ldRes % 4 == 0);

@@ -40,21 +40,36 @@ __global__ __launch_bounds__(256) void pad_const_kernel(const float* s, float* s
 }
 
 // Y[u][t][f] = sum_k H[u][k][f] * X[u][t + 1 - k][f]   (reference subband_filtering :67-74, one pre-impulse frame)
+// A thread owns FOUR consecutive frames of one (utterance, bin): per tap it loads one H value and one new X frame (the other three
+// slide through registers), i.e. 2 loads per 4 complex MACs instead of 8.  Per-output summation order is k ascending, as before.
+constexpr int FT = 4;
 __global__ __launch_bounds__(256) void fir_kernel_sb(const float* X, long long xs, const float* H, float* Y, int U, int T, int Nf) {
-  const long long total = (long long)U * T * FB;
+  const int TG = (T + FT - 1) / FT;
+  const long long total = (long long)U * TG * FB;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int f = (int)(i % FB); const int t = (int)((i / FB) % T); const int u = (int)(i / ((long long)FB * T));
-    const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs);
-    const float2* Hu = reinterpret_cast<const float2*>(H + (long long)u * Nf * LDSP);
-    float ar = 0.f, ai = 0.f;
-    for (int k = 0; k < Nf; ++k) {
-      const int tt = t + 1 - k;
-      if (tt < 0) break;
-      if (tt >= T) continue;
-      const float2 h = Hu[(long long)k * (LDSP / 2) + f], x = Xu[(long long)tt * (LDSP / 2) + f];
-      ar += h.x * x.x - h.y * x.y; ai += h.x * x.y + h.y * x.x;
+    const int f = (int)(i % FB); const int t0 = (int)((i / FB) % TG) * FT; const int u = (int)(i / ((long long)FB * TG));
+    const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs) + f;
+    const float2* Hu = reinterpret_cast<const float2*>(H + (long long)u * Nf * LDSP) + f;
+    auto ldx = [&](int tt) { return (tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2)] : make_float2(0.f, 0.f); };
+    float ar[FT], ai[FT];
+#pragma unroll
+    for (int j = 0; j < FT; ++j) { ar[j] = 0.f; ai[j] = 0.f; }
+    // window w[j] = X[t0 + j + 1 - k]; at k = 0: X[t0+1 .. t0+4]
+    float2 w[FT];
+#pragma unroll
+    for (int j = 0; j < FT; ++j) w[j] = ldx(t0 + j + 1);
+    const int kmax = (t0 + FT < Nf) ? t0 + FT : Nf - 1;          // beyond k = t + 1 every index is negative
+    for (int k = 0; k <= kmax && k < Nf; ++k) {
+      const float2 h = Hu[(long long)k * (LDSP / 2)];
+#pragma unroll
+      for (int j = 0; j < FT; ++j) { ar[j] += h.x * w[j].x - h.y * w[j].y; ai[j] += h.x * w[j].y + h.y * w[j].x; }
+#pragma unroll
+      for (int j = FT - 1; j > 0; --j) w[j] = w[j - 1];
+      w[0] = ldx(t0 - k);
     }
-    reinterpret_cast<float2*>(Y + ((long long)u * T + t) * LDSP)[f] = make_float2(ar, ai);
+#pragma unroll
+    for (int j = 0; j < FT; ++j)
+      if (t0 + j < T) reinterpret_cast<float2*>(Y + ((long long)u * T + t0 + j) * LDSP)[f] = make_float2(ar[j], ai[j]);
   }
 }
 // GX[u][t'][f] = sum_k conj(H[k]) * GY[t' - 1 + k]
@@ -76,23 +91,39 @@ __global__ __launch_bounds__(256) void fir_adjx_kernel(const float* GY, const fl
   }
 }
 // GH[u][k][f] (+)= sum_t conj(X[t + 1 - k]) * GY[t]
+// A thread owns FOUR consecutive taps k0..k0+3 of one (utterance, bin): per frame one GY load and one new X frame.
 __global__ __launch_bounds__(256) void fir_gradh_kernel(const float* X, long long xs, const float* GY, float* GH, int U, int T, int Nf, int accumulate) {
-  const long long total = (long long)U * Nf * FB;
+  const int KG = (Nf + FT - 1) / FT;
+  const long long total = (long long)U * KG * FB;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int f = (int)(i % FB); const int k = (int)((i / FB) % Nf); const int u = (int)(i / ((long long)FB * Nf));
-    const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs);
-    const float2* Gu = reinterpret_cast<const float2*>(GY + (long long)u * T * LDSP);
-    float ar = 0.f, ai = 0.f;
-    const int t0 = k > 0 ? k - 1 : 0;
-    for (int t = t0; t < T; ++t) {
-      const int tt = t + 1 - k;
-      if (tt >= T) break;
-      const float2 x = Xu[(long long)tt * (LDSP / 2) + f], g = Gu[(long long)t * (LDSP / 2) + f];
-      ar += x.x * g.x + x.y * g.y; ai += x.x * g.y - x.y * g.x;
+    const int f = (int)(i % FB); const int k0 = (int)((i / FB) % KG) * FT; const int u = (int)(i / ((long long)FB * KG));
+    const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs) + f;
+    const float2* Gu = reinterpret_cast<const float2*>(GY + (long long)u * T * LDSP) + f;
+    auto ldx = [&](int tt) { return (tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2)] : make_float2(0.f, 0.f); };
+    float ar[FT], ai[FT];
+#pragma unroll
+    for (int j = 0; j < FT; ++j) { ar[j] = 0.f; ai[j] = 0.f; }
+    // window w[j] = X[t + 1 - k0 - j]
+    const int ts = k0 > 0 ? k0 - 1 : 0;                     // first frame with a non-negative index for tap k0
+    float2 w[FT];
+#pragma unroll
+    for (int j = 0; j < FT; ++j) w[j] = ldx(ts + 1 - k0 - j);
+    for (int t = ts; t < T; ++t) {
+      const float2 g = Gu[(long long)t * (LDSP / 2)];
+#pragma unroll
+      for (int j = 0; j < FT; ++j) { ar[j] += w[j].x * g.x + w[j].y * g.y; ai[j] += w[j].x * g.y - w[j].y * g.x; }
+#pragma unroll
+      for (int j = FT - 1; j > 0; --j) w[j] = w[j - 1];
+      w[0] = ldx(t + 2 - k0);
     }
-    float2* o = reinterpret_cast<float2*>(GH + ((long long)u * Nf + k) * LDSP) + f;
-    if (accumulate) { ar += o->x; ai += o->y; }
-    *o = make_float2(ar, ai);
+#pragma unroll
+    for (int j = 0; j < FT; ++j) {
+      if (k0 + j >= Nf) continue;
+      float2* o = reinterpret_cast<float2*>(GH + ((long long)u * Nf + k0 + j) * LDSP) + f;
+      float r = ar[j], im = ai[j];
+      if (accumulate) { r += o->x; im += o->y; }
+      *o = make_float2(r, im);
+    }
   }
 }
 
@@ -535,7 +566,7 @@ struct BlindOp {
   }
   void update_H() { design(); cons_forward(); }
   void fir(const float* X, long long xs, int Tn, float* Y) {
-    hipLaunchKernelGGL(fir_kernel_sb, dim3(gridf((long long)U * Tn * FB)), dim3(256), 0, st, X, xs, (const float*)H, Y, U, Tn, Nf);
+    hipLaunchKernelGGL(fir_kernel_sb, dim3(gridf((long long)U * ((Tn + FT - 1) / FT) * FB)), dim3(256), 0, st, X, xs, (const float*)H, Y, U, Tn, Nf);
   }
   // loss_u (+)= kappa * sum |Rc - comp(Xh)|^2, G optional
   void comp_loss(const float* Rcx, const float* Xh, float* G, int Tn, float weight, float* out, int accumulate) {
@@ -752,7 +783,7 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
   o->comp_loss(o->Yc, o->X2, o->X3, T, w_rec, o->losses, 0);
   o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, o->sig2);
   o->istft_adj(o->sig2, T, WIN + WIN / 2, o->env_T, L, o->norm, o->X2);
-  hipLaunchKernelGGL(fir_gradh_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->X1, (long long)T * LDSP, (const float*)o->X2, o->GH, U, T, Nf, 0);
+  hipLaunchKernelGGL(fir_gradh_kernel, dim3(gridf((long long)U * ((Nf + FT - 1) / FT) * FB)), dim3(256), 0, st, (const float*)o->X1, (long long)T * LDSP, (const float*)o->X2, o->GH, U, T, Nf, 0);
   // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach())
   if (noise) {
     o->time_rir(o->rir);                                                     // Ybuf = FIR(Xdelta, H) consumed inside
@@ -762,7 +793,7 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
     o->comp_loss(o->Rc, o->X2, o->X3, Td, w_reg, o->losses + U, 0);
     o->stft_adj(o->X3, o->Lr, WIN, Td, 1.f / o->norm, o->sig2);
     o->istft_adj(o->sig2, Td, WIN + WIN / 2, o->env_d, o->Lr, o->norm, o->X2);
-    hipLaunchKernelGGL(fir_gradh_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->Xdelta, 0LL, (const float*)o->X2, o->GH, U, Td, Nf, 1);
+    hipLaunchKernelGGL(fir_gradh_kernel, dim3(gridf((long long)U * ((Nf + FT - 1) / FT) * FB)), dim3(256), 0, st, (const float*)o->Xdelta, 0LL, (const float*)o->X2, o->GH, U, Td, Nf, 1);
   }
   o->cons_backward(o->GH);
   hipLaunchKernelGGL(h0_bwd_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->GFin, (const float*)o->A, (const float*)o->phi, o->gA, o->gphi, U, Nf);
