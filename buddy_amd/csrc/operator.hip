@@ -108,7 +108,21 @@ __global__ __launch_bounds__(256) void fir_gradh_kernel(const float* X, long lon
     float2 w[FT];
 #pragma unroll
     for (int j = 0; j < FT; ++j) w[j] = ldx(ts + 1 - k0 - j);
-    for (int t = ts; t < T; ++t) {
+    int t = ts;
+    for (; t + 8 <= T; t += 8) {                            // eight frames per trip: all 16 loads are issued before the arithmetic
+      float2 g8[8], x8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { g8[q] = Gu[(long long)(t + q) * (LDSP / 2)]; x8[q] = ldx(t + q + 2 - k0); }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int j = 0; j < FT; ++j) { ar[j] += w[j].x * g8[q].x + w[j].y * g8[q].y; ai[j] += w[j].x * g8[q].y - w[j].y * g8[q].x; }
+#pragma unroll
+        for (int j = FT - 1; j > 0; --j) w[j] = w[j - 1];
+        w[0] = x8[q];
+      }
+    }
+    for (; t < T; ++t) {
       const float2 g = Gu[(long long)t * (LDSP / 2)];
 #pragma unroll
       for (int j = 0; j < FT; ++j) { ar[j] += w[j].x * g.x + w[j].y * g.y; ai[j] += w[j].x * g.y - w[j].y * g.x; }
@@ -239,7 +253,10 @@ __global__ void design_bwd_knots_kernel(const float* gA, const float* Apre, Desi
   const float* g = gA + ((long long)u * Nf + n) * FB;
   const float* ap = Apre + ((long long)u * Nf + n) * FB;
   float acc = 0.f;
-  for (int f = 0; f < FB; ++f) {
+  // idx[] is non-decreasing in f (bin -> knot interval), so only the contiguous bins with idx in {j-1, j} contribute
+  auto first_ge = [&](int v) { int lo = 0, hi = FB; while (lo < hi) { const int mid = (lo + hi) >> 1; if (tb.idx[mid] >= v) hi = mid; else lo = mid + 1; } return lo; };
+  const int f_lo = first_ge(j - 1), f_hi = first_ge(j + 1);
+  for (int f = f_lo; f < f_hi; ++f) {
     const int id = tb.idx[f];
     if (id == j) acc += (1.f - tb.frac[f]) * g[f] * ap[f];
     else if (id + 1 == j) acc += tb.frac[f] * g[f] * ap[f];
@@ -458,7 +475,7 @@ struct BlindOp {
   hipStream_t st = nullptr;
   std::vector<void*> allocs;
   // tables
-  float *Bf = nullptr, *Bi = nullptr, *ones = nullptr, *env_T = nullptr, *env_d = nullptr, *env_c = nullptr;
+  float *Bf = nullptr, *Bi = nullptr, *BfT = nullptr, *BiT = nullptr, *ones = nullptr, *env_T = nullptr, *env_d = nullptr, *env_c = nullptr;
   float norm = 1.f;
   int* idx = nullptr; float *frac = nullptr, *corr = nullptr, *dpm = nullptr;
   float2 *w101 = nullptr, *w256 = nullptr, *twN = nullptr;
@@ -515,13 +532,13 @@ struct BlindOp {
   }
   // adjoint of stft: g_s from G_X
   void stft_adj(const float* GX, int Ls, int P, int Tn, float scale, float* gs) {
-    gemm(GX, LDSP, 0, Bf, WIN, true, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
+    gemm(GX, LDSP, 0, BfT, LDSP, false, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
     launch_ola(frames, WIN, Tn, WIN, HOP, ones, gs, U, Ls, P, nullptr, nullptr, nullptr, st);
   }
   // adjoint of istft: G_Y from g_y
   void istft_adj(const float* gy, int Tn, int Q, const float* inv_env, int Ls, float scale, float* GY) {
     launch_ola_adj(gy, U, Ls, Q, Tn, WIN, HOP, inv_env, nullptr, frames, WIN, st);
-    gemm(frames, WIN, 0, Bi, LDSP, true, GY, LDSP, 0, U * Tn, LDSP, WIN, scale, 1);
+    gemm(frames, WIN, 0, BiT, WIN, false, GY, LDSP, 0, U * Tn, LDSP, WIN, scale, 1);
   }
   void fft(const float2* x, float2* tmp, float2* X, int sign, float scale) {
     hipLaunchKernelGGL(fft_stage1_kernel, dim3(cdiv(N2, 256), U), dim3(256), 0, st, x, tmp, (const float2*)w101, (const float2*)twN, sign);
@@ -623,6 +640,11 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
   host_tables(o, Bf, Bi, w, norm2);
   o->norm = (float)std::sqrt((double)(float)norm2);
   UP(Bf, Bf); UP(Bi, Bi);
+  {  // transposed copies for the adjoint GEMMs: the k-contiguous operand path of the GEMM kernel is ~25 % faster than its k-major path
+    std::vector<float> BfT((size_t)WIN * LDSP), BiT((size_t)LDSP * WIN);
+    for (int n = 0; n < LDSP; ++n) for (int k = 0; k < WIN; ++k) { BfT[(size_t)k * LDSP + n] = Bf[(size_t)n * WIN + k]; BiT[(size_t)n * WIN + k] = Bi[(size_t)k * LDSP + n]; }
+    UP(BfT, BfT); UP(BiT, BiT);
+  }
   std::vector<float> eT = inv_env_of(w, o->T), ed = inv_env_of(w, o->Td), ec = inv_env_of(w, cfg.Nf + 2);
   UP(env_T, eT); UP(env_d, ed); UP(env_c, ec);
   std::vector<float> ones((size_t)((o->T > o->Td ? o->T : o->Td) + 8) * HOP + NFFT, 1.f); UP(ones, ones);
