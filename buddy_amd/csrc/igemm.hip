@@ -28,12 +28,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int TAPS, bool TA, bool TB, int V = 2>
+// MT = 32-row MFMA tiles per wave along M: 2 -> 128-row block tile (default), 1 -> 64-row block tile for GEMMs whose 128-row
+// tiling would leave CUs idle (the operator's 4040 x 512 x 1028 DFT GEMMs are 128 tiles on 256 CUs).
+template <int TAPS, bool TA, bool TB, int V = 2, int MT = 2>
 __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
+  static_assert(MT == 2 || !TA, "64-row tiles are only built for row-major A");
   constexpr int NBUF = (V >= 4) ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LDS_LD];
+  constexpr int BMt = 64 * MT, AR = BMt / 32;
+  constexpr int SM_MAIN = NBUF * (BMt + BN) * LDS_LD, SM_EPI = 64 * (BN + 4);
+  __shared__ __attribute__((aligned(16))) float smem[SM_MAIN > SM_EPI ? SM_MAIN : SM_EPI];
   float* As = smem;
-  float* Bs = smem + BM * LDS_LD;
+  float* Bs = smem + BMt * LDS_LD;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  const int m0 = (lid / nNt) * BM, n0 = (lid % nNt) * BN;
+  const int m0 = (lid / nNt) * BMt, n0 = (lid % nNt) * BN;
   const long long bz = blockIdx.z;
   const float* __restrict__ A0 = p.A0 + bz * p.sA;
   const float* __restrict__ A1 = p.A1 ? p.A1 + bz * p.sA : nullptr;
@@ -60,10 +65,10 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
   // loader coordinates
   const int lr = tid >> 3, lc4 = tid & 7;     // row-major operands: rows lr + 32 i, float4 column lc4
   const int tk = tid >> 5, tm4 = tid & 31;    // k-major operands:   k rows tk + 8 i, float4 (4 rows of the tile) tm4
-  int ah[4], aw[4];
-  bool am_ok[4];
+  int ah[AR], aw[AR];
+  bool am_ok[AR];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < AR; ++i) {
     const int m = m0 + lr + 32 * i;
     am_ok[i] = m < M;
     if (TAPS == 9) { aw[i] = m % W; ah[i] = (m / W) % H; } else { aw[i] = 0; ah[i] = 0; }
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
       const float* src = A0; int ld = p.ldA0;
       if (A1 != nullptr && cc >= p.C0) { src = A1; ld = p.ldA1; cc -= p.C0; }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < AR; ++i) {
         bool v = am_ok[i] && k_ok;
         if (TAPS == 9) v = v && (unsigned)(ah[i] + dy) < (unsigned)H && (unsigned)(aw[i] + dx) < (unsigned)W;
         const long long pix = (long long)(m0 + lr + 32 * i) + dy * W + dx;
@@ -113,10 +118,10 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
       }
     }
   };
-  auto store_tile = [&](float* S, const float4 (&r)[4], bool trans) {
+  auto store_tile = [&](float* S, const float4 (&r)[4], bool trans, int cnt = 4) {
     if (!trans) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(S + (lr + 32 * i) * LDS_LD + lc4 * 4) = r[i];
+      for (int i = 0; i < 4; ++i) if (i < cnt) *reinterpret_cast<float4*>(S + (lr + 32 * i) * LDS_LD + lc4 * 4) = r[i];
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -129,9 +134,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -140,12 +145,12 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
   float4 ra[4], rb[4];
   loadA(0, ra);
   loadB(0, rb);
-  const float* Af = As + (wm * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
+  const float* Af = As + (wm * 32 * MT + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
   const float* Bf = Bs + (wn * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 4;
 
   auto mfma_group = [&](const float* Afp, const float* Bfp, int g) {
     const float4 a0 = *reinterpret_cast<const float4*>(Afp + g * 8);
-    const float4 a1 = *reinterpret_cast<const float4*>(Afp + 32 * LDS_LD + g * 8);
+    const float4 a1 = (MT == 2) ? *reinterpret_cast<const float4*>(Afp + 32 * LDS_LD + g * 8) : zero4();
     const float4 b0 = *reinterpret_cast<const float4*>(Bfp + g * 8);
     const float4 b1 = *reinterpret_cast<const float4*>(Bfp + 32 * LDS_LD + g * 8);
     const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
@@ -156,14 +161,16 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
       // output channels per register quad -- the epilogue moves 16-byte vectors.  Products and k order are unchanged (bit-identical).
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0[j], av0[j], acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1[j], av0[j], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0[j], av1[j], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1[j], av1[j], acc[1][1], 0, 0, 0);
+      if (MT == 2) {
+        acc[MT - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv0[j], av1[j], acc[MT - 1][0], 0, 0, 0);
+        acc[MT - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv1[j], av1[j], acc[MT - 1][1], 0, 0, 0);
+      }
     }
   };
 
   if (V < 4) {
     for (int kt = 0; kt < nk; ++kt) {
-      store_tile(As, ra, TA);
+      store_tile(As, ra, TA, AR);
       store_tile(Bs, rb, TB);
       __syncthreads();
       if (V == 0 && kt + 1 < nk) { loadA(kt + 1, ra); loadB(kt + 1, rb); }
@@ -178,8 +185,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
     }
   } else {
     // double-buffered LDS: one barrier per K step
-    constexpr int BUFSZ = (BM + BN) * LDS_LD;
-    store_tile(As, ra, TA);
+    constexpr int BUFSZ = (BMt + BN) * LDS_LD;
+    store_tile(As, ra, TA, AR);
     store_tile(Bs, rb, TB);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
         mfma_group(Af + cur, Bf + cur, g);
       }
       if (kt + 1 < nk) {
-        store_tile(As + nxt, ra, TA);
+        store_tile(As + nxt, ra, TA, AR);
         store_tile(Bs + nxt, rb, TB);
       }
       __syncthreads();
@@ -206,16 +213,16 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
     constexpr int SLD = BN + 4;
     float* S = smem;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < MT; ++h) {
       if (h) __syncthreads();
-      if (wm == h) {
+      if (MT == 1 || wm == h) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<float4*>(S + (mt * 32 + (lane & 31)) * SLD + wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5)) =
+              *reinterpret_cast<float4*>(S + ((MT == 2 ? mt * 32 : wm * 32) + (lane & 31)) * SLD + wn * 64 + nt * 32 + 8 * g + 4 * (lane >> 5)) =
                   make_float4(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
       }
       __syncthreads();
@@ -253,8 +260,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
   }
   // generic path (ragged N, unaligned rows): scalar stores
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int m = m0 + wm * 64 + mt * 32 + (lane & 31);
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + wm * 32 * MT + mt * 32 + (lane & 31);
     if (m >= M) continue;
     int bidx = 0; long long res_pix = m;
     if (need_pix) {
@@ -330,6 +337,9 @@ void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st
 
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st) {
   dim3 grid(cdiv(p.N, BN) * cdiv(p.M, BM), 1, batch), block(NT);
+  // fewer than two 128-row tiles per CU: halve the tile height so the grid fills the chip (row-major A only)
+  const bool small_grid = (taps == 1) && !transA && ((long long)grid.x * batch < 2 * 256);
+  if (small_grid) grid.x = cdiv(p.N, BN) * cdiv(p.M, 64);
   IgemmParams pw = p;
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -358,9 +368,11 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
     else if (variant == 4) hipLaunchKernelGGL((igemm_kernel<9, false, false, 4>), grid, block, 0, st, pw);
     else hipLaunchKernelGGL((igemm_kernel<9, false, false, 2>), grid, block, 0, st, pw);
   } else if (!transA && !transB) {
-    hipLaunchKernelGGL((igemm_kernel<1, false, false>), grid, block, 0, st, pw);
+    if (small_grid) hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 1>), grid, block, 0, st, pw);
+    else hipLaunchKernelGGL((igemm_kernel<1, false, false>), grid, block, 0, st, pw);
   } else if (!transA && transB) {
-    hipLaunchKernelGGL((igemm_kernel<1, false, true>), grid, block, 0, st, pw);
+    if (small_grid) hipLaunchKernelGGL((igemm_kernel<1, false, true, 2, 1>), grid, block, 0, st, pw);
+    else hipLaunchKernelGGL((igemm_kernel<1, false, true>), grid, block, 0, st, pw);
   } else if (transA && !transB) {
     hipLaunchKernelGGL((igemm_kernel<1, true, false>), grid, block, 0, st, pw);
   } else {
