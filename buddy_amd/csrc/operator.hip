@@ -302,25 +302,72 @@ __global__ __launch_bounds__(256) void fft_stage1_kernel(const float2* x, float2
   const float tr = t.x, ti = sign * t.y;
   y1[(long long)u * N2 + i] = make_float2(ar * tr - ai * ti, ar * ti + ai * tr);
 }
-// stage 2: X[k1 + 101 k2] = scale * sum_{n2} Y1[n2][k1] W256^(n2 k2)
-__global__ __launch_bounds__(256) void fft_stage2_kernel(const float2* y1, float2* X, const float2* w256, int sign, float scale) {
-  __shared__ float2 W[F2];
-  for (int i = threadIdx.x; i < F2; i += 256) W[i] = w256[i];
-  __syncthreads();
-  const int u = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N2) return;
-  const int k1 = i % F1, k2 = i / F1;
-  const float2* yu = y1 + (long long)u * N2;
-  float ar = 0.f, ai = 0.f;
-  int idx = 0;
-  for (int n2 = 0; n2 < F2; ++n2) {
-    const float2 v = yu[n2 * F1 + k1];
-    const float wr = W[idx].x, wi = sign * W[idx].y;
-    ar += v.x * wr - v.y * wi; ai += v.x * wi + v.y * wr;
-    idx = (idx + k2) & (F2 - 1);
+// stage 2: X[k1 + 101 k2] = scale * sum_{n2} Y1[n2][k1] W256^(n2 k2), a 256-point DFT per (utterance, k1) column done as
+// 16 x 16: n2 = 16 a + r, k2 = b + 16 c  =>  W256^(n2 k2) = W16^(a b) * W256^(r b) * W16^(r c).  A block owns 16 columns; thread (col, r)
+// does the 16-point DFT over a in registers (radix 4 x 4), applies W256^(r b), exchanges through LDS, thread (col, b) does the one over r.
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// y[b] = sum_a x[a] exp(SGN * 2 pi i a b / 16)
+template <int SGN>
+__device__ __forceinline__ void dft16(float2 (&x)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, C2 = 0.70710678118654752f;
+  // w^e = exp(SGN 2 pi i e / 16) for the exponents a0*b0 in {0,1,2,3,4,6,9}
+  const float2 w1 = make_float2(C1, SGN * S1), w2 = make_float2(C2, SGN * C2), w3 = make_float2(S1, SGN * C1), w4 = make_float2(0.f, (float)SGN),
+               w6 = make_float2(-C2, SGN * C2), w9 = make_float2(-C1, -SGN * S1);
+  float2 u[4][4];                                           // u[a0][b0] = sum_{a1} x[4 a1 + a0] j^(a1 b0),  j = SGN * i
+#pragma unroll
+  for (int a0 = 0; a0 < 4; ++a0) {
+    const float2 x0 = x[a0], x1 = x[4 + a0], x2 = x[8 + a0], x3 = x[12 + a0];
+    const float2 s02 = make_float2(x0.x + x2.x, x0.y + x2.y), d02 = make_float2(x0.x - x2.x, x0.y - x2.y);
+    const float2 s13 = make_float2(x1.x + x3.x, x1.y + x3.y), d13 = make_float2(x1.x - x3.x, x1.y - x3.y);
+    const float2 jd = make_float2(-SGN * d13.y, SGN * d13.x);            // j * (x1 - x3)
+    u[a0][0] = make_float2(s02.x + s13.x, s02.y + s13.y);
+    u[a0][1] = make_float2(d02.x + jd.x, d02.y + jd.y);
+    u[a0][2] = make_float2(s02.x - s13.x, s02.y - s13.y);
+    u[a0][3] = make_float2(d02.x - jd.x, d02.y - jd.y);
   }
-  X[(long long)u * N2 + k1 + F1 * k2] = make_float2(ar * scale, ai * scale);
+  u[1][1] = cmul(u[1][1], w1); u[1][2] = cmul(u[1][2], w2); u[1][3] = cmul(u[1][3], w3);
+  u[2][1] = cmul(u[2][1], w2); u[2][2] = cmul(u[2][2], w4); u[2][3] = cmul(u[2][3], w6);
+  u[3][1] = cmul(u[3][1], w3); u[3][2] = cmul(u[3][2], w6); u[3][3] = cmul(u[3][3], w9);
+#pragma unroll
+  for (int b0 = 0; b0 < 4; ++b0) {                          // y[4 b1 + b0] = sum_{a0} u[a0][b0] j^(a0 b1)
+    const float2 x0 = u[0][b0], x1 = u[1][b0], x2 = u[2][b0], x3 = u[3][b0];
+    const float2 s02 = make_float2(x0.x + x2.x, x0.y + x2.y), d02 = make_float2(x0.x - x2.x, x0.y - x2.y);
+    const float2 s13 = make_float2(x1.x + x3.x, x1.y + x3.y), d13 = make_float2(x1.x - x3.x, x1.y - x3.y);
+    const float2 jd = make_float2(-SGN * d13.y, SGN * d13.x);
+    x[b0] = make_float2(s02.x + s13.x, s02.y + s13.y);
+    x[4 + b0] = make_float2(d02.x + jd.x, d02.y + jd.y);
+    x[8 + b0] = make_float2(s02.x - s13.x, s02.y - s13.y);
+    x[12 + b0] = make_float2(d02.x - jd.x, d02.y - jd.y);
+  }
+}
+constexpr int S2_COLS = 16, S2_PITCH = 16 * S2_COLS + 4;
+template <int SGN>
+__global__ __launch_bounds__(256) void fft_stage2_kernel(const float2* y1, float2* X, const float2* w256, float scale) {
+  __shared__ float2 S[16 * S2_PITCH];
+  __shared__ float2 W[F2];
+  for (int i = threadIdx.x; i < F2; i += 256) W[i] = make_float2(w256[i].x, SGN * w256[i].y);
+  const int u = blockIdx.y;
+  const int col = threadIdx.x & (S2_COLS - 1), r = threadIdx.x >> 4;
+  const int k1 = blockIdx.x * S2_COLS + col;
+  const bool ok = k1 < F1;
+  const float2* yu = y1 + (long long)u * N2;
+  float2 v[16];
+#pragma unroll
+  for (int a = 0; a < 16; ++a) v[a] = ok ? yu[(16 * a + r) * F1 + k1] : make_float2(0.f, 0.f);
+  dft16<SGN>(v);
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < 16; ++b) S[b * S2_PITCH + r * S2_COLS + col] = cmul(v[b], W[(r * b) & (F2 - 1)]);
+  __syncthreads();
+  const int b = r;                                          // second role of this thread: output residue b
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) v[rr] = S[b * S2_PITCH + rr * S2_COLS + col];
+  dft16<SGN>(v);
+  if (ok) {
+    float2* Xu = X + (long long)u * N2 + k1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Xu[(long long)F1 * (b + 16 * c)] = make_float2(v[c].x * scale, v[c].y * scale);
+  }
 }
 
 // ---- minimum-phase projection glue (reference reverb_utils.py:9-23) ----
@@ -542,7 +589,8 @@ struct BlindOp {
   }
   void fft(const float2* x, float2* tmp, float2* X, int sign, float scale) {
     hipLaunchKernelGGL(fft_stage1_kernel, dim3(cdiv(N2, 256), U), dim3(256), 0, st, x, tmp, (const float2*)w101, (const float2*)twN, sign);
-    hipLaunchKernelGGL(fft_stage2_kernel, dim3(cdiv(N2, 256), U), dim3(256), 0, st, (const float2*)tmp, X, (const float2*)w256, sign, scale);
+    if (sign > 0) hipLaunchKernelGGL(fft_stage2_kernel<1>, dim3(cdiv(F1, S2_COLS), U), dim3(256), 0, st, (const float2*)tmp, X, (const float2*)w256, scale);
+    else hipLaunchKernelGGL(fft_stage2_kernel<-1>, dim3(cdiv(F1, S2_COLS), U), dim3(256), 0, st, (const float2*)tmp, X, (const float2*)w256, scale);
   }
   DesignTabs tabs() const { DesignTabs t; t.idx = idx; t.frac = frac; t.corr = corr; t.dpm = dpm; return t; }
 
