@@ -91,50 +91,61 @@ __global__ __launch_bounds__(256) void fir_adjx_kernel(const float* GY, const fl
   }
 }
 // GH[u][k][f] (+)= sum_t conj(X[t + 1 - k]) * GY[t]
-// A thread owns FOUR consecutive taps k0..k0+3 of one (utterance, bin): per frame one GY load and one new X frame.
+// A thread owns FOUR consecutive taps k0..k0+3 of one (utterance, bin) and one QUARTER of the frame range (per frame: one GY load and
+// one new X frame, the other three slide through registers); the four partial sums are added in fixed order through LDS.
+constexpr int GH_SEG = 4, GH_F = 64;
 __global__ __launch_bounds__(256) void fir_gradh_kernel(const float* X, long long xs, const float* GY, float* GH, int U, int T, int Nf, int accumulate) {
-  const int KG = (Nf + FT - 1) / FT;
-  const long long total = (long long)U * KG * FB;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int f = (int)(i % FB); const int k0 = (int)((i / FB) % KG) * FT; const int u = (int)(i / ((long long)FB * KG));
-    const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs) + f;
-    const float2* Gu = reinterpret_cast<const float2*>(GY + (long long)u * T * LDSP) + f;
-    auto ldx = [&](int tt) { return (tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2)] : make_float2(0.f, 0.f); };
-    float ar[FT], ai[FT];
+  __shared__ float2 red[GH_SEG][FT][GH_F];
+  const int KG = (Nf + FT - 1) / FT, FGn = (FB + GH_F - 1) / GH_F;
+  const int fl = threadIdx.x & (GH_F - 1), seg = threadIdx.x / GH_F;
+  const int fg = blockIdx.x % FGn, kg = (blockIdx.x / FGn) % KG, u = blockIdx.x / (FGn * KG);
+  const int f = fg * GH_F + fl, k0 = kg * FT;
+  const bool ok = f < FB;
+  const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs) + (ok ? f : 0);
+  const float2* Gu = reinterpret_cast<const float2*>(GY + (long long)u * T * LDSP) + (ok ? f : 0);
+  auto ldx = [&](int tt) { return (tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2)] : make_float2(0.f, 0.f); };
+  float ar[FT], ai[FT];
 #pragma unroll
-    for (int j = 0; j < FT; ++j) { ar[j] = 0.f; ai[j] = 0.f; }
-    // window w[j] = X[t + 1 - k0 - j]
-    const int ts = k0 > 0 ? k0 - 1 : 0;                     // first frame with a non-negative index for tap k0
-    float2 w[FT];
+  for (int j = 0; j < FT; ++j) { ar[j] = 0.f; ai[j] = 0.f; }
+  const int ts = k0 > 0 ? k0 - 1 : 0;                       // first frame with a non-negative index for tap k0
+  const int len = (T - ts + GH_SEG - 1) / GH_SEG;
+  int t = ts + seg * len;
+  const int te = (t + len < T) ? t + len : T;
+  float2 w[FT];                                             // window w[j] = X[t + 1 - k0 - j]
 #pragma unroll
-    for (int j = 0; j < FT; ++j) w[j] = ldx(ts + 1 - k0 - j);
-    int t = ts;
-    for (; t + 8 <= T; t += 8) {                            // eight frames per trip: all 16 loads are issued before the arithmetic
-      float2 g8[8], x8[8];
+  for (int j = 0; j < FT; ++j) w[j] = ldx(t + 1 - k0 - j);
+  for (; t + 8 <= te; t += 8) {                             // eight frames per trip: all 16 loads are issued before the arithmetic
+    float2 g8[8], x8[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { g8[q] = Gu[(long long)(t + q) * (LDSP / 2)]; x8[q] = ldx(t + q + 2 - k0); }
+    for (int q = 0; q < 8; ++q) { g8[q] = Gu[(long long)(t + q) * (LDSP / 2)]; x8[q] = ldx(t + q + 2 - k0); }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 8; ++q) {
 #pragma unroll
-        for (int j = 0; j < FT; ++j) { ar[j] += w[j].x * g8[q].x + w[j].y * g8[q].y; ai[j] += w[j].x * g8[q].y - w[j].y * g8[q].x; }
-#pragma unroll
-        for (int j = FT - 1; j > 0; --j) w[j] = w[j - 1];
-        w[0] = x8[q];
-      }
-    }
-    for (; t < T; ++t) {
-      const float2 g = Gu[(long long)t * (LDSP / 2)];
-#pragma unroll
-      for (int j = 0; j < FT; ++j) { ar[j] += w[j].x * g.x + w[j].y * g.y; ai[j] += w[j].x * g.y - w[j].y * g.x; }
+      for (int j = 0; j < FT; ++j) { ar[j] += w[j].x * g8[q].x + w[j].y * g8[q].y; ai[j] += w[j].x * g8[q].y - w[j].y * g8[q].x; }
 #pragma unroll
       for (int j = FT - 1; j > 0; --j) w[j] = w[j - 1];
-      w[0] = ldx(t + 2 - k0);
+      w[0] = x8[q];
     }
+  }
+  for (; t < te; ++t) {
+    const float2 g = Gu[(long long)t * (LDSP / 2)];
+#pragma unroll
+    for (int j = 0; j < FT; ++j) { ar[j] += w[j].x * g.x + w[j].y * g.y; ai[j] += w[j].x * g.y - w[j].y * g.x; }
+#pragma unroll
+    for (int j = FT - 1; j > 0; --j) w[j] = w[j - 1];
+    w[0] = ldx(t + 2 - k0);
+  }
+#pragma unroll
+  for (int j = 0; j < FT; ++j) red[seg][j][fl] = make_float2(ar[j], ai[j]);
+  __syncthreads();
+  if (seg == 0 && ok) {
 #pragma unroll
     for (int j = 0; j < FT; ++j) {
       if (k0 + j >= Nf) continue;
+      float r = red[0][j][fl].x, im = red[0][j][fl].y;
+#pragma unroll
+      for (int sg = 1; sg < GH_SEG; ++sg) { r += red[sg][j][fl].x; im += red[sg][j][fl].y; }
       float2* o = reinterpret_cast<float2*>(GH + ((long long)u * Nf + k0 + j) * LDSP) + f;
-      float r = ar[j], im = ai[j];
       if (accumulate) { r += o->x; im += o->y; }
       *o = make_float2(r, im);
     }
@@ -853,7 +864,7 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
   o->comp_loss(o->Yc, o->X2, o->X3, T, w_rec, o->losses, 0);
   o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, o->sig2);
   o->istft_adj(o->sig2, T, WIN + WIN / 2, o->env_T, L, o->norm, o->X2);
-  hipLaunchKernelGGL(fir_gradh_kernel, dim3(gridf((long long)U * ((Nf + FT - 1) / FT) * FB)), dim3(256), 0, st, (const float*)o->X1, (long long)T * LDSP, (const float*)o->X2, o->GH, U, T, Nf, 0);
+  hipLaunchKernelGGL(fir_gradh_kernel, dim3(U * ((Nf + FT - 1) / FT) * ((FB + GH_F - 1) / GH_F)), dim3(256), 0, st, (const float*)o->X1, (long long)T * LDSP, (const float*)o->X2, o->GH, U, T, Nf, 0);
   // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach())
   if (noise) {
     o->time_rir(o->rir);                                                     // Ybuf = FIR(Xdelta, H) consumed inside
@@ -863,7 +874,7 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
     o->comp_loss(o->Rc, o->X2, o->X3, Td, w_reg, o->losses + U, 0);
     o->stft_adj(o->X3, o->Lr, WIN, Td, 1.f / o->norm, o->sig2);
     o->istft_adj(o->sig2, Td, WIN + WIN / 2, o->env_d, o->Lr, o->norm, o->X2);
-    hipLaunchKernelGGL(fir_gradh_kernel, dim3(gridf((long long)U * ((Nf + FT - 1) / FT) * FB)), dim3(256), 0, st, (const float*)o->Xdelta, 0LL, (const float*)o->X2, o->GH, U, Td, Nf, 1);
+    hipLaunchKernelGGL(fir_gradh_kernel, dim3(U * ((Nf + FT - 1) / FT) * ((FB + GH_F - 1) / GH_F)), dim3(256), 0, st, (const float*)o->Xdelta, 0LL, (const float*)o->X2, o->GH, U, Td, Nf, 1);
   }
   o->cons_backward(o->GH);
   hipLaunchKernelGGL(h0_bwd_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->GFin, (const float*)o->A, (const float*)o->phi, o->gA, o->gphi, U, Nf);
