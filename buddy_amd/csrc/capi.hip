@@ -213,6 +213,11 @@ int buddy_blindop_rec_loss_grad(void* h, const float* x_den, float weight, float
   BOP_CHECK(h); if (!x_den || !loss) { set_error("null"); return BUDDY_ERR_ARG; }
   return blindop_rec_loss_grad((BlindOp*)h, x_den, weight, loss, g_x, (hipStream_t)stream);
 }
+int buddy_blindop_fir_loss_grad(void* h, const float* x_den, const float* rir, long long rir_stride, int M, float weight, float* loss, float* g_x,
+                                void* stream) {
+  BOP_CHECK(h); if (!x_den || !rir || !loss || M < 1) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  return blindop_fir_loss_grad((BlindOp*)h, x_den, rir, rir_stride, M, weight, loss, g_x, (hipStream_t)stream);
+}
 int buddy_blindop_param_grads(void* h, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, float* g_decay, float* g_weights,
                               float* g_phases, float* losses, void* stream) {
   BOP_CHECK(h); if (!x_den) { set_error("null"); return BUDDY_ERR_ARG; }

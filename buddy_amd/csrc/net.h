@@ -39,6 +39,8 @@ int blindop_set_y(BlindOp* o, const float* y, hipStream_t st);
 int blindop_degrade(BlindOp* o, const float* x, float* y, hipStream_t st);
 int blindop_time_rir(BlindOp* o, float* out, hipStream_t st);
 int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* loss, float* g_x, hipStream_t st);
+int blindop_fir_loss_grad(BlindOp* o, const float* x_den, const float* rir, long long rir_stride, int M, float weight, float* loss, float* g_x,
+                          hipStream_t st);
 int blindop_param_grads(BlindOp* o, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, float* g_decay, float* g_wts,
                         float* g_phases_ref, float* losses, hipStream_t st);
 int blindop_optimize(BlindOp* o, const float* x_den, const float* noise, float t_op, int n_iters, float w_rec, float w_reg, float lr, float b1,

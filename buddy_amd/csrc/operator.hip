@@ -850,6 +850,24 @@ int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* l
   return BUDDY_OK;
 }
 
+// informed likelihood (reference RIROperator.degradation = fast_apply_RIR, reverb.py:33-35, + the same STFT loss): time-domain FIR with the
+// known RIR (U, M) instead of the subband filter; loss_u = weight * l2_comp_stft_summean(y, x_den * rir), g = d sum_u loss_u / d x_den
+void launch_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, hipStream_t st);
+int blindop_fir_loss_grad(BlindOp* o, const float* x_den, const float* rir, long long rir_stride, int M, float weight, float* loss, float* g_x,
+                          hipStream_t st) {
+  o->st = st;
+  const int U = o->U, T = o->T, L = o->L;
+  launch_fir(x_den, rir, rir_stride, o->sig1, U, L, M, 0, st);
+  o->stft(o->sig1, L, WIN, T, 1.f / o->norm, o->X2);
+  o->comp_loss(o->Yc, o->X2, g_x ? o->X3 : nullptr, T, weight, loss, 0);
+  if (g_x) {
+    o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, o->sig2);
+    launch_fir(o->sig2, rir, rir_stride, g_x, U, L, M, 1, st);
+  }
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+
 // one gradient evaluation of  rec_loss_params(y, degrade(x_den)) + reg(rir, rir + t_op * noise)  w.r.t. (decay, weights, phases);
 // H is rebuilt from the parameters first (update_H at the top of each optimize_op iteration, reference :83)
 static int param_grads(BlindOp* o, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, bool have_Xd, const float* t_op_dev = nullptr) {

@@ -23,6 +23,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         super().__init__(model, diff_params, args)
         self.zeta = self.args.tester.posterior_sampling.zeta
         self._hip_op = False
+        self._hip_loss = False
         self.use_hip_update = True      # fused elementwise tail on the GPU (False: torch expressions, as on the CPU)
 
     def initialize_x(self, shape, device, schedule):
@@ -41,7 +42,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         raise NotImplementedError
 
     def get_likelihood_score(self, x_den, x, t):
-        if self._hip_op:
+        if self._hip_op or self._hip_loss:
             rec = self.operator.hip_rec_loss(x_den)               # fused HIP loss + analytic d/dx_den; autograd continues into the net VJP
         else:
             y_hat = self.operator.degradation(x_den, mode="waveform")
@@ -158,8 +159,11 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         self.y = y
         self.rec_loss = get_loss(ps.rec_loss, operator=self.operator)
         self._hip_op = bool(blind and hasattr(operator, "hip_optimize"))
+        self._hip_loss = False
         if self._hip_op:
             operator.hip_bind(y, ps)
+        elif not blind and hasattr(operator, "hip_rec_loss") and y.is_cuda:
+            self._hip_loss = bool(operator.hip_bind(y, ps))       # informed: FIR + STFT loss + adjoints in the HIP library
         elif blind:
             self.rec_loss_params = get_loss(ps.rec_loss_params, operator=self.operator)
             self.optimizer_operator = torch.optim.Adam(self.operator.params + self.operator.params_phases, lr=ps.blind_hp.lr_op,

@@ -9,6 +9,7 @@ import torch.nn.functional as F
 class OperatorSTFT:
     def _init_stft(self, op_hp, sample_rate, device):
         self.sample_rate = sample_rate
+        self.op_hp = op_hp
         self.device = device
         self.n_fft = op_hp.NFFT
         self.win_length = op_hp.win_length

@@ -32,6 +32,40 @@ class RIROperator(Operator, OperatorSTFT):
         else:
             self.params.data = k
 
+    # ---- sampler fast path: likelihood loss + analytic gradient in the HIP library (buddy_blindop_fir_loss_grad) ----
+    def hip_bind(self, y, ps):
+        """True if the HIP likelihood path is usable for this run (CUDA, shipped loss); caches comp(STFT(y)) in a library handle."""
+        from .subband_filtering import create_stft_loss_handle
+        from ... import _lib
+        l, hp = ps.rec_loss, self.op_hp
+        if not (y.is_cuda and y.dim() == 2 and l.name == "l2_comp_stft_summean" and abs(l.compression_factor - 0.667) < 1e-9
+                and (hp.NFFT, hp.win_length, hp.hop, hp.window) == (1024, 512, 128, "hann") and y.shape[1] >= 1024):
+            return False
+        key = (int(y.shape[0]), int(y.shape[1]))
+        if getattr(self, "_hip_key", None) != key:
+            self._hip_release()
+            self._hip_h = create_stft_loss_handle(self.sample_rate, key[0], key[1])
+            self._hip_key = key
+        self._hip_w = float(l.get("weight", 1.0))
+        _lib.check(_lib.load().buddy_blindop_set_y(self._hip_h, _lib.ptr(y.contiguous().float()), _lib.stream_ptr()))
+        return True
+
+    def hip_rec_loss(self, x_den):
+        from .subband_filtering import _HipFirRecLoss
+        return _HipFirRecLoss.apply(x_den, self, self._hip_w)
+
+    def _hip_release(self):
+        try:
+            if getattr(self, "_hip_h", None) is not None:
+                from ... import _lib
+                _lib.load().buddy_blindop_destroy(self._hip_h)
+        except Exception:
+            pass
+        self._hip_h, self._hip_key = None, None
+
+    def __del__(self):
+        self._hip_release()
+
     def optim_fwd(self, Xden, Y):
         return torch.sum((self.degradation(Xden) - Y) ** 2)
 

@@ -294,6 +294,65 @@ class BlindSubbandFiltering(SubbandFiltering):
         return X_rec[..., :L]
 
 
+def create_blindop_handle(op_hp, sample_rate, num_utts, length):
+    """``buddy_blindop_create`` from the reference op_hp block; returns (handle, dict of derived constants)."""
+    import ctypes as C
+    knots = [float(f) for f in op_hp.EQ_freqs]
+    num_bands = len(knots) - 2
+    if op_hp.init_single_value:
+        t60 = [num_bands * [float(t)] for t in op_hp.init_params.T60_breakpoints]
+        wts = [num_bands * [float(w)] for w in op_hp.init_params.multiexp_weighting]
+    else:
+        t60, wts = op_hp.init_params.T60_breakpoints, op_hp.init_params.multiexp_weighting
+    frame_rate = sample_rate / op_hp.hop
+    decay = 6.908 / (torch.tensor(t60, dtype=torch.float32) * frame_rate)
+    max_decay = 6.908 / (op_hp.T60min * frame_rate)
+    min_decay = 6.908 / (op_hp.T60max * frame_rate)
+    lib = _lib.require_gpu()
+    h = C.c_void_p()
+    kn = (C.c_float * len(knots))(*knots)
+    _lib.check(lib.buddy_blindop_create(int(num_utts), int(length), int(op_hp.Nf), int(decay.shape[0]), len(knots), kn, int(sample_rate),
+                                        float(0.667), float(min_decay), float(max_decay), float(10 ** (op_hp.Amin / 20)),
+                                        float(10 ** (op_hp.Amax / 20)), int(bool(op_hp.clamp_decay)),
+                                        int(bool(op_hp.enforce_long_decay_in_second_exponential)), C.byref(h)))
+    return h, dict(num_bands=num_bands, decay=decay, wts=wts, max_decay=max_decay, min_decay=min_decay, comp=0.667)
+
+
+def create_stft_loss_handle(sample_rate, num_utts, length):
+    """Library handle used only for its STFT-1024/512/128 + compressed-spectrum-loss machinery (informed operator): the blind filter
+    parameters of the handle are placeholders."""
+    import ctypes as C
+    lib = _lib.require_gpu()
+    h = C.c_void_p()
+    kn = (C.c_float * 3)(0.0, sample_rate / 4.0, sample_rate / 2.0)
+    _lib.check(lib.buddy_blindop_create(int(num_utts), int(length), 100, 1, 3, kn, int(sample_rate), float(0.667), 0.01, 1.0, 1.0, 100.0, 1, 0,
+                                        C.byref(h)))
+    return h
+
+
+class _HipFirRecLoss(torch.autograd.Function):
+    """sum_u weight * l2_comp_stft_summean(y_u, x_den_u * rir_u) for the informed operator, analytic gradient from the library."""
+
+    @staticmethod
+    def forward(ctx, x_den, op, weight):
+        lib = _lib.require_gpu()
+        x = x_den.contiguous().float()
+        rir = op.params.detach().contiguous().float()
+        M = rir.shape[-1]
+        loss = torch.empty(x.shape[0], device=x.device)
+        g = torch.empty_like(x)
+        _lib.check(lib.buddy_blindop_fir_loss_grad(op._hip_h, _lib.ptr(x), _lib.ptr(rir), 0 if rir.dim() == 1 else M, M, float(weight),
+                                                   _lib.ptr(loss), _lib.ptr(g), _lib.stream_ptr()))
+        ctx.save_for_backward(g)
+        op.last_rec_per_utt = loss
+        return loss.sum()
+
+    @staticmethod
+    def backward(ctx, gout):
+        g, = ctx.saved_tensors
+        return gout * g, None, None
+
+
 class BlindSubbandFilteringHIP(BlindSubbandFiltering):
     """Same interface, hand-written HIP backend (``buddy_blindop_*`` in ``include/buddy_hip.h``): parameters, Adam state, the
     filter H and every intermediate live on the device inside the library handle; forward and analytic backward of

@@ -122,6 +122,10 @@ int buddy_blindop_degrade(void* handle, const float* x, float* y, void* stream);
 int buddy_blindop_time_rir(void* handle, float* rir /*(U, 128*Nf+1024)*/, void* stream);   /* get_time_RIR (:103-113) */
 /* loss[u] = weight * l2_comp_stft_summean(y_u, degrade(x_den_u)); g_x = d sum_u loss / d x_den (NULL to skip) */
 int buddy_blindop_rec_loss_grad(void* handle, const float* x_den, float weight, float* loss, float* g_x, void* stream);
+/* informed counterpart (RIROperator, testing/operators/reverb.py:33-35 + utils/losses.py:59-64): degradation = time-domain FIR with the
+ * known RIR(s) rir[u * rir_stride + m], m < M (fast_apply_RIR semantics: first L output samples); same loss, same cached y (set_y). */
+int buddy_blindop_fir_loss_grad(void* handle, const float* x_den, const float* rir, long long rir_stride, int M, float weight, float* loss,
+                                float* g_x, void* stream);
 /* one gradient evaluation of optimize_op's objective (H rebuilt from the parameters first); losses = [rec (U), reg (U)] */
 int buddy_blindop_param_grads(void* handle, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, float* g_decay,
                               float* g_weights, float* g_phases, float* losses, void* stream);

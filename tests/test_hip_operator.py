@@ -127,3 +127,34 @@ def test_optimize_loop_matches_torch_adam():
     opt.update_H(); oph.update_H()
     assert rel(torch.view_as_real(oph.H), torch.view_as_real(opt.H.detach())) < 2e-2
     assert rel(oph.get_time_RIR(), opt.get_time_RIR().detach()) < 2e-2
+
+
+def test_informed_likelihood_loss_and_gradient():
+    """buddy_blindop_fir_loss_grad (time-domain FIR with the known RIRs + compressed-STFT loss + adjoints) vs the torch-op path."""
+    from buddy_amd.config import compose
+    from buddy_amd.synth import synth_rir
+    from buddy_amd.testing.operators.reverb import RIROperator
+    from buddy_amd.utils.losses import get_loss
+    U, L = 2, 16000
+    args = compose(tester="informed_dereverberation_DPS")
+    ps = args.tester.posterior_sampling
+    op = RIROperator(args.tester.informed_dereverberation.op_hp, time_kernel_size=1500, sample_rate=16000, device="cuda")
+    op.update_params([torch.from_numpy(synth_rir(u, 1500 - 100 * u)) for u in range(U)])       # ragged RIR lengths, zero-padded
+    x, y = signals(U, L)
+    assert op.hip_bind(y, ps) is True
+    xd = (0.9 * x + 0.01 * x.flip(1))
+    xh = xd.clone().requires_grad_(True)
+    rec_h = op.hip_rec_loss(xh)
+    gh, = torch.autograd.grad(rec_h, xh)
+    xt = xd.clone().requires_grad_(True)
+    rec_t = get_loss(ps.rec_loss, operator=op)(y, op.degradation(xt))
+    gt, = torch.autograd.grad(rec_t, xt)
+    assert abs(float(rec_h) - float(rec_t)) < 2e-4 * abs(float(rec_t))
+    assert rel(gh, gt) < 5e-4
+    # one shared RIR (the reference's single-utterance form)
+    op.update_params(torch.from_numpy(synth_rir(7, 1200)))
+    xh = xd.clone().requires_grad_(True)
+    gh, = torch.autograd.grad(op.hip_rec_loss(xh), xh)
+    xt = xd.clone().requires_grad_(True)
+    gt, = torch.autograd.grad(get_loss(ps.rec_loss, operator=op)(y, op.degradation(xt)), xt)
+    assert rel(gh, gt) < 5e-4
