@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 U_FWD = 1.2501e12   # algorithmic FLOPs of one score-network forward for a 4 s utterance (measured with
                     # torch.utils.flop_counter on the reference); forward + input-VJP = 2 * U_FWD
+PEAK_HBM_GBS = 8000.0        # MI355X HBM3E, MI355X_MICROARCH.md
 PEAK_FP32_MFMA = 157.3   # TFLOP/s, MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 
 
@@ -218,6 +219,8 @@ def main():
     log(f"timed region done: {elapsed:.3f} s")
     ms = (C.c_double * 2)(); fl = (C.c_double * 2)(); ln = (C.c_longlong * 2)(); by = (C.c_double * 2)(); xf = (C.c_double * 2)()
     _lib.check(lib.buddy_prof_collect(ms, fl, ln, by, xf))
+    hb_ms, hb_by, hb_n = C.c_double(), C.c_double(), C.c_longlong()
+    _lib.check(lib.buddy_prof_collect_hbm(C.byref(hb_ms), C.byref(hb_by), C.byref(hb_n)))
     el = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -257,6 +260,12 @@ def main():
             "score_evals_per_s": n_utt_steps / elapsed,   # order 1: one forward+VJP evaluation per utterance-step
             "network_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
             "gather_ms": gather_ms,
+            # second roofline SURVEY 8(d) asks for: the HBM-bound GroupNorm(+SiLU, +2x resample) kernels and their backward
+            "roofline_hbm": {"bound": "hbm", "kernel": "GroupNorm statistics / apply(+SiLU,+resample) / backward (chan_reduce, gn_apply, gn_bwd_apply)",
+                             "achieved": hb_by.value / (hb_ms.value * 1e-3) / 1e9 if hb_ms.value > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": (hb_by.value / (hb_ms.value * 1e-3) / 1e9 / PEAK_HBM_GBS) if hb_ms.value > 0 else 0.0,
+                             "launch_groups": int(hb_n.value), "kernel_time_share_of_step": hb_ms.value * 1e-3 / elapsed,
+                             "note": "algorithmic bytes (every pass reads its inputs and writes its output once) / HIP-event time"},
             "operator_update": {"ms_per_step": op_ms / a.steps, "share_of_step": op_ms * 1e-3 / elapsed,
                                 "what": "optimize_op: 10 x (design filter, min-phase projection, subband FIR, loss, analytic backward, Adam, clamps) per step, "
                                         "HIP events on the launch stream (rank 0)"},

@@ -39,6 +39,9 @@ void wino_transform_weights(const float* wt_host, int Cout, int Cin, float* U_ho
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin);
 void igemm_prof_enable(int on);
 bool igemm_prof_enabled();
+void prof_hbm_begin(double algorithmic_bytes, hipStream_t st);   // bracket of an HBM-bound launch group (GroupNorm kernels)
+void prof_hbm_end(hipStream_t st);
+int prof_hbm_collect(double* ms, double* bytes, long long* launches);
 int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], double bytes[2], double exec_flops[2]);
 
 // ---- small-channel direct convs -----------------------------------------------------------------------

@@ -318,6 +318,32 @@ int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], dou
   return 0;
 }
 
+// generic bracket for HBM-bound launches (class 2: GroupNorm statistics / apply / backward): algorithmic bytes only
+namespace { std::vector<ProfRec> g_prof_hbm; ProfRec g_cur_hbm; }
+void prof_hbm_begin(double bytes, hipStream_t st) {
+  if (!g_prof_on) return;
+  (void)hipEventCreate(&g_cur_hbm.e0); (void)hipEventCreate(&g_cur_hbm.e1);
+  g_cur_hbm.bytes = bytes; g_cur_hbm.flops = 0; g_cur_hbm.exec_flops = 0; g_cur_hbm.taps = 0;
+  (void)hipEventRecord(g_cur_hbm.e0, st);
+}
+void prof_hbm_end(hipStream_t st) {
+  if (!g_prof_on) return;
+  (void)hipEventRecord(g_cur_hbm.e1, st);
+  g_prof_hbm.push_back(g_cur_hbm);
+}
+int prof_hbm_collect(double* ms, double* bytes, long long* launches) {
+  *ms = 0; *bytes = 0; *launches = 0;
+  for (auto& r : g_prof_hbm) {
+    if (hipEventSynchronize(r.e1) != hipSuccess) return 1;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return 1;
+    *ms += t; *bytes += r.bytes; *launches += 1;
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+  }
+  g_prof_hbm.clear();
+  return 0;
+}
+
 static ProfRec g_cur;
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin) {
   if (!g_prof_on) return;

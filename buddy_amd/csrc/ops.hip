@@ -536,25 +536,36 @@ static RedArgs make_red(Src2 x, int B, int H, int W, int C, int G, double* parti
 
 void launch_gn_stats(Src2 x, int B, int HW, int C, int G, float eps, double* partial, float* stats, hipStream_t st) {
   RedArgs a = make_red(x, B, 1, HW, C, G, partial);
+  prof_hbm_begin(4.0 * B * HW * C, st);                                   // one read of x
   hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(a.chunks, B), dim3(256), 0, st, a);
   hipLaunchKernelGGL(group_finalize_kernel<0>, dim3(G, B), dim3(64), 0, st, (const double*)partial, stats, C, G, a.chunks, HW, eps);
+  prof_hbm_end(st);
 }
 
 void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float* beta, int B, int H, int W, int C, int G, int mode, int silu,
                      float* out, float* pooled_raw, hipStream_t st) {
   const long long total = (long long)B * (mode == 1 ? (H / 2) * (W / 2) : H * W) * (C / 4);
+  const double n_in = (double)B * H * W * C, n_out = mode == 1 ? n_in / 4 : (mode == 2 ? n_in * 4 : n_in);
+  prof_hbm_begin(4.0 * (n_in + n_out + (pooled_raw ? n_out : 0.0)), st);   // read x, write the (resampled) activation
   hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, B, H, W, C, G, mode, silu, out, pooled_raw);
+  prof_hbm_end(st);
 }
 
 void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G, int mode,
                    int silu, const float* extra, int extra_mode, float extra_scale, double* partial, float* red, Dst2 dx, hipStream_t st) {
   RedArgs a = make_red(x, B, H, W, C, G, partial);
   a.stats = stats; a.gamma = gamma; a.beta = beta; a.da = da; a.mode = mode; a.silu = silu;
+  {
+    const double n_in = (double)B * H * W * C, n_da = mode == 1 ? n_in / 4 : (mode == 2 ? n_in * 4 : n_in);
+    // sums pass reads x and da, apply pass reads them again and writes dx (+ reads the extra gradient): the two-pass minimum
+    prof_hbm_begin(4.0 * (2.0 * (n_in + n_da) + n_in + (extra_mode ? (extra_mode == 2 ? n_in / 4 : n_in) : 0.0)), st);
+  }
   hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(a.chunks, B), dim3(256), 0, st, a);
   hipLaunchKernelGGL(group_finalize_kernel<1>, dim3(G, B), dim3(64), 0, st, (const double*)partial, red, C, G, a.chunks, H * W, 0.f);
   const long long total = (long long)B * H * W * (C / 4);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, da, B, H, W, C, G, mode, silu, extra,
                      extra_mode, extra_scale, (const float*)red, dx);
+  prof_hbm_end(st);
 }
 
 void launch_axpy(float* dst, const float* src, float alpha, long long n, int accumulate, hipStream_t st) {

@@ -57,6 +57,9 @@ int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream);
 int buddy_prof_enable(int on);
 int buddy_prof_collect(double* ms /*[2]*/, double* flops /*[2]*/, long long* launches /*[2]*/, double* bytes /*[2]*/,
                        double* executed_flops /*[2]: = flops except for Winograd launches (4/9 of the direct-conv flops)*/);
+/* same for the HBM-bound GroupNorm launch groups (statistics; apply + SiLU + resample; backward sums + apply): summed time [ms],
+ * algorithmic bytes (each pass reads its inputs once and writes its output once) and launch-group count since the last collect. */
+int buddy_prof_collect_hbm(double* ms, double* bytes, long long* launches);
 
 /* calibration: `blocks` workgroups x 4 waves issue 4*iters fp32 MFMAs (32x32x2) each on operands from seed[1024] with no
  * memory traffic; out[blocks*256] keeps the result live; clk[0] = shader clocks, clk[1] = 100 MHz wall ticks of block 0.
