@@ -2,6 +2,7 @@
 // and their input-gradients, 2-channel direct convs, pooling, softmax rows, small linears, reflect-pad / overlap-add.
 // All tensors fp32 NHWC (see common.h); every kernel moves float4 per lane along the channel axis (coalesced 16 B/lane).
 #include "common.h"
+#include <cstdlib>
 
 namespace buddy {
 namespace {
@@ -195,6 +196,91 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(Src2 x, const float* 
     if (acc) res = add4(res, ld4(o));
     st4(o, res);
   }
+}
+
+// ------------------------------------------------------------------ mode-0 fast paths (most GroupNorms of the network)
+// grid (chunks, B), block = q * pl threads (q = C/4 channel quads, pl pixels in flight per block): a thread keeps its channel quad, so
+// gamma/beta/statistics, the concat-source choice and all address arithmetic except one multiply-add per pixel leave the loop; four
+// pixels per trip with the loads issued first.
+struct GnFast { int HW, C, G, q, pl, ppc; };
+__global__ __launch_bounds__(256) void gn_apply_m0_kernel(Src2 x, const float* stats, const float* gamma, const float* beta, GnFast a, int silu, float* out) {
+  const int tid = threadIdx.x, quad = tid % a.q, lp = tid / a.q, b = blockIdx.y;
+  const int c = quad * 4, g = c / (a.C / a.G);
+  const float mean = stats[((long long)b * a.G + g) * 2], rstd = stats[((long long)b * a.G + g) * 2 + 1];
+  const float4 gm = ld4(gamma + c), bt = ld4(beta + c);
+  const bool second = x.p1 != nullptr && c >= x.C0;
+  const float* src = second ? x.p1 + (c - x.C0) : x.p0 + c;
+  const long long ld = second ? x.ld1 : x.ld0;
+  src += (long long)b * a.HW * ld;
+  float* dst = out + (long long)b * a.HW * a.C + c;
+  const int p0 = blockIdx.x * a.ppc, p1 = min(a.HW, p0 + a.ppc);
+  auto act = [&](float4 v) {
+    float4 z = make_float4((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y,
+                           (v.z - mean) * rstd * gm.z + bt.z, (v.w - mean) * rstd * gm.w + bt.w);
+    if (silu) z = make_float4(silu_f(z.x), silu_f(z.y), silu_f(z.z), silu_f(z.w));
+    return z;
+  };
+  int p = p0 + lp;
+  for (; p + 3 * a.pl < p1; p += 4 * a.pl) {
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ld4(src + (long long)(p + j * a.pl) * ld);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(dst + (long long)(p + j * a.pl) * a.C, act(v[j]));
+  }
+  for (; p < p1; p += a.pl) st4(dst + (long long)p * a.C, act(ld4(src + (long long)p * ld)));
+}
+
+// extra_mode 0 / 1 (same-resolution extra gradient), da at the same resolution
+__global__ __launch_bounds__(256) void gn_bwd_apply_m0_kernel(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da,
+                                                              GnFast a, int silu, const float* extra, float extra_scale, const float* red, Dst2 dx) {
+  const int tid = threadIdx.x, quad = tid % a.q, lp = tid / a.q, b = blockIdx.y;
+  const int c = quad * 4, g = c / (a.C / a.G);
+  const float mean = stats[((long long)b * a.G + g) * 2], rstd = stats[((long long)b * a.G + g) * 2 + 1];
+  const float m1 = red[((long long)b * a.G + g) * 2], m2 = red[((long long)b * a.G + g) * 2 + 1];
+  const float4 gm = ld4(gamma + c), bt = ld4(beta + c);
+  const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+  const bool second = x.p1 != nullptr && c >= x.C0;
+  const float* src = second ? x.p1 + (c - x.C0) : x.p0 + c;
+  const long long ld = second ? x.ld1 : x.ld0;
+  src += (long long)b * a.HW * ld;
+  const float* dap = da + (long long)b * a.HW * a.C + c;
+  const float* ex = extra ? extra + (long long)b * a.HW * a.C + c : nullptr;
+  const bool dsecond = dx.p1 != nullptr && c >= dx.C0;
+  float* o = dsecond ? dx.p1 + (c - dx.C0) : dx.p0 + c;
+  const long long ldo = dsecond ? dx.ld1 : dx.ld0;
+  const int acc = dsecond ? dx.acc1 : dx.acc0;
+  o += (long long)b * a.HW * ldo;
+  const int p0 = blockIdx.x * a.ppc, p1 = min(a.HW, p0 + a.ppc);
+  auto one = [&](float4 v, float4 d, float4 e, float4 prev) {
+    const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w}, ev[4] = {e.x, e.y, e.z, e.w};
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (xv[j] - mean) * rstd;
+      const float z = xh * gv[j] + bv[j];
+      const float dxh = dv[j] * (silu ? dsilu_f(z) : 1.f) * gv[j];
+      r[j] = rstd * (dxh - m1 - xh * m2);
+      if (ex) r[j] += extra_scale * ev[j];
+    }
+    float4 res = make_float4(r[0], r[1], r[2], r[3]);
+    if (acc) res = add4(res, prev);
+    return res;
+  };
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p = p0 + lp;
+  for (; p + a.pl < p1; p += 2 * a.pl) {
+    float4 v[2], d[2], e[2], pr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long long pp = p + j * a.pl;
+      v[j] = ld4(src + pp * ld); d[j] = ld4(dap + pp * a.C); e[j] = ex ? ld4(ex + pp * a.C) : z4; pr[j] = acc ? ld4(o + pp * ldo) : z4;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) st4(o + (long long)(p + j * a.pl) * ldo, one(v[j], d[j], e[j], pr[j]));
+  }
+  for (; p < p1; p += a.pl)
+    st4(o + (long long)p * ldo, one(ld4(src + (long long)p * ld), ld4(dap + (long long)p * a.C), ex ? ld4(ex + (long long)p * a.C) : z4, acc ? ld4(o + (long long)p * ldo) : z4));
 }
 
 // ------------------------------------------------------------------ elementwise helpers
@@ -525,6 +611,15 @@ int gn_num_chunks(int HW) {
   return c;
 }
 
+static GnFast gn_fast(int HW, int C, int G) {
+  GnFast a; a.HW = HW; a.C = C; a.G = G; a.q = C / 4; a.pl = 256 / a.q; if (a.pl < 1) a.pl = 1;
+  // ~2048 blocks over the batch at the big layers, at least 8 trips per thread
+  int chunks = HW / (a.pl * 32); if (chunks < 1) chunks = 1; if (chunks > 512) chunks = 512;
+  a.ppc = (HW + chunks - 1) / chunks;
+  a.ppc = (a.ppc + a.pl - 1) / a.pl * a.pl;
+  return a;
+}
+
 static RedArgs make_red(Src2 x, int B, int H, int W, int C, int G, double* partial) {
   RedArgs a{};
   a.x = x; a.B = B; a.H = H; a.W = W; a.C = C; a.G = G;
@@ -547,7 +642,13 @@ void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float
   const long long total = (long long)B * (mode == 1 ? (H / 2) * (W / 2) : H * W) * (C / 4);
   const double n_in = (double)B * H * W * C, n_out = mode == 1 ? n_in / 4 : (mode == 2 ? n_in * 4 : n_in);
   prof_hbm_begin(4.0 * (n_in + n_out + (pooled_raw ? n_out : 0.0)), st);   // read x, write the (resampled) activation
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, B, H, W, C, G, mode, silu, out, pooled_raw);
+  static const bool fast = !(getenv("BUDDY_GN_FAST") && atoi(getenv("BUDDY_GN_FAST")) == 0);
+  if (fast && mode == 0 && C % 4 == 0 && C / 4 <= 256) {
+    GnFast a = gn_fast(H * W, C, G);
+    hipLaunchKernelGGL(gn_apply_m0_kernel, dim3((H * W + a.ppc - 1) / a.ppc, B), dim3(a.q * a.pl), 0, st, x, stats, gamma, beta, a, silu, out);
+  } else {
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, B, H, W, C, G, mode, silu, out, pooled_raw);
+  }
   prof_hbm_end(st);
 }
 
@@ -563,6 +664,12 @@ void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* 
   hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(a.chunks, B), dim3(256), 0, st, a);
   hipLaunchKernelGGL(group_finalize_kernel<1>, dim3(G, B), dim3(64), 0, st, (const double*)partial, red, C, G, a.chunks, H * W, 0.f);
   const long long total = (long long)B * H * W * (C / 4);
+  static const bool fast = !(getenv("BUDDY_GN_FAST") && atoi(getenv("BUDDY_GN_FAST")) == 0);
+  if (fast && mode == 0 && extra_mode != 2 && C % 4 == 0 && C / 4 <= 256) {
+    GnFast g = gn_fast(H * W, C, G);
+    hipLaunchKernelGGL(gn_bwd_apply_m0_kernel, dim3((H * W + g.ppc - 1) / g.ppc, B), dim3(g.q * g.pl), 0, st, x, stats, gamma, beta, da, g, silu,
+                       extra_mode == 1 ? extra : nullptr, extra_scale, (const float*)red, dx);
+  } else
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, da, B, H, W, C, G, mode, silu, extra,
                      extra_mode, extra_scale, (const float*)red, dx);
   prof_hbm_end(st);
