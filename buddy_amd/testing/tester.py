@@ -111,6 +111,8 @@ class Tester:
             for it in items:                      # only equal-length utterances share a batch
                 groups.setdefault(len(it[0]), []).append(it)
             for L, grp in groups.items():
+                if getattr(self, "noise_factory", None) is not None:      # parity runs: one injected noise stream per utterance
+                    self.sampler.noise = self.noise_factory([it[2] for it in grp])
                 seg, y, operator, rirs = self.prepare_batch(grp, blind)
                 pred = self.sampler.predict_conditional(y, operator, shape=(len(grp), L), blind=blind)
                 est = self.sampler.operator.get_time_RIR().detach().cpu() if blind else None
