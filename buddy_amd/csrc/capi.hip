@@ -188,6 +188,13 @@ int buddy_fir(const float* x, const float* h, long long h_stride, float* y, int 
 }
 
 
+// ---- WPE warm start ----
+int buddy_wpe(const double* Y, double* X, double* scratch, int rows, int T, int taps, int delay, int iterations, void* stream) {
+  if (!Y || !X || !scratch || rows < 1 || T < 1 || taps < 1 || taps > 56 || delay < 0 || iterations < 0) { set_error("bad wpe arguments (taps <= 56)"); return BUDDY_ERR_ARG; }
+  launch_wpe(Y, X, scratch, rows, T, taps, delay, iterations, (hipStream_t)stream);
+  return finish();
+}
+
 // ---- blind operator ----
 int buddy_blindop_create(int U, int L, int Nf, int E, int num_knots, const float* knots, int sample_rate, float comp, float min_decay,
                          float max_decay, float w_lo, float w_hi, int clamp_decay, int long_second, void** handle) {

@@ -67,6 +67,8 @@ void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* 
                    float* red /*[B][G][2]*/, Dst2 dx, hipStream_t st);
 
 // ---- misc elementwise -------------------------------------------------------------------------------------
+// WPE warm start (wpe.hip): rows x T complex128 in/out, scratch rows*T doubles
+void launch_wpe(const double* Y, double* X, double* inv_scratch, int rows, int T, int taps, int delay, int iters, hipStream_t st);
 void launch_axpy(float* dst, const float* src, float alpha, long long n, int accumulate, hipStream_t st);
 void launch_pool2(const float* src, float* dst, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st); // (H,W)->(H/2,W/2), sum*scale
 void launch_up2_acc(const float* src, float* dst, int B, int Hs, int Ws, int C, float scale, int accumulate, hipStream_t st); // (Hs,Ws)->(2Hs,2Ws)

@@ -6,7 +6,8 @@
 is a restatement of its published algorithm (Nakatani et al. 2010; Drude et al. 2018, batch "full statistics" variant) and of
 its STFT conventions (periodic Blackman analysis window, "fading" zero padding of size-shift samples on both sides,
 bi-orthogonal synthesis window).  PARITY UNPINNED: there is no reference output to compare with.
-Runs once per utterance, outside the sampling loop; torch complex128 on the caller's device."""
+Runs once per utterance, outside the sampling loop.  On the GPU the iterations (inverse power, correlation matrix, Cholesky solve,
+prediction filter) are one hand-written kernel per (utterance, bin) row (``csrc/wpe.hip``); STFT / iSTFT stay torch FFTs in float64."""
 from __future__ import annotations
 
 import math
@@ -71,12 +72,27 @@ def wpe(Y, taps=10, delay=3, iterations=3):
     return X
 
 
+def wpe_hip(Y, taps=10, delay=3, iterations=3):
+    """Same as :func:`wpe` for D = 1 on a CUDA tensor through the hand-written kernel (``buddy_wpe``): Y (F, 1, T) complex128."""
+    from .. import _lib
+    lib = _lib.require_gpu()
+    F, D, T = Y.shape
+    assert D == 1 and Y.is_cuda and Y.dtype == torch.complex128
+    Yr = torch.view_as_real(Y.contiguous()).contiguous()                    # (F, 1, T, 2) float64
+    Xr = torch.empty_like(Yr)
+    scratch = torch.empty(F * T, dtype=torch.float64, device=Y.device)
+    _lib.check(lib.buddy_wpe(_lib.ptr(Yr), _lib.ptr(Xr), _lib.ptr(scratch), F, T, int(taps), int(delay), int(iterations), _lib.stream_ptr()))
+    return torch.view_as_complex(Xr)
+
+
 def wpe_dereverb(y, taps=50, delay=2, iterations=5, size=512, shift=128):
-    """y (B, L) float -> (B, <=L) float32: stft -> per-utterance single-channel WPE -> istft (reference :36-51)."""
+    """y (B, L) float -> (B, <=L) float32: stft -> per-utterance single-channel WPE -> istft (reference :36-51).
+    On a CUDA tensor the WPE iterations run in the HIP library (no torch fallback there); the torch form serves CPU tensors."""
     out = []
     for b in range(y.shape[0]):
         Y = stft(y[b:b + 1], size, shift)                   # (1, T, F)
-        Z = wpe(Y.permute(2, 0, 1), taps=taps, delay=delay, iterations=iterations).permute(1, 2, 0)
+        solver = wpe_hip if y.is_cuda else wpe
+        Z = solver(Y.permute(2, 0, 1).contiguous(), taps=taps, delay=delay, iterations=iterations).permute(1, 2, 0)
         out.append(istft(Z, size, shift))
     x = torch.cat(out, dim=0).to(torch.float32)
     return x[..., :y.shape[-1]]

@@ -107,6 +107,11 @@ int buddy_row_moments(const float* x, double* out, int B, int L, void* stream);
  * correlation (its transpose) for the VJP. */
 int buddy_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, void* stream);
 
+/* ---- WPE warm start (`wpe_scaled`, testing/EulerHeunSamplerDPS.py:32-54 -> nara_wpe.wpe.wpe(Y, taps, delay, iterations,
+ * statistics_mode='full'), single channel): Y, X are (rows, T) complex128 as interleaved doubles, one row per (utterance, frequency bin);
+ * scratch: rows*T doubles.  Per row and iteration: inverse power, correlation matrix/vector, Cholesky solve, prediction filter. ---- */
+int buddy_wpe(const double* Y, double* X, double* scratch, int rows, int T, int taps, int delay, int iterations, void* stream);
+
 /* ---- blind subband-filtering reverb operator, batched over U utterances; replaces testing/operators/subband_filtering.py
  * (BlindSubbandFiltering :142-351 incl. SubbandFiltering :8-136), utils/reverb_utils.py:3-23, utils/losses.py:59-64 and the
  * torch.optim.Adam loop of EulerHeunSamplerDPS.optimize_op (testing/EulerHeunSamplerDPS.py:71-113) with hand-written

@@ -169,3 +169,23 @@ def test_row_ops(lib):
     torch.cuda.synchronize()
     assert rel(out, a[:, None] * x + c[:, None] * y) < 1e-6
     assert rel(mom[:, 0], x.double().sum(1)) < 1e-9 and rel(mom[:, 1], (x.double() ** 2).sum(1)) < 1e-9
+
+
+def test_wpe_kernel_vs_torch_restatement(lib):
+    """buddy_wpe (one workgroup per frequency bin, Cholesky in LDS, complex128) vs the torch restatement of the same algorithm."""
+    from buddy_amd.utils import wpe
+    g = torch.Generator(device="cpu").manual_seed(11)
+    L = 16000
+    src = torch.randn(L, generator=g, dtype=torch.float64) * (torch.rand(L, generator=g, dtype=torch.float64) > 0.7)
+    h = torch.randn(3000, generator=g, dtype=torch.float64) * torch.exp(-torch.arange(3000, dtype=torch.float64) / 600.0)
+    y = torch.nn.functional.conv1d(src.view(1, 1, -1), h.flip(0).view(1, 1, -1), padding=2999)[0, 0, :L]
+    Y = wpe.stft(y[None].cuda()).permute(2, 0, 1).contiguous()              # (F, 1, T)
+    Zt = wpe.wpe(Y, taps=50, delay=2, iterations=5)
+    Zh = wpe.wpe_hip(Y, taps=50, delay=2, iterations=5)
+    err = float((torch.view_as_real(Zh) - torch.view_as_real(Zt)).abs().max() / torch.view_as_real(Zt).abs().max())
+    # 50 taps on a reverberant signal: cond(R) ~ 1e9..1e10, so Cholesky (kernel) and LU (torch.linalg.solve) agree to cond * eps_fp64
+    assert err < 1e-4, err
+    # fewer taps / iterations, odd delay
+    Zt = wpe.wpe(Y, taps=7, delay=3, iterations=2)
+    Zh = wpe.wpe_hip(Y, taps=7, delay=3, iterations=2)
+    assert float((torch.view_as_real(Zh) - torch.view_as_real(Zt)).abs().max() / torch.view_as_real(Zt).abs().max()) < 1e-9
