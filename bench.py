@@ -81,9 +81,9 @@ class StepRunner:
                 return r
             op.hip_optimize = timed_optimize
         self.s = s
-        self.t = s.create_schedule().to(device)
-        self.gamma = s.get_gamma(self.t).to(device)
-        self.x = s.initialize_x(tuple(y.shape), device, self.t)
+        t = s.create_schedule()                            # host-side schedule, as in predict(): no device sync inside a step
+        self.t, self.gamma = t.tolist(), s.get_gamma(t).tolist()
+        self.x = s.initialize_x(tuple(y.shape), device, t)
         self.i = 0
         self.x_den = None
 

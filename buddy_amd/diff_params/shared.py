@@ -17,8 +17,10 @@ class SDE:
         xn: (B,1,L) like the reference, or (B,L).  t: 0-dim tensor / float (reference: one sigma for the batch) or a
         (B,) tensor (per-utterance sigma).  If ``net`` exposes ``denoise_fused`` (the MI355X NCSNppTime) the scalars
         are folded into the STFT / overlap-add kernels; otherwise the generic expression is evaluated."""
-        t = torch.as_tensor(t, dtype=torch.float32, device=xn.device)
         B = xn.shape[0]
+        if not torch.is_tensor(t):
+            t = torch.full((1,), float(t), dtype=torch.float32, device=xn.device)      # a fill kernel, not a host-to-device copy
+        t = torch.as_tensor(t, dtype=torch.float32, device=xn.device)
         sigma_b = self._std(t).reshape(-1).expand(B) if t.numel() in (1, B) else None
         if sigma_b is None:
             raise ValueError("t must be a scalar or have one entry per batch element")

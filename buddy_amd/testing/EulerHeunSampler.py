@@ -24,6 +24,12 @@ class EulerHeunSampler(Sampler):
         gamma[indexes] = gamma[indexes] + torch.min(torch.Tensor([self.Schurn / N, 2 ** (1 / 2) - 1])).to(t.device)
         return gamma
 
+    @staticmethod
+    def _scalar(v):
+        """schedule entries as host fp32 scalars: no device round trip inside the loop (a CUDA 0-dim tensor forces a host sync per use)"""
+        import numpy as np
+        return np.float32(float(v))                         # fp32 host arithmetic, like the reference's fp32 0-dim tensors
+
     def stochastic_timestep(self, x, t, gamma, Snoise=1):
         t_hat = t + gamma * t
         epsilon = self._randn(x.shape, x.device) * Snoise     # Snoise from the config never reaches here (reference :41,50)
@@ -34,6 +40,7 @@ class EulerHeunSampler(Sampler):
         return x_hat, t_hat
 
     def step(self, x_i, t_i, t_iplus1, gamma_i, blind=False):
+        t_i, t_iplus1, gamma_i = self._scalar(t_i), self._scalar(t_iplus1), self._scalar(gamma_i)
         with torch.no_grad():
             x_hat, t_hat = self.stochastic_timestep(x_i, t_i, gamma_i)
             x_den = self.get_Tweedie_estimate(x_hat, t_hat)
@@ -52,12 +59,12 @@ class EulerHeunSampler(Sampler):
             return x_iplus1, x_den
 
     def predict(self, shape, device, blind=False):
-        t = self.create_schedule().to(device)
+        t = self.create_schedule()                          # stays on the host: the loop below never waits for the device
         x = self.initialize_x(shape, device, t)
-        gamma = self.get_gamma(t).to(device)
+        tl, gl = t.tolist(), self.get_gamma(t).tolist()
         for i in range(0, self.T, 1):
             self.step_counter = i
-            x, x_den = self.step(x, t[i], t[i + 1], gamma[i], blind)
+            x, x_den = self.step(x, tl[i], tl[i + 1], gl[i], blind)
         return x.detach()
 
     def predict_unconditional(self, shape, device):

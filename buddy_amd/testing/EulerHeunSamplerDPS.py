@@ -127,6 +127,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         return x_next, x_den_out
 
     def step(self, x_i, t_i, t_iplus1, gamma_i, blind=False):
+        t_i, t_iplus1, gamma_i = self._scalar(t_i), self._scalar(t_iplus1), self._scalar(gamma_i)
         if x_i.is_cuda and x_i.dim() == 2 and self.use_hip_update:
             return self._step_hip(x_i, t_i, t_iplus1, gamma_i, blind)
         x_hat, t_hat = self.stochastic_timestep(x_i, t_i, gamma_i)
@@ -141,13 +142,13 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         return x_iplus1.detach_(), x_den.detach()
 
     def predict(self, shape, device, blind=False):
-        t = self.create_schedule().to(device)
+        t = self.create_schedule()                          # host-side schedule: no device sync inside the loop
         x = self.initialize_x(shape, device, t)
-        gamma = self.get_gamma(t).to(device)
+        tl, gl = t.tolist(), self.get_gamma(t).tolist()
         x_den = None
         for i in range(0, self.T, 1):
             self.step_counter = i
-            x, x_den = self.step(x, t[i], t[i + 1], gamma[i], blind)
+            x, x_den = self.step(x, tl[i], tl[i + 1], gl[i], blind)
         return x_den.detach()       # DPS returns the last denoised estimate, not x (reference :178)
 
     def predict_unconditional(self, *args, **kwargs):
