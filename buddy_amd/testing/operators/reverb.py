@@ -61,10 +61,13 @@ class RIROperator(Operator, OperatorSTFT):
                 _lib.load().buddy_blindop_destroy(self._hip_h)
         except Exception:
             pass
-        self._hip_h, self._hip_key = None, None
+        self.__dict__["_hip_h"] = None; self.__dict__["_hip_key"] = None     # not via nn.Module.__setattr__: also runs at interpreter shutdown
 
     def __del__(self):
-        self._hip_release()
+        try:
+            self._hip_release()
+        except Exception:
+            pass
 
     def optim_fwd(self, Xden, Y):
         return torch.sum((self.degradation(Xden) - Y) ** 2)
