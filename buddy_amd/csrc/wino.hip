@@ -18,6 +18,7 @@
 //     residual / 1/sqrt(2) like the direct kernel.
 #include "common.h"
 #include <cstdlib>
+#include <cstdint>
 
 namespace buddy {
 namespace {
@@ -186,6 +187,50 @@ __global__ __launch_bounds__(64 * NW, 2) void wino3_kernel(const IgemmParams p, 
     }
   }
 
+  if (p.wide_epi) {
+    // Output transform in registers, then the (2 NW x 32)-pixel x 32-cout tile goes through LDS (the operand buffers are free now) so that
+    // every pixel's 32 couts leave as 128 contiguous bytes: float4 stores, float4 bias / residual reads.
+    constexpr int EP = WN + 4;                            // floats per staged pixel row
+    float* S = smem;
+    __syncthreads();                                      // all waves are done reading the last chunk's buffers
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        float m[16];
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) m[pos] = acc[pos][nt][r];
+        const float s0 = m[0] + m[4] + m[8], s1 = m[1] + m[5] + m[9], s2 = m[2] + m[6] + m[10], s3 = m[3] + m[7] + m[11];
+        const float u0 = m[4] - m[8] - m[12], u1 = m[5] - m[9] - m[13], u2 = m[6] - m[10] - m[14], u3 = m[7] - m[11] - m[15];
+        const float yv[2][2] = {{s0 + s1 + s2, s1 - s2 - s3}, {u0 + u1 + u2, u1 - u2 - u3}};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx)
+            S[((2 * wid + dy) * (2 * BTX) + 2 * (q * 4 + r) + dx) * EP + nt * 16 + tl] = yv[dy][dx];
+      }
+    __syncthreads();
+    const int c4 = (tid & 7) * 4, n = n0 + c4;
+    float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias_n) add = ld4(p.bias_n + n);
+    if (p.bias_bn) add = f4add(add, ld4(p.bias_bn + (long long)b * p.ld_bias_bn + n));
+    constexpr int NPIX = 2 * V3_BTY * 2 * BTX;            // pixels of the workgroup tile
+#pragma unroll
+    for (int i = 0; i < NPIX / (NT_ / 8); ++i) {
+      const int pl = (tid >> 3) + (NT_ / 8) * i;
+      const int hh = 2 * by * V3_BTY + pl / (2 * BTX), ww = 2 * bx * BTX + pl % (2 * BTX);
+      const long long pix = ((long long)b * H + hh) * W + ww;
+      const float4 y4 = *reinterpret_cast<const float4*>(S + pl * EP + c4);
+      float4 v = make_float4(p.alpha * y4.x + add.x, p.alpha * y4.y + add.y, p.alpha * y4.z + add.z, p.alpha * y4.w + add.w);
+      if (p.res_mode == 1) v = f4add(v, ld4(p.res + pix * p.ldRes + n));
+      else if (p.res_mode == 2) v = f4add(v, ld4(p.res + (((long long)b * (H >> 1) + (hh >> 1)) * (W >> 1) + (ww >> 1)) * p.ldRes + n));
+      v = make_float4(v.x * p.out_scale, v.y * p.out_scale, v.z * p.out_scale, v.w * p.out_scale);
+      float* dst = p.C + pix * p.ldC + n;
+      if (p.accumulate) v = f4add(v, ld4(dst));
+      *reinterpret_cast<float4*>(dst) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int ey = by * V3_BTY + wid, ex = bx * BTX + q * 4 + r;
@@ -226,7 +271,17 @@ bool wino_supported(const IgemmParams& p) {
 }
 
 static float* g_zero_page = nullptr;
-void launch_wino(const IgemmParams& p, const float* Uw, hipStream_t st) {
+void launch_wino(const IgemmParams& p_in, const float* Uw, hipStream_t st) {
+  IgemmParams p = p_in;
+  {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    bool wide = (p.ldC % 4 == 0) && al16(p.C);
+    if (p.bias_n) wide = wide && al16(p.bias_n);
+    if (p.bias_bn) wide = wide && al16(p.bias_bn) && (p.ld_bias_bn % 4 == 0);
+    if (p.res_mode) wide = wide && al16(p.res) && (p.ldRes % 4 == 0);
+    static const bool force_scalar = getenv("BUDDY_WINO_EPI") && atoi(getenv("BUDDY_WINO_EPI")) == 0;     // A/B switch
+    p.wide_epi = (wide && !force_scalar) ? 1 : 0;
+  }
   if (!g_zero_page) { (void)hipMalloc(&g_zero_page, 256); (void)hipMemset(g_zero_page, 0, 256); }
   const int B = p.M / (p.H * p.W);
   const int TH = p.H / 2, TW = p.W / 2;
