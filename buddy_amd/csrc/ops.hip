@@ -520,6 +520,59 @@ __global__ __launch_bounds__(256) void conv_c2out_kernel(const float* x, int ldX
   }
 }
 
+// 3x3, Cin -> 2, LDS-tiled: a block owns an 8 x 32 tile of output pixels (one per thread).  Per 32-channel chunk the (10 x 34)-pixel halo is
+// staged once (coalesced 128 B per pixel; the generic kernel re-reads every input element nine times through L1/L2), then each thread sums its
+// 9 taps x 32 channels from LDS; the weights are wave-uniform (scalar loads).  Channel order of the sum: chunk, tap, channel.
+constexpr int C2O_TH = 8, C2O_TW = 32, C2O_CK = 32, C2O_PITCH = C2O_CK + 4;
+__global__ __launch_bounds__(256) void conv_c2out_tiled_kernel(const float* __restrict__ x, int ldX, const float* __restrict__ w, const float* bias,
+                                                               const float* up_add, float* y, int B, int H, int W, int Cin, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float tile[(C2O_TH + 2) * (C2O_TW + 2) * C2O_PITCH];
+  const int tid = threadIdx.x;
+  const int tx = tid & (C2O_TW - 1), ty = tid / C2O_TW;
+  const int nbx = (W + C2O_TW - 1) / C2O_TW, nby = (H + C2O_TH - 1) / C2O_TH;
+  int blk = blockIdx.x;
+  const int bxi = blk % nbx; blk /= nbx;
+  const int byi = blk % nby; const int b = blk / nby;
+  const int h0 = byi * C2O_TH, w0 = bxi * C2O_TW;
+  const int h = h0 + ty, wq = w0 + tx;
+  float s0 = 0.f, s1 = 0.f;
+  constexpr int NPX = (C2O_TH + 2) * (C2O_TW + 2);        // 340 halo pixels, 8 float4 each
+  for (int c0 = 0; c0 < Cin; c0 += C2O_CK) {
+    for (int e = tid; e < NPX * (C2O_CK / 4); e += 256) {
+      const int px = e >> 3, c4 = (e & 7) * 4;
+      const int hr = px / (C2O_TW + 2), wc = px - hr * (C2O_TW + 2);
+      const int gh = h0 - 1 + hr, gw = w0 - 1 + wc;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) v = ld4(x + (((long long)b * H + gh) * W + gw) * ldX + c0 + c4);
+      *reinterpret_cast<float4*>(tile + px * C2O_PITCH + c4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float* src = tile + ((ty + t / 3) * (C2O_TW + 2) + tx + t % 3) * C2O_PITCH;
+      const float* wt = w + ((long long)t * Cin + c0) * 2;
+#pragma unroll
+      for (int c4 = 0; c4 < C2O_CK; c4 += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + c4);
+        s0 += v.x * wt[c4 * 2 + 0] + v.y * wt[c4 * 2 + 2] + v.z * wt[c4 * 2 + 4] + v.w * wt[c4 * 2 + 6];
+        s1 += v.x * wt[c4 * 2 + 1] + v.y * wt[c4 * 2 + 3] + v.z * wt[c4 * 2 + 5] + v.w * wt[c4 * 2 + 7];
+      }
+    }
+    __syncthreads();
+  }
+  if (h < H && wq < W) {
+    const long long p = ((long long)b * H + h) * W + wq;
+    if (bias) { s0 += bias[0]; s1 += bias[1]; }
+    if (up_add) {
+      const float2 u = reinterpret_cast<const float2*>(up_add)[(((long long)b * (H >> 1)) + (h >> 1)) * (W >> 1) + (wq >> 1)];
+      s0 += u.x; s1 += u.y;
+    }
+    float2* o = reinterpret_cast<float2*>(y) + p;
+    if (accumulate) { s0 += o->x; s1 += o->y; }
+    *o = make_float2(s0, s1);
+  }
+}
+
 // ------------------------------------------------------------------ STFT glue
 __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* x, float* xp, int B, int L, int pad, int Lp, float scale, const float* scale_b) {
   const long long total = (long long)B * Lp;
@@ -735,7 +788,11 @@ void launch_conv_c2out(const float* x, int ldX, const float* w, const float* bia
   const int ppb = 256 / (Cin / 4);
   long long groups = ((long long)B * H * W + ppb - 1) / ppb;
   int grid = (int)(groups < 256 * 8 ? groups : 256 * 8);
-  if (taps == 9)
+  static const bool tiled = !(getenv("BUDDY_C2OUT_TILED") && atoi(getenv("BUDDY_C2OUT_TILED")) == 0);
+  if (taps == 9 && tiled && Cin % C2O_CK == 0 && ldX % 4 == 0) {
+    const int blocks = B * ((H + C2O_TH - 1) / C2O_TH) * ((W + C2O_TW - 1) / C2O_TW);
+    hipLaunchKernelGGL(conv_c2out_tiled_kernel, dim3(blocks), dim3(256), 0, st, x, ldX, w, bias, up_add, y, B, H, W, Cin, accumulate);
+  } else if (taps == 9)
     hipLaunchKernelGGL(conv_c2out_kernel<9>, dim3(grid), dim3(256), 0, st, x, ldX, w, bias, up_add, y, B, H, W, Cin, accumulate);
   else
     hipLaunchKernelGGL(conv_c2out_kernel<1>, dim3(grid), dim3(256), 0, st, x, ldX, w, bias, up_add, y, B, H, W, Cin, accumulate);
