@@ -57,6 +57,38 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const RedArgs a) {
       mean = a.stats[((long long)b * a.G + g) * 2]; rstd = a.stats[((long long)b * a.G + g) * 2 + 1];
       gm = ld4(a.gamma + c); bt = ld4(a.beta + c);
     }
+    if (KIND == 1 && a.mode == 0) {
+      // backward sums, same resolution: fp32 partials over strips of 8 pixels (two loads in flight per tensor), flushed into the fp64 sums
+      // (the forward statistics stay fp64 throughout: E[x^2] - mean^2 cancels)
+      const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+      const bool second = a.x.p1 != nullptr && c >= a.x.C0;
+      const float* xs = (second ? a.x.p1 + (c - a.x.C0) : a.x.p0 + c) + (long long)b * HW * (second ? a.x.ld1 : a.x.ld0);
+      const long long ldx = second ? a.x.ld1 : a.x.ld0;
+      const float* ds = a.da + (long long)b * HW * a.C + c;
+      int p = p0 + lp;
+      while (p < p1) {
+        float fs[4] = {0.f, 0.f, 0.f, 0.f}, ft[4] = {0.f, 0.f, 0.f, 0.f};
+        auto one = [&](float4 v, float4 d) {
+          const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xh = (xv[j] - mean) * rstd;
+            const float z = xh * gv[j] + bv[j];
+            const float dxh = dv[j] * (a.silu ? dsilu_f(z) : 1.f) * gv[j];
+            fs[j] += dxh; ft[j] += dxh * xh;
+          }
+        };
+        int n = 0;
+        for (; n < 8 && p + pl < p1; n += 2, p += 2 * pl) {
+          const float4 v0 = ld4(xs + (long long)p * ldx), v1 = ld4(xs + (long long)(p + pl) * ldx);
+          const float4 d0 = ld4(ds + (long long)p * a.C), d1 = ld4(ds + (long long)(p + pl) * a.C);
+          one(v0, d0); one(v1, d1);
+        }
+        if (n < 8 && p < p1) { one(ld4(xs + (long long)p * ldx), ld4(ds + (long long)p * a.C)); p += pl; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += (double)fs[j]; t[j] += (double)ft[j]; }
+      }
+    } else
     for (int p = p0 + lp; p < p1; p += pl) {
       const float4 v = ld4(src_ptr(a.x, (long long)b * HW + p, c));
       const float xv[4] = {v.x, v.y, v.z, v.w};
