@@ -138,6 +138,25 @@ int buddy_conv3x3_winograd(const float* x, const float* U, const float* bias, fl
   return finish();
 }
 
+int buddy_winograd4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_host) {
+  if (!wt_host || !U4_host || Cout < 1 || Cin < 1) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  wino4_transform_weights(wt_host, Cout, Cin, U4_host);
+  return BUDDY_OK;
+}
+int buddy_conv3x3_winograd4(const float* x, const float* U4, const float* bias, float* y, float* scratch, int B, int H, int W, int Cin, int Cout,
+                            void* stream) {
+  if (!x || !U4 || !y || !scratch) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.A0 = x; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = y; p.ldC = Cout;
+  p.bias_n = bias; p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
+  if (!wino4_supported(p)) { set_error("shape not supported by the F(4x4,3x3) path (H, W, Cin, Cout multiples of 4)"); return BUDDY_ERR_ARG; }
+  long long vf = 0, mf = 0; wino4_scratch(p, &vf, &mf);
+  igemm_prof_record(p, 9, 1, (hipStream_t)stream, true, 0.25);
+  launch_wino4(p, U4, scratch, scratch + vf, (hipStream_t)stream);
+  igemm_prof_record(p, 9, 1, (hipStream_t)stream, false, 0.25);
+  return finish();
+}
+
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B, int H, int W, int C,
                         int G, int mode, int silu, void* stream) {
   if (!x || !y || !stats || !scratch || C % 4 || (C / G) % 4 || C > 1024) { set_error("bad groupnorm arguments"); return BUDDY_ERR_ARG; }

@@ -36,7 +36,12 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
 bool wino_supported(const IgemmParams& p);
 void launch_wino(const IgemmParams& p, const float* Uw, hipStream_t st);
 void wino_transform_weights(const float* wt_host, int Cout, int Cin, float* U_host);
-void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin);
+// Winograd F(4x4,3x3) in three passes (wino4.hip): weights U4[36][Cout][Cin], scratch V (36*M/16*Cin floats) and Mb (36*M/16*N floats)
+bool wino4_supported(const IgemmParams& p);
+void wino4_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats);
+void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st);
+void wino4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_host);
+void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin, double exec_ratio = 4.0 / 9.0);
 void igemm_prof_enable(int on);
 bool igemm_prof_enabled();
 void prof_hbm_begin(double algorithmic_bytes, hipStream_t st);   // bracket of an HBM-bound launch group (GroupNorm kernels)

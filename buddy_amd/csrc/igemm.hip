@@ -345,13 +345,13 @@ int prof_hbm_collect(double* ms, double* bytes, long long* launches) {
 }
 
 static ProfRec g_cur;
-void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin) {
+void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin, double exec_ratio) {
   if (!g_prof_on) return;
   if (begin) {
-    // called for the Winograd launches: algorithmic flops are those of the direct 3x3 conv, executed MACs are 16/36 of them
+    // called for the Winograd launches: algorithmic flops are those of the direct 3x3 conv, executed MACs are exec_ratio of them (4/9 for F(2x2,3x3), 1/4 for F(4x4,3x3))
     (void)hipEventCreate(&g_cur.e0); (void)hipEventCreate(&g_cur.e1);
     g_cur.flops = 2.0 * (double)p.M * (double)p.N * (double)p.Cin * (double)taps * (double)batch; g_cur.taps = taps;
-    g_cur.exec_flops = g_cur.flops * 4.0 / 9.0;
+    g_cur.exec_flops = g_cur.flops * exec_ratio;
     g_cur.M = p.M; g_cur.N = p.N; g_cur.K = p.Cin; g_cur.batch = batch; g_cur.kind = 9;
     g_cur.bytes = 4.0 * (double)batch * ((double)p.M * p.Cin + (double)p.N * p.Cin * taps + (double)p.M * p.N * (p.res_mode ? 2.0 : 1.0));
     (void)hipEventRecord(g_cur.e0, st);

@@ -104,7 +104,8 @@ struct Arena {
 };
 
 struct ConvW { int cin = 0, cout = 0, taps = 0; float* wf = nullptr; float* wb = nullptr; float* bias = nullptr;
-               float* uf = nullptr; float* ub = nullptr; };   // uf/ub: Winograd-domain weights (forward / data-gradient)
+               float* uf = nullptr; float* ub = nullptr;      // uf/ub: Winograd F(2x2,3x3)-domain weights (forward / data-gradient)
+               float* uf4 = nullptr; float* ub4 = nullptr; }; // F(4x4,3x3)-domain weights [36][Cout][Cin]
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResW { GNW gn0, gn1; ConvW c0, c1, c2; bool has_c2 = false; int cin = 0, cout = 0, dense_off = 0; };
 struct AttnW { GNW gn; float* Wt[4]; float* Wn[4]; float* b[4]; int C = 0; };
@@ -139,6 +140,7 @@ struct Net {
   Tens* spec = nullptr; Tens* pyr0 = nullptr;
   const float* k_cin = nullptr; const float* k_cskip = nullptr; const float* k_cout = nullptr;
 
+  float* w4_scratch = nullptr; size_t w4_cap = 0, w4_need = 0;   // V / M buffers of the three-pass F(4x4,3x3) convolutions (floats)
   bool dry() const { return arena.dry; }
   Tens* mk(int B_, int H, int W, int C, bool grad) {
     pool.emplace_back();
@@ -241,6 +243,9 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
       std::vector<float> u((size_t)16 * cin * cout);
       wino_transform_weights(wfv.data(), cout, cin, u.data()); packed(&c.uf, u);
       wino_transform_weights(wbv.data(), cin, cout, u.data()); packed(&c.ub, u);
+      std::vector<float> u4((size_t)36 * cin * cout);
+      wino4_transform_weights(wfv.data(), cout, cin, u4.data()); packed(&c.uf4, u4);
+      wino4_transform_weights(wbv.data(), cin, cout, u4.data()); packed(&c.ub4, u4);
     }
   };
   auto load_res = [&](int cin, int cout, bool resample) {
@@ -352,6 +357,7 @@ void net_destroy(Net* N) {
   if (!N) return;
   if (N->dparams) (void)hipFree(N->dparams);
   if (N->dpacked) (void)hipFree(N->dpacked);
+  if (N->w4_scratch) (void)hipFree(N->w4_scratch);
   if (N->arena.base) (void)hipFree(N->arena.base);
   if (N->inv_env) (void)hipFree(N->inv_env);
   delete N;
@@ -377,15 +383,29 @@ static inline int gn_groups(int C) { int g = C / 4; return g < 32 ? g : 32; }
 
 // conv3x3 over an NHWC tensor (single source) -> out
 static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const float* wt, int Cout, const float* bias, const float* bias_bn,
-                  int ld_bn, const float* res, int ldRes, int res_mode, float alpha, float out_scale, float* out, const float* U = nullptr) {
-  if (N->dry()) return;
-  static const bool use_wino = !(getenv("BUDDY_CONV") && std::string(getenv("BUDDY_CONV")) == "direct");
+                  int ld_bn, const float* res, int ldRes, int res_mode, float alpha, float out_scale, float* out, const float* U = nullptr,
+                  const float* U4 = nullptr) {
+  // BUDDY_CONV = direct | wino2 | (default) F(4x4,3x3) three-pass where the shape allows, else fused F(2x2,3x3), else direct
+  static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
+  static const bool use_wino = mode != "direct", use_wino4 = mode != "direct" && mode != "wino2";
+  if (N->dry()) {
+    if (use_wino4 && U4 != nullptr && H % 4 == 0 && W % 4 == 0) {
+      const size_t need = (size_t)36 * ((size_t)B * H * W / 16) * (size_t)(Cin + Cout);
+      if (need > N->w4_need) N->w4_need = need;
+    }
+    return;
+  }
   IgemmParams p = ig_base();
   p.A0 = a; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout;
   p.Bt = wt; p.ldB = 9 * Cin; p.C = out; p.ldC = Cout;
   p.bias_n = bias; p.bias_bn = bias_bn; p.ld_bias_bn = ld_bn; p.rows_per_batch = H * W;
   p.res = res; p.ldRes = ldRes; p.res_mode = res_mode; p.alpha = alpha; p.out_scale = out_scale;
-  if (use_wino && U != nullptr && wino_supported(p)) {
+  if (use_wino4 && U4 != nullptr && N->w4_scratch != nullptr && wino4_supported(p)) {
+    long long vf = 0, mf = 0; wino4_scratch(p, &vf, &mf);
+    igemm_prof_record(p, 9, 1, N->st, true, 0.25);
+    launch_wino4(p, U4, N->w4_scratch, N->w4_scratch + vf, N->st);
+    igemm_prof_record(p, 9, 1, N->st, false, 0.25);
+  } else if (use_wino && U != nullptr && wino_supported(p)) {
     igemm_prof_record(p, 9, 1, N->st, true);
     launch_wino(p, U, N->st);
     igemm_prof_record(p, 9, 1, N->st, false);
@@ -421,7 +441,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
   if (!N->dry()) {
     launch_gn_stats(src_of(x), B, H * W, Cin, G0, 1e-6f, N->partial, stats0, st);
     launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
-    conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p, R.c0.uf);
+    conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p, R.c0.uf, R.c0.uf4);
     launch_gn_stats(single(h1->p, Cout), B, Ho * Wo, Cout, G1, 1e-6f, N->partial, stats1, st);
     launch_gn_apply(single(h1->p, Cout), stats1, R.gn1.gamma, R.gn1.beta, B, Ho, Wo, Cout, G1, 0, 1, a1, nullptr, st);
     const float* res; int res_mode = 1;
@@ -432,7 +452,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
     } else {
       res = x.a->p;   // identity skip: single source, same resolution, Cin == Cout
     }
-    conv3(N, a1, B, Ho, Wo, Cout, R.c1.wf, Cout, R.c1.bias, nullptr, 0, res, Cout, res_mode, 1.f, INV_SQRT2, out->p, R.c1.uf);
+    conv3(N, a1, B, Ho, Wo, Cout, R.c1.wf, Cout, R.c1.bias, nullptr, 0, res, Cout, res_mode, 1.f, INV_SQRT2, out->p, R.c1.uf, R.c1.uf4);
   }
   N->arena.off = mark;
   if (rec) {
@@ -463,12 +483,12 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       float* da1 = n->tmp((long long)B * Ho * Wo * Cout);
       float* dh1 = n->tmp((long long)B * Ho * Wo * Cout);
       float* da0 = n->tmp((long long)B * Ho * Wo * Cin);
-      conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub);
+      conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub, Rp->c1.ub4);
       Dst2 d1; d1.p0 = dh1; d1.p1 = nullptr; d1.C0 = Cout; d1.ld0 = Cout; d1.ld1 = 0; d1.acc0 = 0; d1.acc1 = 0;
       if (!n->dry())
         launch_gn_bwd(single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, da1, B, Ho, Wo, Cout, G1, 0, 1, nullptr, 0, 0.f, n->partial,
                       n->red, d1, s);
-      conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub);
+      conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub, Rp->c0.ub4);
       Dst2 d0 = gdst_of(x);
       if (!n->dry())
         launch_gn_bwd(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0, B, H, W, Cin, G0, mode, 1, extra, extra_mode, extra_scale,
@@ -732,13 +752,20 @@ static void run_vjp(Net* N, const float* cot, float* gx) {
 
 int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes) {
   Arena saved = N->arena;
+  N->w4_need = 0;
   N->arena = Arena(); N->arena.dry = true;
   run_forward(N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, L, with_vjp != 0);
   if (with_vjp) run_vjp(N, nullptr, nullptr);
   const size_t need = N->arena.peak + (1 << 20);
   N->arena = saved;
   N->pool.clear(); N->tape.clear(); N->taps.clear(); N->have_tape = false;
-  if (bytes) *bytes = (long long)need;
+  if (bytes) *bytes = (long long)need + (long long)N->w4_need * 4;
+  if (N->w4_cap < N->w4_need) {
+    if (N->w4_scratch) (void)hipFree(N->w4_scratch);
+    N->w4_scratch = nullptr; N->w4_cap = 0;
+    HIPCHK(hipMalloc(&N->w4_scratch, N->w4_need * 4));
+    N->w4_cap = N->w4_need;
+  }
   if (N->arena.cap < need) {
     if (N->arena.base) (void)hipFree(N->arena.base);
     N->arena.base = nullptr; N->arena.cap = 0;

@@ -81,6 +81,11 @@ int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, 
 int buddy_winograd_transform_weights(const float* wt_host, int Cout, int Cin, float* U_host);
 int buddy_conv3x3_winograd(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                            void* stream);
+/* F(4x4,3x3) three-pass variant (input transform, 36 batched GEMMs, output transform) used for the large layers: U4[36][Cout][Cin];
+ * scratch: 36 * (B*H*W/16) * (Cin + Cout) floats. */
+int buddy_winograd4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_host);
+int buddy_conv3x3_winograd4(const float* x, const float* U4, const float* bias, float* y, float* scratch, int B, int H, int W, int Cin, int Cout,
+                            void* stream);
 /* GroupNorm(G, C, eps=1e-6) [+SiLU] [+2x down(mode 1)/up(mode 2)] forward; replaces nn.GroupNorm + nn.SiLU +
  * naive_{up,down}sample_2d (layerspp.py:243-258). stats: [B][G][2] out; scratch: >= B*256*C*16 bytes. */
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B,
