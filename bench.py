@@ -219,6 +219,8 @@ def main():
     log(f"timed region done: {elapsed:.3f} s")
     ms = (C.c_double * 2)(); fl = (C.c_double * 2)(); ln = (C.c_longlong * 2)(); by = (C.c_double * 2)(); xf = (C.c_double * 2)()
     _lib.check(lib.buddy_prof_collect(ms, fl, ln, by, xf))
+    w4_ms = (C.c_double * 3)(); w4_fl, w4_bi, w4_bo, w4_n = C.c_double(), C.c_double(), C.c_double(), C.c_longlong()
+    _lib.check(lib.buddy_prof_collect_wino4(w4_ms, C.byref(w4_fl), C.byref(w4_bi), C.byref(w4_bo), C.byref(w4_n)))
     hb_ms, hb_by, hb_n = C.c_double(), C.c_double(), C.c_longlong()
     _lib.check(lib.buddy_prof_collect_hbm(C.byref(hb_ms), C.byref(hb_by), C.byref(hb_n)))
     el = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
@@ -269,13 +271,23 @@ def main():
             "operator_update": {"ms_per_step": op_ms / a.steps, "share_of_step": op_ms * 1e-3 / elapsed,
                                 "what": "optimize_op: 10 x (design filter, min-phase projection, subband FIR, loss, analytic backward, Adam, clamps) per step, "
                                         "HIP events on the launch stream (rank 0)"},
-            "roofline": {"bound": "mfma", "kernel": "3x3 convolutions: wino3_kernel (fused Winograd F(2x2,3x3), fp32 MFMA 16x16x4) where the shape allows, "
-                                                     "else igemm_kernel<9> (direct implicit GEMM, fp32 MFMA 32x32x2)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "3x3 convolution (94 % of the network FLOPs) = Winograd F(4x4,3x3) in three launches: w4_input_kernel (HBM-bound transform), "
+                                   "igemm_kernel<1,false,false,2,2,36> (36 batched GEMMs, fp32 MFMA 32x32x2 -- the dominant kernel), w4_output_kernel (HBM-bound "
+                                   "transform + fused epilogue); shapes it does not take fall back to the fused F(2x2,3x3) wino3_kernel / direct igemm_kernel<9>",
                          "achieved": conv_tf, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": conv_tf / PEAK_FP32_MFMA,
-                         "achieved_note": "ALGORITHMIC flops of the direct 3x3 convolution (2*M*N*9*Cin) / kernel time; Winograd executes 4/9 of them, "
-                                          "so frac can exceed 1 -- executed_tflops / peak is the matrix-pipe utilisation",
-                         "executed_tflops": xf[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0,
-                         "executed_frac": (xf[0] / (ms[0] * 1e-3) / 1e12 / PEAK_FP32_MFMA) if ms[0] > 0 else 0.0,
+                         "achieved_note": "ALGORITHMIC flops of the direct 3x3 convolution (2*M*N*9*Cin) / time of the whole three-launch group; F(4x4,3x3) executes "
+                                          "1/4 of them on the matrix cores, so frac can exceed 1 -- gemm_pass.frac is the matrix-pipe utilisation of the dominant kernel",
+                         "gemm_pass": {"executed_tflops": w4_fl.value / (w4_ms[1] * 1e-3) / 1e12 if w4_ms[1] > 0 else 0.0,
+                                       "frac": (w4_fl.value / (w4_ms[1] * 1e-3) / 1e12 / PEAK_FP32_MFMA) if w4_ms[1] > 0 else 0.0,
+                                       "avg_launch_ms": w4_ms[1] / max(1, w4_n.value), "share_of_step": w4_ms[1] * 1e-3 / elapsed},
+                         "transform_passes": {"input_GBps": w4_bi.value / (w4_ms[0] * 1e-3) / 1e9 if w4_ms[0] > 0 else 0.0,
+                                              "output_GBps": w4_bo.value / (w4_ms[2] * 1e-3) / 1e9 if w4_ms[2] > 0 else 0.0,
+                                              "peak_GBps": PEAK_HBM_GBS, "share_of_step": (w4_ms[0] + w4_ms[2]) * 1e-3 / elapsed,
+                                              "note": "algorithmic bytes: input read once + 36/16 transformed values written; 36/16 read + output (and residual) once"},
+                         "executed_tflops": w4_fl.value / (w4_ms[1] * 1e-3) / 1e12 if w4_ms[1] > 0 else (xf[0] / (ms[0] * 1e-3) / 1e12 if ms[0] > 0 else 0.0),
+                         "executed_frac": (w4_fl.value / (w4_ms[1] * 1e-3) / 1e12 / PEAK_FP32_MFMA) if w4_ms[1] > 0 else
+                                          ((xf[0] / (ms[0] * 1e-3) / 1e12 / PEAK_FP32_MFMA) if ms[0] > 0 else 0.0),
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by[0] / max(1, ln[0]),
                          "launches": int(ln[0]), "avg_launch_ms": ms[0] / max(1, ln[0]),
                          "kernel_time_share_of_step": ms[0] * 1e-3 / elapsed,

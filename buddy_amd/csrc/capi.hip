@@ -101,6 +101,12 @@ int buddy_prof_collect_hbm(double* ms, double* bytes, long long* launches) {
   return BUDDY_OK;
 }
 
+int buddy_prof_collect_wino4(double* ms, double* gemm_flops, double* bytes_in, double* bytes_out, long long* launches) {
+  if (!ms || !gemm_flops || !bytes_in || !bytes_out || !launches) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  if (prof_w4_collect(ms, gemm_flops, bytes_in, bytes_out, launches)) { set_error("event timing failed"); return BUDDY_ERR_HIP; }
+  return BUDDY_OK;
+}
+
 int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, int transB, float* C, int ldC, int M, int N, int K, float alpha,
                const float* bias_n, int accumulate, int batch, long long strideA, long long strideB, long long strideC, void* stream) {
   if (!A || !Bt || !C || K % 4 || (transA && M % 4) || (transB && N % 4)) { set_error("bad gemm arguments (K, and M/N of k-major operands, must be multiples of 4)"); return BUDDY_ERR_ARG; }

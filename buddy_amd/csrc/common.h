@@ -30,6 +30,7 @@ struct IgemmParams {
   const float* res; int ldRes; int res_mode;   // 0 none, 1 same pixel, 2 nearest-upsampled source (H/2 x W/2)
   float alpha, out_scale; int accumulate;
   int wide_epi;            // set by launch_igemm: full-width aligned tile -> LDS-staged float4 epilogue
+  int tag;                 // 36: the batched GEMM of a F(4x4,3x3) convolution (own kernel instantiation, profiling only)
 };
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st);
 // Winograd F(2x2,3x3) variant of the 3x3 conv (wino.hip): same IgemmParams, pre-transformed weights U[Cin/16][16][Cout][16]
@@ -44,6 +45,8 @@ void wino4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin, double exec_ratio = 4.0 / 9.0);
 void igemm_prof_enable(int on);
 bool igemm_prof_enabled();
+void prof_w4_push(hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, double gemm_flops, double bytes_in, double bytes_out);
+int prof_w4_collect(double ms[3], double* gemm_flops, double* bytes_in, double* bytes_out, long long* launches);
 void prof_hbm_begin(double algorithmic_bytes, hipStream_t st);   // bracket of an HBM-bound launch group (GroupNorm kernels)
 void prof_hbm_end(hipStream_t st);
 int prof_hbm_collect(double* ms, double* bytes, long long* launches);

@@ -30,7 +30,8 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 
 // MT = 32-row MFMA tiles per wave along M: 2 -> 128-row block tile (default), 1 -> 64-row block tile for GEMMs whose 128-row
 // tiling would leave CUs idle (the operator's 4040 x 512 x 1028 DFT GEMMs are 128 tiles on 256 CUs).
-template <int TAPS, bool TA, bool TB, int V = 2, int MT = 2>
+// TAG only names an instantiation (the 36-batch GEMM of the F(4x4,3x3) convolutions shows up as its own row in rocprofv3 summaries).
+template <int TAPS, bool TA, bool TB, int V = 2, int MT = 2, int TAG = 0>
 __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
   static_assert(MT == 2 || !TA, "64-row tiles are only built for row-major A");
   constexpr int NBUF = (V >= 4) ? 2 : 1;
@@ -344,6 +345,23 @@ int prof_hbm_collect(double* ms, double* bytes, long long* launches) {
   return 0;
 }
 
+// per-pass timing of the three-pass F(4x4,3x3) convolutions (bench.py roofline): [input transform, batched GEMM, output transform]
+namespace { struct W4Rec { hipEvent_t e[4]; double gemm_flops, bytes_in, bytes_out; }; std::vector<W4Rec> g_prof_w4; }
+void prof_w4_push(hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, double gemm_flops, double bytes_in, double bytes_out) {
+  g_prof_w4.push_back(W4Rec{{e0, e1, e2, e3}, gemm_flops, bytes_in, bytes_out});
+}
+int prof_w4_collect(double ms[3], double* gemm_flops, double* bytes_in, double* bytes_out, long long* launches) {
+  ms[0] = ms[1] = ms[2] = 0; *gemm_flops = 0; *bytes_in = 0; *bytes_out = 0; *launches = 0;
+  for (auto& r : g_prof_w4) {
+    if (hipEventSynchronize(r.e[3]) != hipSuccess) return 1;
+    for (int i = 0; i < 3; ++i) { float t = 0.f; if (hipEventElapsedTime(&t, r.e[i], r.e[i + 1]) != hipSuccess) return 1; ms[i] += t; }
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(r.e[i]);
+    *gemm_flops += r.gemm_flops; *bytes_in += r.bytes_in; *bytes_out += r.bytes_out; *launches += 1;
+  }
+  g_prof_w4.clear();
+  return 0;
+}
+
 static ProfRec g_cur;
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin, double exec_ratio) {
   if (!g_prof_on) return;
@@ -393,6 +411,8 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
     if (variant == 0) hipLaunchKernelGGL((igemm_kernel<9, false, false, 0>), grid, block, 0, st, pw);
     else if (variant == 4) hipLaunchKernelGGL((igemm_kernel<9, false, false, 4>), grid, block, 0, st, pw);
     else hipLaunchKernelGGL((igemm_kernel<9, false, false, 2>), grid, block, 0, st, pw);
+  } else if (!transA && !transB && p.tag == 36 && !small_grid) {
+    hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 2, 36>), grid, block, 0, st, pw);
   } else if (!transA && !transB) {
     if (small_grid) hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 1>), grid, block, 0, st, pw);
     else hipLaunchKernelGGL((igemm_kernel<1, false, false>), grid, block, 0, st, pw);

@@ -137,17 +137,28 @@ void wino4_scratch(const IgemmParams& p, long long* v_floats, long long* m_float
 void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st) {
   const int B = p.M / (p.H * p.W);
   const long long Mt = (long long)p.M / 16;
+  const bool prof = igemm_prof_enabled();                   // the caller brackets the three passes as ONE 3x3 convolution; passes timed here
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (prof) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], st); }
   hipLaunchKernelGGL(w4_input_kernel, dim3((unsigned)((Mt * (p.Cin / 4) + 255) / 256)), dim3(256), 0, st, p.A0, p.ldA0, V, B, p.H, p.W, p.Cin);
+  if (prof) (void)hipEventRecord(ev[1], st);
   IgemmParams g; std::memset(&g, 0, sizeof(g));
   g.A0 = V; g.ldA0 = p.Cin; g.sA = Mt * p.Cin; g.Cin = p.Cin;
   g.Bt = U4; g.ldB = p.Cin; g.sB = (long long)p.N * p.Cin;
   g.C = Mb; g.ldC = p.N; g.sC = Mt * p.N;
   g.M = (int)Mt; g.N = p.N; g.H = 1; g.W = 1; g.rows_per_batch = 1; g.alpha = 1.f; g.out_scale = 1.f;
-  const bool prof = igemm_prof_enabled();                   // the caller brackets the three passes as ONE 3x3 convolution
+  g.tag = 36;
   igemm_prof_enable(0);
   launch_igemm(g, 1, false, false, 36, st);
   igemm_prof_enable(prof ? 1 : 0);
+  if (prof) (void)hipEventRecord(ev[2], st);
   hipLaunchKernelGGL(w4_output_kernel, dim3((unsigned)((Mt * (p.N / 4) + 255) / 256)), dim3(256), 0, st, (const float*)Mb, p, B);
+  if (prof) {
+    (void)hipEventRecord(ev[3], st);
+    const double mt = (double)Mt, m = (double)p.M;
+    prof_w4_push(ev[0], ev[1], ev[2], ev[3], 2.0 * 36.0 * mt * p.Cin * p.N, 4.0 * (m * p.Cin + 36.0 * mt * p.Cin),
+                 4.0 * (36.0 * mt * p.N + m * p.N * (p.res_mode ? 2.0 : 1.0)));
+  }
 }
 
 // host: U4[pos][cout][cin] = (G g G^T)[pos] from tap-major packed weights wt[cout][(dy*3+dx)*Cin + cin]

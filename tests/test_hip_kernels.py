@@ -100,6 +100,28 @@ def test_conv3x3_winograd(lib, B, H, W, Cin, Cout):
     assert rel(y.permute(0, 3, 1, 2), ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 24, 16, 12), (1, 64, 32, 128, 256), (3, 8, 12, 40, 8), (2, 16, 16, 384, 128)])
+def test_conv3x3_winograd4(lib, B, H, W, Cin, Cout):
+    """Three-pass Winograd F(4x4,3x3) (input transform, 36 batched fp32 GEMMs, output transform).  Stated tolerance 1e-4 relative to the
+    abs-max (the interpolation points 0, +-1, +-2, inf amplify fp32 round-off by about one decimal digit over the direct form: measured 3e-6)."""
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin + Cout + 4)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = F.conv2d(x.double(), w.cuda().double(), b.double(), padding=1).float()
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().numpy()
+    U = np.empty(36 * Cin * Cout, dtype=np.float32)
+    _lib.check(lib.buddy_winograd4_transform_weights(wt.ctypes.data, Cout, Cin, U.ctypes.data))
+    Ud = torch.from_numpy(U).cuda()
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    y = torch.empty(B, H, W, Cout, device="cuda")
+    scratch = torch.empty(36 * (B * H * W // 16) * (Cin + Cout), device="cuda")
+    _lib.check(lib.buddy_conv3x3_winograd4(P(x_nhwc), P(Ud), P(b), P(y), P(scratch), B, H, W, Cin, Cout, S()))
+    torch.cuda.synchronize()
+    assert rel(y.permute(0, 3, 1, 2), ref) < 1e-4
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("C,silu", [(32, 1), (96, 1), (128, 0), (384, 1), (512, 1)])
 def test_groupnorm_act_fwd_bwd(lib, mode, C, silu):
