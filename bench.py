@@ -246,10 +246,10 @@ def main():
         # HBM bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of this same command
         # (tools/pmc_summary.py -> profiles/*_conv_traffic_pmc.json); counters cannot be read from inside the process
         traffic, traffic_src = None, None
-        tp = os.path.join(ROOT, "profiles", "r01g_conv_traffic_pmc.json")
+        tp = os.path.join(ROOT, "profiles", "r01h_conv_traffic_pmc.json")
         if os.path.exists(tp) and B == 8 and a.length == 64000:
             traffic = json.load(open(tp))["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01g_conv_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH x2 gfx950 correction)"
+            traffic_src = "profiles/r01h_conv_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; FETCH x2 gfx950 correction)"
         res = {
             "metric": f"diffusion steps/sec ({a.length / 16000:g} s@16 kHz utterance, blind Euler-Heun DPS, order 1, 10 operator updates/step)",
             "value": n_utt_steps / elapsed, "unit": "utterance-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

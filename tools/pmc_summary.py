@@ -1,22 +1,32 @@
-"""Summarise rocprofv3 --pmc passes of bench.py into per-launch HBM traffic of the dominant kernel.
-usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [kernel-substring]
-FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads
-(MI355X_MICROARCH.md, HBM section) -> doubled here."""
+"""Summarise rocprofv3 --pmc passes of bench.py into per-convolution HBM traffic of the dominant kernel group.
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+A 3x3 convolution is three launches (w4_input_kernel, the 36-batch igemm_kernel<...,36>, w4_output_kernel); their counters are summed and
+divided by the number of convolutions (= w4_input launches).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the
+bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> doubled here."""
 import csv, json, sys
 
-KERNEL = sys.argv[4] if len(sys.argv) > 4 else "wino3_kernel"
+GROUP = ("w4_input_kernel", "2, 2, 36>", "w4_output_kernel")
 
 
-def avg(path, counter, kernel=None):
-    kernel = kernel or KERNEL
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and kernel in r["Kernel_Name"]]
-    return sum(v) / len(v), len(v)
+def per_kernel(path, counter):
+    tot = {k: [0.0, 0] for k in GROUP}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        for k in GROUP:
+            if k in r["Kernel_Name"]:
+                tot[k][0] += float(r["Counter_Value"]); tot[k][1] += 1
+    return tot
 
-f, nf = avg(sys.argv[1], "FETCH_SIZE")
-w, nw = avg(sys.argv[2], "WRITE_SIZE")
-out = {"kernel": KERNEL, "launches_fetch_pass": nf, "launches_write_pass": nw,
-       "fetch_bytes_per_launch": 2 * f * 1024, "write_bytes_per_launch": w * 1024,
-       "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
+
+f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+nconv = f[GROUP[0]][1]
+out = {"kernel_group": "3x3 convolution = w4_input_kernel + igemm_kernel<1,false,false,2,2,36> (36 batched GEMMs) + w4_output_kernel",
+       "convolutions_in_fetch_pass": nconv, "convolutions_in_write_pass": w[GROUP[0]][1],
+       "per_kernel_bytes_per_convolution": {k: {"fetch": 2 * f[k][0] * 1024 / nconv, "write": w[k][0] * 1024 / max(1, w[GROUP[0]][1])} for k in GROUP},
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`; FETCH_SIZE x2 (gfx950 correction)"}
+out["fetch_bytes_per_launch"] = sum(v["fetch"] for v in out["per_kernel_bytes_per_convolution"].values())
+out["write_bytes_per_launch"] = sum(v["write"] for v in out["per_kernel_bytes_per_convolution"].values())
+out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(out)
+print(json.dumps(out)[:900])
