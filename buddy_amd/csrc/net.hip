@@ -438,6 +438,10 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
   float* xr = (mode == 1) ? N->tmp((long long)B * Ho * Wo * Cin) : nullptr;
   float* xs = R.has_c2 ? N->tmp((long long)B * (mode == 2 ? H * W : Ho * Wo) * Cout) : nullptr;
   float* a1 = N->tmp((long long)B * Ho * Wo * Cout);
+  if (N->dry()) {                                         // sizing pass: let the convolutions note their F(4x4,3x3) scratch need
+    conv3(N, nullptr, B, Ho, Wo, Cin, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c0.uf, R.c0.uf4);
+    conv3(N, nullptr, B, Ho, Wo, Cout, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c1.uf, R.c1.uf4);
+  }
   if (!N->dry()) {
     launch_gn_stats(src_of(x), B, H * W, Cin, G0, 1e-6f, N->partial, stats0, st);
     launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
