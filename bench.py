@@ -219,8 +219,8 @@ def main():
     log(f"timed region done: {elapsed:.3f} s")
     ms = (C.c_double * 2)(); fl = (C.c_double * 2)(); ln = (C.c_longlong * 2)(); by = (C.c_double * 2)(); xf = (C.c_double * 2)()
     _lib.check(lib.buddy_prof_collect(ms, fl, ln, by, xf))
-    w4_ms = (C.c_double * 3)(); w4_fl, w4_bi, w4_bo, w4_n = C.c_double(), C.c_double(), C.c_double(), C.c_longlong()
-    _lib.check(lib.buddy_prof_collect_wino4(w4_ms, C.byref(w4_fl), C.byref(w4_bi), C.byref(w4_bo), C.byref(w4_n)))
+    w4_ms = (C.c_double * 3)(); w4_fl, w4_bi, w4_bo, w4_bg, w4_n = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_longlong()
+    _lib.check(lib.buddy_prof_collect_wino4(w4_ms, C.byref(w4_fl), C.byref(w4_bi), C.byref(w4_bo), C.byref(w4_bg), C.byref(w4_n)))
     hb_ms, hb_by, hb_n = C.c_double(), C.c_double(), C.c_longlong()
     _lib.check(lib.buddy_prof_collect_hbm(C.byref(hb_ms), C.byref(hb_by), C.byref(hb_n)))
     el = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
@@ -289,6 +289,10 @@ def main():
                          "executed_frac": (w4_fl.value / (w4_ms[1] * 1e-3) / 1e12 / PEAK_FP32_MFMA) if w4_ms[1] > 0 else
                                           ((xf[0] / (ms[0] * 1e-3) / 1e12 / PEAK_FP32_MFMA) if ms[0] > 0 else 0.0),
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by[0] / max(1, ln[0]),
+                         "three_pass_bytes_per_launch": (w4_bi.value + w4_bg.value + w4_bo.value) / max(1, w4_n.value),
+                         "traffic_note": "algorithmic_bytes_per_launch = input + weights + output of the convolution (what a fused kernel would move); "
+                                         "three_pass_bytes_per_launch = the minimum of the three-launch form (transformed operands written and read once); "
+                                         "traffic (PMC) is compared with the latter",
                          "launches": int(ln[0]), "avg_launch_ms": ms[0] / max(1, ln[0]),
                          "kernel_time_share_of_step": ms[0] * 1e-3 / elapsed,
                          "other_matrix_kernels": {"tflops": fl[1] / (ms[1] * 1e-3) / 1e12 if ms[1] > 0 else 0.0, "ms": ms[1], "launches": int(ln[1])}},

@@ -101,9 +101,9 @@ int buddy_prof_collect_hbm(double* ms, double* bytes, long long* launches) {
   return BUDDY_OK;
 }
 
-int buddy_prof_collect_wino4(double* ms, double* gemm_flops, double* bytes_in, double* bytes_out, long long* launches) {
-  if (!ms || !gemm_flops || !bytes_in || !bytes_out || !launches) { set_error("null argument"); return BUDDY_ERR_ARG; }
-  if (prof_w4_collect(ms, gemm_flops, bytes_in, bytes_out, launches)) { set_error("event timing failed"); return BUDDY_ERR_HIP; }
+int buddy_prof_collect_wino4(double* ms, double* gemm_flops, double* bytes_in, double* bytes_out, double* bytes_gemm, long long* launches) {
+  if (!ms || !gemm_flops || !bytes_in || !bytes_out || !bytes_gemm || !launches) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  if (prof_w4_collect(ms, gemm_flops, bytes_in, bytes_out, bytes_gemm, launches)) { set_error("event timing failed"); return BUDDY_ERR_HIP; }
   return BUDDY_OK;
 }
 

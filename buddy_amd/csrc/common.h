@@ -45,8 +45,8 @@ void wino4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin, double exec_ratio = 4.0 / 9.0);
 void igemm_prof_enable(int on);
 bool igemm_prof_enabled();
-void prof_w4_push(hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, double gemm_flops, double bytes_in, double bytes_out);
-int prof_w4_collect(double ms[3], double* gemm_flops, double* bytes_in, double* bytes_out, long long* launches);
+void prof_w4_push(hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, double gemm_flops, double bytes_in, double bytes_out, double bytes_gemm);
+int prof_w4_collect(double ms[3], double* gemm_flops, double* bytes_in, double* bytes_out, double* bytes_gemm, long long* launches);
 void prof_hbm_begin(double algorithmic_bytes, hipStream_t st);   // bracket of an HBM-bound launch group (GroupNorm kernels)
 void prof_hbm_end(hipStream_t st);
 int prof_hbm_collect(double* ms, double* bytes, long long* launches);

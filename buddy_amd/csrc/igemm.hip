@@ -346,17 +346,17 @@ int prof_hbm_collect(double* ms, double* bytes, long long* launches) {
 }
 
 // per-pass timing of the three-pass F(4x4,3x3) convolutions (bench.py roofline): [input transform, batched GEMM, output transform]
-namespace { struct W4Rec { hipEvent_t e[4]; double gemm_flops, bytes_in, bytes_out; }; std::vector<W4Rec> g_prof_w4; }
-void prof_w4_push(hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, double gemm_flops, double bytes_in, double bytes_out) {
-  g_prof_w4.push_back(W4Rec{{e0, e1, e2, e3}, gemm_flops, bytes_in, bytes_out});
+namespace { struct W4Rec { hipEvent_t e[4]; double gemm_flops, bytes_in, bytes_out, bytes_gemm; }; std::vector<W4Rec> g_prof_w4; }
+void prof_w4_push(hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, double gemm_flops, double bytes_in, double bytes_out, double bytes_gemm) {
+  g_prof_w4.push_back(W4Rec{{e0, e1, e2, e3}, gemm_flops, bytes_in, bytes_out, bytes_gemm});
 }
-int prof_w4_collect(double ms[3], double* gemm_flops, double* bytes_in, double* bytes_out, long long* launches) {
-  ms[0] = ms[1] = ms[2] = 0; *gemm_flops = 0; *bytes_in = 0; *bytes_out = 0; *launches = 0;
+int prof_w4_collect(double ms[3], double* gemm_flops, double* bytes_in, double* bytes_out, double* bytes_gemm, long long* launches) {
+  ms[0] = ms[1] = ms[2] = 0; *gemm_flops = 0; *bytes_in = 0; *bytes_out = 0; *bytes_gemm = 0; *launches = 0;
   for (auto& r : g_prof_w4) {
     if (hipEventSynchronize(r.e[3]) != hipSuccess) return 1;
     for (int i = 0; i < 3; ++i) { float t = 0.f; if (hipEventElapsedTime(&t, r.e[i], r.e[i + 1]) != hipSuccess) return 1; ms[i] += t; }
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(r.e[i]);
-    *gemm_flops += r.gemm_flops; *bytes_in += r.bytes_in; *bytes_out += r.bytes_out; *launches += 1;
+    *gemm_flops += r.gemm_flops; *bytes_in += r.bytes_in; *bytes_out += r.bytes_out; *bytes_gemm += r.bytes_gemm; *launches += 1;
   }
   g_prof_w4.clear();
   return 0;

@@ -157,7 +157,7 @@ void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hi
     (void)hipEventRecord(ev[3], st);
     const double mt = (double)Mt, m = (double)p.M;
     prof_w4_push(ev[0], ev[1], ev[2], ev[3], 2.0 * 36.0 * mt * p.Cin * p.N, 4.0 * (m * p.Cin + 36.0 * mt * p.Cin),
-                 4.0 * (36.0 * mt * p.N + m * p.N * (p.res_mode ? 2.0 : 1.0)));
+                 4.0 * (36.0 * mt * p.N + m * p.N * (p.res_mode ? 2.0 : 1.0)), 4.0 * 36.0 * (mt * p.Cin + mt * p.N + (double)p.N * p.Cin));
   }
 }
 

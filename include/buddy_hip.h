@@ -61,8 +61,8 @@ int buddy_prof_collect(double* ms /*[2]*/, double* flops /*[2]*/, long long* lau
  * algorithmic bytes (each pass reads its inputs once and writes its output once) and launch-group count since the last collect. */
 int buddy_prof_collect_hbm(double* ms, double* bytes, long long* launches);
 /* per-pass totals of the three-pass F(4x4,3x3) convolutions since the last collect: ms[3] = {input transform, 36 batched GEMMs, output
- * transform}, executed FLOPs of the GEMM pass (2 * 36 * tiles * Cin * Cout), algorithmic bytes of the two transform passes. */
-int buddy_prof_collect_wino4(double* ms /*[3]*/, double* gemm_flops, double* bytes_in, double* bytes_out, long long* launches);
+ * transform}, executed FLOPs of the GEMM pass (2 * 36 * tiles * Cin * Cout), algorithmic bytes of the two transform passes and of the GEMM pass. */
+int buddy_prof_collect_wino4(double* ms /*[3]*/, double* gemm_flops, double* bytes_in, double* bytes_out, double* bytes_gemm, long long* launches);
 
 /* calibration: `blocks` workgroups x 4 waves issue 4*iters fp32 MFMAs (32x32x2) each on operands from seed[1024] with no
  * memory traffic; out[blocks*256] keeps the result live; clk[0] = shader clocks, clk[1] = 100 MHz wall ticks of block 0.
