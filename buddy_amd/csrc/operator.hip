@@ -291,27 +291,39 @@ __global__ void design_bwd_params_kernel(const float* gdm, const float* decay, c
 }
 
 // ---- 25856-point complex FFT, two stages (N2 = 101 * 256): n = 256 n1 + n2, k = k1 + 101 k2 ----
-// stage 1: Y1[u][n2][k1] = tw(n2 k1) * sum_{n1} x[256 n1 + n2] W101^(n1 k1)
+// stage 1: Y1[u][n2][k1] = tw(n2 k1) * sum_{n1} x[256 n1 + n2] W101^(n1 k1).  101 is prime: a naive 101-point DFT per column n2, but a block
+// parks its S1_COLS columns of x (101 x 4 complex) and the twiddles in LDS first, so the inner loop is two LDS reads and a complex FMA.
+constexpr int S1_COLS = 4;
 __global__ __launch_bounds__(256) void fft_stage1_kernel(const float2* x, float2* y1, const float2* w101, const float2* twN, int sign) {
   __shared__ float2 W[F1];
-  for (int i = threadIdx.x; i < F1; i += 256) W[i] = w101[i];
-  __syncthreads();
-  const int u = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= F2 * F1) return;
-  const int k1 = i % F1, n2 = i / F1;
+  __shared__ float2 X[F1 * S1_COLS];
+  const int u = blockIdx.y, n20 = blockIdx.x * S1_COLS;
   const float2* xu = x + (long long)u * N2;
-  float ar = 0.f, ai = 0.f;
-  int idx = 0;
-  for (int n1 = 0; n1 < F1; ++n1) {
-    const float2 v = xu[F2 * n1 + n2];
-    const float wr = W[idx].x, wi = sign * W[idx].y;
-    ar += v.x * wr - v.y * wi; ai += v.x * wi + v.y * wr;
-    idx += k1; if (idx >= F1) idx -= F1;
+  for (int i = threadIdx.x; i < F1; i += 256) W[i] = make_float2(w101[i].x, sign * w101[i].y);
+  for (int i = threadIdx.x; i < F1 * S1_COLS; i += 256) { const int n1 = i / S1_COLS, c = i - n1 * S1_COLS; X[i] = xu[F2 * n1 + n20 + c]; }
+  __syncthreads();
+  for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
+    const int c = o / F1, k1 = o - c * F1;                  // consecutive threads: consecutive k1 of one column (coalesced store)
+    float ar = 0.f, ai = 0.f;
+    int idx = 0;
+    int n1 = 0;
+    for (; n1 + 4 <= F1; n1 += 4) {                        // four LDS pairs in flight per trip
+      float2 v[4], w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = X[(n1 + j) * S1_COLS + c]; w[j] = W[idx]; idx += k1; if (idx >= F1) idx -= F1; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ar += v[j].x * w[j].x - v[j].y * w[j].y; ai += v[j].x * w[j].y + v[j].y * w[j].x; }
+    }
+    for (; n1 < F1; ++n1) {
+      const float2 v = X[n1 * S1_COLS + c], w = W[idx];
+      ar += v.x * w.x - v.y * w.y; ai += v.x * w.y + v.y * w.x;
+      idx += k1; if (idx >= F1) idx -= F1;
+    }
+    const int n2 = n20 + c;
+    const float2 t = twN[(long long)n2 * F1 + k1];
+    const float tr = t.x, ti = sign * t.y;
+    y1[(long long)u * N2 + (long long)n2 * F1 + k1] = make_float2(ar * tr - ai * ti, ar * ti + ai * tr);
   }
-  const float2 t = twN[(long long)n2 * F1 + k1];
-  const float tr = t.x, ti = sign * t.y;
-  y1[(long long)u * N2 + i] = make_float2(ar * tr - ai * ti, ar * ti + ai * tr);
 }
 // stage 2: X[k1 + 101 k2] = scale * sum_{n2} Y1[n2][k1] W256^(n2 k2), a 256-point DFT per (utterance, k1) column done as
 // 16 x 16: n2 = 16 a + r, k2 = b + 16 c  =>  W256^(n2 k2) = W16^(a b) * W256^(r b) * W16^(r c).  A block owns 16 columns; thread (col, r)
@@ -599,7 +611,7 @@ struct BlindOp {
     gemm(frames, WIN, 0, BiT, WIN, false, GY, LDSP, 0, U * Tn, LDSP, WIN, scale, 1);
   }
   void fft(const float2* x, float2* tmp, float2* X, int sign, float scale) {
-    hipLaunchKernelGGL(fft_stage1_kernel, dim3(cdiv(N2, 256), U), dim3(256), 0, st, x, tmp, (const float2*)w101, (const float2*)twN, sign);
+    hipLaunchKernelGGL(fft_stage1_kernel, dim3(F2 / S1_COLS, U), dim3(256), 0, st, x, tmp, (const float2*)w101, (const float2*)twN, sign);
     if (sign > 0) hipLaunchKernelGGL(fft_stage2_kernel<1>, dim3(cdiv(F1, S2_COLS), U), dim3(256), 0, st, (const float2*)tmp, X, (const float2*)w256, scale);
     else hipLaunchKernelGGL(fft_stage2_kernel<-1>, dim3(cdiv(F1, S2_COLS), U), dim3(256), 0, st, (const float2*)tmp, X, (const float2*)w256, scale);
   }
