@@ -307,12 +307,12 @@ __global__ __launch_bounds__(256) void fft_stage1_kernel(const float2* x, float2
     float ar = 0.f, ai = 0.f;
     int idx = 0;
     int n1 = 0;
-    for (; n1 + 4 <= F1; n1 += 4) {                        // four LDS pairs in flight per trip
-      float2 v[4], w[4];
+    for (; n1 + 8 <= F1; n1 += 8) {                        // eight LDS pairs in flight per trip
+      float2 v[8], w[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { v[j] = X[(n1 + j) * S1_COLS + c]; w[j] = W[idx]; idx += k1; if (idx >= F1) idx -= F1; }
+      for (int j = 0; j < 8; ++j) { v[j] = X[(n1 + j) * S1_COLS + c]; w[j] = W[idx]; idx += k1; if (idx >= F1) idx -= F1; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { ar += v[j].x * w[j].x - v[j].y * w[j].y; ai += v[j].x * w[j].y + v[j].y * w[j].x; }
+      for (int j = 0; j < 8; ++j) { ar += v[j].x * w[j].x - v[j].y * w[j].y; ai += v[j].x * w[j].y + v[j].y * w[j].x; }
     }
     for (; n1 < F1; ++n1) {
       const float2 v = X[n1 * S1_COLS + c], w = W[idx];
