@@ -64,6 +64,11 @@ _SIGS = {
     "buddy_blindop_set_y": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
     "buddy_blindop_degrade": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_void_p]),
     "buddy_blindop_time_rir": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
+    "buddy_blindop_design_filter": (C.c_int, [C.c_void_p, _f32p, C.c_void_p]),
+    "buddy_blindop_apply_stft": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_void_p]),
+    "buddy_blindop_minphase": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_void_p]),
+    "buddy_blindop_project": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "buddy_blindop_get_adam": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.POINTER(C.c_int), C.c_void_p]),
     "buddy_blindop_rec_loss_grad": (C.c_int, [C.c_void_p, _f32p, C.c_float, _f32p, _f32p, C.c_void_p]),
     "buddy_blindop_fir_loss_grad": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_longlong, C.c_int, C.c_float, _f32p, _f32p, C.c_void_p]),
     "buddy_blindop_param_grads": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p, C.c_void_p]),

@@ -247,6 +247,14 @@ int buddy_blindop_get_H(void* h, float* out, void* stream) { BOP_CHECK(h); if (!
 int buddy_blindop_set_y(void* h, const float* y, void* stream) { BOP_CHECK(h); if (!y) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_set_y((BlindOp*)h, y, (hipStream_t)stream); }
 int buddy_blindop_degrade(void* h, const float* x, float* y, void* stream) { BOP_CHECK(h); if (!x || !y) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_degrade((BlindOp*)h, x, y, (hipStream_t)stream); }
 int buddy_blindop_time_rir(void* h, float* out, void* stream) { BOP_CHECK(h); if (!out) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_time_rir((BlindOp*)h, out, (hipStream_t)stream); }
+int buddy_blindop_design_filter(void* h, float* A, void* stream) { BOP_CHECK(h); if (!A) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_design_filter((BlindOp*)h, A, (hipStream_t)stream); }
+int buddy_blindop_apply_stft(void* h, const float* x, float* X, void* stream) { BOP_CHECK(h); if (!x || !X) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_apply_stft((BlindOp*)h, x, X, (hipStream_t)stream); }
+int buddy_blindop_minphase(void* h, const float* hin, float* out, void* stream) { BOP_CHECK(h); if (!hin || !out) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_minphase((BlindOp*)h, hin, out, (hipStream_t)stream); }
+int buddy_blindop_project(void* h, void* stream) { BOP_CHECK(h); return blindop_project((BlindOp*)h, (hipStream_t)stream); }
+int buddy_blindop_get_adam(void* h, float* m_decay, float* v_decay, float* m_weights, float* v_weights, float* m_phases, float* v_phases, int* step,
+                           void* stream) {
+  BOP_CHECK(h); return blindop_get_adam((BlindOp*)h, m_decay, v_decay, m_weights, v_weights, m_phases, v_phases, step, (hipStream_t)stream);
+}
 int buddy_blindop_rec_loss_grad(void* h, const float* x_den, float weight, float* loss, float* g_x, void* stream) {
   BOP_CHECK(h); if (!x_den || !loss) { set_error("null"); return BUDDY_ERR_ARG; }
   return blindop_rec_loss_grad((BlindOp*)h, x_den, weight, loss, g_x, (hipStream_t)stream);

@@ -38,6 +38,11 @@ int blindop_get_H(BlindOp* o, float* out, hipStream_t st);
 int blindop_set_y(BlindOp* o, const float* y, hipStream_t st);
 int blindop_degrade(BlindOp* o, const float* x, float* y, hipStream_t st);
 int blindop_time_rir(BlindOp* o, float* out, hipStream_t st);
+int blindop_design_filter(BlindOp* o, float* A_ref, hipStream_t st);
+int blindop_apply_stft(BlindOp* o, const float* x, float* X_ref, hipStream_t st);
+int blindop_minphase(BlindOp* o, const float* h, float* out, hipStream_t st);
+int blindop_project(BlindOp* o, hipStream_t st);
+int blindop_get_adam(BlindOp* o, float* m_decay, float* v_decay, float* m_wts, float* v_wts, float* m_phases, float* v_phases, int* step, hipStream_t st);
 int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* loss, float* g_x, hipStream_t st);
 int blindop_fir_loss_grad(BlindOp* o, const float* x_den, const float* rir, long long rir_stride, int M, float weight, float* loss, float* g_x,
                           hipStream_t st);

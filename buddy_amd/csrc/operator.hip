@@ -535,6 +535,22 @@ __global__ __launch_bounds__(256) void copy_h_kernel(const float* H, float* out,
   }
 }
 
+__global__ __launch_bounds__(256) void copy_spec_kernel(const float* X, float* out, int U, int T) {   // padded frame-major -> reference (U,F,T,2)
+  const long long total = (long long)U * T * FB;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % FB), t = (int)((i / FB) % T), u = (int)(i / ((long long)FB * T));
+    reinterpret_cast<float2*>(out)[((long long)u * FB + f) * T + t] = reinterpret_cast<const float2*>(X + ((long long)u * T + t) * LDSP)[f];
+  }
+}
+// plain minimum-phase output: hm = Re(o)[:Lm] (no direct-path override)
+__global__ __launch_bounds__(256) void mp_out_plain_kernel(const float2* o, float* hm, int Lm, int U) {
+  const long long total = (long long)U * Lm;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int u = (int)(i / Lm), n = (int)(i % Lm);
+    hm[i] = o[(long long)u * N2 + n].x;
+  }
+}
+
 inline int gridf(long long total) { long long g = (total + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1; return (int)g; }
 }  // namespace
 
@@ -621,12 +637,10 @@ struct BlindOp {
     hipLaunchKernelGGL(design_dm_kernel, dim3(cdiv(U * Nf * K, 256)), dim3(256), 0, st, (const float*)decay, (const float*)wts, logdm, dmv, U, E, NB, Nf);
     hipLaunchKernelGGL(design_A_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)logdm, tabs(), A, Apre, U, K, Nf);
   }
-  // H = cons(A * exp(j phi))   (reference :333-351)
-  void cons_forward() {
-    hipLaunchKernelGGL(h0_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)A, (const float*)phi, Fin, U, Nf);
-    istft(Fin, Nf + 2, WIN, env_c, Lh, 1.f, h0);
+  // minimum_phase_version (reference reverb_utils.py:9-23) of hin (U, Lin <= Lm samples, zero-padded to N2): result (complex, real part = signal) in c1
+  void minphase_core(const float* hin, int Lin) {
     const long long tot = (long long)U * N2;
-    hipLaunchKernelGGL(mp_pack_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float*)h0, Lh, c1, U);
+    hipLaunchKernelGGL(mp_pack_kernel, dim3(gridf(tot)), dim3(256), 0, st, hin, Lin, c1, U);
     fft(c1, c2, Hf, -1, 1.f);
     hipLaunchKernelGGL(mp_logabs_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)Hf, Mabs, c1, tot);
     fft(c1, c2, c3, -1, 1.f);
@@ -634,6 +648,12 @@ struct BlindOp {
     fft(c3, c2, c1, +1, 1.f / N2);
     hipLaunchKernelGGL(mp_phase_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)c1, (const float*)Mabs, phim, c3, tot);
     fft(c3, c2, c1, +1, 1.f / N2);
+  }
+  // H = cons(A * exp(j phi))   (reference :333-351)
+  void cons_forward() {
+    hipLaunchKernelGGL(h0_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)A, (const float*)phi, Fin, U, Nf);
+    istft(Fin, Nf + 2, WIN, env_c, Lh, 1.f, h0);
+    minphase_core(h0, Lh);
     hipLaunchKernelGGL(mp_out_kernel, dim3(gridf((long long)U * Lm)), dim3(256), 0, st, (const float2*)c1, hm, Lm, U, (float)(WIN / (HOP * 2.0)));
     stft(hm, Lm, WIN - HOP, Nf, 1.f, H);          // frames 1..Nf of the centred STFT: frame k starts at 128 (k+1) - 512
   }
@@ -842,6 +862,55 @@ int blindop_set_y(BlindOp* o, const float* y, hipStream_t st) {
 }
 int blindop_degrade(BlindOp* o, const float* x, float* y, hipStream_t st) { o->st = st; o->degrade(x, y); HIPCHK(hipGetLastError()); return BUDDY_OK; }
 int blindop_time_rir(BlindOp* o, float* out, hipStream_t st) { o->st = st; o->time_rir(out); HIPCHK(hipGetLastError()); return BUDDY_OK; }
+
+// ---- per-function views for the parity tests (each is the piece optimize_op / the likelihood call internally) ----
+// design_filter (:241-251) from the current decay / weights: A in the reference layout (U, 513, Nf)
+int blindop_design_filter(BlindOp* o, float* A_ref, hipStream_t st) {
+  o->st = st;
+  o->design();
+  hipLaunchKernelGGL(transpose_fk_kernel, dim3(gridf((long long)o->U * o->Nf * FB)), dim3(256), 0, st, (const float*)o->A, A_ref, o->U, o->Nf, 0);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+// apply_stft (:41-52) of x (U, L): (U, 513, T, 2), T = 1 + (L + 512) / 128
+int blindop_apply_stft(BlindOp* o, const float* x, float* X_ref, hipStream_t st) {
+  o->st = st;
+  o->stft(x, o->L, WIN, o->T, 1.f / o->norm, o->X2);
+  hipLaunchKernelGGL(copy_spec_kernel, dim3(gridf((long long)o->U * o->T * FB)), dim3(256), 0, st, (const float*)o->X2, X_ref, o->U, o->T);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+// minimum_phase_version (reverb_utils.py:9-23) of h (U, 128 * (Nf + 1)) -- the size cons() uses; no direct-path override
+int blindop_minphase(BlindOp* o, const float* h, float* out, hipStream_t st) {
+  o->st = st;
+  o->minphase_core(h, o->Lm);
+  hipLaunchKernelGGL(mp_out_plain_kernel, dim3(gridf((long long)o->U * o->Lm)), dim3(256), 0, st, (const float2*)o->c1, out, o->Lm, o->U);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+// project_params (:298-331) on the current decay / weights
+int blindop_project(BlindOp* o, hipStream_t st) {
+  o->st = st;
+  hipLaunchKernelGGL(project_kernel, dim3(cdiv(o->U * o->NB, 256)), dim3(256), 0, st, o->decay, o->wts, o->U, o->E, o->NB, o->c.min_decay, o->c.max_decay,
+                     o->c.w_lo, o->c.w_hi, o->c.clamp_decay, o->c.long2nd);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+// Adam moments (torch.optim.Adam exp_avg / exp_avg_sq) in the reference layouts; any pointer may be NULL
+int blindop_get_adam(BlindOp* o, float* m_decay, float* v_decay, float* m_wts, float* v_wts, float* m_phases, float* v_phases, int* step, hipStream_t st) {
+  o->st = st;
+  const size_t nb = (size_t)o->U * o->E * o->NB * 4;
+  if (m_decay) HIPCHK(hipMemcpyAsync(m_decay, o->m_d, nb, hipMemcpyDeviceToDevice, st));
+  if (v_decay) HIPCHK(hipMemcpyAsync(v_decay, o->v_d, nb, hipMemcpyDeviceToDevice, st));
+  if (m_wts) HIPCHK(hipMemcpyAsync(m_wts, o->m_w, nb, hipMemcpyDeviceToDevice, st));
+  if (v_wts) HIPCHK(hipMemcpyAsync(v_wts, o->v_w, nb, hipMemcpyDeviceToDevice, st));
+  const dim3 g(gridf((long long)o->U * o->Nf * FB));
+  if (m_phases) hipLaunchKernelGGL(transpose_fk_kernel, g, dim3(256), 0, st, (const float*)o->m_p, m_phases, o->U, o->Nf, 0);
+  if (v_phases) hipLaunchKernelGGL(transpose_fk_kernel, g, dim3(256), 0, st, (const float*)o->v_p, v_phases, o->U, o->Nf, 0);
+  if (step) *step = o->adam_step;
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
 
 // likelihood: loss_u = w_rec * l2_comp_stft_summean(y, degrade(x_den)), g = d sum_u loss_u / d x_den  (uses the CURRENT H)
 int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* loss, float* g_x, hipStream_t st) {

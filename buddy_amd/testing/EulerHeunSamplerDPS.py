@@ -86,7 +86,8 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
             for p in self.operator.params:
                 p.requires_grad = True
 
-    def _guided_eval(self, x_in, t, blind):
+    def _guided_eval(self, x_in, t, blind, rescale=True):
+        """one guided evaluation; ``rescale=False`` is the Heun corrector, which the reference leaves un-rescaled (:139-149)"""
         x_in.requires_grad = True
         x_den = self.get_Tweedie_estimate(x_in, t)
         if blind:
@@ -94,7 +95,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         lh_score, _ = self.get_likelihood_score(x_den, x_in, t)
         x_in.detach_()
         csm = self.args.tester.posterior_sampling.constraint_speech_magnitude
-        if csm.use:
+        if csm.use and rescale:
             x_den = csm.speech_scaling / _row_std(x_den.detach()) * x_den
         score = self.Tweedie2score(x_den, x_in, t)
         return self.diff_params._ode_integrand(x_in, t, score) + lh_score, x_den
@@ -120,8 +121,8 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         if t_iplus1 != 0 and self.order == 2:
             x_prime, d1, _ = _hipops.dps_update(x_hat, x_den, lh, scale, x_hat, None, float(t_hat), dt, 0.0, 1.0, want_d=True)
             lh2, x_den2 = self._eval_parts(x_prime, t_iplus1, blind)
-            scale2 = (csm.speech_scaling / _hipops.row_std(x_den2)).reshape(-1) if csm.use else None
-            x_next, _, x_den_out = _hipops.dps_update(x_prime, x_den2, lh2, scale2, x_hat, d1, float(t_iplus1), dt, 0.5, 0.5)
+            # the reference rescales x_den only in the first evaluation (:127-129); the corrector uses and returns the raw estimate (:139-149)
+            x_next, _, x_den_out = _hipops.dps_update(x_prime, x_den2, lh2, None, x_hat, d1, float(t_iplus1), dt, 0.5, 0.5)
         else:
             x_next, _, x_den_out = _hipops.dps_update(x_hat, x_den, lh, scale, x_hat, None, float(t_hat), dt, 0.0, 1.0)
         return x_next, x_den_out
@@ -135,7 +136,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         dt = t_iplus1 - t_hat
         if t_iplus1 != 0 and self.order == 2:
             x_prime = (x_hat + dt * ode_integrand).detach()
-            ode_integrand_next, x_den = self._guided_eval(x_prime, t_iplus1, blind)
+            ode_integrand_next, x_den = self._guided_eval(x_prime, t_iplus1, blind, rescale=False)
             x_iplus1 = x_hat + dt * (.5 * (ode_integrand + ode_integrand_next))
         else:
             x_iplus1 = x_hat + dt * ode_integrand

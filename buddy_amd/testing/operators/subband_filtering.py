@@ -3,9 +3,13 @@
 per utterance: every parameter / filter tensor carries a leading utterance axis ``U`` (U = 1 reproduces the
 reference exactly; U > 1 is the per-utterance vmap of it -- no cross-utterance coupling anywhere).
 
-State of this operator path: device-resident and batched, built from torch-ROCm ops + autograd
-(rocFFT transforms, grouped complex conv1d); the hand-written HIP version of this small, latency-bound path is a
-later round.  The score network / STFT / RIR operator it feeds are hand-written HIP.
+Two implementations of ``BlindSubbandFiltering`` behind one constructor:
+
+* ``BlindSubbandFilteringHIP`` -- the product path on the GPU: parameters, Adam state and every intermediate live inside a
+  ``buddy_blindop_*`` handle of ``libbuddy_hip.so`` (hand-written forward + analytic backward kernels, one library call per
+  ``optimize_op``); selected whenever the signal ``length`` is given and the device is a GPU (what ``Tester.prepare_batch`` does).
+* the torch-op class body below (rocFFT / grouped conv1d / autograd): host-logic tests on CPU and an on-GPU cross-check
+  (``backend="torch"``); it is not what the bench or the sampler run.
 """
 from __future__ import annotations
 
@@ -454,7 +458,45 @@ class BlindSubbandFilteringHIP(BlindSubbandFiltering):
         _lib.check(_lib.load().buddy_blindop_update_H(self._h, _lib.ptr(n), _lib.stream_ptr()))
 
     def project_params(self):
-        pass    # done inside buddy_blindop_optimize after every Adam step
+        """reference :298-331 on the device-resident parameters (also applied inside buddy_blindop_optimize after every Adam step)"""
+        _lib.check(_lib.load().buddy_blindop_project(self._h, _lib.stream_ptr()))
+
+    def design_filter(self, correct_OLA=True):
+        """reference :241-251 -> (U, F, Nf) magnitudes from the current decay / weights"""
+        assert correct_OLA
+        A = torch.empty(self.U, self.n_fft // 2 + 1, self.Nf, device=self.device)
+        _lib.check(_lib.load().buddy_blindop_design_filter(self._h, _lib.ptr(A), _lib.stream_ptr()))
+        return A
+
+    def apply_stft(self, x):
+        """reference :41-52 for signals of the bound length: (U, F, T) complex64"""
+        xx = (x.unsqueeze(0) if x.dim() == 1 else x).contiguous().float()
+        if tuple(xx.shape) != (self.U, self.length):
+            raise NotImplementedError(f"the HIP operator transforms (U={self.U}, L={self.length}) signals, got {tuple(xx.shape)}")
+        T = 1 + (self.length + self.win_length) // self.hop_length
+        X = torch.empty(self.U, self.n_fft // 2 + 1, T, 2, device=self.device)
+        _lib.check(_lib.load().buddy_blindop_apply_stft(self._h, _lib.ptr(xx), _lib.ptr(X), _lib.stream_ptr()))
+        return torch.view_as_complex(X)
+
+    def minimum_phase(self, h):
+        """utils/reverb_utils.py:9-23 at the size cons() uses: h (U, hop * (Nf + 1))"""
+        hh = h.to(self.device).float().contiguous()
+        assert tuple(hh.shape) == (self.U, self.length_rir + self.hop_length)
+        out = torch.empty_like(hh)
+        _lib.check(_lib.load().buddy_blindop_minphase(self._h, _lib.ptr(hh), _lib.ptr(out), _lib.stream_ptr()))
+        return out
+
+    def adam_state(self):
+        """torch.optim.Adam state of [decay, weights, phases] in the reference layouts: dict of (exp_avg, exp_avg_sq), and the step count"""
+        import ctypes as C
+        E, NB, F = self.num_exponentials, self.num_bands, self.n_fft // 2 + 1
+        mk = lambda *sh: torch.empty(*sh, device=self.device)
+        md, vd, mw, vw = mk(self.U, E, NB), mk(self.U, E, NB), mk(self.U, E, NB), mk(self.U, E, NB)
+        mp, vp = mk(self.U, F, self.Nf), mk(self.U, F, self.Nf)
+        step = C.c_int(0)
+        _lib.check(_lib.load().buddy_blindop_get_adam(self._h, _lib.ptr(md), _lib.ptr(vd), _lib.ptr(mw), _lib.ptr(vw), _lib.ptr(mp), _lib.ptr(vp),
+                                                      C.byref(step), _lib.stream_ptr()))
+        return dict(decay=(md, vd), weights=(mw, vw), phases=(mp, vp)), int(step.value)
 
     def degradation(self, x, mode="waveform", H=None, detach_operator=False):
         assert mode == "waveform" and H is None
@@ -473,12 +515,15 @@ class BlindSubbandFilteringHIP(BlindSubbandFiltering):
     # ---- sampler fast paths ----
     def hip_bind(self, y, ps):
         """cache comp(STFT(y)); read loss weights / compression from the posterior_sampling config"""
-        for l in (ps.rec_loss, ps.rec_loss_params, ps.RIR_noise_regularization.loss):
+        # the regulariser is gated like the reference gates it (EulerHeunSamplerDPS.py:94,200): only loss.name == "none" turns it off;
+        # RIR_noise_regularization.use is never read there
+        reg_loss = ps.RIR_noise_regularization.loss
+        for l in (ps.rec_loss, ps.rec_loss_params) + (() if reg_loss.name == "none" else (reg_loss,)):
             assert l.name == "l2_comp_stft_summean" and abs(l.compression_factor - self._comp_created) < 1e-9, \
                 "HIP operator supports l2_comp_stft_summean with compression_factor 0.667"
         self.w_rec = float(ps.rec_loss.get("weight", 1.0))
         self.w_rec_params = float(ps.rec_loss_params.get("weight", 1.0))
-        self.w_reg = float(ps.RIR_noise_regularization.loss.get("weight", 1.0)) if ps.RIR_noise_regularization.use else None
+        self.w_reg = None if reg_loss.name == "none" else float(reg_loss.get("weight", 1.0))
         self.reg = ps.RIR_noise_regularization
         self.hp = ps.blind_hp
         yy = y.contiguous().float()

@@ -41,27 +41,35 @@ class Tester:
         self.results = []
         self.blind_backend = None      # None: HIP operator on a GPU; "torch" forces the torch-op implementation
 
-    # ---- checkpoints (reference :34-98): the EMA weights are what gets loaded ------------------------------------
+    # ---- checkpoints (reference :34-67): the EMA weights are what gets loaded -------------------------------------
     def load_checkpoint(self, path):
+        """reference :60-67: ``it`` if present, then utils/training_utils.load_state_dict(state_dict, ema=self.network)
+        (strict EMA, EMA with strict=False, shape-matched EMA, 'state_dict' key) -- never the raw 'network' weights."""
+        from ..utils.training_utils import load_state_dict
         state_dict = torch.load(path, map_location="cpu", weights_only=False)
-        self.it = state_dict.get("it", 0) if isinstance(state_dict, dict) else 0
-        for key in ("ema", "network", "model"):
-            if isinstance(state_dict, dict) and key in state_dict:
-                try:
-                    self.network.load_state_dict(state_dict[key])
-                    return True
-                except Exception as e:  # try next key, like the reference's fallback chain (training_utils.py:6-178)
-                    print(f"load_checkpoint: key '{key}' failed: {e}")
-        self.network.load_state_dict(state_dict)
-        return True
+        try:
+            self.it = state_dict["it"]
+        except Exception:
+            self.it = 0
+        print("loading checkpoint")
+        return load_state_dict(state_dict, ema=self.network)
 
     def load_latest_checkpoint(self):
+        """reference :34-58: newest ``<model_dir>/<exp_name>-<it>.pt``; strict 'ema', else 'model' with strict=False."""
         try:
             name = f"{self.args.model_dir}/{self.args.exp.exp_name}-*.pt"
             rx = re.compile(f"{self.args.exp.exp_name}-(\\d*)\\.pt")
             ids = [int(rx.search(w).groups()[0]) for w in glob(name)]
             cid = max(ids)
-            return self.load_checkpoint(f"{self.args.model_dir}/{self.args.exp.exp_name}-{cid}.pt")
+            state_dict = torch.load(f"{self.args.model_dir}/{self.args.exp.exp_name}-{cid}.pt", map_location="cpu", weights_only=False)
+            try:
+                self.network.load_state_dict(state_dict["ema"])
+            except Exception as e:
+                print(e)
+                print("Failed to load in strict mode, trying again without strict mode")
+                self.network.load_state_dict(state_dict["model"], strict=False)
+            print(f"Loaded checkpoint {cid}")
+            return True
         except (FileNotFoundError, ValueError):
             raise ValueError("No checkpoint found")
 
@@ -111,9 +119,10 @@ class Tester:
             for it in items:                      # only equal-length utterances share a batch
                 groups.setdefault(len(it[0]), []).append(it)
             for L, grp in groups.items():
-                if getattr(self, "noise_factory", None) is not None:      # parity runs: one injected noise stream per utterance
-                    self.sampler.noise = self.noise_factory([it[2] for it in grp])
-                seg, y, operator, rirs = self.prepare_batch(grp, blind)
+                # parity runs: one injected noise stream per utterance, shared by the sampler AND the blind operator (random phases,
+                # update_H(use_noise=True), per-step RIR-regulariser draws) in the reference's call order; otherwise the torch RNG
+                self.sampler.noise = self.noise_factory([it[2] for it in grp]) if getattr(self, "noise_factory", None) is not None else None
+                seg, y, operator, rirs = self.prepare_batch(grp, blind, noise=self.sampler.noise)
                 pred = self.sampler.predict_conditional(y, operator, shape=(len(grp), L), blind=blind)
                 est = self.sampler.operator.get_time_RIR().detach().cpu() if blind else None
                 for b, (_, _, filename) in enumerate(grp):

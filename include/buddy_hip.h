@@ -136,6 +136,16 @@ int buddy_blindop_get_H(void* handle, float* H_out, void* stream);
 int buddy_blindop_set_y(void* handle, const float* y /*(U,L)*/, void* stream);            /* caches comp(STFT(y)) for the losses */
 int buddy_blindop_degrade(void* handle, const float* x, float* y, void* stream);           /* degradation (:82-101) with the current H */
 int buddy_blindop_time_rir(void* handle, float* rir /*(U, 128*Nf+1024)*/, void* stream);   /* get_time_RIR (:103-113) */
+/* per-function views (what optimize_op / the likelihood run internally), used by the parity tests against reference fixtures:
+ * design_filter (subband_filtering.py:241-251) -> A (U,513,Nf); apply_stft (:41-52) of x (U,L) -> (U,513,T,2), T = 1+(L+512)/128;
+ * minimum_phase_version (utils/reverb_utils.py:9-23) of h (U, 128*(Nf+1)); project_params (:298-331) on the current decay/weights;
+ * Adam moments (torch.optim.Adam exp_avg / exp_avg_sq; any pointer may be NULL) and the step count. */
+int buddy_blindop_design_filter(void* handle, float* A, void* stream);
+int buddy_blindop_apply_stft(void* handle, const float* x, float* X, void* stream);
+int buddy_blindop_minphase(void* handle, const float* h, float* out, void* stream);
+int buddy_blindop_project(void* handle, void* stream);
+int buddy_blindop_get_adam(void* handle, float* m_decay, float* v_decay, float* m_weights, float* v_weights, float* m_phases, float* v_phases,
+                           int* step /*host*/, void* stream);
 /* loss[u] = weight * l2_comp_stft_summean(y_u, degrade(x_den_u)); g_x = d sum_u loss / d x_den (NULL to skip) */
 int buddy_blindop_rec_loss_grad(void* handle, const float* x_den, float weight, float* loss, float* g_x, void* stream);
 /* informed counterpart (RIROperator, testing/operators/reverb.py:33-35 + utils/losses.py:59-64): degradation = time-domain FIR with the

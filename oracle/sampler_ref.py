@@ -165,7 +165,7 @@ class EulerHeunDPSRef(EulerHeunRef):
             for p in op.params:
                 p.requires_grad = True
 
-    def _eval(self, x_in, t, blind):
+    def _eval(self, x_in, t, blind, rescale=True):
         x_in.requires_grad = True
         x_den = self.tweedie(x_in, t)
         if blind:
@@ -173,7 +173,7 @@ class EulerHeunDPSRef(EulerHeunRef):
         lh, _ = self.likelihood_score(x_den, x_in)
         x_in.detach_()
         csm = self.ps.constraint_speech_magnitude
-        if csm.use:
+        if csm.use and rescale:                       # :127-129 -- the second-order evaluation (:139-149) does not rescale
             x_den = csm.speech_scaling / x_den.detach().std() * x_den
         score = self.edm.tweedie2score(x_den, x_in, t)
         return self.edm.ode_integrand(x_in, t, score) + lh, x_den
@@ -185,7 +185,7 @@ class EulerHeunDPSRef(EulerHeunRef):
         dt = t_next - t_hat
         if t_next != 0 and self.order == 2:
             x_p = (x_hat + dt * d).detach()
-            d2, x_den = self._eval(x_p, t_next, blind)
+            d2, x_den = self._eval(x_p, t_next, blind, rescale=False)
             x_new = x_hat + dt * (.5 * (d + d2))
         else:
             x_new = x_hat + dt * d

@@ -5,7 +5,8 @@
         tester.sampling_params.T=201 model_dir=experiments/run +gpu=0 dset.test.path=audio_examples dset.test.num_examples=2
 
 without Hydra (not installable offline): `group=name` picks conf/<group>/<name>.yaml, `a.b.c=value` overrides a key.
-Extra keys: +batch_size=N (utterances per sampler call), and torchrun environment variables for utterance sharding."""
+Extra keys: +batch_size=N (utterances per sampler call), +allow_random_init=true (no checkpoint: synthetic runs), and the torchrun
+environment variables for utterance sharding (rank 0 ends up with every prediction: one RCCL gather at the end)."""
 import os
 import sys
 
@@ -60,8 +61,11 @@ def _main(args):
     ckpt = args.tester.get("checkpoint", None)
     if ckpt is not None:
         tester.load_checkpoint(ckpt if os.path.isabs(ckpt) or os.path.exists(ckpt) else os.path.join(args.model_dir, ckpt))   # :73-93
+    elif bool(args.get("allow_random_init", False)):
+        print("+allow_random_init: sampling with the randomly initialised network (synthetic runs only)")
     else:
-        print("no tester.checkpoint given: sampling with the randomly initialised network")
+        print("trying to load latest checkpoint")
+        tester.load_latest_checkpoint()                                   # :95-96 -- raises "No checkpoint found"
     tester.do_test()                                                      # :98
 
 

@@ -300,8 +300,120 @@ def gen_uncond():
     save("e2e_uncond", pred=x, n_draws=ns.k, meta=np.array([32, 8192, 3, 2, 7, 2000]))
 
 
+def gen_opt():
+    """optimize_op itself (reference EulerHeunSamplerDPS.py:71-113): parameters and torch.optim.Adam state after ONE full iteration
+    (update_H, both losses, backward, Adam step, projection) and after the shipped ten, plus the minimum-phase projection at the
+    size cons() uses (12 928 samples) and the filter the next update_H builds from the updated parameters."""
+    import utils.reverb_utils as ru
+    from diff_params.edm import EDM
+    from utils.losses import get_loss
+    from testing.EulerHeunSamplerDPS import EulerHeunSamplerDPS
+    from testing.operators.reverb import RIROperator
+    from testing.operators.subband_filtering import BlindSubbandFiltering
+    args = compose(overrides=["tester.posterior_sampling.blind_hp.op_updates_per_step=1"])
+    ps = args.tester.posterior_sampling
+    op_hp = args.tester.informed_dereverberation.op_hp
+    L = 16000
+    x = torch.from_numpy(synth_clean(0, L))
+    rir = torch.from_numpy(synth_rir(0, taps=3000))
+    op = RIROperator(op_hp, time_kernel_size=rir.shape[-1], sample_rate=16000)
+    op.update_params(rir)
+    y = op.degradation(x[None])
+    x_den = (x[None] * 0.9 + 0.01 * torch.from_numpy(synth_clean(1, L))[None])
+    out = dict(y=y, x_den=x_den, t=np.float32(0.02), meta=np.array([L, 21]))
+    ns = NoiseStream(21)
+    smp = EulerHeunSamplerDPS(torch.nn.Identity(), EDM(args.diff_params.type, args.diff_params.sde_hp), args)
+    with patched_noise(ns):
+        with torch.no_grad():
+            bop = BlindSubbandFiltering(op_hp, 16000)
+            bop.update_H(use_noise=True)
+        out["phases0"] = bop.params_phases[0].detach().clone()
+        smp.operator, smp.y = bop, y
+        smp.rec_loss_params = get_loss(ps.rec_loss_params, operator=bop)
+        smp.RIR_noise_regularization_loss = get_loss(ps.RIR_noise_regularization.loss, operator=bop)
+        smp.optimizer_operator = torch.optim.Adam(bop.params + bop.params_phases, lr=ps.blind_hp.lr_op, weight_decay=ps.blind_hp.weight_decay,
+                                                  betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
+        t = torch.tensor(0.02)
+
+        def snap(tag):
+            out[f"{tag}_decay"], out[f"{tag}_weights"] = bop.params[0].detach().clone(), bop.params[1].detach().clone()
+            out[f"{tag}_phases"] = bop.params_phases[0].detach().clone()
+            st = smp.optimizer_operator.state
+            for nm, p in (("decay", bop.params[0]), ("weights", bop.params[1]), ("phases", bop.params_phases[0])):
+                out[f"{tag}_m_{nm}"], out[f"{tag}_v_{nm}"] = st[p]["exp_avg"].clone(), st[p]["exp_avg_sq"].clone()
+            out[f"{tag}_H_stale"] = torch.view_as_real(bop.H.detach().clone())       # H built from the parameters BEFORE the last step
+            out[f"{tag}_n_draws"] = ns.k
+
+        smp.optimize_op(x_den.clone(), t)
+        snap("it1")
+        args.tester.posterior_sampling.blind_hp.op_updates_per_step = 9
+        smp.optimize_op(x_den.clone(), t)
+        snap("it10")
+        with torch.no_grad():
+            bop.update_H()
+        out["it10_H"] = torch.view_as_real(bop.H.detach())
+        out["it10_rir"] = bop.get_time_RIR().detach()
+    h = torch.from_numpy(synth_rir(2, taps=1500))
+    hp = torch.nn.functional.pad(h * torch.exp(-torch.arange(1500) / 400.0), (0, 12928 - 1500))
+    out["minphase_in"], out["minphase_out"] = hp, ru.minimum_phase_version(hp)
+    save("opt", **out)
+
+
+def gen_e2e_blind_o2():
+    """blind, second-order (Heun) with the speech-magnitude constraint on: the corrector evaluation does NOT rescale x_den
+    (reference EulerHeunSamplerDPS.py:139-149)."""
+    _e2e("e2e_blind_o2", "blind_dereverberation_BUDDy", blind=True, T=3, order=2,
+         overrides=["tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+                    "tester.posterior_sampling.blind_hp.op_updates_per_step=2"], utt=3)
+
+
+def gen_e2e_blind10():
+    """blind, T=10 with the shipped 10 operator updates per step (conf/tester/blind_dereverberation_BUDDy.yaml:72)."""
+    _e2e("e2e_blind10", "blind_dereverberation_BUDDy", blind=True, T=10, order=1,
+         overrides=["tester.posterior_sampling.warm_initialization.mode=reverb_scaled"], utt=5)
+
+
+def gen_config1():
+    """BASELINE config 1: audio_examples/clean/p226/p226_003.wav + its RIR, informed DPS, order 2, T=10 (reference testing/tester.py:123-153,
+    conf/tester/informed_dereverberation_DPS.yaml), full-width network (nf=128) on seeded weights.  The clip (133 829 samples: not a
+    hop multiple; 8 083-tap RIR after the direct-path trim) goes through the reference's own preprocessing (datasets/vctk.py:209-214,
+    tester.py:134-135)."""
+    from scipy.io import wavfile
+    from diff_params.edm import EDM
+    from testing.EulerHeunSamplerDPS import EulerHeunSamplerDPS
+    from testing.operators.reverb import RIROperator
+    import testing.EulerHeunSamplerDPS as M
+    M.tqdm = lambda it, *a, **k: it
+    fs, d = wavfile.read(os.path.join(REF, "audio_examples/clean/p226/p226_003.wav"))
+    fs2, r = wavfile.read(os.path.join(REF, "audio_examples/rir/p226/p226_003.wav"))
+    assert fs == 16000 and fs2 == 16000
+    conv = lambda a: a.astype(np.float64) / 32768.0 if a.dtype == np.int16 else a.astype(np.float64)     # soundfile's PCM16 scaling
+    data, data_rir = conv(d), conv(r)
+    data_rir = data_rir[np.argmax(np.abs(data_rir)):]
+    data_rir = data_rir / np.abs(data_rir).max()
+    args = compose(tester="informed_dereverberation_DPS", overrides=["tester.sampling_params.T=10"])
+    assert args.tester.sampling_params.order == 2
+    nf, seed, nseed = 128, 9, 4242
+    net = build_ref_net(nf, 510, 128, seed)
+    edm = EDM(args.diff_params.type, args.diff_params.sde_hp)
+    sampler = EulerHeunSamplerDPS(net, edm, args)
+    seg = torch.from_numpy(data).float()
+    seg = args.tester.posterior_sampling.warm_initialization.scaling_factor * seg / seg.std()
+    RIR = torch.Tensor(data_rir)
+    ns = NoiseStream(nseed)
+    with patched_noise(ns):
+        with torch.no_grad():
+            op = RIROperator(args.tester.informed_dereverberation.op_hp, time_kernel_size=RIR.shape[-1], sample_rate=16000)
+            op.update_params(RIR)
+            y = op.degradation(seg.unsqueeze(0))
+        pred = sampler.predict_conditional(y, op, shape=(1, seg.shape[-1]), blind=False)
+    save("config1", clean_raw=data.astype(np.float32), rir=data_rir.astype(np.float32), seg=seg, y=y, pred=pred, n_draws=ns.k,
+         meta=np.array([nf, seg.shape[-1], 10, 2, seed, nseed, RIR.shape[-1]]))
+
+
 GENS = dict(edm_sched=gen_edm_sched, net_small=gen_net_small, net_full=gen_net_full, ops=gen_ops,
-            e2e_informed=gen_e2e_informed, e2e_blind=gen_e2e_blind, e2e_uncond=gen_uncond)
+            e2e_informed=gen_e2e_informed, e2e_blind=gen_e2e_blind, e2e_uncond=gen_uncond,
+            opt=gen_opt, e2e_blind_o2=gen_e2e_blind_o2, e2e_blind10=gen_e2e_blind10, config1=gen_config1)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -26,7 +26,7 @@ def test_cli_end_to_end(tmp_path, tester, mode):
     _dataset(data)
     out = str(tmp_path / "exp")
     cli.main(["--config-name=conf_VCTK.yaml", f"tester={tester}", "tester.sampling_params.T=2", f"model_dir={out}", "+gpu=0",
-              f"dset.test.path={data}", "dset.test.num_examples=2", "network.nf=32", "+batch_size=2", "tester.overriden_name=run"])
+              f"dset.test.path={data}", "dset.test.num_examples=2", "network.nf=32", "+batch_size=2", "tester.overriden_name=run", "+allow_random_init=true"])
     base = os.path.join(out, "run", mode, "VCTK_16k_4s_time")
     subs = ["original", "degraded", "reconstructed", "true_rir"] + (["estimated_rir"] if "blind" in mode else [])
     for s in subs:

@@ -1,0 +1,144 @@
+"""GPU parity of the hand-written blind operator (``buddy_blindop_*``, csrc/operator.hip) against vectors recorded from the
+REFERENCE itself (tests/golden/ops.npz, opt.npz; generator tests/golden/make_golden.py), function by function:
+design_filter, update_H / cons (incl. the minimum-phase projection), apply_stft, degradation, get_time_RIR, both losses, the three
+parameter gradients, project_params (bit-exact), torch.optim.Adam state and parameters after one and after ten full optimize_op
+iterations.  Tolerances are relative to the tensor's abs-max and are the ones tests/test_oracle_golden.py holds the CPU oracle to,
+widened only where stated (fp32 25 856-point FFTs and DFT-GEMMs instead of the reference's CPU FFT)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _make(seed, L, extra=()):
+    from buddy_amd.config import compose
+    from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering, BlindSubbandFilteringHIP
+    from oracle.sampler_ref import NoiseStream
+    args = compose(overrides=list(extra))
+    ns = [NoiseStream(seed)]
+    op = BlindSubbandFiltering(args.tester.informed_dereverberation.op_hp, 16000, num_utts=1, noise=ns, device="cuda", length=L)
+    assert isinstance(op, BlindSubbandFilteringHIP)
+    op.update_H(use_noise=True)        # the fixtures construct the operator and then call update_H(use_noise=True), like tester.py:143-146
+    return args, op, ns
+
+
+def test_forward_pieces_vs_reference(golden):
+    g = golden("ops")
+    L = g["x"].shape[-1]
+    args, op, ns = _make(11, L)
+    x = torch.from_numpy(g["x"])[None].cuda()
+    assert rel(op.design_filter()[0], g["blind_A"]) < 1e-5
+    assert rel(torch.view_as_real(op.H)[0], g["blind_H"]) < 1e-4
+    # phases = angle(H): compare as |H| e^{j phi} (angles of near-zero bins and +-pi wraps are ill-conditioned)
+    Hm = torch.from_numpy(g["blind_H"]).pow(2).sum(-1).sqrt()
+    ref = torch.view_as_real(Hm * torch.exp(1j * torch.from_numpy(g["blind_phases"])))
+    got = torch.view_as_real(Hm.cuda() * torch.exp(1j * op.params_phases[0][0]))
+    assert rel(got, ref) < 2e-4
+    assert rel(op.degradation(x), g["blind_deg"]) < 1e-4
+    assert rel(op.get_time_RIR(), g["blind_rir"]) < 1e-4
+    assert rel(torch.view_as_real(op.apply_stft(x)), g["blind_stft_x"]) < 1e-5
+
+
+def test_losses_and_parameter_gradients_vs_reference(golden):
+    from buddy_amd import _lib
+    g = golden("ops")
+    L = g["x"].shape[-1]
+    args, op, ns = _make(11, L)
+    ps = args.tester.posterior_sampling
+    x = torch.from_numpy(g["x"])[None].cuda().contiguous()
+    y = torch.from_numpy(g["y_rir"]).cuda()
+    op.hip_bind(y, ps)
+    n = ns[0].randn((op.length_rir + 1024,))[None].cuda().contiguous()      # the draw the fixture took for the regulariser
+    U = 1
+    gd = torch.empty(U, 1, 25, device="cuda"); gw = torch.empty_like(gd); gp = torch.empty(U, 513, 100, device="cuda")
+    ls = torch.empty(2 * U, device="cuda")
+    _lib.check(_lib.load().buddy_blindop_param_grads(op._h, x.data_ptr(), n.data_ptr(), 0.005, float(ps.rec_loss_params.weight),
+                                                     float(ps.RIR_noise_regularization.loss.weight), gd.data_ptr(), gw.data_ptr(), gp.data_ptr(),
+                                                     ls.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert abs(float(ls[0]) - float(g["blind_l_rec"])) < 1e-4 * abs(float(g["blind_l_rec"]))
+    assert abs(float(ls[1]) - float(g["blind_l_reg"])) < 1e-4 * abs(float(g["blind_l_reg"]))
+    assert rel(gd[0], g["blind_g_decay"]) < 2e-3
+    assert rel(gw[0], g["blind_g_weights"]) < 2e-3
+    assert rel(gp[0], g["blind_g_phases"]) < 2e-3
+    # likelihood w.r.t. the signal (rec_loss, same operator): value against the fixture's rec term scaled by the weights
+    xg = x.clone().requires_grad_(True)
+    rec = op.hip_rec_loss(xg)
+    assert abs(float(rec) * float(ps.rec_loss_params.weight) / float(ps.rec_loss.weight) - float(g["blind_l_rec"])) < 1e-4 * abs(float(g["blind_l_rec"]))
+
+
+def test_project_params_bit_exact(golden):
+    g = golden("ops")
+    args, op, ns = _make(11, 16000)
+    op.set_params(decay=torch.linspace(0.0, 0.8, 25)[None, None], weights=torch.linspace(0.2, 150.0, 25)[None, None])
+    op.project_params()
+    d, w = op.params
+    assert np.array_equal(d[0].cpu().numpy(), g["proj_decay"])
+    assert np.array_equal(w[0].cpu().numpy(), g["proj_weights"])
+
+
+def test_minimum_phase_vs_reference(golden):
+    g = golden("opt")
+    args, op, ns = _make(21, 16000)
+    out = op.minimum_phase(torch.from_numpy(g["minphase_in"])[None])
+    # fp32 two-stage 25 856-point FFTs (four of them chained, log|H| in between) vs the reference's CPU FFT: stated 5e-5 of the peak
+    assert rel(out[0], g["minphase_out"]) < 5e-5
+
+
+def test_optimize_op_vs_reference(golden):
+    """ONE full optimize_op iteration and then the shipped TEN (reference EulerHeunSamplerDPS.py:71-113 run on the reference operator):
+    Adam moments, parameters, the filter and the time-domain RIR they produce."""
+    g = golden("opt")
+    L = int(g["meta"][0])
+    args, op, ns = _make(int(g["meta"][1]), L, ["tester.posterior_sampling.blind_hp.op_updates_per_step=1"])
+    ps = args.tester.posterior_sampling
+    y = torch.from_numpy(g["y"]).cuda()
+    x_den = torch.from_numpy(g["x_den"]).cuda()
+    Hm0 = op.H.abs()[0].cpu()
+    assert rel(torch.view_as_real(Hm0 * torch.exp(1j * op.params_phases[0][0].cpu())),
+               torch.view_as_real(Hm0 * torch.exp(1j * torch.from_numpy(g["phases0"])))) < 2e-4
+    op.hip_bind(y, ps)
+    t = float(g["t"])
+
+    def check(tag, tol_m, tol_p):
+        st, step = op.adam_state()
+        torch.cuda.synchronize()
+        assert ns[0].k == int(g[f"{tag}_n_draws"])
+        res = {}
+        for nm, par in (("decay", op.params[0]), ("weights", op.params[1])):
+            res[f"m_{nm}"] = rel(st[nm][0][0], g[f"{tag}_m_{nm}"])
+            res[f"v_{nm}"] = rel(st[nm][1][0], g[f"{tag}_v_{nm}"])
+            res[nm] = rel(par[0], g[f"{tag}_{nm}"])
+        res["m_phases"] = rel(st["phases"][0][0], g[f"{tag}_m_phases"])
+        res["v_phases"] = rel(st["phases"][1][0], g[f"{tag}_v_phases"])
+        # phases move by ~lr * sign(g) per step under Adam: an entry whose gradient is at round-off level can take the other sign on
+        # either implementation; they carry no magnitude (|H| ~ 0 there), so compare what the phases produce: A e^{j phi}
+        A = op.design_filter()[0].cpu()
+        ph, phr = op.params_phases[0][0].cpu(), torch.from_numpy(g[f"{tag}_phases"])
+        res["A_e^jphi"] = rel(torch.view_as_real(A * torch.exp(1j * ph)), torch.view_as_real(A * torch.exp(1j * phr)))
+        res["phase_outliers"] = float(((ph - phr).abs() > 1e-3).float().mean())
+        print(tag, {k: f"{v:.2e}" for k, v in res.items()})
+        for k in ("m_decay", "m_weights", "m_phases", "v_decay", "v_weights", "v_phases"):
+            assert res[k] < tol_m, (tag, k, res[k])
+        for k in ("decay", "weights", "A_e^jphi"):
+            assert res[k] < tol_p, (tag, k, res[k])
+        assert res["phase_outliers"] < 0.02
+        return step
+
+    op.hip_optimize(x_den, t)
+    assert check("it1", 2e-3, 2e-3) == 1
+    assert rel(torch.view_as_real(op.H)[0], g["it1_H_stale"]) < 1e-4          # H is the filter of the parameters BEFORE the step
+    ps.blind_hp.op_updates_per_step = 9
+    op.hip_optimize(x_den, t)
+    assert check("it10", 1e-2, 1e-2) == 10
+    assert rel(torch.view_as_real(op.H)[0], g["it10_H_stale"]) < 1e-2
+    op.update_H()
+    assert rel(torch.view_as_real(op.H)[0], g["it10_H"]) < 1e-2
+    assert rel(op.get_time_RIR(), g["it10_rir"]) < 1e-2

@@ -56,31 +56,93 @@ def test_informed_dps_vs_reference_fixture(golden):
     assert abs(_sisdr(p, g["clean"]) - _sisdr(g["pred"], g["clean"])) < 0.1
 
 
-def test_blind_dps_vs_reference_fixture(golden):
-    from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering
+def _run_blind(g, extra, backend):
+    from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering, BlindSubbandFilteringHIP
     from buddy_amd.instantiate import instantiate
     from oracle.sampler_ref import NoiseStream
-    g = golden("e2e_blind")
-    args, net, edm, meta = _setup(g, "blind_dereverberation_BUDDy",
-                                  ["tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
-                                   "tester.posterior_sampling.blind_hp.op_updates_per_step=3"])
+    args, net, edm, meta = _setup(g, "blind_dereverberation_BUDDy", extra)
     ns = [NoiseStream(meta[6])]
     smp = instantiate(args.tester.sampler, net, edm, args)
     smp.noise = ns
-    op = BlindSubbandFiltering(args.tester.informed_dereverberation.op_hp, 16000, num_utts=1, noise=ns, device="cuda")
+    kw = dict(length=meta[1]) if backend == "hip" else dict(backend="torch")
+    op = BlindSubbandFiltering(args.tester.informed_dereverberation.op_hp, 16000, num_utts=1, noise=ns, device="cuda", **kw)
+    assert isinstance(op, BlindSubbandFilteringHIP) == (backend == "hip")
     op.update_H(use_noise=True)
     y = torch.from_numpy(g["y"]).cuda()
     pred = smp.predict_conditional(y, op, shape=(1, meta[1]), blind=True)
     assert ns[0].k == int(g["n_draws"])
-    p = pred.cpu().numpy()
+    assert smp._hip_op == (backend == "hip")
+    return pred.cpu().numpy(), op, smp
+
+
+@pytest.mark.parametrize("backend", ["hip", "torch"])
+def test_blind_dps_vs_reference_fixture(golden, backend):
+    """backend "hip": the hand-written operator (csrc/operator.hip -- what the bench and the Tester run); "torch": the torch-op class."""
+    g = golden("e2e_blind")
+    p, op, smp = _run_blind(g, ["tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+                                "tester.posterior_sampling.blind_hp.op_updates_per_step=3"], backend)
     assert rel(p, g["pred"]) < 3e-3
     assert _sisdr(p, g["pred"]) > 40.0
     assert abs(_sisdr(p, g["clean"]) - _sisdr(g["pred"], g["clean"])) < 0.1
-    # operator parameters after 9 Adam updates: Adam's m/sqrt(v) is scale-free, so fp32 FFT round-off differences (rocFFT vs the
-    # reference's CPU FFT, 25856-point transforms inside the min-phase projection) move individual bands by ~1 %
+    # operator parameters after 9 Adam updates: Adam's m/sqrt(v) is scale-free, so fp32 FFT round-off differences (25856-point
+    # transforms inside the min-phase projection) move individual bands by ~1 %
     assert rel(op.params[0][0].detach().cpu().numpy(), g["decay"]) < 3e-2
     assert rel(op.params[1][0].detach().cpu().numpy(), g["weights"]) < 3e-2
     assert rel(smp.operator.get_time_RIR().detach().cpu().numpy(), g["est_rir"]) < 3e-2
+
+
+def test_blind_second_order_with_magnitude_constraint(golden):
+    """order 2 + constraint_speech_magnitude on the HIP operator: the Heun corrector leaves x_den un-rescaled
+    (reference EulerHeunSamplerDPS.py:139-149)."""
+    g = golden("e2e_blind_o2")
+    p, op, smp = _run_blind(g, ["tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+                                "tester.posterior_sampling.blind_hp.op_updates_per_step=2"], "hip")
+    assert rel(p, g["pred"]) < 3e-3
+    assert _sisdr(p, g["pred"]) > 40.0
+    assert abs(_sisdr(p, g["clean"]) - _sisdr(g["pred"], g["clean"])) < 0.1
+
+
+def test_blind_T10_shipped_updates_vs_reference_fixture(golden):
+    """T = 10 schedule with the shipped op_updates_per_step = 10 (conf/tester/blind_dereverberation_BUDDy.yaml:72) on the HIP operator.
+    Ten guided steps x ten scale-free Adam updates amplify fp32 round-off (see profiles/r02_arbiter_*.json for the fp64-arbitrated
+    divergence of the reference's own fp32 arithmetic); stated: SI-SDR(build; reference) > 30 dB and |delta SI-SDR to clean| < 0.1 dB."""
+    g = golden("e2e_blind10")
+    p, op, smp = _run_blind(g, ["tester.posterior_sampling.warm_initialization.mode=reverb_scaled"], "hip")
+    s = _sisdr(p, g["pred"])
+    d = abs(_sisdr(p, g["clean"]) - _sisdr(g["pred"], g["clean"]))
+    print(f"T10/10 updates: SI-SDR(build; reference) {s:.1f} dB, delta to clean {d:.4f} dB")
+    assert s > 30.0
+    assert d < 0.1
+
+
+def test_config1_real_clip_informed(golden):
+    """BASELINE config 1: audio_examples p226_003 + its RIR (133 829 samples, 8 083 taps), informed DPS, order 2, T = 10, full-width
+    network, through the Tester's own preprocessing (reference testing/tester.py:123-153)."""
+    from buddy_amd.testing.tester import Tester
+    from oracle.sampler_ref import NoiseStream
+    g = golden("config1")
+    nf, L, T, order, seed, nseed, M = [int(v) for v in g["meta"]]
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_state_dict
+    args = compose(tester="informed_dereverberation_DPS", overrides=[f"tester.sampling_params.T={T}"])
+    assert args.tester.sampling_params.order == order and args.network.nf == nf
+    net = instantiate(args.network)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(seed, nf).items()})
+    net = net.cuda().eval()
+    tester = Tester(args, net, instantiate(args.diff_params), test_set=None, device="cuda", in_training=True)
+    tester.sampler.noise = [NoiseStream(nseed)]
+    seg, y, op, _ = tester.prepare_batch([(g["clean_raw"].astype(np.float64), g["rir"].astype(np.float64), "p226_003.wav")], blind=False)
+    assert rel(seg[0].cpu().numpy(), g["seg"]) < 1e-6
+    assert rel(y[0].cpu().numpy(), g["y"][0]) < 2e-5
+    pred = tester.sampler.predict_conditional(torch.from_numpy(g["y"]).cuda(), op, shape=(1, L), blind=False)
+    assert tester.sampler.noise[0].k == int(g["n_draws"])
+    p = pred.cpu().numpy()
+    s = _sisdr(p, g["pred"])
+    d = abs(_sisdr(p, g["seg"]) - _sisdr(g["pred"], g["seg"]))
+    print(f"config 1: SI-SDR(build; reference) {s:.1f} dB, delta to clean {d:.5f} dB, rel {rel(p, g['pred']):.2e}")
+    assert s > 40.0
+    assert d < 0.1
 
 
 def test_unconditional_vs_reference_fixture(golden):

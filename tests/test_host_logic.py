@@ -210,3 +210,59 @@ def test_cli_parser_matches_reference_command_line():
     args = compose(tester=groups["tester"], overrides=ov)
     assert args.tester.sampling_params.T == 201 and args.gpu == 0 and args.dset.test.path == "audio_examples"
     assert args.tester.checkpoint == "x.pt" and args.model_dir == "experiments/run"
+
+
+def test_load_checkpoint_reference_fallback_chain(tmp_path):
+    """Tester.load_checkpoint / load_latest_checkpoint on synthetic .pt files laid out like the reference trainer writes them
+    (training/trainer.py:171-178: it, network, optimizer, ema, args): the EMA weights are loaded -- strict, then strict=False, then
+    shape-matched (reference utils/training_utils.py:6-111, testing/tester.py:34-67) -- and the raw 'network' weights never are."""
+    from buddy_amd.synth import synth_state_dict
+    from buddy_amd.testing.tester import Tester
+    args = compose(overrides=["network.nf=32", f"model_dir={tmp_path}"])
+    net = instantiate(args.network)
+    t = Tester(args, net, instantiate(args.diff_params), test_set=None, device="cpu", in_training=True)
+    ema = {k: torch.from_numpy(v) for k, v in synth_state_dict(11, 32).items()}
+    raw = {k: torch.from_numpy(v) for k, v in synth_state_dict(12, 32).items()}
+    assert list(ema) == list(net.state_dict())                     # reference key order == state_dict order
+    key = "all_modules.4.Conv_0.weight"
+
+    def fresh():
+        net.load_state_dict({k: torch.zeros_like(v) for k, v in ema.items()})
+
+    # 1. strict EMA
+    p = tmp_path / "a.pt"
+    torch.save({"it": 1234, "network": raw, "optimizer": {}, "ema": ema, "args": {}}, p)
+    fresh()
+    assert t.load_checkpoint(str(p)) is True and t.it == 1234
+    assert all(torch.equal(net.state_dict()[k], ema[k]) for k in ema)
+    # 2. a key missing from the EMA dict: strict fails, strict=False loads the rest; the missing tensor keeps its value (NOT the raw weights)
+    part = {k: v for k, v in ema.items() if k != key}
+    torch.save({"network": raw, "ema": part}, p)
+    fresh()
+    assert t.load_checkpoint(str(p)) is True and t.it == 0
+    sd = net.state_dict()
+    assert torch.equal(sd["all_modules.3.weight"], ema["all_modules.3.weight"]) and float(sd[key].abs().max()) == 0.0
+    # 3. a tensor of the wrong shape: both load_state_dict attempts raise, the shape-matched assignment takes every other tensor
+    bad = dict(ema); bad[key] = torch.ones(3, 3)
+    torch.save({"network": raw, "ema": bad}, p)
+    fresh()
+    assert t.load_checkpoint(str(p)) is True
+    sd = net.state_dict()
+    assert torch.equal(sd["all_modules.3.weight"], ema["all_modules.3.weight"]) and float(sd[key].abs().max()) == 0.0
+    # 4. weights stored under 'state_dict'
+    torch.save({"state_dict": ema}, p)
+    fresh()
+    assert t.load_checkpoint(str(p)) is True
+    assert torch.equal(net.state_dict()[key], ema[key])
+    # nothing loadable
+    torch.save({"foo": 1}, p)
+    assert t.load_checkpoint(str(p)) is False
+    # load_latest_checkpoint: highest iteration wins; no file -> ValueError("No checkpoint found")
+    with pytest.raises(ValueError, match="No checkpoint found"):
+        t.load_latest_checkpoint()
+    name = args.exp.exp_name
+    torch.save({"it": 5, "ema": raw}, tmp_path / f"{name}-5.pt")
+    torch.save({"it": 70, "ema": ema}, tmp_path / f"{name}-70.pt")
+    fresh()
+    assert t.load_latest_checkpoint() is True
+    assert torch.equal(net.state_dict()[key], ema[key])

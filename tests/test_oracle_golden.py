@@ -157,3 +157,49 @@ def test_e2e_unconditional(golden):
     x = smp.predict_unconditional((2, L))
     assert ns.k == int(g["n_draws"])
     assert rel(x, g["pred"]) < 1e-3
+
+
+def test_e2e_blind_second_order_with_magnitude_constraint(golden):
+    """order 2 + constraint_speech_magnitude: the Heun corrector leaves x_den un-rescaled (reference EulerHeunSamplerDPS.py:139-149)."""
+    g = golden("e2e_blind_o2")
+    pred, op = _run_e2e(g, "blind_dereverberation_BUDDy", True,
+                        ["tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+                         "tester.posterior_sampling.blind_hp.op_updates_per_step=2"])
+    assert rel(pred, g["pred"]) < 2e-3
+    assert rel(op.get_time_RIR().detach(), g["est_rir"]) < 1e-2
+
+
+def test_optimize_op_one_and_ten_iterations(golden):
+    """optimize_op (reference EulerHeunSamplerDPS.py:71-113): Adam state and parameters after one and after ten full iterations."""
+    g = golden("opt")
+    args = compose(overrides=["tester.posterior_sampling.blind_hp.op_updates_per_step=1"])
+    ps, op_hp = args.tester.posterior_sampling, args.tester.informed_dereverberation.op_hp
+    ns = S.NoiseStream(int(g["meta"][1]))
+    bop = O.BlindSubbandFilteringRef(op_hp, 16000, ns)
+    bop.update_H(use_noise=True, noise=ns)
+    smp = S.EulerHeunDPSRef(None, S.EDMRef(args.diff_params.sde_hp), args, ns)
+    smp.operator, smp.y = bop, torch.from_numpy(g["y"])
+    smp.rec_loss_params = O.get_loss_ref(ps.rec_loss_params, bop)
+    smp.rir_reg_loss = O.get_loss_ref(ps.RIR_noise_regularization.loss, bop)
+    smp.optim = torch.optim.Adam(bop.params + bop.params_phases, lr=ps.blind_hp.lr_op, weight_decay=ps.blind_hp.weight_decay,
+                                 betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
+    x_den, t = torch.from_numpy(g["x_den"]), torch.tensor(float(g["t"]))
+
+    def check(tag, tol):
+        assert ns.k == int(g[f"{tag}_n_draws"])
+        for nm, p in (("decay", bop.params[0]), ("weights", bop.params[1]), ("phases", bop.params_phases[0])):
+            st = smp.optim.state[p]
+            assert rel(st["exp_avg"], g[f"{tag}_m_{nm}"]) < tol
+            assert rel(st["exp_avg_sq"], g[f"{tag}_v_{nm}"]) < tol
+        assert rel(bop.params[0].detach(), g[f"{tag}_decay"]) < tol
+        assert rel(bop.params[1].detach(), g[f"{tag}_weights"]) < tol
+        A = bop.design_filter().detach()
+        assert rel(torch.view_as_real(A * torch.exp(1j * bop.params_phases[0].detach())),
+                   torch.view_as_real(A * torch.exp(1j * torch.from_numpy(g[f"{tag}_phases"])))) < tol
+
+    smp.optimize_op(x_den.clone(), t)
+    check("it1", 2e-3)
+    ps.blind_hp.op_updates_per_step = 9
+    smp.optimize_op(x_den.clone(), t)
+    check("it10", 1e-2)
+    assert rel(O.minimum_phase_ref(torch.from_numpy(g["minphase_in"])), g["minphase_out"]) < 1e-5
