@@ -145,7 +145,7 @@ class BlindSubbandFilteringRef(_OpSTFT):
         """design_subband_filter + correct_OLA + direct path -- reference :212-251."""
         Nf = self.Nf
         decay_bp = torch.exp(self.params[0])
-        n = torch.arange(0, Nf).float()[None, None, :]
+        n = torch.arange(0, Nf).to(torch.get_default_dtype())[None, None, :]
         inner = (self.params[1].unsqueeze(-1) * decay_bp.unsqueeze(-1) ** (-n)).sum(0)   # (25, Nf)
         zero = torch.zeros(1, Nf)
         dm = torch.cat([zero, inner, zero], dim=0)                                      # rows 0 and 26 stay 0

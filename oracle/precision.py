@@ -1,0 +1,28 @@
+"""fp64 arbiter mode of the oracle.  TEST INFRASTRUCTURE (see ``oracle/__init__.py``).
+
+The reference computes in fp32 and its blind sampler is chaotic on the time scale of a 50-step run (scale-free Adam updates of the
+operator coupled to a guidance term normalised by its own norm), so two fp32 executions of the SAME algorithm with different summation
+orders drift apart.  To judge an implementation against that, the same restated algorithm is run in float64 -- whose round-off is nine
+orders of magnitude below fp32's, i.e. the "exact" trajectory of the algorithm for these inputs -- and every fp32 execution (the oracle at
+several thread counts, the MI355X build) is measured against it.
+
+    with oracle.precision.fp64():
+        P = ncsnpp_ref.to_torch(sd)          # parameters, windows, noise draws, schedules: all float64 inside the context
+        ...
+
+Only the default dtype changes; the code path is the one pinned in fp32 against the reference fixtures."""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+
+
+@contextlib.contextmanager
+def fp64():
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        yield
+    finally:
+        torch.set_default_dtype(prev)

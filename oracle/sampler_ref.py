@@ -15,7 +15,8 @@ from .operators_ref import get_loss_ref
 
 
 class NoiseStream:
-    """k-th draw = RandomState(seed*100003 + k) of the requested shape (float32)."""
+    """k-th draw = RandomState(seed*100003 + k) of the requested shape: float32 values (cast to the default dtype, so the fp64 arbiter
+    mode of ``oracle.precision`` sees exactly the same draws)."""
 
     def __init__(self, seed):
         self.seed, self.k = int(seed), 0
@@ -26,10 +27,10 @@ class NoiseStream:
         return rs
 
     def randn(self, shape):
-        return torch.from_numpy(self._rs().standard_normal(tuple(shape)).astype(np.float32))
+        return torch.from_numpy(self._rs().standard_normal(tuple(shape)).astype(np.float32)).to(torch.get_default_dtype())
 
     def rand(self, shape):
-        return torch.from_numpy(self._rs().random_sample(tuple(shape)).astype(np.float32))
+        return torch.from_numpy(self._rs().random_sample(tuple(shape)).astype(np.float32)).to(torch.get_default_dtype())
 
 
 # --------------------------------------------------------------------------- EDM (reference diff_params/edm.py)

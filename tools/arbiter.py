@@ -1,0 +1,212 @@
+"""fp64-arbitrated parity of full blind DPS runs.
+
+For each utterance / noise seed u the SAME run (blind DPS, T-step schedule, order 1, 10 operator updates per step, full-width network,
+identical weights / inputs / injected noise draws) is executed
+  * by the CPU oracle in float64           (``oracle.precision.fp64``: the algorithm's exact trajectory for these inputs),
+  * by the CPU oracle in float32 at two intra-op thread counts (the reference arithmetic, two summation orders),
+  * by the MI355X build (fp32),
+and every fp32 execution is measured against the fp64 trajectory: per-step SI-SDR of x_den, SI-SDR of the final estimate, and the
+difference of SI-SDR-to-clean.  The build passes if its deviation from the fp64 trajectory is not larger than the fp32 oracle's own.
+
+  python tools/arbiter.py oracle --seeds 0-7 [--L 64000 --T 50 --nf 128 --workers 2 --threads 8,4]     # CPU, writes traces
+  python tools/arbiter.py build  --seeds 0-7 [...]                                                       # GPU, writes traces
+  python tools/arbiter.py report --seeds 0-7 [...] > profiles/r02_arbiter_*.json
+
+Traces (x_den per step, float32) live under oracle/_ref/arbiter/ (git-ignored scratch that still travels to the GPU box)."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def parse_seeds(s):
+    out = []
+    for part in s.split(","):
+        if "-" in part:
+            a, b = part.split("-"); out += list(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def tdir(a):
+    d = os.path.join(ROOT, "oracle", "_ref", "arbiter", f"L{a.L}_T{a.T}_nf{a.nf}_up{a.updates}")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def overrides(a):
+    return [f"tester.sampling_params.T={a.T}", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+            f"tester.posterior_sampling.blind_hp.op_updates_per_step={a.updates}", f"network.nf={a.nf}"]
+
+
+def oracle_job(a, seed, variant):
+    """one CPU run; variant = fp64 | fp32tN"""
+    import numpy as np
+    import torch
+    from buddy_amd.config import compose
+    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
+    from oracle import ncsnpp_ref, operators_ref as O, sampler_ref as S, precision
+    import contextlib
+    threads = int(variant.split("t")[1]) if variant.startswith("fp32t") else a.fp64_threads
+    torch.set_num_threads(threads)
+    args = compose(overrides=overrides(a))
+    ctx = precision.fp64() if variant == "fp64" else contextlib.nullcontext()
+    t0 = time.time()
+    with ctx:
+        dt = torch.get_default_dtype()
+        P = ncsnpp_ref.to_torch(synth_state_dict(0, a.nf))
+        onet = lambda z, cn: ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
+        c0 = torch.from_numpy(synth_clean(seed, a.L)).to(dt)
+        c0 = 0.05 * c0 / c0.std()
+        rir = torch.from_numpy(synth_rir(seed, a.rir_taps)).to(dt)
+        nr = S.NoiseStream(9000 + seed)
+        ref = S.EulerHeunDPSRef(onet, S.EDMRef(args.diff_params.sde_hp), args, nr)
+        op_hp = args.tester.informed_dereverberation.op_hp
+        oo = O.RIROperatorRef(op_hp); oo.update_params(rir)
+        y0 = oo.degradation(c0[None])
+        bo = O.BlindSubbandFilteringRef(op_hp, 16000, nr); bo.update_H(use_noise=True, noise=nr)
+        tr = []
+        ref.predict_conditional(y0, bo, shape=(1, a.L), blind=True, trace=tr)
+    xden = torch.stack([t[1][0] for t in tr]).float().numpy()
+    np.savez(os.path.join(tdir(a), f"seed{seed}_{variant}.npz"), xden=xden, clean=c0.float().numpy(), n_draws=nr.k, seconds=time.time() - t0, threads=threads)
+    print(f"seed {seed} {variant}: {time.time() - t0:.0f} s ({threads} threads)", flush=True)
+
+
+def phase_oracle(a):
+    jobs = [(s, v) for s in a.seeds for v in a.variants if not os.path.exists(os.path.join(tdir(a), f"seed{s}_{v}.npz"))]
+    running = []
+    while jobs or running:
+        running = [p for p in running if p.poll() is None]
+        while jobs and len(running) < a.workers:
+            s, v = jobs.pop(0)
+            cmd = [sys.executable, os.path.abspath(__file__), "job", "--seed", str(s), "--variant", v] + a.common
+            running.append(subprocess.Popen(cmd))
+        time.sleep(1.0)
+
+
+def phase_build(a):
+    """all seeds as ONE batched run on the GPU (per-utterance semantics: row b == the B=1 run of utterance b)"""
+    import numpy as np
+    import torch
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
+    from buddy_amd.testing.tester import Tester
+    from buddy_amd.utils.losses import get_loss
+    from oracle.sampler_ref import NoiseStream          # deterministic noise stream only
+    args = compose(overrides=overrides(a))
+    net = instantiate(args.network)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(0, a.nf).items()})
+    net = net.cuda().eval()
+    edm = instantiate(args.diff_params)
+    for lo in range(0, len(a.seeds), a.batch):
+        seeds = a.seeds[lo:lo + a.batch]
+        items = [(synth_clean(s, a.L), synth_rir(s, a.rir_taps), f"u{s}.wav") for s in seeds]
+        t = Tester(args, net, edm, test_set=None, device="cuda", in_training=True)
+        ns = [NoiseStream(9000 + s) for s in seeds]
+        t.sampler.noise = ns
+        seg, y, op, _ = t.prepare_batch(items, blind=True, noise=ns)
+        smp = t.sampler
+        smp.operator, smp.y = op, y
+        smp.rec_loss = get_loss(args.tester.posterior_sampling.rec_loss, operator=op)
+        smp._hip_op = True
+        op.hip_bind(y, args.tester.posterior_sampling)
+        sched = smp.create_schedule()
+        gam = smp.get_gamma(sched).tolist()
+        x = smp.initialize_x(tuple(y.shape), "cuda", sched)
+        tl = sched.tolist()
+        tr = []
+        t0 = time.time()
+        for i in range(a.T):
+            x, xd = smp.step(x, tl[i], tl[i + 1], gam[i], blind=True)
+            tr.append(xd.cpu())
+        torch.cuda.synchronize()
+        print(f"build: seeds {seeds} {time.time() - t0:.1f} s", flush=True)
+        tr = torch.stack(tr)                              # (T, B, L)
+        for b, s in enumerate(seeds):
+            np.savez(os.path.join(tdir(a), f"seed{s}_{a.build_tag}.npz"), xden=tr[:, b].numpy(), clean=seg[b].cpu().numpy(), n_draws=ns[b].k)
+
+
+def phase_report(a):
+    import numpy as np
+    import torch
+    from buddy_amd.utils.metrics import si_sdr
+    sd = lambda x, y: float(si_sdr(torch.from_numpy(np.asarray(x, dtype=np.float64))[None], torch.from_numpy(np.asarray(y, dtype=np.float64))[None]))
+    others = [v for v in a.variants if v != "fp64"] + [a.build_tag]
+    per_seed, steps = {}, {v: [] for v in others}
+    final, dclean = {v: [] for v in others}, {v: [] for v in others}
+    for s in a.seeds:
+        p64 = os.path.join(tdir(a), f"seed{s}_fp64.npz")
+        if not os.path.exists(p64):
+            continue
+        g = np.load(p64)
+        row = {"fp64_si_sdr_to_clean_dB": sd(g["xden"][-1], g["clean"])}
+        for v in others:
+            pv = os.path.join(tdir(a), f"seed{s}_{v}.npz")
+            if not os.path.exists(pv):
+                continue
+            h = np.load(pv)
+            assert int(h["n_draws"]) == int(g["n_draws"]), "noise streams out of step"
+            ps = [sd(h["xden"][i], g["xden"][i]) for i in range(g["xden"].shape[0])]
+            row[v] = {"per_step_si_sdr_vs_fp64_dB": [round(x, 1) for x in ps], "final_si_sdr_vs_fp64_dB": ps[-1],
+                      "delta_si_sdr_to_clean_dB": sd(h["xden"][-1], g["clean"]) - row["fp64_si_sdr_to_clean_dB"]}
+            steps[v].append(ps); final[v].append(ps[-1]); dclean[v].append(row[v]["delta_si_sdr_to_clean_dB"])
+        per_seed[str(s)] = row
+    summ = {}
+    for v in others:
+        if not steps[v]:
+            continue
+        A = np.array(steps[v])
+        summ[v] = {"n_seeds": int(A.shape[0]), "median_per_step_dB": [round(float(x), 1) for x in np.median(A, 0)],
+                   "min_per_step_dB": [round(float(x), 1) for x in A.min(0)],
+                   "final_vs_fp64_dB": {"median": float(np.median(final[v])), "min": float(np.min(final[v])), "max": float(np.max(final[v]))},
+                   "abs_delta_si_sdr_to_clean_dB": {"median": float(np.median(np.abs(dclean[v]))), "max": float(np.max(np.abs(dclean[v]))),
+                                                    "mean_signed": float(np.mean(dclean[v]))}}
+    verdict = None
+    o32 = [v for v in others if v.startswith("fp32") and v in summ]
+    if a.build_tag in summ and o32:
+        b = np.array(summ[a.build_tag]["median_per_step_dB"])
+        o = np.min(np.array([summ[v]["median_per_step_dB"] for v in o32]), 0)        # the worse of the two fp32 oracle runs, per step
+        verdict = {"build_minus_worst_fp32_oracle_median_dB_per_step": [round(float(x), 1) for x in (b - o)],
+                   "min_margin_dB": float((b - o).min()),
+                   "build_no_worse_than_fp32_oracle_within_3dB_at_every_step": bool(((b - o) > -3.0).all())}
+    print(json.dumps({"config": {"L": a.L, "T": a.T, "nf": a.nf, "op_updates_per_step": a.updates, "rir_taps": a.rir_taps, "seeds": a.seeds,
+                                 "weights": "synth_state_dict(0, nf)", "noise": "NoiseStream(9000 + seed)"},
+                      "summary": summ, "verdict": verdict, "per_seed": per_seed}))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("phase", choices=["oracle", "build", "report", "job"])
+    ap.add_argument("--seeds", default="0-7")
+    ap.add_argument("--L", type=int, default=64000)
+    ap.add_argument("--T", type=int, default=50)
+    ap.add_argument("--nf", type=int, default=128)
+    ap.add_argument("--updates", type=int, default=10)
+    ap.add_argument("--rir_taps", type=int, default=8000)
+    ap.add_argument("--threads", default="8,4", help="thread counts of the two fp32 oracle runs")
+    ap.add_argument("--fp64_threads", type=int, default=8)
+    ap.add_argument("--workers", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--build_tag", default="build")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--variant", default="fp64")
+    a = ap.parse_args()
+    a.seeds = parse_seeds(a.seeds)
+    a.variants = ["fp64"] + [f"fp32t{t}" for t in a.threads.split(",")]
+    a.common = ["--L", str(a.L), "--T", str(a.T), "--nf", str(a.nf), "--updates", str(a.updates), "--rir_taps", str(a.rir_taps),
+                "--fp64_threads", str(a.fp64_threads)]
+    if a.phase == "job":
+        oracle_job(a, a.seed, a.variant)
+    elif a.phase == "oracle":
+        phase_oracle(a)
+    elif a.phase == "build":
+        phase_build(a)
+    else:
+        phase_report(a)
