@@ -118,18 +118,17 @@ def test_optimize_op_vs_reference(golden):
             res[nm] = rel(par[0], g[f"{tag}_{nm}"])
         res["m_phases"] = rel(st["phases"][0][0], g[f"{tag}_m_phases"])
         res["v_phases"] = rel(st["phases"][1][0], g[f"{tag}_v_phases"])
-        # phases move by ~lr * sign(g) per step under Adam: an entry whose gradient is at round-off level can take the other sign on
-        # either implementation; they carry no magnitude (|H| ~ 0 there), so compare what the phases produce: A e^{j phi}
+        # most (frame, bin) entries of the filter sit at the 1e-6 magnitude floor: their phase angle(H) is round-off of the 25 856-point FFTs
+        # on either implementation (77 % of the raw angles differ by > 1e-3 right after the FIRST update_H), and Adam then moves each by
+        # ~lr * sign(g).  They carry no magnitude, so compare what the phases produce: A e^{j phi}
         A = op.design_filter()[0].cpu()
         ph, phr = op.params_phases[0][0].cpu(), torch.from_numpy(g[f"{tag}_phases"])
         res["A_e^jphi"] = rel(torch.view_as_real(A * torch.exp(1j * ph)), torch.view_as_real(A * torch.exp(1j * phr)))
-        res["phase_outliers"] = float(((ph - phr).abs() > 1e-3).float().mean())
         print(tag, {k: f"{v:.2e}" for k, v in res.items()})
         for k in ("m_decay", "m_weights", "m_phases", "v_decay", "v_weights", "v_phases"):
             assert res[k] < tol_m, (tag, k, res[k])
         for k in ("decay", "weights", "A_e^jphi"):
             assert res[k] < tol_p, (tag, k, res[k])
-        assert res["phase_outliers"] < 0.02
         return step
 
     op.hip_optimize(x_den, t)

@@ -41,40 +41,18 @@ def tdir(a):
 
 
 def overrides(a):
-    return [f"tester.sampling_params.T={a.T}", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
-            f"tester.posterior_sampling.blind_hp.op_updates_per_step={a.updates}", f"network.nf={a.nf}"]
+    from oracle.arbiter_runs import overrides as ov
+    return ov(a.T, a.updates, a.nf)
 
 
 def oracle_job(a, seed, variant):
     """one CPU run; variant = fp64 | fp32tN"""
     import numpy as np
-    import torch
-    from buddy_amd.config import compose
-    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
-    from oracle import ncsnpp_ref, operators_ref as O, sampler_ref as S, precision
-    import contextlib
+    from oracle.arbiter_runs import run_blind
     threads = int(variant.split("t")[1]) if variant.startswith("fp32t") else a.fp64_threads
-    torch.set_num_threads(threads)
-    args = compose(overrides=overrides(a))
-    ctx = precision.fp64() if variant == "fp64" else contextlib.nullcontext()
     t0 = time.time()
-    with ctx:
-        dt = torch.get_default_dtype()
-        P = ncsnpp_ref.to_torch(synth_state_dict(0, a.nf))
-        onet = lambda z, cn: ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
-        c0 = torch.from_numpy(synth_clean(seed, a.L)).to(dt)
-        c0 = 0.05 * c0 / c0.std()
-        rir = torch.from_numpy(synth_rir(seed, a.rir_taps)).to(dt)
-        nr = S.NoiseStream(9000 + seed)
-        ref = S.EulerHeunDPSRef(onet, S.EDMRef(args.diff_params.sde_hp), args, nr)
-        op_hp = args.tester.informed_dereverberation.op_hp
-        oo = O.RIROperatorRef(op_hp); oo.update_params(rir)
-        y0 = oo.degradation(c0[None])
-        bo = O.BlindSubbandFilteringRef(op_hp, 16000, nr); bo.update_H(use_noise=True, noise=nr)
-        tr = []
-        ref.predict_conditional(y0, bo, shape=(1, a.L), blind=True, trace=tr)
-    xden = torch.stack([t[1][0] for t in tr]).float().numpy()
-    np.savez(os.path.join(tdir(a), f"seed{seed}_{variant}.npz"), xden=xden, clean=c0.float().numpy(), n_draws=nr.k, seconds=time.time() - t0, threads=threads)
+    xden, c0, k = run_blind(seed, a.L, a.T, a.nf, a.updates, a.rir_taps, fp64=(variant == "fp64"), threads=threads)
+    np.savez(os.path.join(tdir(a), f"seed{seed}_{variant}.npz"), xden=xden.numpy(), clean=c0.numpy(), n_draws=k, seconds=time.time() - t0, threads=threads)
     print(f"seed {seed} {variant}: {time.time() - t0:.0f} s ({threads} threads)", flush=True)
 
 
