@@ -44,3 +44,21 @@ def gather_rows(local, n_items, rank, world):
         idx = shard_indices(n_items, r, world)
         out[idx] = bufs[r][: len(idx)]
     return out
+
+
+def gather_ragged(rows, n_items, rank, world, device=None):
+    """End-of-run gather for the harness: ``rows`` = this rank's 1-D results (utterances ``shard_indices(n_items, rank, world)``, in that
+    order, any lengths) -> list of all ``n_items`` rows in utterance order on every rank.  Two collectives in total (lengths, then the
+    rows zero-padded to the longest): RCCL over xGMI on the GPU box, gloo in the CPU tests."""
+    if world == 1:
+        return list(rows)
+    import torch.distributed as dist
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    lens = torch.tensor([r.shape[-1] for r in rows], dtype=torch.int64, device=dev).reshape(-1, 1)
+    all_lens = gather_rows(lens, n_items, rank, world).reshape(-1)
+    lmax = int(all_lens.max())
+    local = torch.zeros((len(rows), lmax), dtype=torch.float32, device=dev)
+    for i, r in enumerate(rows):
+        local[i, : r.shape[-1]] = r.to(dev)
+    full = gather_rows(local, n_items, rank, world)
+    return [full[i, : int(all_lens[i])] for i in range(n_items)]

@@ -112,13 +112,16 @@ class Tester:
             return
         mine = [i for i in range(len(self.test_set)) if i % self.world_size == self.rank]
         sr = self.args.exp.sample_rate
+        local = {}
         for s in range(0, len(mine), self.batch_size):
             idx = mine[s:s + self.batch_size]
-            items = [self.test_set[i] for i in idx]
+            items = [self.test_set[i] + (i,) for i in idx]
             groups = {}
             for it in items:                      # only equal-length utterances share a batch
                 groups.setdefault(len(it[0]), []).append(it)
             for L, grp in groups.items():
+                uidx = [it[3] for it in grp]
+                grp = [it[:3] for it in grp]
                 # parity runs: one injected noise stream per utterance, shared by the sampler AND the blind operator (random phases,
                 # update_H(use_noise=True), per-step RIR-regulariser draws) in the reference's call order; otherwise the torch RNG
                 self.sampler.noise = self.noise_factory([it[2] for it in grp]) if getattr(self, "noise_factory", None) is not None else None
@@ -128,6 +131,7 @@ class Tester:
                 for b, (_, _, filename) in enumerate(grp):
                     name = os.path.basename(filename)[:-4]
                     self.results.append((name, pred[b].detach().cpu()))
+                    local[uidx[b]] = pred[b].detach()
                     if self.in_training or not self.paths:
                         continue
                     write_audio_file(seg[b], sr, name, path=self.paths[mode + "original"])
@@ -137,6 +141,11 @@ class Tester:
                     if blind:
                         write_audio_file(est[b] if est.dim() == 2 else est, sr, name, path=self.paths[mode + "estimated_rir"])
                     print(p)
+        # utterance-batch data parallelism: ONE gather at the end of the run (RCCL over xGMI on the GPU box) -- afterwards every rank, in
+        # particular rank 0, holds all predictions in utterance order, independent of the world size
+        from .. import dist as bdist
+        rows = bdist.gather_ragged([local[i] for i in mine], len(self.test_set), self.rank, self.world_size, device=self.device)
+        self.gathered = [(os.path.basename(self.test_set[i][2])[:-4], rows[i].detach().cpu()) for i in range(len(self.test_set))]
 
     def prepare_directories(self, mode, unconditional=False, blind=False):
         today = date.today()

@@ -61,3 +61,27 @@ def test_two_ranks_equal_single_process(tmp_path):
     assert gathered.shape == (n_utts, L)
     err = float((gathered - single).abs().max() / single.abs().max())
     assert err < 1e-4, err
+
+
+def _ragged_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from buddy_amd import dist as bd
+    bd.init(backend="gloo")
+    lengths = [5000, 4096, 7001, 300, 4096]
+    mine = bd.shard_indices(len(lengths), rank, world)
+    rows = [torch.full((lengths[i],), float(i + 1)) + torch.arange(lengths[i]) * 1e-4 for i in mine]
+    full = bd.gather_ragged(rows, len(lengths), rank, world)
+    ok = all(full[i].shape[0] == lengths[i] and torch.equal(full[i], torch.full((lengths[i],), float(i + 1)) + torch.arange(lengths[i]) * 1e-4)
+             for i in range(len(lengths)))
+    torch.save(ok, out_path + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_ragged_rows_two_ranks(tmp_path):
+    """the harness's end-of-run gather: utterances of different lengths, uneven shards, every rank ends up with all rows in order"""
+    out_path = str(tmp_path / "ok")
+    mp.spawn(_ragged_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    assert torch.load(out_path + ".0") is True and torch.load(out_path + ".1") is True

@@ -1,0 +1,63 @@
+"""GPU: utterance-sharded data parallelism through the harness (Tester + dist.gather_ragged) with TWO ranks sharing the one GPU of the
+test box (gloo control plane, HIP compute): after the end-of-run gather rank 0 holds every prediction, bit-identical to the single-process
+run with the same injected noise streams (results are independent of the world size)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LENGTHS = [8192, 6000, 8192]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _run(rank, world):
+    sys.path.insert(0, ROOT)
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
+    from buddy_amd.testing.tester import Tester
+    from oracle.sampler_ref import NoiseStream
+    args = compose(overrides=["tester.sampling_params.T=2", "network.nf=32", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+                              "tester.posterior_sampling.blind_hp.op_updates_per_step=2"])
+    net = instantiate(args.network)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(2, 32).items()})
+    net = net.cuda().eval()
+    items = [(synth_clean(u, L), synth_rir(u, 1500), f"u{u}.wav") for u, L in enumerate(LENGTHS)]
+    t = Tester(args, net, instantiate(args.diff_params), test_set=items, device="cuda", in_training=True, batch_size=1, rank=rank, world_size=world)
+    t.noise_factory = lambda names: [NoiseStream(700 + int(n[1:-4])) for n in names]
+    t.test_dereverberation("blind_dereverberation", blind=True)
+    return t.gathered
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from buddy_amd import dist as bd
+    bd.init(backend="gloo")
+    g = _run(rank, world)
+    if rank == 0:
+        torch.save(g, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_equal_single_process(tmp_path):
+    out_path = str(tmp_path / "g.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    got = torch.load(out_path)
+    ref = _run(0, 1)
+    assert [n for n, _ in got] == [n for n, _ in ref] == ["u0", "u1", "u2"]
+    for (n, a), (_, b), L in zip(got, ref, LENGTHS):
+        assert a.shape == (L,) and torch.isfinite(a).all()
+        assert torch.equal(a, b), (n, float((a - b).abs().max()))

@@ -3,7 +3,7 @@ usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter
 A 3x3 convolution is three launches (w4_input_kernel, the 36-batch igemm_kernel<...,36>, w4_output_kernel); their counters are summed and
 divided by the number of convolutions (= w4_input launches).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the
 bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> doubled here."""
-import csv, json, sys
+import csv, hashlib, json, os, sys
 
 GROUP = ("w4_input_kernel", "2, 2, 36>", "w4_output_kernel")
 
@@ -25,8 +25,16 @@ out = {"kernel_group": "3x3 convolution = w4_input_kernel + igemm_kernel<1,false
        "convolutions_in_fetch_pass": nconv, "convolutions_in_write_pass": w[GROUP[0]][1],
        "per_kernel_bytes_per_convolution": {k: {"fetch": 2 * f[k][0] * 1024 / nconv, "write": w[k][0] * 1024 / max(1, w[GROUP[0]][1])} for k in GROUP},
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`; FETCH_SIZE x2 (gfx950 correction)"}
+_h = hashlib.sha1()
+for _f in ("igemm.hip", "wino4.hip", "common.h"):        # same stamp as bench.py conv_source_stamp(): the summary is tied to these kernels
+    _h.update(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "buddy_amd", "csrc", _f), "rb").read())
+out["source_stamp"] = _h.hexdigest()[:12]
 out["fetch_bytes_per_launch"] = sum(v["fetch"] for v in out["per_kernel_bytes_per_convolution"].values())
 out["write_bytes_per_launch"] = sum(v["write"] for v in out["per_kernel_bytes_per_convolution"].values())
-out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+out["hbm_bytes_per_launch"] = _h = hashlib.sha1()
+for _f in ("igemm.hip", "wino4.hip", "common.h"):        # same stamp as bench.py conv_source_stamp(): the summary is tied to these kernels
+    _h.update(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "buddy_amd", "csrc", _f), "rb").read())
+out["source_stamp"] = _h.hexdigest()[:12]
+out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out)[:900])
