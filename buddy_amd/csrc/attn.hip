@@ -1,0 +1,289 @@
+// Single-head self-attention over all H*W positions without materialising the T x T matrix (gfx950, fp32 MFMA 16x16x4, wave64).
+// Replaces the three einsum / softmax steps of reference AttnBlockpp.forward (networks/ncsnpp_utils/layerspp.py:82-86):
+//     w = einsum('bchw,bcij->bhwij', q, k) * C^-0.5 ; w = softmax(w over ij) ; h = einsum('bhwij,bcij->bchw', w, v)
+// and their gradients.  q, k, v, O and all gradients are token-major [B][T][C] (NHWC activations flattened), C in {64, 128, 256}.
+//
+// Forward  (flash_fwd_kernel): a workgroup owns 64 query rows (4 waves x 16 rows), walks the keys / values in blocks of 32 staged through
+//   LDS; per block: S = q K^T (MFMA, q fragments live in registers), online softmax with the running row max / row sum kept per lane and
+//   reduced across the 16 lanes that share a row by wave shuffles, P -> wave-private LDS tile -> A operand of O += P V.  Writes O and the
+//   row log-sum-exp L = m + log(l).  The 905 MB/utterance attention matrix of a 30 s input is never formed.
+// Backward (two kernels, no atomics, deterministic): with D = rowsum(dO o O),
+//   flash_bwd_dq_kernel  per 64 query rows:  P = exp(S - L), dP = dO V^T, dS = P o (dP - D) * scale, dq += dS K
+//   flash_bwd_dkv_kernel per 64 key rows:    the same tiles transposed (S^T = K q^T, dP^T = V dO^T), dv += P^T dO, dk += dS^T q
+// Everything is fp32 (exact-fp32 MFMA, expf/logf); only the summation order differs from the materialised form.
+#include "common.h"
+
+namespace buddy {
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int BR = 64, BC = 32, PLD = BC + 4;
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ f32x4 zero_acc() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+// reduce over the 16 lanes that hold one accumulator row (lanes with equal lane >> 4)
+__device__ __forceinline__ float row_max16(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float row_sum16(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// stage rows [r0, r0 + 32) of a [T][C] matrix into LDS [32][C + 4] (rows >= T zero-filled)
+template <int C>
+__device__ __forceinline__ void stage32(const float* __restrict__ src, int r0, int T, float* dst) {
+  constexpr int LD = C + 4, Q = C / 4;
+  for (int i = threadIdx.x; i < 32 * Q; i += 256) {
+    const int r = i / Q, c = (i - r * Q) * 4;
+    const float4 v = (r0 + r < T) ? ld4(src + (long long)(r0 + r) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(dst + r * LD + c) = v;
+  }
+}
+
+// acc[t] (16 x 16, t = 0, 1) = sum_k A[row][k] * Bs[16 t + col][k]  with A in registers (float4 per 16-wide k chunk) and Bs in LDS
+template <int C>
+__device__ __forceinline__ void tile_abt(const float4 (&a)[C / 16], const float* Bs, int i, int g, f32x4 (&acc)[2]) {
+  constexpr int LD = C + 4;
+#pragma unroll
+  for (int kk = 0; kk < C / 16; ++kk) {
+    const float av[4] = {a[kk].x, a[kk].y, a[kk].z, a[kk].w};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 b = *reinterpret_cast<const float4*>(Bs + (16 * t + i) * LD + 16 * kk + 4 * g);
+      const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[t], 0, 0, 0);
+    }
+  }
+}
+// o[c] (16 x 16 each, c < C / 16) += Ps[row][k] * Bs[k][16 c + col], k < 32; Ps is the wave's 16 x 32 tile in LDS (row stride PLD)
+template <int C>
+__device__ __forceinline__ void tile_pb(const float* Ps, const float* Bs, int i, int g, f32x4 (&o)[C / 16]) {
+  constexpr int LD = C + 4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 p = *reinterpret_cast<const float4*>(Ps + i * PLD + 16 * h + 4 * g);
+    const float pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* brow = Bs + (16 * h + 4 * g + j) * LD + i;
+#pragma unroll
+      for (int c = 0; c < C / 16; ++c) o[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[j], brow[16 * c], o[c], 0, 0, 0);
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void flash_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                        float* __restrict__ O, float* __restrict__ Lse, int T, float scale) {
+  constexpr int LD = C + 4;
+  __shared__ __attribute__((aligned(16))) float Ks[32 * LD];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * LD];
+  __shared__ __attribute__((aligned(16))) float Ps[4][16 * PLD];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const long long base = (long long)b * T * C;
+  const int row_a = blockIdx.x * BR + 16 * w + i;            // this lane's A-operand row
+  const int row0 = blockIdx.x * BR + 16 * w + 4 * g;         // first of this lane's four accumulator rows
+  float4 qa[C / 16];
+#pragma unroll
+  for (int kk = 0; kk < C / 16; ++kk) qa[kk] = row_a < T ? ld4(q + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x4 o[C / 16];
+#pragma unroll
+  for (int c = 0; c < C / 16; ++c) o[c] = zero_acc();
+  float m[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+  for (int j0 = 0; j0 < T; j0 += BC) {
+    __syncthreads();
+    stage32<C>(k + base, j0, T, Ks);
+    stage32<C>(v + base, j0, T, Vs);
+    __syncthreads();
+    f32x4 s[2] = {zero_acc(), zero_acc()};
+    tile_abt<C>(qa, Ks, i, g, s);
+    float alpha[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s0 = (j0 + i < T) ? s[0][r] * scale : -INFINITY;
+      float s1 = (j0 + 16 + i < T) ? s[1][r] * scale : -INFINITY;
+      const float mx = row_max16(fmaxf(s0, s1));
+      const float mn = fmaxf(m[r], mx);                       // finite: column j0 of every block is valid
+      alpha[r] = expf(m[r] - mn);
+      s0 = expf(s0 - mn); s1 = expf(s1 - mn);
+      l[r] = l[r] * alpha[r] + row_sum16(s0 + s1);
+      m[r] = mn;
+      Ps[w][(4 * g + r) * PLD + i] = s0;
+      Ps[w][(4 * g + r) * PLD + 16 + i] = s1;
+    }
+#pragma unroll
+    for (int c = 0; c < C / 16; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[c][r] *= alpha[r];
+    __syncthreads();
+    tile_pb<C>(Ps[w], Vs, i, g, o);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + r;
+    if (row >= T) continue;
+    const float inv = 1.f / l[r];
+#pragma unroll
+    for (int c = 0; c < C / 16; ++c) O[base + (long long)row * C + 16 * c + i] = o[c][r] * inv;
+    if (i == 0) Lse[(long long)b * T + row] = m[r] + logf(l[r]);
+  }
+}
+
+// D[b][t] = sum_c dO * O
+template <int C>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ D, long long rows) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float acc = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const float4 a = ld4(dO + row * C + c), o = ld4(O + row * C + c);
+    acc += a.x * o.x + a.y * o.y + a.z * o.z + a.w * o.w;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) D[row] = acc;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                           const float* __restrict__ dO, const float* __restrict__ Lse, const float* __restrict__ D,
+                                                           float* __restrict__ dq, int T, float scale) {
+  constexpr int LD = C + 4;
+  __shared__ __attribute__((aligned(16))) float Ks[32 * LD];
+  __shared__ __attribute__((aligned(16))) float Vs[32 * LD];
+  __shared__ __attribute__((aligned(16))) float Ps[4][16 * PLD];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const long long base = (long long)b * T * C;
+  const int row_a = blockIdx.x * BR + 16 * w + i, row0 = blockIdx.x * BR + 16 * w + 4 * g;
+  float4 qa[C / 16], da[C / 16];
+#pragma unroll
+  for (int kk = 0; kk < C / 16; ++kk) {
+    qa[kk] = row_a < T ? ld4(q + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    da[kk] = row_a < T ? ld4(dO + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float lse[4], dl[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = row0 + r < T;
+    lse[r] = ok ? Lse[(long long)b * T + row0 + r] : 0.f;
+    dl[r] = ok ? D[(long long)b * T + row0 + r] : 0.f;
+  }
+  f32x4 acc[C / 16];
+#pragma unroll
+  for (int c = 0; c < C / 16; ++c) acc[c] = zero_acc();
+  for (int j0 = 0; j0 < T; j0 += BC) {
+    __syncthreads();
+    stage32<C>(k + base, j0, T, Ks);
+    stage32<C>(v + base, j0, T, Vs);
+    __syncthreads();
+    f32x4 s[2] = {zero_acc(), zero_acc()}, dp[2] = {zero_acc(), zero_acc()};
+    tile_abt<C>(qa, Ks, i, g, s);
+    tile_abt<C>(da, Vs, i, g, dp);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bool ok = (j0 + 16 * t + i < T) && (row0 + r < T);
+        const float p = ok ? expf(s[t][r] * scale - lse[r]) : 0.f;
+        Ps[w][(4 * g + r) * PLD + 16 * t + i] = p * (dp[t][r] - dl[r]) * scale;
+      }
+    }
+    __syncthreads();
+    tile_pb<C>(Ps[w], Ks, i, g, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + r;
+    if (row >= T) continue;
+#pragma unroll
+    for (int c = 0; c < C / 16; ++c) dq[base + (long long)row * C + 16 * c + i] = acc[c][r];
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                            const float* __restrict__ dO, const float* __restrict__ Lse, const float* __restrict__ D,
+                                                            float* __restrict__ dk, float* __restrict__ dv, int T, float scale) {
+  constexpr int LD = C + 4;
+  __shared__ __attribute__((aligned(16))) float Qs[32 * LD];
+  __shared__ __attribute__((aligned(16))) float Os[32 * LD];          // dO rows of the current query block
+  __shared__ __attribute__((aligned(16))) float Ps[4][16 * PLD];      // P^T tile
+  __shared__ __attribute__((aligned(16))) float Ss[4][16 * PLD];      // dS^T tile
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const long long base = (long long)b * T * C;
+  const int row_a = blockIdx.x * BR + 16 * w + i, row0 = blockIdx.x * BR + 16 * w + 4 * g;     // key / value rows
+  float4 ka[C / 16], va[C / 16];
+#pragma unroll
+  for (int kk = 0; kk < C / 16; ++kk) {
+    ka[kk] = row_a < T ? ld4(k + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    va[kk] = row_a < T ? ld4(v + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  f32x4 gk[C / 16], gv[C / 16];
+#pragma unroll
+  for (int c = 0; c < C / 16; ++c) { gk[c] = zero_acc(); gv[c] = zero_acc(); }
+  for (int i0 = 0; i0 < T; i0 += BC) {
+    __syncthreads();
+    stage32<C>(q + base, i0, T, Qs);
+    stage32<C>(dO + base, i0, T, Os);
+    __syncthreads();
+    f32x4 s[2] = {zero_acc(), zero_acc()}, dp[2] = {zero_acc(), zero_acc()};
+    tile_abt<C>(ka, Qs, i, g, s);              // S^T[key row][query col]
+    tile_abt<C>(va, Os, i, g, dp);             // dP^T
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qc = i0 + 16 * t + i;          // this lane's query column
+      const bool qok = qc < T;
+      const float lse = qok ? Lse[(long long)b * T + qc] : 0.f, dl = qok ? D[(long long)b * T + qc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = (qok && row0 + r < T) ? expf(s[t][r] * scale - lse) : 0.f;
+        Ps[w][(4 * g + r) * PLD + 16 * t + i] = p;
+        Ss[w][(4 * g + r) * PLD + 16 * t + i] = p * (dp[t][r] - dl) * scale;
+      }
+    }
+    __syncthreads();
+    tile_pb<C>(Ps[w], Os, i, g, gv);
+    tile_pb<C>(Ss[w], Qs, i, g, gk);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row0 + r;
+    if (row >= T) continue;
+#pragma unroll
+    for (int c = 0; c < C / 16; ++c) {
+      dk[base + (long long)row * C + 16 * c + i] = gk[c][r];
+      dv[base + (long long)row * C + 16 * c + i] = gv[c][r];
+    }
+  }
+}
+}  // namespace
+
+bool flash_attn_supported(int C) { return C == 64 || C == 128 || C == 256; }
+
+// O [B][T][C], Lse [B][T]
+void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, hipStream_t st) {
+  const dim3 grid(cdiv(T, BR), B), block(256);
+  if (C == 64) hipLaunchKernelGGL(flash_fwd_kernel<64>, grid, block, 0, st, q, k, v, O, Lse, T, scale);
+  else if (C == 128) hipLaunchKernelGGL(flash_fwd_kernel<128>, grid, block, 0, st, q, k, v, O, Lse, T, scale);
+  else hipLaunchKernelGGL(flash_fwd_kernel<256>, grid, block, 0, st, q, k, v, O, Lse, T, scale);
+}
+// dq, dk, dv [B][T][C]; D [B][T] scratch
+void launch_flash_attn_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* Lse, float* D, float* dq,
+                           float* dk, float* dv, int B, int T, int C, float scale, hipStream_t st) {
+  const long long rows = (long long)B * T;
+  const dim3 grid(cdiv(T, BR), B), block(256), gd((unsigned)((rows + 3) / 4));
+#define FA_BWD(CC)                                                                                                        \
+  hipLaunchKernelGGL(attn_delta_kernel<CC>, gd, block, 0, st, dO, O, D, rows);                                              \
+  hipLaunchKernelGGL(flash_bwd_dq_kernel<CC>, grid, block, 0, st, q, k, v, dO, Lse, (const float*)D, dq, T, scale);         \
+  hipLaunchKernelGGL(flash_bwd_dkv_kernel<CC>, grid, block, 0, st, q, k, v, dO, Lse, (const float*)D, dk, dv, T, scale);
+  if (C == 64) { FA_BWD(64) } else if (C == 128) { FA_BWD(128) } else { FA_BWD(256) }
+#undef FA_BWD
+}
+
+}  // namespace buddy

@@ -181,6 +181,20 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
   return finish();
 }
 
+int buddy_flash_attention_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, void* stream) {
+  if (!q || !k || !v || !O || !lse || B < 1 || T < 1 || !flash_attn_supported(C)) { set_error("bad attention arguments (C in {64, 128, 256})"); return BUDDY_ERR_ARG; }
+  launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, (hipStream_t)stream);
+  return finish();
+}
+int buddy_flash_attention_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta, float* dq,
+                              float* dk, float* dv, int B, int T, int C, float scale, void* stream) {
+  if (!q || !k || !v || !O || !dO || !lse || !delta || !dq || !dk || !dv || B < 1 || T < 1 || !flash_attn_supported(C)) {
+    set_error("bad attention arguments (C in {64, 128, 256})"); return BUDDY_ERR_ARG;
+  }
+  launch_flash_attn_bwd(q, k, v, O, dO, lse, delta, dq, dk, dv, B, T, C, scale, (hipStream_t)stream);
+  return finish();
+}
+
 int buddy_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, void* stream) {
   if (!x || !a || !out || (y && !c)) { set_error("null argument"); return BUDDY_ERR_ARG; }
   launch_axpby_rows(x, y, a, c, out, B, L, (hipStream_t)stream);

@@ -512,7 +512,61 @@ static void gemm_b(Net* N, const float* A, int ldA, long long sA, bool tA, const
   launch_igemm(p, 1, tA, tB, batch, N->st);
 }
 
+// BUDDY_ATTN=matrix keeps the materialised T x T form (P in HBM: 16.8 MB / utterance at 4 s, 905 MB at 30 s); default = flash (attn.hip)
+static bool attn_use_flash(int C) {
+  static const bool want_matrix = getenv("BUDDY_ATTN") && std::string(getenv("BUDDY_ATTN")) == "matrix";
+  return !want_matrix && flash_attn_supported(C);
+}
+
+static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
+  const int B = x->B, H = x->H, W = x->W, C = A.C, T = H * W, G = gn_groups(C);
+  hipStream_t st = N->st;
+  const float scale = 1.f / std::sqrt((float)C);
+  const long long BTC = (long long)B * T * C;
+  Tens* out = N->mk(B, H, W, C, rec);
+  float* stats = N->tmp((long long)B * G * 2);
+  float* q = N->tmp(BTC); float* k = N->tmp(BTC); float* v = N->tmp(BTC); float* O = N->tmp(BTC);
+  float* lse = N->tmp((long long)B * T);
+  const size_t mark = N->arena.off;
+  float* hn = N->tmp(BTC);
+  if (!N->dry()) {
+    launch_gn_stats(single(x->p, C), B, T, C, G, 1e-6f, N->partial, stats, st);
+    launch_gn_apply(single(x->p, C), stats, A.gn.gamma, A.gn.beta, B, H, W, C, G, 0, 0, hn, nullptr, st);
+    gemm_b(N, hn, C, 0, false, A.Wt[0], C, 0, false, q, C, 0, B * T, C, C, A.b[0], nullptr, 1.f, 0, 1);
+    gemm_b(N, hn, C, 0, false, A.Wt[1], C, 0, false, k, C, 0, B * T, C, C, A.b[1], nullptr, 1.f, 0, 1);
+    gemm_b(N, hn, C, 0, false, A.Wt[2], C, 0, false, v, C, 0, B * T, C, C, A.b[2], nullptr, 1.f, 0, 1);
+    launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, st);
+    IgemmParams p = ig_base();
+    p.A0 = O; p.ldA0 = C; p.Cin = C; p.M = B * T; p.N = C; p.Bt = A.Wt[3]; p.ldB = C; p.C = out->p; p.ldC = C; p.bias_n = A.b[3];
+    p.res = x->p; p.ldRes = C; p.res_mode = 1; p.out_scale = INV_SQRT2;
+    launch_igemm(p, 1, false, false, 1, st);
+  }
+  N->arena.off = mark;
+  if (rec) {
+    const AttnW* Ap = &A;
+    N->tape.push_back([=]() {
+      Net* n = N; hipStream_t s = n->st;
+      const size_t mk = n->arena.off;
+      const float* dout = out->g;
+      float* dO = n->tmp(BTC); float* dq = n->tmp(BTC); float* dk = n->tmp(BTC); float* dv = n->tmp(BTC); float* dhn = n->tmp(BTC);
+      float* dl = n->tmp((long long)B * T);
+      gemm_b(n, dout, C, 0, false, Ap->Wn[3], C, 0, false, dO, C, 0, B * T, C, C, nullptr, nullptr, INV_SQRT2, 0, 1);
+      if (!n->dry()) launch_flash_attn_bwd(q, k, v, O, dO, lse, dl, dq, dk, dv, B, T, C, scale, s);
+      gemm_b(n, dq, C, 0, false, Ap->Wn[0], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 0, 1);
+      gemm_b(n, dk, C, 0, false, Ap->Wn[1], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);
+      gemm_b(n, dv, C, 0, false, Ap->Wn[2], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);
+      View xv; xv.a = x;
+      Dst2 d = gdst_of(xv);
+      if (!n->dry())
+        launch_gn_bwd(single(x->p, C), stats, Ap->gn.gamma, Ap->gn.beta, dhn, B, H, W, C, G, 0, 0, dout, 1, INV_SQRT2, n->partial, n->red, d, s);
+      n->arena.off = mk;
+    });
+  }
+  return out;
+}
+
 static Tens* attnblock(Net* N, const AttnW& A, Tens* x, bool rec) {
+  if (attn_use_flash(A.C)) return attnblock_flash(N, A, x, rec);
   const int B = x->B, H = x->H, W = x->W, C = A.C, T = H * W, G = gn_groups(C);
   hipStream_t st = N->st;
   const float scale = 1.f / std::sqrt((float)C);

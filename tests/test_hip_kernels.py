@@ -211,3 +211,28 @@ def test_wpe_kernel_vs_torch_restatement(lib):
     Zt = wpe.wpe(Y, taps=7, delay=3, iterations=2)
     Zh = wpe.wpe_hip(Y, taps=7, delay=3, iterations=2)
     assert float((torch.view_as_real(Zh) - torch.view_as_real(Zt)).abs().max() / torch.view_as_real(Zt).abs().max()) < 1e-9
+
+
+@pytest.mark.parametrize("B,T,Cc", [(2, 2048, 256), (3, 144, 64), (1, 320, 128), (2, 1000, 256)])
+def test_flash_attention_fwd_bwd(lib, B, T, Cc):
+    """online-softmax attention (no T x T matrix) vs the reference formulation in fp64: w = softmax(q k^T C^-1/2), h = w v
+    (networks/ncsnpp_utils/layerspp.py:82-86) and its three input gradients; ragged T (not a multiple of the 64-row / 32-column blocks)."""
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + T + Cc)
+    q, k, v, dO = (torch.randn(B, T, Cc, generator=g).cuda() for _ in range(4))
+    q = q * 1.5                                                   # some peaky rows
+    scale = Cc ** -0.5
+    O = torch.empty_like(q); lse = torch.empty(B, T, device="cuda")
+    _lib.check(lib.buddy_flash_attention_fwd(P(q), P(k), P(v), P(O), P(lse), B, T, Cc, scale, S()))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    delta = torch.empty(B, T, device="cuda")
+    _lib.check(lib.buddy_flash_attention_bwd(P(q), P(k), P(v), P(O), P(dO), P(lse), P(delta), P(dq), P(dk), P(dv), B, T, Cc, scale, S()))
+    torch.cuda.synchronize()
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    w = torch.softmax(torch.einsum("bic,bjc->bij", qd, kd) * scale, dim=-1)
+    ref = torch.einsum("bij,bjc->bic", w, vd)
+    gq, gk, gv = torch.autograd.grad(ref, (qd, kd, vd), dO.double())
+    lse_ref = torch.logsumexp(torch.einsum("bic,bjc->bij", qd, kd) * scale, dim=-1)
+    assert rel(O, ref.detach()) < 1e-5
+    assert float((lse.double() - lse_ref.detach()).abs().max()) < 1e-4
+    assert rel(dq, gq) < 2e-5 and rel(dk, gk) < 2e-5 and rel(dv, gv) < 2e-5
