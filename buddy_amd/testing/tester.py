@@ -147,6 +147,31 @@ class Tester:
         rows = bdist.gather_ragged([local[i] for i in mine], len(self.test_set), self.rank, self.world_size, device=self.device)
         self.gathered = [(os.path.basename(self.test_set[i][2])[:-4], rows[i].detach().cpu()) for i in range(len(self.test_set))]
 
+    def dereverberate_long(self, original, rir, blind, chunk_seconds=8.0, overlap_seconds=1.0, noise=None):
+        """Long-form policy (testing/longform.py): one long clean/RIR pair -> the reverberant signal cut into overlapping equal chunks,
+        sampled as ONE batch of independent utterances (own operator / RIR estimate each), cross-faded back.  Returns (seg, y, pred)."""
+        from . import longform
+        sr = self.args.exp.sample_rate
+        seg, y, _, _ = self.prepare_batch([(original, rir, "long.wav")], blind=False)
+        chunk, overlap = int(chunk_seconds * sr), int(overlap_seconds * sr)
+        ps = self.args.tester.posterior_sampling
+        op_hp = self.args.tester.informed_dereverberation.op_hp
+
+        def sample_batch(parts):
+            n, clen = parts.shape
+            self.sampler.noise = noise(n) if noise is not None else None
+            if blind:
+                op = BlindSubbandFiltering(op_hp, sample_rate=sr, num_utts=n, noise=self.sampler.noise, device=self.device, length=clen,
+                                           backend=self.blind_backend)
+                op.update_H(use_noise=True)
+            else:
+                op = RIROperator(op_hp, time_kernel_size=len(rir), sample_rate=sr, device=self.device)
+                op.update_params(torch.as_tensor(rir, dtype=torch.float32))
+            return self.sampler.predict_conditional(parts.contiguous(), op, shape=(n, clen), blind=blind)
+
+        pred = longform.predict_chunked(sample_batch, y[0], chunk, overlap)
+        return seg[0], y[0], pred
+
     def prepare_directories(self, mode, unconditional=False, blind=False):
         today = date.today()
         self.paths = {}

@@ -90,8 +90,9 @@ def test_fullsize_adjoint_identity_and_linearity(net):
     assert torch.equal(yb[:1], y0)
 
 
-def test_fullsize_blind_sampler_two_steps_vs_oracle(net):
-    """Two blind DPS steps at full size: utterance 0 of a B=2 batch against the oracle's B=1 run (same noise draws)."""
+def _two_blind_steps_vs_oracle(net, L, B, rir_taps):
+    """Two blind DPS steps (network forward + VJP, HIP operator optimisation, likelihood, fused update): utterance 0 of a batch of B
+    against the oracle's B=1 run (same noise draws)."""
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
@@ -102,9 +103,9 @@ def test_fullsize_blind_sampler_two_steps_vs_oracle(net):
           "tester.posterior_sampling.blind_hp.op_updates_per_step=3"]
     args = compose(overrides=ov)
     edm = instantiate(args.diff_params)
-    items = [(synth_clean(u, L), synth_rir(u, 4000), f"u{u}.wav") for u in range(2)]
+    items = [(synth_clean(u, L), synth_rir(u, rir_taps), f"u{u}.wav") for u in range(B)]
     t = Tester(args, net, edm, test_set=None, device="cuda", in_training=True)
-    ns = [S.NoiseStream(70 + u) for u in range(2)]
+    ns = [S.NoiseStream(70 + u) for u in range(B)]
     t.sampler.noise = ns
     seg, y, op, _ = t.prepare_batch(items, blind=True, noise=ns)
     smp = t.sampler
@@ -143,5 +144,40 @@ def test_fullsize_blind_sampler_two_steps_vs_oracle(net):
         xr, xdr = ref.step(xr, ts[i], ts[i + 1], gm[i], True)
     assert nr.k == ns[0].k
     s = float(si_sdr(x_den[:1].cpu(), xdr))
+    print(f"L={L} B={B}: two blind steps, SI-SDR(build; oracle) = {s:.1f} dB, rel {rel(x_den[:1], xdr):.2e}")
     assert s > 40.0, f"SI-SDR(build; oracle) = {s:.1f} dB"
     assert rel(x_den[:1], xdr) < 1e-2
+
+
+def test_fullsize_blind_sampler_two_steps_vs_oracle(net):
+    _two_blind_steps_vs_oracle(net, 64000, 2, 4000)
+
+
+def test_longform_blind_sampler_two_steps_vs_oracle(net):
+    """BASELINE config 5 shape on one GPU: 30 s utterances (480 000 samples, 15 040 attention tokens through the flash kernel -- no
+    905 MB attention matrix), B = 4, un-chunked."""
+    _two_blind_steps_vs_oracle(net, 480000, 4, 8000)
+
+
+def test_longform_chunked_policy(net):
+    """testing/longform.py through the Tester: a 10 s clip as overlapping 4 s chunks sampled as one batch (informed, 2 steps) and cross-faded;
+    a clip that fits one chunk takes the un-chunked path bit for bit."""
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_clean, synth_rir
+    from buddy_amd.testing.tester import Tester
+    from buddy_amd.utils.metrics import si_sdr
+    from oracle.sampler_ref import NoiseStream
+    args = compose(tester="informed_dereverberation_DPS", overrides=["tester.sampling_params.T=3"])
+    t = Tester(args, net, instantiate(args.diff_params), test_set=None, device="cuda", in_training=True)
+    LL = 160000
+    clean, rir = synth_clean(3, LL), synth_rir(3, 4000)
+    mk = lambda n: [NoiseStream(40 + u) for u in range(n)]
+    seg, y, pred = t.dereverberate_long(clean, rir, blind=False, chunk_seconds=4.0, overlap_seconds=0.5, noise=mk)
+    assert pred.shape == (LL,) and torch.isfinite(pred).all()
+    seg1, y1, whole = t.dereverberate_long(clean, rir, blind=False, chunk_seconds=10.0, overlap_seconds=0.5, noise=mk)
+    t.sampler.noise = mk(1)
+    _, yb, op, _ = t.prepare_batch([(clean, rir, "long.wav")], blind=False)
+    direct = t.sampler.predict_conditional(yb, op, shape=(1, LL), blind=False)
+    assert torch.equal(whole, direct[0])
+    print(f"chunked (4 s / 0.5 s overlap) vs un-chunked, 10 s clip, 3-step informed run: SI-SDR {float(si_sdr(pred[None].cpu(), whole[None].cpu())):.1f} dB")

@@ -266,3 +266,24 @@ def test_load_checkpoint_reference_fallback_chain(tmp_path):
     fresh()
     assert t.load_latest_checkpoint() is True
     assert torch.equal(net.state_dict()[key], ema[key])
+
+
+def test_longform_chunk_plan_and_crossfade():
+    """long-form policy (buddy_amd/testing/longform.py): equal chunks cover the clip, the cross-fade is a partition of unity (chunking the
+    identity sampler returns the input exactly), a clip shorter than one chunk is passed through untouched"""
+    from buddy_amd.testing import longform as lf
+    for L, chunk, ov in [(480000, 128000, 16000), (100001, 64000, 8000), (64000, 64000, 8000), (30000, 64000, 8000), (200000, 64000, 0 + 1)]:
+        starts, clen = lf.chunk_plan(L, chunk, ov)
+        assert starts[0] == 0 and starts[-1] + clen == L
+        assert all(b - a <= clen - ov for a, b in zip(starts, starts[1:]))
+        y = torch.randn(L)
+        parts, st = lf.split(y, chunk, ov)
+        assert parts.shape == (len(starts), clen)
+        if len(starts) > 1:
+            w = lf.crossfade_weights(st, clen, L)
+            tot = torch.zeros(L)
+            for i, s0 in enumerate(st):
+                tot[s0:s0 + clen] += w[i]
+            assert float((tot - 1).abs().max()) < 1e-6 and float(w.min()) >= 0.0
+        out = lf.predict_chunked(lambda p: p, y, chunk, ov)
+        assert out.shape == (L,) and float((out - y).abs().max()) < 1e-6
