@@ -5,6 +5,7 @@
 #include "common.h"
 #include "net.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -201,6 +202,11 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   N->specs = build_specs(cfg);
   if (n != param_count(cfg)) { set_error("parameter blob size mismatch"); delete N; return BUDDY_ERR_ARG; }
   if (cfg.n_fft % 2) { set_error("n_fft must be even"); delete N; return BUDDY_ERR_ARG; }
+  {  // the GroupNorm partial-sum scratch is sized for at most 1024 channels; the widest tensor is a skip concatenation (2 x the level width)
+    int cmax = 0;
+    for (int l = 0; l < cfg.nlev; ++l) cmax = std::max(cmax, cfg.nf * cfg.ch_mult[l]);
+    if (2 * cmax > 1024) { set_error("nf * max(ch_mult) must be <= 512 (concatenated skip tensors of up to 1024 channels)"); delete N; return BUDDY_ERR_ARG; }
+  }
   N->Fb = cfg.n_fft / 2 + 1;
   N->Kp = (cfg.n_fft + 3) / 4 * 4;
   N->pad = cfg.n_fft / 2;

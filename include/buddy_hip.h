@@ -80,7 +80,7 @@ int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, in
 int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                   void* stream);
 /* the same convolution through the fused Winograd F(2x2,3x3) kernel (4*Cin instead of 9*Cin MACs per output, fp32):
- * transform_weights (host -> host): wt[Cout][9*Cin] -> U[Cin/16][16][Cout][16]; conv takes U on the device. */
+ * transform_weights (host -> host): wt[Cout][9*Cin] -> U[Cin/8][16 positions][Cout][8]; conv takes U on the device. */
 int buddy_winograd_transform_weights(const float* wt_host, int Cout, int Cin, float* U_host);
 int buddy_conv3x3_winograd(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
                            void* stream);
