@@ -49,9 +49,9 @@ _SIGS = {
                                       C.c_int, C.c_int, C.c_void_p]),
     "buddy_groupnorm_act_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "buddy_flash_attention_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "buddy_flash_attention_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "buddy_flash_attention_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,
-                                            C.c_void_p]),
+                                            C.c_int, C.c_void_p]),
     "buddy_axpby_rows": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_void_p]),
     "buddy_perturb": (C.c_int, [_f32p, _f32p, C.c_float, _f32p, C.c_longlong, C.c_void_p]),
     "buddy_dps_update": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p,

@@ -523,6 +523,11 @@ static bool attn_use_flash(int C) {
   static const bool want_matrix = getenv("BUDDY_ATTN") && std::string(getenv("BUDDY_ATTN")) == "matrix";
   return !want_matrix && flash_attn_supported(C);
 }
+// BUDDY_ATTN=bf16 | f16: 16-bit MFMA operands in the attention products (opt-in fast mode, not the reference arithmetic)
+static int attn_prec() {
+  static const int p = [] { const char* e = getenv("BUDDY_ATTN"); const std::string m = e ? e : ""; return m == "bf16" ? 1 : m == "f16" ? 2 : 0; }();
+  return p;
+}
 
 static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
   const int B = x->B, H = x->H, W = x->W, C = A.C, T = H * W, G = gn_groups(C);
@@ -541,7 +546,7 @@ static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
     gemm_b(N, hn, C, 0, false, A.Wt[0], C, 0, false, q, C, 0, B * T, C, C, A.b[0], nullptr, 1.f, 0, 1);
     gemm_b(N, hn, C, 0, false, A.Wt[1], C, 0, false, k, C, 0, B * T, C, C, A.b[1], nullptr, 1.f, 0, 1);
     gemm_b(N, hn, C, 0, false, A.Wt[2], C, 0, false, v, C, 0, B * T, C, C, A.b[2], nullptr, 1.f, 0, 1);
-    launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, st);
+    launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, attn_prec(), st);
     IgemmParams p = ig_base();
     p.A0 = O; p.ldA0 = C; p.Cin = C; p.M = B * T; p.N = C; p.Bt = A.Wt[3]; p.ldB = C; p.C = out->p; p.ldC = C; p.bias_n = A.b[3];
     p.res = x->p; p.ldRes = C; p.res_mode = 1; p.out_scale = INV_SQRT2;
@@ -557,7 +562,7 @@ static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
       float* dO = n->tmp(BTC); float* dq = n->tmp(BTC); float* dk = n->tmp(BTC); float* dv = n->tmp(BTC); float* dhn = n->tmp(BTC);
       float* dl = n->tmp((long long)B * T);
       gemm_b(n, dout, C, 0, false, Ap->Wn[3], C, 0, false, dO, C, 0, B * T, C, C, nullptr, nullptr, INV_SQRT2, 0, 1);
-      if (!n->dry()) launch_flash_attn_bwd(q, k, v, O, dO, lse, dl, dq, dk, dv, B, T, C, scale, s);
+      if (!n->dry()) launch_flash_attn_bwd(q, k, v, O, dO, lse, dl, dq, dk, dv, B, T, C, scale, attn_prec(), s);
       gemm_b(n, dq, C, 0, false, Ap->Wn[0], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 0, 1);
       gemm_b(n, dk, C, 0, false, Ap->Wn[1], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);
       gemm_b(n, dv, C, 0, false, Ap->Wn[2], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);

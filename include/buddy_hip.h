@@ -99,10 +99,11 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
 
 /* single-head attention over T tokens without the T x T matrix (online softmax, fp32 MFMA), token-major q, k, v, O [B][T][C], C in {64,128,256}:
  * O = softmax(scale * q k^T) v, lse [B][T] = row log-sum-exp; replaces the einsum / softmax / einsum of AttnBlockpp.forward
- * (networks/ncsnpp_utils/layerspp.py:82-86).  bwd: gradients of the same three steps given dO (delta [B][T] is scratch). */
-int buddy_flash_attention_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, void* stream);
+ * (networks/ncsnpp_utils/layerspp.py:82-86).  bwd: gradients of the same three steps given dO (delta [B][T] is scratch).
+ * prec: 0 = fp32 operands (the reference arithmetic), 1 = bf16, 2 = f16 MFMA operands with fp32 accumulation and fp32 softmax (opt-in fast mode). */
+int buddy_flash_attention_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, int prec, void* stream);
 int buddy_flash_attention_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta,
-                              float* dq, float* dk, float* dv, int B, int T, int C, float scale, void* stream);
+                              float* dq, float* dk, float* dv, int B, int T, int C, float scale, int prec, void* stream);
 
 /* ---- sampler elementwise / reductions (replace the tensor expressions of testing/EulerHeunSampler.py:41-72,
  * testing/EulerHeunSamplerDPS.py:61-69,115-157, diff_params/edm.py:83-96), per-utterance (row) semantics ---- */
