@@ -393,6 +393,97 @@ __global__ __launch_bounds__(256) void fft_stage2_kernel(const float2* y1, float
   }
 }
 
+// ---- 1024-point FFTs for the operator STFT (n_fft 1024, hann(512) zero-padded, hop 128: reference subband_filtering.py:41-80) ----
+// One wave per frame, 16 points per lane, three in-register passes (16 x 16 x 4) with two LDS exchanges:
+//   n = 64 a + r, k = b + 16 (c0 + 4 c1):  W^(nk) = W16^(ab) * W1024^(rb) * W4^(r1 c0) * W64^(r0 c0) * W16^(r0 c1),  r = 16 r1 + r0.
+// Replaces the four DFT-as-GEMM products (forward, inverse and their two adjoints: 2 x 512 x 1028 MACs per frame on the matrix cores) by
+// 5 N log2 N flops per frame; the window, the 1/sqrt(sum w^2) norm, the one-sided factors {1, 2, ..., 2, 1}/N and the scale are folded in.
+constexpr int FLD = 66;                       // LDS row stride (complex) of the [16][64] exchange image
+template <int SGN>
+__device__ __forceinline__ void fft1024_core(float2 (&v)[16], float2* S, const float2* W, int r) {
+  dft16<SGN>(v);                                                       // over a: v[b] = sum_a x[64 a + r] W16^(a b)
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const float2 w = W[(r * b) & 1023];
+    S[b * FLD + r] = cmul(v[b], make_float2(w.x, SGN * w.y));
+  }
+  __syncthreads();
+  const int r0 = r & 15;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                                        // 4-point DFTs over r1, in place
+    const int b = 4 * j + (r >> 4);
+    float2* q = S + b * FLD + r0;
+    const float2 x0 = q[0], x1 = q[16], x2 = q[32], x3 = q[48];
+    const float2 s02 = make_float2(x0.x + x2.x, x0.y + x2.y), d02 = make_float2(x0.x - x2.x, x0.y - x2.y);
+    const float2 s13 = make_float2(x1.x + x3.x, x1.y + x3.y), d13 = make_float2(x1.x - x3.x, x1.y - x3.y);
+    const float2 jd = make_float2(-SGN * d13.y, SGN * d13.x);           // (SGN i) (x1 - x3)
+    const float2 z0 = make_float2(s02.x + s13.x, s02.y + s13.y), z1 = make_float2(d02.x + jd.x, d02.y + jd.y);
+    const float2 z2 = make_float2(s02.x - s13.x, s02.y - s13.y), z3 = make_float2(d02.x - jd.x, d02.y - jd.y);
+    const float2 w1 = W[(16 * r0) & 1023], w2 = W[(32 * r0) & 1023], w3 = W[(48 * r0) & 1023];     // W64^(r0 c0)
+    q[0] = z0;
+    q[16] = cmul(z1, make_float2(w1.x, SGN * w1.y));
+    q[32] = cmul(z2, make_float2(w2.x, SGN * w2.y));
+    q[48] = cmul(z3, make_float2(w3.x, SGN * w3.y));
+  }
+  __syncthreads();
+  const float2* q = S + (r & 15) * FLD + 16 * (r >> 4);               // lane = (b = r & 15, c0 = r >> 4)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = q[i];
+  dft16<SGN>(v);                                                       // over r0: v[c1] = X[r + 64 c1]
+}
+// rows of real, windowed 512-sample frames -> [rows][1028] one-sided spectra.  frame (row) starts at src[(row / Tn) * sA + (row % Tn) * hop];
+// out[k] = fac * (cf ? cf(k) : 1) * sum_n src[n] win[n] exp(-2 pi i k n / 1024)
+__global__ __launch_bounds__(256) void fft1024_r2c_kernel(const float* __restrict__ src, long long sA, int hop, int Tn, long long rows,
+                                                          const float* __restrict__ win, const float2* __restrict__ Wg, float* __restrict__ out,
+                                                          float fac, int cf) {
+  __shared__ float2 W[1024];
+  __shared__ float2 S[4][16 * FLD];
+  for (int i = threadIdx.x; i < 1024; i += 256) W[i] = Wg[i];
+  const int w = threadIdx.x >> 6, r = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + w;
+  const bool ok = row < rows;
+  const float* f = src + (ok ? (row / Tn) * sA + (row % Tn) * (long long)hop : 0);
+  float2 v[16];
+#pragma unroll
+  for (int a = 0; a < 16; ++a) v[a] = (a < 8 && ok) ? make_float2(f[64 * a + r] * win[64 * a + r], 0.f) : make_float2(0.f, 0.f);
+  __syncthreads();
+  fft1024_core<-1>(v, S[w], W, r);
+  if (!ok) return;
+  float2* o = reinterpret_cast<float2*>(out + row * LDSP);
+#pragma unroll
+  for (int c1 = 0; c1 < 8; ++c1) {
+    const int k = r + 64 * c1;
+    const float g = (cf && k != 0) ? 2.f * fac : fac;
+    o[k] = make_float2(v[c1].x * g, v[c1].y * g);
+  }
+  if (r == 0) o[512] = make_float2(v[8].x * fac, v[8].y * fac);
+  if (r == 1) o[513] = make_float2(0.f, 0.f);
+}
+// [rows][1028] one-sided spectra -> [rows][512] real frames: frames[n] = fac * win[n] * Re sum_{k <= 512} (cf ? cf(k) : 1) in[k] exp(+2 pi i k n / 1024)
+__global__ __launch_bounds__(256) void fft1024_c2r_kernel(const float* __restrict__ in, long long rows, const float* __restrict__ win,
+                                                          const float2* __restrict__ Wg, float* __restrict__ frames, float fac, int cf) {
+  __shared__ float2 W[1024];
+  __shared__ float2 S[4][16 * FLD];
+  for (int i = threadIdx.x; i < 1024; i += 256) W[i] = Wg[i];
+  const int w = threadIdx.x >> 6, r = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + w;
+  const bool ok = row < rows;
+  const float2* f = reinterpret_cast<const float2*>(in + (ok ? row : 0) * LDSP);
+  float2 v[16];
+#pragma unroll
+  for (int a = 0; a < 16; ++a) {
+    const int k = 64 * a + r;
+    float2 x = make_float2(0.f, 0.f);
+    if (ok && k <= 512) { x = f[k]; if (cf && k != 0 && k != 512) { x.x *= 2.f; x.y *= 2.f; } }
+    v[a] = x;
+  }
+  __syncthreads();
+  fft1024_core<1>(v, S[w], W, r);
+  if (!ok) return;
+#pragma unroll
+  for (int c1 = 0; c1 < 8; ++c1) { const int n = r + 64 * c1; frames[row * WIN + n] = fac * win[n] * v[c1].x; }
+}
+
 // ---- minimum-phase projection glue (reference reverb_utils.py:9-23) ----
 __global__ __launch_bounds__(256) void mp_pack_kernel(const float* h0, int Lh, float2* hp, int U) {      // hp = [h0, zeros] as complex
   const long long total = (long long)U * N2;
@@ -564,7 +655,7 @@ struct BlindOp {
   float *Bf = nullptr, *Bi = nullptr, *BfT = nullptr, *BiT = nullptr, *ones = nullptr, *env_T = nullptr, *env_d = nullptr, *env_c = nullptr;
   float norm = 1.f;
   int* idx = nullptr; float *frac = nullptr, *corr = nullptr, *dpm = nullptr;
-  float2 *w101 = nullptr, *w256 = nullptr, *twN = nullptr;
+  float2 *w101 = nullptr, *w256 = nullptr, *twN = nullptr, *w1024 = nullptr; float* win = nullptr; bool use_fft = true;
   // parameters + Adam state
   float *decay = nullptr, *wts = nullptr, *phi = nullptr;
   float *m_d = nullptr, *v_d = nullptr, *m_w = nullptr, *v_w = nullptr, *m_p = nullptr, *v_p = nullptr;
@@ -605,26 +696,37 @@ struct BlindOp {
     p.alpha = alpha; p.out_scale = 1.f; p.H = 1; p.W = 1; p.rows_per_batch = 1;
     launch_igemm(p, 1, false, tB, batch, st);
   }
+  // the four STFT-type transforms: 1024-point FFT kernels (default) or DFT-as-GEMM on the matrix cores (BUDDY_OP_FFT=0)
+  void r2c(const float* src, long long sA, int hop, int Tn, long long rows, float* out, float fac, int cf) {
+    hipLaunchKernelGGL(fft1024_r2c_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src, sA, hop, Tn, rows, (const float*)win, (const float2*)w1024, out, fac, cf);
+  }
+  void c2r(const float* in, long long rows, float* fr, float fac, int cf) {
+    hipLaunchKernelGGL(fft1024_c2r_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, in, rows, (const float*)win, (const float2*)w1024, fr, fac, cf);
+  }
   // X[u][t][:] = scale * STFT frames of s (frame t starts at sample 128 t - P), Tn frames
   void stft(const float* s, int Ls, int P, int Tn, float scale, float* X, const float* add = nullptr, float add_scale = 0.f, const float* add_scale_dev = nullptr) {
     const int Lpad = ((Tn - 1) * HOP + WIN + 3) / 4 * 4;
     hipLaunchKernelGGL(pad_const_kernel, dim3(gridf((long long)U * Lpad)), dim3(256), 0, st, s, sp, U, Ls, P, Lpad, add, add_scale, add_scale_dev);
-    gemm(sp, HOP, Lpad, Bf, WIN, false, X, LDSP, (long long)Tn * LDSP, Tn, LDSP, WIN, scale, U);
+    if (use_fft) r2c(sp, Lpad, HOP, Tn, (long long)U * Tn, X, scale, 0);
+    else gemm(sp, HOP, Lpad, Bf, WIN, false, X, LDSP, (long long)Tn * LDSP, Tn, LDSP, WIN, scale, U);
   }
   // y[u][s] = sum_t frames_t[s + Q - 128 t] * inv_env[s + Q],  frames = scale * iDFT(Y) * window
   void istft(const float* Y, int Tn, int Q, const float* inv_env, int Ls, float scale, float* y) {
-    gemm(Y, LDSP, 0, Bi, LDSP, false, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
+    if (use_fft) c2r(Y, (long long)U * Tn, frames, scale / NFFT, 1);
+    else gemm(Y, LDSP, 0, Bi, LDSP, false, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
     launch_ola(frames, WIN, Tn, WIN, HOP, inv_env, y, U, Ls, Q, nullptr, nullptr, nullptr, st);
   }
   // adjoint of stft: g_s from G_X
   void stft_adj(const float* GX, int Ls, int P, int Tn, float scale, float* gs) {
-    gemm(GX, LDSP, 0, BfT, LDSP, false, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
+    if (use_fft) c2r(GX, (long long)U * Tn, frames, scale, 0);
+    else gemm(GX, LDSP, 0, BfT, LDSP, false, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
     launch_ola(frames, WIN, Tn, WIN, HOP, ones, gs, U, Ls, P, nullptr, nullptr, nullptr, st);
   }
   // adjoint of istft: G_Y from g_y
   void istft_adj(const float* gy, int Tn, int Q, const float* inv_env, int Ls, float scale, float* GY) {
     launch_ola_adj(gy, U, Ls, Q, Tn, WIN, HOP, inv_env, nullptr, frames, WIN, st);
-    gemm(frames, WIN, 0, BiT, WIN, false, GY, LDSP, 0, U * Tn, LDSP, WIN, scale, 1);
+    if (use_fft) r2c(frames, 0, WIN, U * Tn, (long long)U * Tn, GY, scale / NFFT, 1);
+    else gemm(frames, WIN, 0, BiT, WIN, false, GY, LDSP, 0, U * Tn, LDSP, WIN, scale, 1);
   }
   void fft(const float2* x, float2* tmp, float2* X, int sign, float scale) {
     hipLaunchKernelGGL(fft_stage1_kernel, dim3(F2 / S1_COLS, U), dim3(256), 0, st, x, tmp, (const float2*)w101, (const float2*)twN, sign);
@@ -762,6 +864,10 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
     tw[(size_t)n2 * F1 + k1] = make_float2((float)std::cos(a), (float)(std::sin(a)));
   }
   UP(w101, w101); UP(w256, w256); UP(twN, tw);
+  { std::vector<float2> w1k(1024);
+    for (int i = 0; i < 1024; ++i) w1k[i] = make_float2((float)std::cos(2 * PI * i / 1024), (float)std::sin(2 * PI * i / 1024));
+    UP(w1024, w1k); UP(win, w);
+    o->use_fft = !(getenv("BUDDY_OP_FFT") && atoi(getenv("BUDDY_OP_FFT")) == 0); }
   const int U_ = U, Nf = cfg.Nf, Td = o->Td;
   const int T = o->T > Td ? o->T : Td;            // work buffers hold either the signal (T frames) or the time-RIR (Td frames)
   const int Lmax = L > o->Lr ? L : o->Lr;

@@ -8,6 +8,8 @@
 // Transform constants are the standard interpolation points {0, +-1, +-2, inf}; everything stays fp32 (round-off grows by about one decimal
 // digit over the direct form: unit test tolerance 1e-4 instead of 2e-5).
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -38,13 +40,14 @@ __device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&y)[4]) {
 }
 
 // thread = (tile, channel quad); V[(pos * Mt + tile) * Cin + c]
-__global__ __launch_bounds__(256) void w4_input_kernel(const float* __restrict__ x, int ldX, float* __restrict__ V, int B, int H, int W, int Cin) {
+// tile0 / Mc: this launch covers tiles [tile0, tile0 + Mc) and V holds only that chunk (whole tensor: tile0 = 0, Mc = all tiles)
+__global__ __launch_bounds__(256) void w4_input_kernel(const float* __restrict__ x, int ldX, float* __restrict__ V, int B, int H, int W, int Cin,
+                                                       long long tile0, long long Mc) {
   const int q = Cin >> 2, TH = H >> 2, TW = W >> 2;
-  const long long Mt = (long long)B * TH * TW;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Mt * q) return;
+  if (idx >= Mc * q) return;
   const int c = (int)(idx % q) * 4;
-  const long long tile = idx / q;
+  const long long ltile = idx / q, tile = tile0 + ltile;
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
   const int gy0 = 4 * ty - 1, gx0 = 4 * tx - 1;
   float4 d[6][6];
@@ -65,8 +68,8 @@ __global__ __launch_bounds__(256) void w4_input_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 6; ++r) d[r][cc] = t[r];
   }
-  float* out = V + tile * Cin + c;
-  const long long ps = Mt * Cin;
+  float* out = V + ltile * Cin + c;
+  const long long ps = Mc * Cin;
 #pragma unroll
   for (int r = 0; r < 6; ++r) {                             // rows: v[r, :] = t[r, :] B
     float4 t[6];
@@ -77,17 +80,16 @@ __global__ __launch_bounds__(256) void w4_input_kernel(const float* __restrict__
 }
 
 // thread = (tile, cout quad); Mb[(pos * Mt + tile) * N + n]
-__global__ __launch_bounds__(256) void w4_output_kernel(const float* __restrict__ Mb, const IgemmParams p, int B) {
+__global__ __launch_bounds__(256) void w4_output_kernel(const float* __restrict__ Mb, const IgemmParams p, int B, long long tile0, long long Mc) {
   const int H = p.H, W = p.W, N = p.N;
   const int q = N >> 2, TH = H >> 2, TW = W >> 2;
-  const long long Mt = (long long)B * TH * TW;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Mt * q) return;
+  if (idx >= Mc * q) return;
   const int n = (int)(idx % q) * 4;
-  const long long tile = idx / q;
+  const long long ltile = idx / q, tile = tile0 + ltile;
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
-  const float* src = Mb + tile * N + n;
-  const long long ps = Mt * N;
+  const float* src = Mb + ltile * N + n;
+  const long long ps = Mc * N;
   float4 s[4][6];                                          // s = A^T m  (4 x 6)
 #pragma unroll
   for (int cc = 0; cc < 6; ++cc) {
@@ -134,25 +136,37 @@ void wino4_scratch(const IgemmParams& p, long long* v_floats, long long* m_float
   *v_floats = 36 * Mt * p.Cin; *m_floats = 36 * Mt * p.N;
 }
 
+// BUDDY_W4_CHUNK=<tiles>: run the three passes chunk by chunk over the tile dimension, so that the transformed operands of a chunk (36 x chunk x
+// (Cin + Cout) floats, the SAME scratch addresses for every chunk) are produced and consumed while they are still in the 256 MB Infinity Cache.
+static long long w4_chunk_tiles() {
+  static const long long c = getenv("BUDDY_W4_CHUNK") ? atoll(getenv("BUDDY_W4_CHUNK")) : 0;
+  return c;
+}
 void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st) {
   const int B = p.M / (p.H * p.W);
   const long long Mt = (long long)p.M / 16;
   const bool prof = igemm_prof_enabled();                   // the caller brackets the three passes as ONE 3x3 convolution; passes timed here
+  long long chunk = w4_chunk_tiles();
+  if (chunk <= 0 || chunk >= Mt || prof) chunk = Mt;
+  else chunk = (chunk + 127) / 128 * 128;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   if (prof) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], st); }
-  hipLaunchKernelGGL(w4_input_kernel, dim3((unsigned)((Mt * (p.Cin / 4) + 255) / 256)), dim3(256), 0, st, p.A0, p.ldA0, V, B, p.H, p.W, p.Cin);
-  if (prof) (void)hipEventRecord(ev[1], st);
-  IgemmParams g; std::memset(&g, 0, sizeof(g));
-  g.A0 = V; g.ldA0 = p.Cin; g.sA = Mt * p.Cin; g.Cin = p.Cin;
-  g.Bt = U4; g.ldB = p.Cin; g.sB = (long long)p.N * p.Cin;
-  g.C = Mb; g.ldC = p.N; g.sC = Mt * p.N;
-  g.M = (int)Mt; g.N = p.N; g.H = 1; g.W = 1; g.rows_per_batch = 1; g.alpha = 1.f; g.out_scale = 1.f;
-  g.tag = 36;
-  igemm_prof_enable(0);
-  launch_igemm(g, 1, false, false, 36, st);
-  igemm_prof_enable(prof ? 1 : 0);
-  if (prof) (void)hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(w4_output_kernel, dim3((unsigned)((Mt * (p.N / 4) + 255) / 256)), dim3(256), 0, st, (const float*)Mb, p, B);
+  for (long long t0 = 0; t0 < Mt; t0 += chunk) {
+    const long long Mc = std::min(chunk, Mt - t0);
+    hipLaunchKernelGGL(w4_input_kernel, dim3((unsigned)((Mc * (p.Cin / 4) + 255) / 256)), dim3(256), 0, st, p.A0, p.ldA0, V, B, p.H, p.W, p.Cin, t0, Mc);
+    if (prof) (void)hipEventRecord(ev[1], st);
+    IgemmParams g; std::memset(&g, 0, sizeof(g));
+    g.A0 = V; g.ldA0 = p.Cin; g.sA = Mc * p.Cin; g.Cin = p.Cin;
+    g.Bt = U4; g.ldB = p.Cin; g.sB = (long long)p.N * p.Cin;
+    g.C = Mb; g.ldC = p.N; g.sC = Mc * p.N;
+    g.M = (int)Mc; g.N = p.N; g.H = 1; g.W = 1; g.rows_per_batch = 1; g.alpha = 1.f; g.out_scale = 1.f;
+    g.tag = 36;
+    igemm_prof_enable(0);
+    launch_igemm(g, 1, false, false, 36, st);
+    igemm_prof_enable(prof ? 1 : 0);
+    if (prof) (void)hipEventRecord(ev[2], st);
+    hipLaunchKernelGGL(w4_output_kernel, dim3((unsigned)((Mc * (p.N / 4) + 255) / 256)), dim3(256), 0, st, (const float*)Mb, p, B, t0, Mc);
+  }
   if (prof) {
     (void)hipEventRecord(ev[3], st);
     const double mt = (double)Mt, m = (double)p.M;
