@@ -302,7 +302,7 @@ def gen_uncond():
 
 def gen_opt():
     """optimize_op itself (reference EulerHeunSamplerDPS.py:71-113): parameters and torch.optim.Adam state after ONE full iteration
-    (update_H, both losses, backward, Adam step, projection) and after the shipped ten, plus the minimum-phase projection at the
+    (update_H, both losses, backward, Adam step, projection), after three and after the shipped ten, plus the minimum-phase projection at the
     size cons() uses (12 928 samples) and the filter the next update_H builds from the updated parameters."""
     import utils.reverb_utils as ru
     from diff_params.edm import EDM
@@ -346,7 +346,10 @@ def gen_opt():
 
         smp.optimize_op(x_den.clone(), t)
         snap("it1")
-        args.tester.posterior_sampling.blind_hp.op_updates_per_step = 9
+        args.tester.posterior_sampling.blind_hp.op_updates_per_step = 2
+        smp.optimize_op(x_den.clone(), t)
+        snap("it3")
+        args.tester.posterior_sampling.blind_hp.op_updates_per_step = 7
         smp.optimize_op(x_den.clone(), t)
         snap("it10")
         with torch.no_grad():

@@ -93,8 +93,14 @@ def test_minimum_phase_vs_reference(golden):
 
 
 def test_optimize_op_vs_reference(golden):
-    """ONE full optimize_op iteration and then the shipped TEN (reference EulerHeunSamplerDPS.py:71-113 run on the reference operator):
-    Adam moments, parameters, the filter and the time-domain RIR they produce."""
+    """One, three and the shipped TEN full optimize_op iterations (reference EulerHeunSamplerDPS.py:71-113 run on the reference operator):
+    Adam moments, parameters, the filter and the time-domain RIR they produce.
+
+    Tolerances follow the algorithm's own fp32 sensitivity, measured by running the SAME restated loop in float64 (oracle.precision) next
+    to fp32: Adam's scale-free update turns round-off into parameter differences that grow per iteration -- fp32 vs fp64 of the reference
+    arithmetic itself: A e^{j phi} 1e-5 (it 1), 3e-4 (it 3), 3e-3 (it 4), 3e-2 (it 6), 2-4e-2 (it 9-10); exp_avg of the decays up to 9e-2
+    around it 7.  So: 2e-3 through iteration 3 (measured here 1e-6 / 2e-5 at it 1), and 1e-1 at iteration 10 (any fp32 execution differs
+    from any other by a few 1e-2 there, including the reference from its own fp64 trajectory)."""
     g = golden("opt")
     L = int(g["meta"][0])
     args, op, ns = _make(int(g["meta"][1]), L, ["tester.posterior_sampling.blind_hp.op_updates_per_step=1"])
@@ -134,10 +140,14 @@ def test_optimize_op_vs_reference(golden):
     op.hip_optimize(x_den, t)
     assert check("it1", 2e-3, 2e-3) == 1
     assert rel(torch.view_as_real(op.H)[0], g["it1_H_stale"]) < 1e-4          # H is the filter of the parameters BEFORE the step
-    ps.blind_hp.op_updates_per_step = 9
+    ps.blind_hp.op_updates_per_step = 2
     op.hip_optimize(x_den, t)
-    assert check("it10", 1e-2, 1e-2) == 10
-    assert rel(torch.view_as_real(op.H)[0], g["it10_H_stale"]) < 1e-2
+    assert check("it3", 2e-3, 2e-3) == 3
+    assert rel(torch.view_as_real(op.H)[0], g["it3_H_stale"]) < 2e-3
+    ps.blind_hp.op_updates_per_step = 7
+    op.hip_optimize(x_den, t)
+    assert check("it10", 1e-1, 1e-1) == 10
+    assert rel(torch.view_as_real(op.H)[0], g["it10_H_stale"]) < 1e-1
     op.update_H()
-    assert rel(torch.view_as_real(op.H)[0], g["it10_H"]) < 1e-2
-    assert rel(op.get_time_RIR(), g["it10_rir"]) < 1e-2
+    assert rel(torch.view_as_real(op.H)[0], g["it10_H"]) < 1e-1
+    assert rel(op.get_time_RIR(), g["it10_rir"]) < 1e-1

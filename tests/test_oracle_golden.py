@@ -170,7 +170,9 @@ def test_e2e_blind_second_order_with_magnitude_constraint(golden):
 
 
 def test_optimize_op_one_and_ten_iterations(golden):
-    """optimize_op (reference EulerHeunSamplerDPS.py:71-113): Adam state and parameters after one and after ten full iterations."""
+    """optimize_op (reference EulerHeunSamplerDPS.py:71-113): Adam state and parameters after one, three and ten full iterations (the
+    oracle runs the reference's own torch CPU kernels, so it tracks the fixture far inside the fp32 divergence described in
+    tests/test_hip_operator_golden.py::test_optimize_op_vs_reference)."""
     g = golden("opt")
     args = compose(overrides=["tester.posterior_sampling.blind_hp.op_updates_per_step=1"])
     ps, op_hp = args.tester.posterior_sampling, args.tester.informed_dereverberation.op_hp
@@ -199,7 +201,10 @@ def test_optimize_op_one_and_ten_iterations(golden):
 
     smp.optimize_op(x_den.clone(), t)
     check("it1", 2e-3)
-    ps.blind_hp.op_updates_per_step = 9
+    ps.blind_hp.op_updates_per_step = 2
+    smp.optimize_op(x_den.clone(), t)
+    check("it3", 2e-3)
+    ps.blind_hp.op_updates_per_step = 7
     smp.optimize_op(x_den.clone(), t)
     check("it10", 1e-2)
     assert rel(O.minimum_phase_ref(torch.from_numpy(g["minphase_in"])), g["minphase_out"]) < 1e-5
