@@ -136,19 +136,13 @@ void wino4_scratch(const IgemmParams& p, long long* v_floats, long long* m_float
   *v_floats = 36 * Mt * p.Cin; *m_floats = 36 * Mt * p.N;
 }
 
-// BUDDY_W4_CHUNK=<tiles>: run the three passes chunk by chunk over the tile dimension, so that the transformed operands of a chunk (36 x chunk x
-// (Cin + Cout) floats, the SAME scratch addresses for every chunk) are produced and consumed while they are still in the 256 MB Infinity Cache.
-static long long w4_chunk_tiles() {
-  static const long long c = getenv("BUDDY_W4_CHUNK") ? atoll(getenv("BUDDY_W4_CHUNK")) : 0;
-  return c;
-}
 void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st) {
   const int B = p.M / (p.H * p.W);
   const long long Mt = (long long)p.M / 16;
   const bool prof = igemm_prof_enabled();                   // the caller brackets the three passes as ONE 3x3 convolution; passes timed here
-  long long chunk = w4_chunk_tiles();
-  if (chunk <= 0 || chunk >= Mt || prof) chunk = Mt;
-  else chunk = (chunk + 127) / 128 * 128;
+  // the passes take a tile range [t0, t0 + Mc): one range = the whole tensor.  (Running them chunk by chunk so that V / M stay in the 256 MB
+  // Infinity Cache was measured and lost at every chunk size: +3...+27 % per convolution, profiles/README.md r02.)
+  const long long chunk = Mt;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   if (prof) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], st); }
   for (long long t0 = 0; t0 < Mt; t0 += chunk) {
