@@ -12,6 +12,7 @@
 //   flash_bwd_dkv_kernel per 64 key rows:    the same tiles transposed (S^T = K q^T, dP^T = V dO^T), dv += P^T dO, dk += dS^T q
 // Everything is fp32 (exact-fp32 MFMA, expf/logf); only the summation order differs from the materialised form.
 #include "common.h"
+#include <cstdlib>
 
 namespace buddy {
 namespace {
@@ -32,10 +33,10 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 // stage rows [r0, r0 + 32) of a [T][C] matrix into LDS [32][C + 4] (rows >= T zero-filled)
-template <int C>
+template <int C, int NT = 256>
 __device__ __forceinline__ void stage32(const float* __restrict__ src, int r0, int T, float* dst) {
   constexpr int LD = C + 4, Q = C / 4;
-  for (int i = threadIdx.x; i < 32 * Q; i += 256) {
+  for (int i = threadIdx.x; i < 32 * Q; i += NT) {
     const int r = i / Q, c = (i - r * Q) * 4;
     const float4 v = (r0 + r < T) ? ld4(src + (long long)(r0 + r) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(dst + r * LD + c) = v;
@@ -75,17 +76,18 @@ __device__ __forceinline__ void tile_pb(const float* Ps, const float* Bs, int i,
   }
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void flash_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                        float* __restrict__ O, float* __restrict__ Lse, int T, float scale) {
+// NW waves per workgroup = 16 NW query rows share every staged key / value block (NW = 8: half the L2 -> LDS traffic per FLOP of NW = 4)
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                            float* __restrict__ O, float* __restrict__ Lse, int T, float scale) {
   constexpr int LD = C + 4;
   __shared__ __attribute__((aligned(16))) float Ks[32 * LD];
   __shared__ __attribute__((aligned(16))) float Vs[32 * LD];
-  __shared__ __attribute__((aligned(16))) float Ps[4][16 * PLD];
+  __shared__ __attribute__((aligned(16))) float Ps[NW][16 * PLD];
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const long long base = (long long)b * T * C;
-  const int row_a = blockIdx.x * BR + 16 * w + i;            // this lane's A-operand row
-  const int row0 = blockIdx.x * BR + 16 * w + 4 * g;         // first of this lane's four accumulator rows
+  const int row_a = blockIdx.x * 16 * NW + 16 * w + i;       // this lane's A-operand row
+  const int row0 = blockIdx.x * 16 * NW + 16 * w + 4 * g;    // first of this lane's four accumulator rows
   float4 qa[C / 16];
 #pragma unroll
   for (int kk = 0; kk < C / 16; ++kk) qa[kk] = row_a < T ? ld4(q + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const float* __restrict_
   for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
   for (int j0 = 0; j0 < T; j0 += BC) {
     __syncthreads();
-    stage32<C>(k + base, j0, T, Ks);
-    stage32<C>(v + base, j0, T, Vs);
+    stage32<C, 64 * NW>(k + base, j0, T, Ks);
+    stage32<C, 64 * NW>(v + base, j0, T, Vs);
     __syncthreads();
     f32x4 s[2] = {zero_acc(), zero_acc()};
     tile_abt<C>(qa, Ks, i, g, s);
@@ -498,10 +500,15 @@ bool flash_attn_supported(int C) { return C == 64 || C == 128 || C == 256; }
 // O [B][T][C], Lse [B][T]; prec: 0 = fp32 operands (exact-fp32 MFMA), 1 = bf16 operands, 2 = f16 operands (fp32 accumulate)
 void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, int prec, hipStream_t st) {
   const dim3 grid(cdiv(T, BR), B), block(256);
+  // fp32: 128-row workgroups (8 waves) once there are enough of them to fill the chip, 64-row ones otherwise (BUDDY_ATTN_NW=4|8 forces one)
+  static const int force_nw = getenv("BUDDY_ATTN_NW") ? atoi(getenv("BUDDY_ATTN_NW")) : 0;
+  const bool wide = force_nw ? force_nw == 8 : (long long)cdiv(T, 128) * B >= 512;
+  const dim3 grid8(cdiv(T, 128), B), block8(512);
 #define FA_FWD(CC)                                                                                                           \
   if (prec == 1) hipLaunchKernelGGL((flash16_fwd_kernel<CC, __bf16>), grid, block, 0, st, q, k, v, O, Lse, T, scale);            \
   else if (prec == 2) hipLaunchKernelGGL((flash16_fwd_kernel<CC, _Float16>), grid, block, 0, st, q, k, v, O, Lse, T, scale);    \
-  else hipLaunchKernelGGL(flash_fwd_kernel<CC>, grid, block, 0, st, q, k, v, O, Lse, T, scale);
+  else if (wide) hipLaunchKernelGGL((flash_fwd_kernel<CC, 8>), grid8, block8, 0, st, q, k, v, O, Lse, T, scale);                 \
+  else hipLaunchKernelGGL((flash_fwd_kernel<CC, 4>), grid, block, 0, st, q, k, v, O, Lse, T, scale);
   if (C == 64) { FA_FWD(64) } else if (C == 128) { FA_FWD(128) } else { FA_FWD(256) }
 #undef FA_FWD
 }

@@ -31,10 +31,6 @@ for _f in ("igemm.hip", "wino4.hip", "common.h"):        # same stamp as bench.p
 out["source_stamp"] = _h.hexdigest()[:12]
 out["fetch_bytes_per_launch"] = sum(v["fetch"] for v in out["per_kernel_bytes_per_convolution"].values())
 out["write_bytes_per_launch"] = sum(v["write"] for v in out["per_kernel_bytes_per_convolution"].values())
-out["hbm_bytes_per_launch"] = _h = hashlib.sha1()
-for _f in ("igemm.hip", "wino4.hip", "common.h"):        # same stamp as bench.py conv_source_stamp(): the summary is tied to these kernels
-    _h.update(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "buddy_amd", "csrc", _f), "rb").read())
-out["source_stamp"] = _h.hexdigest()[:12]
-out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out)[:900])
