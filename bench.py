@@ -132,6 +132,28 @@ def cpu_baseline(length, n_threads, reps, utt=0):
     return {"step_seconds": times[1:], "warmup_seconds": times[0], "threads": n_threads}
 
 
+def _effective_cores():
+    """logical CPUs this process may actually use: the cgroup CPU quota (cpu.max) can be far below os.cpu_count() on shared hosts"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def _cpu_model():
     try:
         for l in open("/proc/cpuinfo"):
@@ -147,8 +169,9 @@ def run_cpu_baseline(length, reps=3):
     B=8 (eight independent utterances side by side, cores/8 threads each), 1 warm-up + `reps` timed steps each, median; bounded by hard
     timeouts so the bench always finishes in minutes."""
     import subprocess
-    cores = os.cpu_count() or 1
-    out = {"value": None, "unit": "utterance-steps/s", "cores": None, "kind": "port", "cpu_model": _cpu_model(), "host_logical_cores": cores}
+    cores = _effective_cores()
+    out = {"value": None, "unit": "utterance-steps/s", "cores": None, "kind": "port", "cpu_model": _cpu_model(), "host_logical_cores": os.cpu_count(),
+           "usable_cores": cores}
 
     def spawn(threads, utt):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
@@ -173,7 +196,7 @@ def run_cpu_baseline(length, reps=3):
         med = float(np.median(r1["step_seconds"]))
         out.update(value=1.0 / med, cores=t1)
         out["B1"] = {"utterance_steps_per_s": 1.0 / med, "threads": t1, "step_seconds": r1["step_seconds"], "warmup_seconds": r1["warmup_seconds"]}
-    t8 = max(1, min(32, cores // 8))
+    t8 = max(1, min(32, min(cores, 32 if cores < 64 else cores) // 8))     # B8 shares the same core budget as B1 unless the host really has >= 64 usable cores
     r8 = collect([spawn(t8, u) for u in range(8)], 300)
     if all(r8):
         per_step = np.max(np.array([r["step_seconds"] for r in r8]), axis=0)       # a batch step is done when its slowest utterance is

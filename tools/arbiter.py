@@ -57,7 +57,9 @@ def oracle_job(a, seed, variant):
 
 
 def phase_oracle(a):
-    jobs = [(s, v) for s in a.seeds for v in a.variants if not os.path.exists(os.path.join(tdir(a), f"seed{s}_{v}.npz"))]
+    # fp64 + the first fp32 run of every seed first, the second fp32 thread count afterwards (a partial run still yields complete pairs)
+    order = [(s, v) for s in a.seeds for v in a.variants[:2]] + [(s, v) for v in a.variants[2:] for s in a.seeds]
+    jobs = [(s, v) for s, v in order if not os.path.exists(os.path.join(tdir(a), f"seed{s}_{v}.npz"))]
     running = []
     while jobs or running:
         running = [p for p in running if p.poll() is None]
