@@ -182,6 +182,14 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
   return finish();
 }
 
+int buddy_ncsnpp_set_fir(void* h, int fir) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_set_fir((Net*)h, fir); }
+int buddy_fir_resample2(const float* x, float* y, int B, int H, int W, int C, int up, float scale, int accumulate, void* stream) {
+  if (!x || !y || B < 1 || H < 1 || W < 1 || C < 1 || (!up && ((H | W) & 1))) { set_error("bad resample arguments"); return BUDDY_ERR_ARG; }
+  if (up) launch_fir_up2(x, y, B, H, W, C, scale, accumulate, (hipStream_t)stream);
+  else launch_fir_down2(x, y, B, H, W, C, scale, accumulate, (hipStream_t)stream);
+  return finish();
+}
+
 int buddy_flash_attention_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, int prec,
                               void* stream) {
   if (!q || !k || !v || !O || !lse || B < 1 || T < 1 || !flash_attn_supported(C) || prec < 0 || prec > 2) { set_error("bad attention arguments (C in {64, 128, 256})"); return BUDDY_ERR_ARG; }

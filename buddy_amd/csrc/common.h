@@ -78,6 +78,9 @@ void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* 
 // WPE warm start (wpe.hip): rows x T complex128 in/out, scratch rows*T doubles
 void launch_wpe(const double* Y, double* X, double* inv_scratch, int rows, int T, int taps, int delay, int iters, hipStream_t st);
 void launch_axpy(float* dst, const float* src, float alpha, long long n, int accumulate, hipStream_t st);
+// fir=True resampling with the (1,3,3,1) kernel: (H,W)->(2H,2W) / (H,W)->(H/2,W/2); adjoints: up^T = 4 down, down^T = up / 4
+void launch_fir_up2(const float* x, float* y, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st);
+void launch_fir_down2(const float* x, float* y, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st);
 void launch_pool2(const float* src, float* dst, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st); // (H,W)->(H/2,W/2), sum*scale
 void launch_up2_acc(const float* src, float* dst, int B, int Hs, int Ws, int C, float scale, int accumulate, hipStream_t st); // (Hs,Ws)->(2Hs,2Ws)
 bool flash_attn_supported(int C);

@@ -141,6 +141,7 @@ struct Net {
   Tens* spec = nullptr; Tens* pyr0 = nullptr;
   const float* k_cin = nullptr; const float* k_cskip = nullptr; const float* k_cout = nullptr;
 
+  bool fir = false;            // fir=True: FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257)
   float* w4_scratch = nullptr; size_t w4_cap = 0, w4_need = 0;   // V / M buffers of the three-pass F(4x4,3x3) convolutions (floats)
   bool dry() const { return arena.dry; }
   Tens* mk(int B_, int H, int W, int C, bool grad) {
@@ -359,6 +360,7 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   return BUDDY_OK;
 }
 
+int net_set_fir(Net* N, int fir) { N->fir = fir != 0; return BUDDY_OK; }
 void net_destroy(Net* N) {
   if (!N) return;
   if (N->dparams) (void)hipFree(N->dparams);
@@ -440,25 +442,32 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
   float* stats0 = N->tmp((long long)B * G0 * 2);
   float* stats1 = N->tmp((long long)B * G1 * 2);
   const size_t mark = N->arena.off;
+  const bool firm = N->fir && mode != 0;                  // FIR resampling: explicit passes on h = act(GN(x)) and on x (layerspp.py:246-255)
   float* a0 = N->tmp((long long)B * Ho * Wo * Cin);
-  float* xr = (mode == 1) ? N->tmp((long long)B * Ho * Wo * Cin) : nullptr;
-  float* xs = R.has_c2 ? N->tmp((long long)B * (mode == 2 ? H * W : Ho * Wo) * Cout) : nullptr;
+  float* xr = (mode == 1 || firm) ? N->tmp((long long)B * Ho * Wo * Cin) : nullptr;
+  float* xs = R.has_c2 ? N->tmp((long long)B * ((mode == 2 && !firm) ? H * W : Ho * Wo) * Cout) : nullptr;
   float* a1 = N->tmp((long long)B * Ho * Wo * Cout);
+  float* a0f = firm ? N->tmp((long long)B * H * W * Cin) : nullptr;
   if (N->dry()) {                                         // sizing pass: let the convolutions note their F(4x4,3x3) scratch need
     conv3(N, nullptr, B, Ho, Wo, Cin, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c0.uf, R.c0.uf4);
     conv3(N, nullptr, B, Ho, Wo, Cout, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c1.uf, R.c1.uf4);
   }
   if (!N->dry()) {
     launch_gn_stats(src_of(x), B, H * W, Cin, G0, 1e-6f, N->partial, stats0, st);
+    if (firm) {
+      launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, 0, 1, a0f, nullptr, st);
+      if (mode == 2) { launch_fir_up2(a0f, a0, B, H, W, Cin, 1.f, 0, st); launch_fir_up2(x.a->p, xr, B, H, W, Cin, 1.f, 0, st); }
+      else { launch_fir_down2(a0f, a0, B, H, W, Cin, 1.f, 0, st); launch_fir_down2(x.a->p, xr, B, H, W, Cin, 1.f, 0, st); }
+    } else
     launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
     conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p, R.c0.uf, R.c0.uf4);
     launch_gn_stats(single(h1->p, Cout), B, Ho * Wo, Cout, G1, 1e-6f, N->partial, stats1, st);
     launch_gn_apply(single(h1->p, Cout), stats1, R.gn1.gamma, R.gn1.beta, B, Ho, Wo, Cout, G1, 0, 1, a1, nullptr, st);
     const float* res; int res_mode = 1;
     if (R.has_c2) {
-      if (mode == 1) conv1(N, single(xr, Cin), (long long)B * Ho * Wo, Cin, R.c2.wf, Cout, R.c2.bias, 1.f, xs, 0);
+      if (mode == 1 || firm) conv1(N, single(xr, Cin), (long long)B * Ho * Wo, Cin, R.c2.wf, Cout, R.c2.bias, 1.f, xs, 0);
       else conv1(N, src_of(x), (long long)B * H * W, Cin, R.c2.wf, Cout, R.c2.bias, 1.f, xs, 0);
-      res = xs; if (mode == 2) res_mode = 2;
+      res = xs; if (mode == 2 && !firm) res_mode = 2;
     } else {
       res = x.a->p;   // identity skip: single source, same resolution, Cin == Cout
     }
@@ -474,7 +483,15 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       const float* extra; int extra_mode = 1; float extra_scale = 1.f;
       if (Rp->has_c2) {
         float* tx;
-        if (mode == 2) {
+        if (firm) {                                        // d x_resampled at (Ho, Wo), then the FIR adjoint back to (H, W)
+          float* txr = n->tmp((long long)B * Ho * Wo * Cin);
+          tx = n->tmp((long long)B * H * W * Cin);
+          conv1(n, single(dout, Cout), (long long)B * Ho * Wo, Cout, Rp->c2.wb, Cin, nullptr, INV_SQRT2, txr, 0);
+          if (!n->dry()) {
+            if (mode == 2) launch_fir_down2(txr, tx, B, Ho, Wo, Cin, 4.f, 0, s);      // up^T = 4 down
+            else launch_fir_up2(txr, tx, B, Ho, Wo, Cin, 0.25f, 0, s);                // down^T = up / 4
+          }
+        } else if (mode == 2) {
           float* pooled = n->tmp((long long)B * H * W * Cout);
           tx = n->tmp((long long)B * H * W * Cin);
           if (!n->dry()) {
@@ -500,6 +517,14 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
                       n->red, d1, s);
       conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub, Rp->c0.ub4);
       Dst2 d0 = gdst_of(x);
+      if (firm) {
+        float* da0f = n->tmp((long long)B * H * W * Cin);
+        if (!n->dry()) {
+          if (mode == 2) launch_fir_down2(da0, da0f, B, Ho, Wo, Cin, 4.f, 0, s);
+          else launch_fir_up2(da0, da0f, B, Ho, Wo, Cin, 0.25f, 0, s);
+          launch_gn_bwd(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0f, B, H, W, Cin, G0, 0, 1, extra, 1, 1.f, n->partial, n->red, d0, s);
+        }
+      } else
       if (!n->dry())
         launch_gn_bwd(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0, B, H, W, Cin, G0, mode, 1, extra, extra_mode, extra_scale,
                       n->partial, n->red, d0, s);
@@ -722,9 +747,15 @@ static void run_forward(Net* N, const float* x, const float* cnoise, const float
       Tens* h = resblock(N, N->res[ri++], v, 1, temb_all, rec); tap(mi, h); ++mi;
       Tens* pin = N->mk(B, pyr_in->H / 2, pyr_in->W / 2, 2, rec);
       Tens* prev = pyr_in;
-      if (!N->dry()) launch_pool2(prev->p, pin->p, B, prev->H, prev->W, 2, 0.25f, 0, st);          // F.avg_pool2d (layerspp.py:156)
+      if (!N->dry()) {
+        if (N->fir) launch_fir_down2(prev->p, pin->p, B, prev->H, prev->W, 2, 1.f, 0, st);          // downsample_2d (layerspp.py:159)
+        else launch_pool2(prev->p, pin->p, B, prev->H, prev->W, 2, 0.25f, 0, st);                   // F.avg_pool2d (layerspp.py:156)
+      }
       if (rec) N->tape.push_back([=]() {
-        if (!N->dry()) launch_up2_acc(pin->g, prev->g, B, pin->H, pin->W, 2, 0.25f, prev->ginit, N->st);
+        if (!N->dry()) {
+          if (N->fir) launch_fir_up2(pin->g, prev->g, B, pin->H, pin->W, 2, 0.25f, prev->ginit, N->st);
+          else launch_up2_acc(pin->g, prev->g, B, pin->H, pin->W, 2, 0.25f, prev->ginit, N->st);
+        }
         prev->ginit = 1;
       });
       pyr_in = pin;
@@ -763,6 +794,10 @@ static void run_forward(Net* N, const float* x, const float* cnoise, const float
       if (!N->dry()) {
         launch_gn_stats(single(h->p, C), B, Hh * Ww, C, G, 1e-6f, N->partial, stats, st);
         launch_gn_apply(single(h->p, C), stats, gw.gamma, gw.beta, B, Hh, Ww, C, G, 0, 1, a, nullptr, st);
+        if (N->fir) {                                      // upsample_2d of the running pyramid (layerspp.py:122) instead of nearest
+          launch_conv_c2out(a, C, cw.wf, cw.bias, nullptr, np->p, B, Hh, Ww, C, 9, 0, st);
+          if (prevp) launch_fir_up2(prevp->p, np->p, B, Hh / 2, Ww / 2, 2, 1.f, 1, st);
+        } else
         launch_conv_c2out(a, C, cw.wf, cw.bias, prevp ? prevp->p : nullptr, np->p, B, Hh, Ww, C, 9, 0, st);
       }
       N->arena.off = mark;
@@ -770,7 +805,8 @@ static void run_forward(Net* N, const float* x, const float* cnoise, const float
         const size_t mk = N->arena.off;
         float* da = N->tmp(hh->numel());
         if (!N->dry()) {
-          if (prevp) launch_pool2(np->g, prevp->g, B, Hh, Ww, 2, 1.f, prevp->ginit, N->st);
+          if (prevp && N->fir) launch_fir_down2(np->g, prevp->g, B, Hh, Ww, 2, 4.f, prevp->ginit, N->st);
+          else if (prevp) launch_pool2(np->g, prevp->g, B, Hh, Ww, 2, 1.f, prevp->ginit, N->st);
           launch_conv_c2in(np->g, cp->wb, nullptr, nullptr, 0, da, C, B, Hh, Ww, C, 9, 0, N->st);
         }
         if (prevp) prevp->ginit = 1;

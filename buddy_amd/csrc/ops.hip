@@ -686,6 +686,67 @@ inline int grid_for(long long total) {
   return (int)g;
 }
 
+
+// ------------------------------------------------------------------ FIR resampling (fir=True): upfirdn2d with the (1,3,3,1) kernel
+// reference networks/ncsnpp_utils/up_or_down_sampling.py:195-257 (upsample_2d / downsample_2d, factor 2, zero padding) -> op/upfirdn2d_kernel.cu.
+// For k = (1,3,3,1) the separable taps are, per axis:  up:   y[2i] = (x[i-1] + 3 x[i]) / 4,  y[2i+1] = (3 x[i] + x[i+1]) / 4
+//                                                      down: y[i]  = (x[2i-1] + 3 x[2i] + 3 x[2i+1] + x[2i+2]) / 8       (x = 0 outside)
+// and the two are adjoint up to a factor: up^T = 4 down, down^T = up / 4 (so the VJP needs no third kernel).  NHWC, any C.
+__global__ __launch_bounds__(256) void fir_up2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, float scale, int accumulate) {
+  const long long total = (long long)B * 2 * H * 2 * W * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C); long long r = idx / C;
+    const int ox = (int)(r % (2 * W)); r /= 2 * W;
+    const int oy = (int)(r % (2 * H)); const int b = (int)(r / (2 * H));
+    const int iy = oy >> 1, ix = ox >> 1;
+    const int y0 = (oy & 1) ? iy : iy - 1, x0 = (ox & 1) ? ix : ix - 1;          // the two contributing rows / columns are (y0, y0 + 1)
+    const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int yy = y0 + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      const float wy = dy ? 1.f - wy0 : wy0;
+      float row = 0.f;
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int xx = x0 + dx;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        row += (dx ? 1.f - wx0 : wx0) * x[(((long long)b * H + yy) * W + xx) * C + c];
+      }
+      acc += wy * row;
+    }
+    acc *= scale;
+    y[idx] = accumulate ? y[idx] + acc : acc;
+  }
+}
+// (H, W) -> (H/2, W/2)
+__global__ __launch_bounds__(256) void fir_down2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, float scale, int accumulate) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)B * Ho * Wo * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C); long long r = idx / C;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho); const int b = (int)(r / Ho);
+    const float wt[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+      const int yy = 2 * oy - 1 + dy;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      float row = 0.f;
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        const int xx = 2 * ox - 1 + dx;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        row += wt[dx] * x[(((long long)b * H + yy) * W + xx) * C + c];
+      }
+      acc += wt[dy] * row;
+    }
+    acc *= scale;
+    y[idx] = accumulate ? y[idx] + acc : acc;
+  }
+}
 }  // namespace
 
 // ================================================================== launchers
@@ -762,6 +823,13 @@ void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* 
 
 void launch_axpy(float* dst, const float* src, float alpha, long long n, int accumulate, hipStream_t st) {
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, dst, src, alpha, n / 4, accumulate);
+}
+
+void launch_fir_up2(const float* x, float* y, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(fir_up2_kernel, dim3(grid_for((long long)B * 4 * H * W * C)), dim3(256), 0, st, x, y, B, H, W, C, scale, accumulate);
+}
+void launch_fir_down2(const float* x, float* y, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(fir_down2_kernel, dim3(grid_for((long long)B * (H / 2) * (W / 2) * C)), dim3(256), 0, st, x, y, B, H, W, C, scale, accumulate);
 }
 
 void launch_pool2(const float* src, float* dst, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st) {

@@ -5,8 +5,8 @@ Same surface as the reference class: constructor kwargs = ``conf/network/ncsnpp.
 ``stft:{n_fft,hop_length,center}``), ``nn.Module`` protocol with the reference ``state_dict`` key names
 (``all_modules.N.*``, ``output_layer.*``), ``forward(x:(B,1,L) f32, time_cond:(B,) f32) -> (B,1,L)``,
 differentiable w.r.t. ``x`` (the input-VJP runs in HIP; no weight gradients -- inference only).
-Only the shipped architecture family is supported (biggan resblocks, input_skip/sum, output_skip, fir=False, one
-bottleneck attention); anything else raises ``NotImplementedError`` at construction.
+Only the shipped architecture family is supported (biggan resblocks, input_skip/sum, output_skip, one bottleneck attention;
+``fir`` False or True with the (1,3,3,1) kernel); anything else raises ``NotImplementedError`` at construction.
 """
 from __future__ import annotations
 
@@ -73,7 +73,7 @@ class NCSNppTime(nn.Module):
         assert stft is not None, "stft must be provided"          # reference ncsnpp.py:459
         unsupported = []
         if nonlinearity != "swish": unsupported.append("nonlinearity")
-        if fir: unsupported.append("fir=True")
+        if fir and tuple(int(v) for v in fir_kernel) != (1, 3, 3, 1): unsupported.append("fir_kernel other than (1, 3, 3, 1)")
         if not skip_rescale: unsupported.append("skip_rescale=False")
         if str(resblock_type).lower() != "biggan": unsupported.append("resblock_type")
         if str(progressive).lower() != "output_skip": unsupported.append("progressive")
@@ -93,6 +93,7 @@ class NCSNppTime(nn.Module):
         self.n_fft, self.hop_length = int(get("n_fft")), int(get("hop_length"))
         assert bool(get("center")), "center=False not supported"
         self.nf, self.ch_mult, self.num_res_blocks = int(nf), tuple(int(c) for c in ch_mult), int(num_res_blocks)
+        self.fir = bool(fir)            # FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257); no parameters
         self._specs = module_specs(self.nf, self.ch_mult, self.num_res_blocks)
         # parameter containers under the reference names
         n_mod = 1 + max(int(n.split(".")[1]) for n, *_ in self._specs if n.startswith("all_modules."))
@@ -147,6 +148,8 @@ class NCSNppTime(nn.Module):
             h = C.c_void_p()
             _lib.check(lib.buddy_ncsnpp_create(blob.ctypes.data, blob.size, self.nf, cm, len(self.ch_mult),
                                                self.num_res_blocks, self.n_fft, self.hop_length, C.byref(h)))
+            if self.fir:
+                _lib.check(lib.buddy_ncsnpp_set_fir(h, 1))
             self._handle = h
         return self._handle
 

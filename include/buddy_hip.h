@@ -97,6 +97,12 @@ int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, f
 int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* beta, const float* stats, const float* dy, float* dx,
                             void* scratch, float* red, int B, int H, int W, int C, int G, int mode, int silu, void* stream);
 
+/* fir=True resampling (networks/ncsnpp_utils/up_or_down_sampling.py:195-257 upsample_2d / downsample_2d -> upfirdn2d, op/upfirdn2d_kernel.cu)
+ * with the (1,3,3,1) kernel, factor 2, NHWC: up != 0: (H,W) -> (2H,2W), else (H,W) -> (H/2,W/2); y = (accumulate ? y : 0) + scale * resample(x).
+ * The transposes are the other direction times 4 resp. 1/4.  buddy_ncsnpp_set_fir switches a network handle to this resampling (no parameters). */
+int buddy_fir_resample2(const float* x, float* y, int B, int H, int W, int C, int up, float scale, int accumulate, void* stream);
+int buddy_ncsnpp_set_fir(void* handle, int fir);
+
 /* single-head attention over T tokens without the T x T matrix (online softmax, fp32 MFMA), token-major q, k, v, O [B][T][C], C in {64,128,256}:
  * O = softmax(scale * q k^T) v, lse [B][T] = row log-sum-exp; replaces the einsum / softmax / einsum of AttnBlockpp.forward
  * (networks/ncsnpp_utils/layerspp.py:82-86).  bwd: gradients of the same three steps given dO (delta [B][T] is scratch).

@@ -49,14 +49,43 @@ def down2(x):
     return x.reshape(B, C, H // 2, 2, W // 2, 2).mean(dim=(3, 5))
 
 
-def resblock(P, m, x, temb, mode=None):
-    """ResnetBlockBigGANpp.forward -- reference layerspp.py:242-274."""
+def _upfirdn(x, k2, up, down, pad0, pad1):
+    """upfirdn2d_native -- reference op/upfirdn2d.py:171-215 (zero-insert by ``up``, zero-pad, correlate with the flipped kernel, decimate),
+    the function the reference's dispatcher runs on CPU (:145-156)."""
+    B, C, H, W = x.shape
+    z = x.reshape(B * C, 1, H, 1, W, 1)
+    z = F.pad(z, [0, up - 1, 0, 0, 0, up - 1]).reshape(B * C, 1, H * up, W * up)
+    z = F.pad(z, [pad0, pad1, pad0, pad1])
+    z = F.conv2d(z, torch.flip(k2, [0, 1])[None, None])
+    return z[:, :, ::down, ::down].reshape(B, C, z.shape[2] // down + (z.shape[2] % down > 0), -1)
+
+
+def _fir_kernel(k=(1, 3, 3, 1)):
+    k1 = torch.tensor(k, dtype=torch.get_default_dtype())
+    k2 = torch.outer(k1, k1)
+    return k2 / k2.sum()
+
+
+def fir_up2(x, k=(1, 3, 3, 1)):
+    """upsample_2d(x, k, factor=2) -- reference up_or_down_sampling.py:195-224: kernel * factor^2, pad ((p+1)//2 + factor - 1, p//2), p = len(k) - factor."""
+    p = len(k) - 2
+    return _upfirdn(x, _fir_kernel(k) * 4, 2, 1, (p + 1) // 2 + 1, p // 2)
+
+
+def fir_down2(x, k=(1, 3, 3, 1)):
+    """downsample_2d(x, k, factor=2) -- reference up_or_down_sampling.py:227-257: pad ((p+1)//2, p//2)."""
+    p = len(k) - 2
+    return _upfirdn(x, _fir_kernel(k), 1, 2, (p + 1) // 2, p // 2)
+
+
+def resblock(P, m, x, temb, mode=None, fir=False):
+    """ResnetBlockBigGANpp.forward -- reference layerspp.py:242-274 (fir=True: FIR resampling of both h and x, :246-255)."""
     pre = f"all_modules.{m}"
     h = F.silu(group_norm(P, pre + ".GroupNorm_0", x))
     if mode == "up":
-        h, x = up2(h), up2(x)
+        h, x = (fir_up2(h), fir_up2(x)) if fir else (up2(h), up2(x))
     elif mode == "down":
-        h, x = down2(h), down2(x)
+        h, x = (fir_down2(h), fir_down2(x)) if fir else (down2(h), down2(x))
     h = conv(P, pre + ".Conv_0", h, 1)
     h = h + F.linear(F.silu(temb), _t(P, pre + ".Dense_0.weight"), _t(P, pre + ".Dense_0.bias"))[:, :, None, None]
     h = F.silu(group_norm(P, pre + ".GroupNorm_1", h))
@@ -90,7 +119,7 @@ def time_embedding(P, cnoise):
     return temb
 
 
-def unet(P, x, cnoise, ch_mult=(1, 2, 2, 2), num_res_blocks=1, taps=None):
+def unet(P, x, cnoise, ch_mult=(1, 2, 2, 2), num_res_blocks=1, taps=None, fir=False):
     """NCSNpp.forward on real/imag channels -- reference ncsnpp.py:281-449.
     x: (B, 2, F, T) real.  Returns (B, 2, F, T).  ``taps`` (optional dict) records intermediate
     tensors by all_modules index for per-module parity checks."""
@@ -111,8 +140,8 @@ def unet(P, x, cnoise, ch_mult=(1, 2, 2, 2), num_res_blocks=1, taps=None):
             h = resblock(P, m, hs[-1], temb); rec(m, h); m += 1
             hs.append(h)
         if lvl != nres - 1:
-            h = resblock(P, m, hs[-1], temb, "down"); rec(m, h); m += 1
-            pyr_in = F.avg_pool2d(pyr_in, 2, stride=2)                      # layerspp.py:156
+            h = resblock(P, m, hs[-1], temb, "down", fir); rec(m, h); m += 1
+            pyr_in = fir_down2(pyr_in) if fir else F.avg_pool2d(pyr_in, 2, stride=2)   # layerspp.py:159 / :156
             h = conv(P, f"all_modules.{m}.Conv_0", pyr_in, 0) + h           # Combine(sum), layerspp.py:52-57
             rec(m, h); m += 1
             hs.append(h)
@@ -126,10 +155,13 @@ def unet(P, x, cnoise, ch_mult=(1, 2, 2, 2), num_res_blocks=1, taps=None):
             h = resblock(P, m, torch.cat([h, hs.pop()], dim=1), temb); rec(m, h); m += 1
         ph = F.silu(group_norm(P, f"all_modules.{m}", h)); m += 1
         ph = conv(P, f"all_modules.{m}", ph, 1); m += 1
-        pyr = ph if pyr is None else F.interpolate(pyr, scale_factor=2, mode="nearest") + ph  # layerspp.py:117
+        if pyr is None:
+            pyr = ph
+        else:
+            pyr = (fir_up2(pyr) if fir else F.interpolate(pyr, scale_factor=2, mode="nearest")) + ph   # layerspp.py:122 / :117
         rec(m - 1, pyr)
         if lvl != 0:
-            h = resblock(P, m, h, temb, "up"); rec(m, h); m += 1
+            h = resblock(P, m, h, temb, "up", fir); rec(m, h); m += 1
     assert not hs
     out = F.conv2d(pyr, _t(P, "output_layer.weight"), _t(P, "output_layer.bias"))
     return out
@@ -152,14 +184,14 @@ def istft(spec, length, n_fft=510, hop=128):
     return torch.istft(spec, n_fft=n_fft, hop_length=hop, window=win, center=True, length=length)[..., :length]
 
 
-def ncsnpp_time(P, x, cnoise, n_fft=510, hop=128, ch_mult=(1, 2, 2, 2), num_res_blocks=1, taps=None):
+def ncsnpp_time(P, x, cnoise, n_fft=510, hop=128, ch_mult=(1, 2, 2, 2), num_res_blocks=1, taps=None, fir=False):
     """NCSNppTime.forward -- reference ncsnpp.py:498-506.  x: (B,1,L) or (B,L); returns same shape."""
     squeeze = x.dim() == 3
     sig = x[:, 0] if squeeze else x
     L = sig.shape[-1]
     S = stft(sig, n_fft, hop)
     xri = torch.stack([S.real, S.imag], dim=1)                # ncsnpp.py:291-297
-    o = unet(P, xri, cnoise, ch_mult, num_res_blocks, taps)
+    o = unet(P, xri, cnoise, ch_mult, num_res_blocks, taps, fir)
     So = torch.complex(o[:, 0].contiguous(), o[:, 1].contiguous())  # ncsnpp.py:446-448
     y = istft(So, L, n_fft, hop)
     return y[:, None] if squeeze else y

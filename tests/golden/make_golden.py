@@ -414,9 +414,66 @@ def gen_config1():
          meta=np.array([nf, seg.shape[-1], 10, 2, seed, nseed, RIR.shape[-1]]))
 
 
+def _enable_reference_fir():
+    """The reference's fir=True path calls ``upfirdn2d`` (networks/ncsnpp_utils/up_or_down_sampling.py:220-257), but the import of
+    it is commented out there (:10) and ``op/upfirdn2d.py`` JIT-compiles a CUDA extension on import.  Its pure-PyTorch twin
+    ``upfirdn2d_native`` (op/upfirdn2d.py:171-215) is what the reference's own dispatcher runs on CPU (:145-156): lift exactly that function
+    out of the file (no extension build) and bind the dispatcher's CPU branch under the missing name."""
+    import ast
+    import torch.nn.functional as F
+    src = open(os.path.join(REF, "networks/ncsnpp_utils/op/upfirdn2d.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "upfirdn2d_native"][0]
+    ns = {"torch": torch, "F": F}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "upfirdn2d_native", "exec"), ns)
+    native = ns["upfirdn2d_native"]
+    from networks.ncsnpp_utils import up_or_down_sampling as U
+    U.upfirdn2d = lambda input, kernel, up=1, down=1, pad=(0, 0): native(input, kernel, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
+    return U
+
+
+def gen_fir():
+    """fir=True resampling: upsample_2d / downsample_2d with the (1,3,3,1) kernel and their input gradients, and a small
+    network built with fir=True (forward, input-VJP, per-module statistics)."""
+    U = _enable_reference_fir()
+    rs = np.random.RandomState(77)
+    x = torch.from_numpy(rs.standard_normal((2, 6, 10, 12)).astype(np.float32)).requires_grad_(True)
+    k = (1, 3, 3, 1)
+    up, dn = U.upsample_2d(x, k, factor=2), U.downsample_2d(x, k, factor=2)
+    cu = torch.from_numpy(rs.standard_normal(tuple(up.shape)).astype(np.float32))
+    cd = torch.from_numpy(rs.standard_normal(tuple(dn.shape)).astype(np.float32))
+    gu, = torch.autograd.grad(up, x, cu, retain_graph=True)
+    gd, = torch.autograd.grad(dn, x, cd)
+    save("fir_ops", x=x.detach(), up=up.detach(), down=dn.detach(), cot_up=cu, cot_down=cd, vjp_up=gu, vjp_down=gd)
+    # network with fir=True
+    from networks.ncsnpp import NCSNppTime
+    cfg = load_yaml(os.path.join(ROOT, "conf/network/ncsnpp.yaml"))
+    cfg.pop("_target_")
+    nf, n_fft, hop, L, B, seed = 32, 126, 32, 4096, 2, 13
+    cfg.update(nf=nf, fir=True, stft=AttrDict(n_fft=n_fft, hop_length=hop, center=True))
+    net = NCSNppTime(**cfg)
+    sd = synth_state_dict(seed, nf)
+    net.load_state_dict({k_: torch.from_numpy(v) for k_, v in sd.items()}, strict=True)
+    net.eval()
+    rs = np.random.RandomState(seed + 100)
+    xi = torch.from_numpy((0.5 * rs.standard_normal((B, 1, L))).astype(np.float32)).requires_grad_(True)
+    cn = torch.from_numpy(rs.uniform(-2.0, 0.3, size=(B,)).astype(np.float32))
+    cot = torch.from_numpy(rs.standard_normal((B, 1, L)).astype(np.float32))
+    taps, hooks = {}, []
+    from networks.ncsnpp_utils import layerspp
+    for i, mod in enumerate(net.all_modules):
+        if isinstance(mod, (layerspp.ResnetBlockBigGANpp, layerspp.AttnBlockpp)):
+            hooks.append(mod.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(i, o.detach())))
+    y = net(xi, cn)
+    g, = torch.autograd.grad(y, xi, cot)
+    arrs = dict(x=xi.detach(), cnoise=cn, cot=cot, y=y.detach(), vjp=g, meta=np.array([nf, n_fft, hop, L, B, seed]))
+    for i, t in taps.items():
+        arrs[f"tap{i}_absmax"], arrs[f"tap{i}_std"] = t.abs().max(), t.std()
+    save("net_small_fir", **arrs)
+
+
 GENS = dict(edm_sched=gen_edm_sched, net_small=gen_net_small, net_full=gen_net_full, ops=gen_ops,
             e2e_informed=gen_e2e_informed, e2e_blind=gen_e2e_blind, e2e_uncond=gen_uncond,
-            opt=gen_opt, e2e_blind_o2=gen_e2e_blind_o2, e2e_blind10=gen_e2e_blind10, config1=gen_config1)
+            opt=gen_opt, e2e_blind_o2=gen_e2e_blind_o2, e2e_blind10=gen_e2e_blind10, config1=gen_config1, fir=gen_fir)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

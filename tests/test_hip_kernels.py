@@ -241,3 +241,22 @@ def test_flash_attention_fwd_bwd(lib, B, T, Cc, prec):
     print(prec, (B, T, Cc), {k_: f"{v_:.1e}" for k_, v_ in errs.items()})
     assert errs["O"] < tf and errs["lse"] < tl
     assert errs["dq"] < tb and errs["dk"] < tb and errs["dv"] < tb
+
+
+def test_fir_resample2_vs_reference(lib, golden):
+    """upsample_2d / downsample_2d with the (1,3,3,1) kernel (reference up_or_down_sampling.py:195-257 -> upfirdn2d) and their transposes
+    against vectors recorded from the reference's pure-PyTorch upfirdn2d; NHWC, C = 6 (scalar path) and via the adjoint identities."""
+    from buddy_amd import _lib
+    g = golden("fir_ops")
+    nhwc = lambda a: torch.from_numpy(a).permute(0, 2, 3, 1).contiguous().cuda()
+    x = nhwc(g["x"]); B, H, W, Cc = x.shape
+    up = torch.empty(B, 2 * H, 2 * W, Cc, device="cuda"); dn = torch.empty(B, H // 2, W // 2, Cc, device="cuda")
+    _lib.check(lib.buddy_fir_resample2(P(x), P(up), B, H, W, Cc, 1, 1.0, 0, S()))
+    _lib.check(lib.buddy_fir_resample2(P(x), P(dn), B, H, W, Cc, 0, 1.0, 0, S()))
+    assert rel(up, nhwc(g["up"])) < 1e-6 and rel(dn, nhwc(g["down"])) < 1e-6
+    # VJPs: up^T = 4 down, down^T = up / 4; the second call accumulates on top of the first
+    gu = torch.empty_like(x); cu, cd = nhwc(g["cot_up"]), nhwc(g["cot_down"])
+    _lib.check(lib.buddy_fir_resample2(P(cu), P(gu), B, 2 * H, 2 * W, Cc, 0, 4.0, 0, S()))
+    assert rel(gu, nhwc(g["vjp_up"])) < 1e-6
+    _lib.check(lib.buddy_fir_resample2(P(cd), P(gu), B, H // 2, W // 2, Cc, 1, 0.25, 1, S()))
+    assert rel(gu, nhwc(g["vjp_up"]) + nhwc(g["vjp_down"])) < 1e-6

@@ -18,23 +18,25 @@ def rel(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
-def build(nf, n_fft, hop, seed):
+def build(nf, n_fft, hop, seed, fir=False):
     from buddy_amd.config import load_yaml, CONF_DIR, AttrDict
     from buddy_amd.networks.ncsnpp import NCSNppTime
     from buddy_amd.synth import synth_state_dict
     cfg = load_yaml(os.path.join(CONF_DIR, "network", "ncsnpp.yaml"))
     cfg.pop("_target_")
-    cfg.update(nf=nf, stft=AttrDict(n_fft=n_fft, hop_length=hop, center=True))
+    cfg.update(nf=nf, fir=fir, stft=AttrDict(n_fft=n_fft, hop_length=hop, center=True))
     net = NCSNppTime(**cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(seed, nf).items()})
     return net.cuda().eval()
 
 
-@pytest.mark.parametrize("name", ["net_small", "net_full"])
+@pytest.mark.parametrize("name", ["net_small", "net_full", "net_small_fir"])
 def test_forward_vjp_vs_golden(golden, name):
+    """net_small_fir: the same small network built with fir=True (FIR (1,3,3,1) resampling in the up / down blocks and both pyramids,
+    reference up_or_down_sampling.py:195-257), fixture recorded through the reference's pure-PyTorch upfirdn2d."""
     g = golden(name)
     nf, n_fft, hop, L, B, seed = [int(v) for v in g["meta"]]
-    net = build(nf, n_fft, hop, seed)
+    net = build(nf, n_fft, hop, seed, fir=name.endswith("_fir"))
     x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
     y = net(x, torch.from_numpy(g["cnoise"]).cuda())
     report = []
