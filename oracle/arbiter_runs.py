@@ -14,7 +14,7 @@ def overrides(T, updates, nf):
             f"tester.posterior_sampling.blind_hp.op_updates_per_step={updates}", f"network.nf={nf}"]
 
 
-def run_blind(seed, L, T, nf, updates, rir_taps, fp64=False, threads=8, weight_seed=0):
+def run_blind(seed, L, T, nf, updates, rir_taps, fp64=False, threads=8, weight_seed=0, device=None):
     """utterance ``seed`` (buddy_amd.synth clean/RIR), noise stream 9000 + seed -> (x_den per step (T, L) float32, clean (L,), n_draws)"""
     from buddy_amd.config import compose
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
@@ -22,22 +22,22 @@ def run_blind(seed, L, T, nf, updates, rir_taps, fp64=False, threads=8, weight_s
     torch.set_num_threads(threads)
     try:
         args = compose(overrides=overrides(T, updates, nf))
-        with (precision.fp64() if fp64 else contextlib.nullcontext()):
-            dt = torch.get_default_dtype()
+        with (precision.fp64(device) if fp64 else contextlib.nullcontext()):
+            dt, dev = torch.get_default_dtype(), torch.get_default_device()
             P = ncsnpp_ref.to_torch(synth_state_dict(weight_seed, nf))
             net = lambda z, cn: ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
-            c0 = torch.from_numpy(synth_clean(seed, L)).to(dt)
+            c0 = torch.from_numpy(synth_clean(seed, L)).to(device=dev, dtype=dt)
             c0 = 0.05 * c0 / c0.std()
             nr = S.NoiseStream(9000 + seed)
             ref = S.EulerHeunDPSRef(net, S.EDMRef(args.diff_params.sde_hp), args, nr)
             op_hp = args.tester.informed_dereverberation.op_hp
             oo = O.RIROperatorRef(op_hp)
-            oo.update_params(torch.from_numpy(synth_rir(seed, rir_taps)).to(dt))
+            oo.update_params(torch.from_numpy(synth_rir(seed, rir_taps)).to(device=dev, dtype=dt))
             y0 = oo.degradation(c0[None])
             bo = O.BlindSubbandFilteringRef(op_hp, 16000, nr)
             bo.update_H(use_noise=True, noise=nr)
             tr = []
             ref.predict_conditional(y0, bo, shape=(1, L), blind=True, trace=tr)
-        return torch.stack([t[1][0] for t in tr]).float(), c0.float(), nr.k
+        return torch.stack([t[1][0] for t in tr]).float().cpu(), c0.float().cpu(), nr.k
     finally:
         torch.set_num_threads(prev)

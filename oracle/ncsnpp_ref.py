@@ -199,5 +199,5 @@ def ncsnpp_time(P, x, cnoise, n_fft=510, hop=128, ch_mult=(1, 2, 2, 2), num_res_
 
 def to_torch(sd):
     """state dict (numpy or torch) -> torch tensors of the default dtype (fp32; fp64 inside ``oracle.precision.fp64()``)"""
-    dt = torch.get_default_dtype()
-    return {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(v)).to(dt) for k, v in sd.items()}
+    dt, dev = torch.get_default_dtype(), torch.get_default_device()
+    return {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(v)).to(device=dev, dtype=dt) for k, v in sd.items()}

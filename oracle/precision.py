@@ -10,7 +10,7 @@ several thread counts, the MI355X build) is measured against it.
         P = ncsnpp_ref.to_torch(sd)          # parameters, windows, noise draws, schedules: all float64 inside the context
         ...
 
-Only the default dtype changes; the code path is the one pinned in fp32 against the reference fixtures."""
+Only the default dtype (and optionally the default device) changes; the code path is the one pinned in fp32 against the reference fixtures."""
 from __future__ import annotations
 
 import contextlib
@@ -19,10 +19,18 @@ import torch
 
 
 @contextlib.contextmanager
-def fp64():
+def fp64(device=None):
+    """default dtype float64 (and, optionally, default device ``device``: the float64 run of a full-size 50-step chain takes an hour per
+    utterance on 8 CPU cores -- torch has no fast fp64 CPU convolution -- and under a minute on the MI355X through the same torch ops)"""
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
+    prev_dev = None
+    if device is not None:
+        prev_dev = torch.get_default_device()
+        torch.set_default_device(device)
     try:
         yield
     finally:
         torch.set_default_dtype(prev)
+        if prev_dev is not None:
+            torch.set_default_device(prev_dev)

@@ -27,10 +27,10 @@ class NoiseStream:
         return rs
 
     def randn(self, shape):
-        return torch.from_numpy(self._rs().standard_normal(tuple(shape)).astype(np.float32)).to(torch.get_default_dtype())
+        return torch.from_numpy(self._rs().standard_normal(tuple(shape)).astype(np.float32)).to(device=torch.get_default_device(), dtype=torch.get_default_dtype())
 
     def rand(self, shape):
-        return torch.from_numpy(self._rs().random_sample(tuple(shape)).astype(np.float32)).to(torch.get_default_dtype())
+        return torch.from_numpy(self._rs().random_sample(tuple(shape)).astype(np.float32)).to(device=torch.get_default_device(), dtype=torch.get_default_dtype())
 
 
 # --------------------------------------------------------------------------- EDM (reference diff_params/edm.py)

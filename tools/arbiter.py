@@ -51,7 +51,8 @@ def oracle_job(a, seed, variant):
     from oracle.arbiter_runs import run_blind
     threads = int(variant.split("t")[1]) if variant.startswith("fp32t") else a.fp64_threads
     t0 = time.time()
-    xden, c0, k = run_blind(seed, a.L, a.T, a.nf, a.updates, a.rir_taps, fp64=(variant == "fp64"), threads=threads)
+    xden, c0, k = run_blind(seed, a.L, a.T, a.nf, a.updates, a.rir_taps, fp64=(variant == "fp64"), threads=threads,
+                            device=(a.fp64_device if variant == "fp64" and a.fp64_device != "cpu" else None))
     np.savez(os.path.join(tdir(a), f"seed{seed}_{variant}.npz"), xden=xden.numpy(), clean=c0.numpy(), n_draws=k, seconds=time.time() - t0, threads=threads)
     print(f"seed {seed} {variant}: {time.time() - t0:.0f} s ({threads} threads)", flush=True)
 
@@ -59,7 +60,7 @@ def oracle_job(a, seed, variant):
 def phase_oracle(a):
     # fp64 + the first fp32 run of every seed first, the second fp32 thread count afterwards (a partial run still yields complete pairs)
     order = [(s, v) for s in a.seeds for v in a.variants[:2]] + [(s, v) for v in a.variants[2:] for s in a.seeds]
-    jobs = [(s, v) for s, v in order if not os.path.exists(os.path.join(tdir(a), f"seed{s}_{v}.npz"))]
+    jobs = [(s, v) for s, v in order if v in a.run_variants and not os.path.exists(os.path.join(tdir(a), f"seed{s}_{v}.npz"))]
     running = []
     while jobs or running:
         running = [p for p in running if p.poll() is None]
@@ -172,6 +173,8 @@ if __name__ == "__main__":
     ap.add_argument("--rir_taps", type=int, default=8000)
     ap.add_argument("--threads", default="8,4", help="thread counts of the two fp32 oracle runs")
     ap.add_argument("--fp64_threads", type=int, default=8)
+    ap.add_argument("--fp64_device", default="cpu", help="cuda: run the float64 arbiter through the same torch ops on the GPU (an hour -> under a minute per utterance)")
+    ap.add_argument("--only", default="", help="comma-separated subset of variants for the oracle phase (e.g. fp64 or fp32t8,fp32t4)")
     ap.add_argument("--workers", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--build_tag", default="build")
@@ -180,8 +183,9 @@ if __name__ == "__main__":
     a = ap.parse_args()
     a.seeds = parse_seeds(a.seeds)
     a.variants = ["fp64"] + [f"fp32t{t}" for t in a.threads.split(",")]
+    a.run_variants = [v for v in a.variants if not a.only or v in a.only.split(",")]
     a.common = ["--L", str(a.L), "--T", str(a.T), "--nf", str(a.nf), "--updates", str(a.updates), "--rir_taps", str(a.rir_taps),
-                "--fp64_threads", str(a.fp64_threads)]
+                "--fp64_threads", str(a.fp64_threads), "--fp64_device", a.fp64_device]
     if a.phase == "job":
         oracle_job(a, a.seed, a.variant)
     elif a.phase == "oracle":
