@@ -14,7 +14,7 @@ def overrides(T, updates, nf):
             f"tester.posterior_sampling.blind_hp.op_updates_per_step={updates}", f"network.nf={nf}"]
 
 
-def run_blind(seed, L, T, nf, updates, rir_taps, fp64=False, threads=8, weight_seed=0, device=None):
+def run_blind(seed, L, T, nf, updates, rir_taps, fp64=False, threads=8, weight_seed=0, device=None, perturb=0.0):
     """utterance ``seed`` (buddy_amd.synth clean/RIR), noise stream 9000 + seed -> (x_den per step (T, L) float32, clean (L,), n_draws)"""
     from buddy_amd.config import compose
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
@@ -28,6 +28,8 @@ def run_blind(seed, L, T, nf, updates, rir_taps, fp64=False, threads=8, weight_s
             net = lambda z, cn: ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
             c0 = torch.from_numpy(synth_clean(seed, L)).to(device=dev, dtype=dt)
             c0 = 0.05 * c0 / c0.std()
+            if perturb:                                   # sensitivity probe: the same run with the input scaled by (1 + perturb)
+                c0 = c0 * (1.0 + perturb)
             nr = S.NoiseStream(9000 + seed)
             ref = S.EulerHeunDPSRef(net, S.EDMRef(args.diff_params.sde_hp), args, nr)
             op_hp = args.tester.informed_dereverberation.op_hp

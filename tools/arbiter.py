@@ -5,7 +5,9 @@ identical weights / inputs / injected noise draws) is executed
   * by the CPU oracle in float64           (``oracle.precision.fp64``: the algorithm's exact trajectory for these inputs),
   * by the CPU oracle in float32 at two intra-op thread counts (the reference arithmetic, two summation orders),
   * by the MI355X build (fp32),
-and every fp32 execution is measured against the fp64 trajectory: per-step SI-SDR of x_den, SI-SDR of the final estimate, and the
+  * once more in float64 with the input scaled by 1 + 1e-13 ("fp64b": how far two float64 executions of this chaotic chain separate, i.e. the
+    resolution of the arbiter itself),
+and every execution is measured against the fp64 trajectory: per-step SI-SDR of x_den, SI-SDR of the final estimate, and the
 difference of SI-SDR-to-clean.  The build passes if its deviation from the fp64 trajectory is not larger than the fp32 oracle's own.
 
   python tools/arbiter.py oracle --seeds 0-7 [--L 64000 --T 50 --nf 128 --workers 2 --threads 8,4]     # CPU, writes traces
@@ -51,8 +53,9 @@ def oracle_job(a, seed, variant):
     from oracle.arbiter_runs import run_blind
     threads = int(variant.split("t")[1]) if variant.startswith("fp32t") else a.fp64_threads
     t0 = time.time()
-    xden, c0, k = run_blind(seed, a.L, a.T, a.nf, a.updates, a.rir_taps, fp64=(variant == "fp64"), threads=threads,
-                            device=(a.fp64_device if variant == "fp64" and a.fp64_device != "cpu" else None))
+    is64 = variant.startswith("fp64")
+    xden, c0, k = run_blind(seed, a.L, a.T, a.nf, a.updates, a.rir_taps, fp64=is64, threads=threads,
+                            device=(a.fp64_device if is64 and a.fp64_device != "cpu" else None), perturb=(1e-13 if variant == "fp64b" else 0.0))
     np.savez(os.path.join(tdir(a), f"seed{seed}_{variant}.npz"), xden=xden.numpy(), clean=c0.numpy(), n_draws=k, seconds=time.time() - t0, threads=threads)
     print(f"seed {seed} {variant}: {time.time() - t0:.0f} s ({threads} threads)", flush=True)
 
@@ -119,7 +122,7 @@ def phase_report(a):
     import torch
     from buddy_amd.utils.metrics import si_sdr
     sd = lambda x, y: float(si_sdr(torch.from_numpy(np.asarray(x, dtype=np.float64))[None], torch.from_numpy(np.asarray(y, dtype=np.float64))[None]))
-    others = [v for v in a.variants if v != "fp64"] + [a.build_tag]
+    others = [v for v in a.variants if v != "fp64"] + [a.build_tag]      # incl. fp64b = the resolution of the arbiter itself
     per_seed, steps = {}, {v: [] for v in others}
     final, dclean = {v: [] for v in others}, {v: [] for v in others}
     for s in a.seeds:
@@ -182,7 +185,7 @@ if __name__ == "__main__":
     ap.add_argument("--variant", default="fp64")
     a = ap.parse_args()
     a.seeds = parse_seeds(a.seeds)
-    a.variants = ["fp64"] + [f"fp32t{t}" for t in a.threads.split(",")]
+    a.variants = ["fp64"] + [f"fp32t{t}" for t in a.threads.split(",")] + ["fp64b"]     # fp64b: fp64 with the input scaled by 1 + 1e-13
     a.run_variants = [v for v in a.variants if not a.only or v in a.only.split(",")]
     a.common = ["--L", str(a.L), "--T", str(a.T), "--nf", str(a.nf), "--updates", str(a.updates), "--rir_taps", str(a.rir_taps),
                 "--fp64_threads", str(a.fp64_threads), "--fp64_device", a.fp64_device]
