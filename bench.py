@@ -30,22 +30,25 @@ PEAK_HBM_GBS = 8000.0        # MI355X HBM3E, MI355X_MICROARCH.md
 PEAK_FP32_MFMA = 157.3   # TFLOP/s, MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 
 
-def build_stack(args_ns, device, B, rank):
+def build_stack(args_ns, device, B, first_utt, net=None):
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
     from buddy_amd.testing.tester import Tester
     ov = [f"tester.sampling_params.T={args_ns.T}", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled"]
     args = compose(tester="blind_dereverberation_BUDDy", overrides=ov)
-    net = instantiate(args.network)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(0, args.network.nf).items()})
-    net = net.to(device).eval()
+    if net is None:
+        net = instantiate(args.network)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(0, args.network.nf).items()})
+        net = net.to(device).eval()
+    else:
+        net = net.replica()             # same weights, own activation arena / VJP tape: a second sub-batch on another stream
     edm = instantiate(args.diff_params)
     tester = Tester(args, net, edm, test_set=None, device=device, in_training=True)
     tester.blind_backend = None if args_ns.operator == "hip" else "torch"
     L = args_ns.length
-    items = [(synth_clean(rank * B + u, L), synth_rir(rank * B + u, 8000), f"utt{rank * B + u}.wav") for u in range(B)]
-    torch.manual_seed(1234 + rank)
+    items = [(synth_clean(first_utt + u, L), synth_rir(first_utt + u, 8000), f"utt{first_utt + u}.wav") for u in range(B)]
+    torch.manual_seed(1234 + first_utt)
     seg, y, op, _ = tester.prepare_batch(items, blind=True)
     return args, net, edm, tester, seg, y, op
 
@@ -261,6 +264,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
     ap.add_argument("--length", type=int, default=64000)
     ap.add_argument("--T", type=int, default=50)
+    ap.add_argument("--sub-batches", type=int, default=2, help="the B utterances of a GPU are sampled as this many concurrent sub-batches on their own HIP "
+                    "streams (buddy_amd/testing/concurrent.py: identical results, the latency-bound operator update of one runs beside the network of the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
     ap.add_argument("--operator", default="hip", choices=["hip", "torch"], help="blind operator backend (torch = interim torch-op path)")
@@ -297,9 +302,25 @@ def main():
     from buddy_amd import _lib
     lib = _lib.require_gpu()
     B = a.batch
-    log(f"building stack: B={B}/GPU, L={a.length}, world={world}")
-    args, net, edm, tester, seg, y, op = build_stack(a, device, B, rank)
-    run = StepRunner(tester, y, op, device)
+    S = a.sub_batches if (a.sub_batches > 1 and B % a.sub_batches == 0 and B // a.sub_batches >= 1) else 1
+    log(f"building stack: B={B}/GPU as {S} concurrent sub-batch(es), L={a.length}, world={world}")
+    runs, streams, net0 = [], [], None
+    for k in range(S):
+        st = torch.cuda.Stream() if S > 1 else torch.cuda.current_stream()
+        with torch.cuda.stream(st):
+            args, net, edm, tester, seg, y, op = build_stack(a, device, B // S, rank * B + k * (B // S), net0)
+            net0 = net0 or net
+            runs.append(StepRunner(tester, y, op, device))
+        streams.append(st)
+
+    class _All:                      # one diffusion step of the whole batch = one step of every sub-batch, issued from this host thread
+        op_events = None
+
+        def step(self):
+            for r, st in zip(runs, streams):
+                with torch.cuda.stream(st):
+                    r.step()
+    run = _All()
 
     def barrier():
         torch.cuda.synchronize()
@@ -314,15 +335,17 @@ def main():
     barrier()
     log("timed region")
     lib.buddy_prof_enable(1)
-    run.op_events = []
+    for r in runs:
+        r.op_events = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         run.step()
     barrier()
     elapsed = time.perf_counter() - t0
     lib.buddy_prof_enable(0)
-    op_ms = sum(e0.elapsed_time(e1) for e0, e1 in run.op_events)
-    run.op_events = None
+    op_ms = sum(e0.elapsed_time(e1) for r in runs for e0, e1 in r.op_events)
+    for r in runs:
+        r.op_events = None
     log(f"timed region done: {elapsed:.3f} s")
     ms = (C.c_double * 2)(); fl = (C.c_double * 2)(); ln = (C.c_longlong * 2)(); by = (C.c_double * 2)(); xf = (C.c_double * 2)()
     _lib.check(lib.buddy_prof_collect(ms, fl, ln, by, xf))
@@ -337,7 +360,7 @@ def main():
 
     # end-of-run gather of the (B_local, L) outputs: the only collective on this path (RCCL over xGMI)
     gather_ms = 0.0
-    out = run.x_den.contiguous()
+    out = torch.cat([r.x_den for r in runs]).contiguous()
     if dist is not None:
         torch.cuda.synchronize(); tg = time.perf_counter()
         out_c = out.to(coll_dev)
@@ -375,7 +398,7 @@ def main():
             "config": {"workload": f"blind DPS sampler step, B={B} utterances/GPU x {a.length} samples ({a.length / 16000:g} s@16 kHz), T={a.T}-step schedule, "
                                    f"NCSN++ nf=128 STFT 510/128" + (" (BASELINE.json configs[1])" if (B == 8 and a.length == 64000) else ""),
                        "batch_per_gpu": B, "length": a.length, "T": a.T, "order": 1, "op_updates_per_step": 10,
-                       "parallelism": f"utterance-sharded x{world}", "attention": os.environ.get("BUDDY_ATTN", "default")},
+                       "parallelism": f"utterance-sharded x{world}", "sub_batches_per_gpu": S, "attention": os.environ.get("BUDDY_ATTN", "default")},
             "score_evals_per_s": n_utt_steps / elapsed,   # order 1: one forward+VJP evaluation per utterance-step
             "network_algorithmic_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
             "gather_ms": gather_ms,

@@ -70,6 +70,13 @@ class NCSNppTime(nn.Module):
                  image_size=256, embedding_type="fourier", input_channels=2, spatial_channels=1, dropout=0.0,
                  centered=True, discriminative=False, **kwargs):
         super().__init__()
+        self._init_kwargs = dict(stft=stft, nonlinearity=nonlinearity, nf=nf, ch_mult=ch_mult, num_res_blocks=num_res_blocks,
+                                 attn_resolutions=attn_resolutions, resamp_with_conv=resamp_with_conv, time_conditional=time_conditional,
+                                 fir=fir, fir_kernel=fir_kernel, skip_rescale=skip_rescale, resblock_type=resblock_type,
+                                 progressive=progressive, progressive_input=progressive_input, progressive_combine=progressive_combine,
+                                 init_scale=init_scale, fourier_scale=fourier_scale, image_size=image_size, embedding_type=embedding_type,
+                                 input_channels=input_channels, spatial_channels=spatial_channels, dropout=dropout, centered=centered,
+                                 discriminative=discriminative)
         assert stft is not None, "stft must be provided"          # reference ncsnpp.py:459
         unsupported = []
         if nonlinearity != "swish": unsupported.append("nonlinearity")
@@ -152,6 +159,14 @@ class NCSNppTime(nn.Module):
                 _lib.check(lib.buddy_ncsnpp_set_fir(h, 1))
             self._handle = h
         return self._handle
+
+    def replica(self):
+        """A second module with the SAME weights and its own library handle (activation arena + VJP tape): lets another sub-batch run
+        concurrently on another HIP stream (buddy_amd/testing/concurrent.py).  110 MB of parameters are copied once."""
+        dev = next(self.parameters()).device
+        r = NCSNppTime(**self._init_kwargs)
+        r.load_state_dict(self.state_dict())
+        return r.to(dev).eval()
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)

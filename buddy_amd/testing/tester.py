@@ -40,6 +40,10 @@ class Tester:
         self.paths = {}
         self.results = []
         self.blind_backend = None      # None: HIP operator on a GPU; "torch" forces the torch-op implementation
+        # a batch of >= 2 * sub_batches utterances is sampled as that many concurrent sub-batches on their own HIP streams
+        # (testing/concurrent.py; identical results, better occupancy); 1 = one batch, one stream
+        self.sub_batches = int(args.tester.get("sub_batches", 1)) if hasattr(args.tester, "get") else 1
+        self._concurrent = None
 
     # ---- checkpoints (reference :34-67): the EMA weights are what gets loaded -------------------------------------
     def load_checkpoint(self, path):
@@ -125,9 +129,12 @@ class Tester:
                 # parity runs: one injected noise stream per utterance, shared by the sampler AND the blind operator (random phases,
                 # update_H(use_noise=True), per-step RIR-regulariser draws) in the reference's call order; otherwise the torch RNG
                 self.sampler.noise = self.noise_factory([it[2] for it in grp]) if getattr(self, "noise_factory", None) is not None else None
-                seg, y, operator, rirs = self.prepare_batch(grp, blind, noise=self.sampler.noise)
-                pred = self.sampler.predict_conditional(y, operator, shape=(len(grp), L), blind=blind)
-                est = self.sampler.operator.get_time_RIR().detach().cpu() if blind else None
+                if self.sub_batches > 1 and len(grp) >= 2 * self.sub_batches and str(self.device).startswith("cuda"):
+                    seg, y, pred, est, rirs = self._sample_concurrent(grp, L, blind)
+                else:
+                    seg, y, operator, rirs = self.prepare_batch(grp, blind, noise=self.sampler.noise)
+                    pred = self.sampler.predict_conditional(y, operator, shape=(len(grp), L), blind=blind)
+                    est = self.sampler.operator.get_time_RIR().detach().cpu() if blind else None
                 for b, (_, _, filename) in enumerate(grp):
                     name = os.path.basename(filename)[:-4]
                     self.results.append((name, pred[b].detach().cpu()))
@@ -146,6 +153,25 @@ class Tester:
         from .. import dist as bdist
         rows = bdist.gather_ragged([local[i] for i in mine], len(self.test_set), self.rank, self.world_size, device=self.device)
         self.gathered = [(os.path.basename(self.test_set[i][2])[:-4], rows[i].detach().cpu()) for i in range(len(self.test_set))]
+
+    def _sample_concurrent(self, grp, L, blind):
+        """one equal-length group as ``sub_batches`` concurrent sub-batches (testing/concurrent.py)"""
+        from .concurrent import ConcurrentSampler, split_rows
+        if self._concurrent is None:
+            self._concurrent = ConcurrentSampler(self.args, self.network, self.diff_params, self.sub_batches)
+        parts = split_rows(len(grp), self.sub_batches)
+        noise = self.sampler.noise
+        segs, ys, ops, rirs, noises = [], [], [], [], []
+        for lo, hi in parts:
+            nz = None if noise is None else noise[lo:hi]
+            seg, y, op, rr = self.prepare_batch(grp[lo:hi], blind, noise=nz)
+            segs.append(seg); ys.append(y); ops.append(op); rirs += rr; noises.append(nz)
+        preds = self._concurrent.predict_conditional(ys, ops, blind, None if noise is None else noises)
+        est = None
+        if blind:
+            e = [sb.s.operator.get_time_RIR().detach().cpu() for sb in self._concurrent.last]
+            est = torch.cat([v if v.dim() == 2 else v[None] for v in e])
+        return torch.cat(segs), torch.cat(ys), torch.cat(preds), est, rirs
 
     def dereverberate_long(self, original, rir, blind, chunk_seconds=8.0, overlap_seconds=1.0, noise=None):
         """Long-form policy (testing/longform.py): one long clean/RIR pair -> the reverberant signal cut into overlapping equal chunks,
