@@ -264,8 +264,11 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="utterances per GPU")
     ap.add_argument("--length", type=int, default=64000)
     ap.add_argument("--T", type=int, default=50)
-    ap.add_argument("--sub-batches", type=int, default=2, help="the B utterances of a GPU are sampled as this many concurrent sub-batches on their own HIP "
-                    "streams (buddy_amd/testing/concurrent.py: identical results, the latency-bound operator update of one runs beside the network of the other)")
+    ap.add_argument("--sub-batches", type=int, default=1, help="sample the B utterances of a GPU as this many concurrent sub-batches on their own HIP "
+                    "streams in the MAIN timed region (buddy_amd/testing/concurrent.py).  Default 1: one batch, one stream, so that per-kernel event "
+                    "times and the rocprofv3 summary attribute cleanly (co-running kernels stretch each other's durations)")
+    ap.add_argument("--also-concurrent", type=int, default=2, help="after the main region, time the same workload as this many concurrent sub-batches "
+                    "in a second region and report it as `concurrent_sub_batches` (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
     ap.add_argument("--operator", default="hip", choices=["hip", "torch"], help="blind operator backend (torch = interim torch-op path)")
@@ -302,25 +305,32 @@ def main():
     from buddy_amd import _lib
     lib = _lib.require_gpu()
     B = a.batch
-    S = a.sub_batches if (a.sub_batches > 1 and B % a.sub_batches == 0 and B // a.sub_batches >= 1) else 1
-    log(f"building stack: B={B}/GPU as {S} concurrent sub-batch(es), L={a.length}, world={world}")
-    runs, streams, net0 = [], [], None
-    for k in range(S):
-        st = torch.cuda.Stream() if S > 1 else torch.cuda.current_stream()
-        with torch.cuda.stream(st):
-            args, net, edm, tester, seg, y, op = build_stack(a, device, B // S, rank * B + k * (B // S), net0)
-            net0 = net0 or net
-            runs.append(StepRunner(tester, y, op, device))
-        streams.append(st)
+    net0 = [None]
+
+    def make_runners(S):
+        rr, ss = [], []
+        for k in range(S):
+            st = torch.cuda.Stream() if S > 1 else torch.cuda.current_stream()
+            with torch.cuda.stream(st):
+                _, net, _, tester, _, y, op = build_stack(a, device, B // S, rank * B + k * (B // S), net0[0])
+                net0[0] = net0[0] or net
+                rr.append(StepRunner(tester, y, op, device))
+            ss.append(st)
+        return rr, ss
 
     class _All:                      # one diffusion step of the whole batch = one step of every sub-batch, issued from this host thread
-        op_events = None
+        def __init__(self, rr, ss):
+            self.rr, self.ss = rr, ss
 
         def step(self):
-            for r, st in zip(runs, streams):
+            for r, st in zip(self.rr, self.ss):
                 with torch.cuda.stream(st):
                     r.step()
-    run = _All()
+
+    S = a.sub_batches if (a.sub_batches > 1 and B % a.sub_batches == 0) else 1
+    log(f"building stack: B={B}/GPU as {S} sub-batch(es), L={a.length}, world={world}")
+    runs, streams = make_runners(S)
+    run = _All(runs, streams)
 
     def barrier():
         torch.cuda.synchronize()
@@ -357,6 +367,31 @@ def main():
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+
+    # second region: the same workload as concurrent sub-batches (identical per-utterance results, better occupancy; not used for the rooflines)
+    conc = None
+    S2 = a.also_concurrent
+    if S2 > 1 and S == 1 and B % S2 == 0:
+        log(f"second region: {S2} concurrent sub-batches")
+        runs2, streams2 = make_runners(S2)
+        run2 = _All(runs2, streams2)
+        for _ in range(a.warmup):
+            run2.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run2.step()
+        barrier()
+        e2 = torch.tensor([time.perf_counter() - t0], device=coll_dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+        e2 = float(e2.item())
+        assert all(torch.isfinite(r.x_den).all() for r in runs2), "sampler diverged"
+        conc = {"sub_batches_per_gpu": S2, "value": world * B * a.steps / e2, "unit": "utterance-steps/s", "ms_per_step": e2 / a.steps * 1e3,
+                "what": "the same B utterances per GPU sampled as concurrent sub-batches on their own HIP streams (buddy_amd/testing/concurrent.py, "
+                        "`tester.sub_batches` / `bench.py --sub-batches`): the latency-bound operator update and bottleneck layers of one sub-batch run "
+                        "beside the large kernels of the other; separate timed region, same steps / warm-up"}
+        del runs2, run2
 
     # end-of-run gather of the (B_local, L) outputs: the only collective on this path (RCCL over xGMI)
     gather_ms = 0.0
@@ -439,6 +474,8 @@ def main():
                                         "HIP events on the launch stream (rank 0)"},
             "peaks": {"nominal": {"fp32_mfma_tflops": PEAK_FP32_MFMA, "hbm_GBps": PEAK_HBM_GBS}, "measured_on_this_box": peaks},
         }
+        if conc is not None:
+            res["concurrent_sub_batches"] = conc
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")
             res["cpu_baseline"] = run_cpu_baseline(a.length)

@@ -13,7 +13,7 @@ runners, streams = [], []
 for s in range(S):
     st = torch.cuda.Stream() if S > 1 else torch.cuda.current_stream()
     with torch.cuda.stream(st):
-        args, net, edm, tester, seg, y, op = bench.build_stack(a, dev, B // S, s)
+        args, net, edm, tester, seg, y, op = bench.build_stack(a, dev, B // S, s * (B // S))
         runners.append(bench.StepRunner(tester, y, op, dev))
     streams.append(st)
 def go(n):
