@@ -61,3 +61,34 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path):
     for (n, a), (_, b), L in zip(got, ref, LENGTHS):
         assert a.shape == (L,) and torch.isfinite(a).all()
         assert torch.equal(a, b), (n, float((a - b).abs().max()))
+
+
+def test_concurrent_sub_batches_equal_single_batch():
+    """tester.sub_batches = 2 (testing/concurrent.py: two sub-batches on two HIP streams, own network replica each) returns exactly what the
+    single-batch run returns -- rows never interact, so the result is independent of how a batch is cut."""
+    sys.path.insert(0, ROOT)
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
+    from buddy_amd.testing.tester import Tester
+    from oracle.sampler_ref import NoiseStream
+    L = 8192
+    items = [(synth_clean(u, L), synth_rir(u, 1500), f"u{u}.wav") for u in range(4)]
+
+    def run(sub):
+        args = compose(overrides=["tester.sampling_params.T=3", "network.nf=32", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+                                  "tester.posterior_sampling.blind_hp.op_updates_per_step=2", f"+tester.sub_batches={sub}"])
+        net = instantiate(args.network)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(2, 32).items()})
+        net = net.cuda().eval()
+        t = Tester(args, net, instantiate(args.diff_params), test_set=items, device="cuda", in_training=True, batch_size=4)
+        assert t.sub_batches == sub
+        t.noise_factory = lambda names: [NoiseStream(800 + int(n[1:-4])) for n in names]
+        t.test_dereverberation("blind_dereverberation", blind=True)
+        torch.cuda.synchronize()
+        return t.gathered
+
+    one, two = run(1), run(2)
+    for (n1, a), (n2, b) in zip(one, two):
+        assert n1 == n2 and torch.isfinite(a).all()
+        assert torch.equal(a, b), (n1, float((a - b).abs().max()))
