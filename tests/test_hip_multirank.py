@@ -64,8 +64,9 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path):
 
 
 def test_concurrent_sub_batches_equal_single_batch():
-    """tester.sub_batches = 2 (testing/concurrent.py: two sub-batches on two HIP streams, own network replica each) returns exactly what the
-    single-batch run returns -- rows never interact, so the result is independent of how a batch is cut."""
+    """tester.sub_batches = 2 (testing/concurrent.py: two sub-batches on two HIP streams, own network replica each) returns what the single-batch
+    run returns -- rows never interact; a different batch size only changes tile shapes / reduction chunking of a few kernels, i.e. fp32
+    round-off, amplified by the guidance normalisation over the three steps: same 1e-3 bound as the batched-vs-single sampler test."""
     sys.path.insert(0, ROOT)
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
@@ -91,4 +92,5 @@ def test_concurrent_sub_batches_equal_single_batch():
     one, two = run(1), run(2)
     for (n1, a), (n2, b) in zip(one, two):
         assert n1 == n2 and torch.isfinite(a).all()
-        assert torch.equal(a, b), (n1, float((a - b).abs().max()))
+        err = float((a.double() - b.double()).abs().max() / b.double().abs().max())
+        assert err < 1e-3, (n1, err)
