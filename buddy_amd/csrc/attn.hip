@@ -43,6 +43,26 @@ __device__ __forceinline__ void stage32(const float* __restrict__ src, int r0, i
   }
 }
 
+// the same staging split in two (global -> registers, registers -> LDS) so the loads of block j + 1 fly under the matrix work of block j
+template <int C>
+__device__ __forceinline__ void fetch32(const float* __restrict__ src, int r0, int T, float4 (&r)[32 * (C / 4) / 256]) {
+  constexpr int Q = C / 4;
+#pragma unroll
+  for (int n = 0; n < 32 * Q / 256; ++n) {
+    const int i = threadIdx.x + 256 * n, row = i / Q, c = (i - row * Q) * 4;
+    r[n] = (r0 + row < T) ? ld4(src + (long long)(r0 + row) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int C>
+__device__ __forceinline__ void put32(const float4 (&r)[32 * (C / 4) / 256], float* dst) {
+  constexpr int LD = C + 4, Q = C / 4;
+#pragma unroll
+  for (int n = 0; n < 32 * Q / 256; ++n) {
+    const int i = threadIdx.x + 256 * n, row = i / Q, c = (i - row * Q) * 4;
+    *reinterpret_cast<float4*>(dst + row * LD + c) = r[n];
+  }
+}
+
 // acc[t] (16 x 16, t = 0, 1) = sum_k A[row][k] * Bs[16 t + col][k]  with A in registers (float4 per 16-wide k chunk) and Bs in LDS
 template <int C>
 __device__ __forceinline__ void tile_abt(const float4 (&a)[C / 16], const float* Bs, int i, int g, f32x4 (&acc)[2]) {
@@ -179,11 +199,15 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const float* __restri
   f32x4 acc[C / 16];
 #pragma unroll
   for (int c = 0; c < C / 16; ++c) acc[c] = zero_acc();
+  float4 pk[32 * (C / 4) / 256], pv[32 * (C / 4) / 256];
+  fetch32<C>(k + base, 0, T, pk);
+  fetch32<C>(v + base, 0, T, pv);
   for (int j0 = 0; j0 < T; j0 += BC) {
     __syncthreads();
-    stage32<C>(k + base, j0, T, Ks);
-    stage32<C>(v + base, j0, T, Vs);
+    put32<C>(pk, Ks);
+    put32<C>(pv, Vs);
     __syncthreads();
+    if (j0 + BC < T) { fetch32<C>(k + base, j0 + BC, T, pk); fetch32<C>(v + base, j0 + BC, T, pv); }
     f32x4 s[2] = {zero_acc(), zero_acc()}, dp[2] = {zero_acc(), zero_acc()};
     tile_abt<C>(qa, Ks, i, g, s);
     tile_abt<C>(da, Vs, i, g, dp);
@@ -229,11 +253,15 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const float* __restr
   f32x4 gk[C / 16], gv[C / 16];
 #pragma unroll
   for (int c = 0; c < C / 16; ++c) { gk[c] = zero_acc(); gv[c] = zero_acc(); }
+  float4 pq[32 * (C / 4) / 256], po[32 * (C / 4) / 256];
+  fetch32<C>(q + base, 0, T, pq);
+  fetch32<C>(dO + base, 0, T, po);
   for (int i0 = 0; i0 < T; i0 += BC) {
     __syncthreads();
-    stage32<C>(q + base, i0, T, Qs);
-    stage32<C>(dO + base, i0, T, Os);
+    put32<C>(pq, Qs);
+    put32<C>(po, Os);
     __syncthreads();
+    if (i0 + BC < T) { fetch32<C>(q + base, i0 + BC, T, pq); fetch32<C>(dO + base, i0 + BC, T, po); }
     f32x4 s[2] = {zero_acc(), zero_acc()}, dp[2] = {zero_acc(), zero_acc()};
     tile_abt<C>(ka, Qs, i, g, s);              // S^T[key row][query col]
     tile_abt<C>(va, Os, i, g, dp);             // dP^T
