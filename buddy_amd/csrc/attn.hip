@@ -44,21 +44,21 @@ __device__ __forceinline__ void stage32(const float* __restrict__ src, int r0, i
 }
 
 // the same staging split in two (global -> registers, registers -> LDS) so the loads of block j + 1 fly under the matrix work of block j
-template <int C>
-__device__ __forceinline__ void fetch32(const float* __restrict__ src, int r0, int T, float4 (&r)[32 * (C / 4) / 256]) {
+template <int C, int NT = 256>
+__device__ __forceinline__ void fetch32(const float* __restrict__ src, int r0, int T, float4 (&r)[32 * (C / 4) / NT]) {
   constexpr int Q = C / 4;
 #pragma unroll
-  for (int n = 0; n < 32 * Q / 256; ++n) {
-    const int i = threadIdx.x + 256 * n, row = i / Q, c = (i - row * Q) * 4;
+  for (int n = 0; n < 32 * Q / NT; ++n) {
+    const int i = threadIdx.x + NT * n, row = i / Q, c = (i - row * Q) * 4;
     r[n] = (r0 + row < T) ? ld4(src + (long long)(r0 + row) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
-template <int C>
-__device__ __forceinline__ void put32(const float4 (&r)[32 * (C / 4) / 256], float* dst) {
+template <int C, int NT = 256>
+__device__ __forceinline__ void put32(const float4 (&r)[32 * (C / 4) / NT], float* dst) {
   constexpr int LD = C + 4, Q = C / 4;
 #pragma unroll
-  for (int n = 0; n < 32 * Q / 256; ++n) {
-    const int i = threadIdx.x + 256 * n, row = i / Q, c = (i - row * Q) * 4;
+  for (int n = 0; n < 32 * Q / NT; ++n) {
+    const int i = threadIdx.x + NT * n, row = i / Q, c = (i - row * Q) * 4;
     *reinterpret_cast<float4*>(dst + row * LD + c) = r[n];
   }
 }
@@ -117,11 +117,17 @@ __global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(const float* __restr
   float m[4], l[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+  constexpr int NT = 64 * NW;
+  static_assert(32 * (C / 4) % NT == 0, "staging assumes whole float4 rounds per thread");
+  float4 pk[32 * (C / 4) / NT], pv[32 * (C / 4) / NT];
+  fetch32<C, NT>(k + base, 0, T, pk);
+  fetch32<C, NT>(v + base, 0, T, pv);
   for (int j0 = 0; j0 < T; j0 += BC) {
     __syncthreads();
-    stage32<C, 64 * NW>(k + base, j0, T, Ks);
-    stage32<C, 64 * NW>(v + base, j0, T, Vs);
+    put32<C, NT>(pk, Ks);
+    put32<C, NT>(pv, Vs);
     __syncthreads();
+    if (j0 + BC < T) { fetch32<C, NT>(k + base, j0 + BC, T, pk); fetch32<C, NT>(v + base, j0 + BC, T, pv); }
     f32x4 s[2] = {zero_acc(), zero_acc()};
     tile_abt<C>(qa, Ks, i, g, s);
     float alpha[4];
@@ -530,7 +536,7 @@ void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float
   const dim3 grid(cdiv(T, BR), B), block(256);
   // fp32: 128-row workgroups (8 waves) once there are enough of them to fill the chip, 64-row ones otherwise (BUDDY_ATTN_NW=4|8 forces one)
   static const int force_nw = getenv("BUDDY_ATTN_NW") ? atoi(getenv("BUDDY_ATTN_NW")) : 0;
-  const bool wide = force_nw ? force_nw == 8 : (long long)cdiv(T, 128) * B >= 512;
+  const bool wide = force_nw ? force_nw == 8 : (long long)cdiv(T, 128) * B >= 256;
   const dim3 grid8(cdiv(T, 128), B), block8(512);
 #define FA_FWD(CC)                                                                                                           \
   if (prec == 1) hipLaunchKernelGGL((flash16_fwd_kernel<CC, __bf16>), grid, block, 0, st, q, k, v, O, Lse, T, scale);            \
