@@ -24,7 +24,7 @@ nconv = f[GROUP[0]][1]
 out = {"kernel_group": "3x3 convolution = w4_input_kernel + igemm_kernel<1,false,false,2,2,36> (36 batched GEMMs) + w4_output_kernel",
        "convolutions_in_fetch_pass": nconv, "convolutions_in_write_pass": w[GROUP[0]][1],
        "per_kernel_bytes_per_convolution": {k: {"fetch": 2 * f[k][0] * 1024 / nconv, "write": w[k][0] * 1024 / max(1, w[GROUP[0]][1])} for k in GROUP},
-       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline`; FETCH_SIZE x2 (gfx950 correction)"}
+       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --also-concurrent 0`; FETCH_SIZE x2 (gfx950 correction)"}
 _h = hashlib.sha1()
 for _f in ("igemm.hip", "wino4.hip", "common.h"):        # same stamp as bench.py conv_source_stamp(): the summary is tied to these kernels
     _h.update(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "buddy_amd", "csrc", _f), "rb").read())
