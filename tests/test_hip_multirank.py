@@ -66,7 +66,8 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path):
 def test_concurrent_sub_batches_equal_single_batch():
     """tester.sub_batches = 2 (testing/concurrent.py: two sub-batches on two HIP streams, own network replica each) returns what the single-batch
     run returns -- rows never interact; a different batch size only changes tile shapes / reduction chunking of a few kernels, i.e. fp32
-    round-off, amplified by the guidance normalisation over the three steps: same 1e-3 bound as the batched-vs-single sampler test."""
+    round-off.  Informed mode (no operator optimisation, not chaotic): 1e-4 of the peak.  Blind mode: the six scale-free Adam updates of this
+    short run amplify that round-off (oracle/precision.py analysis: 3e-2 at iteration 6), so only 5e-2 is asserted there."""
     sys.path.insert(0, ROOT)
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
@@ -76,21 +77,26 @@ def test_concurrent_sub_batches_equal_single_batch():
     L = 8192
     items = [(synth_clean(u, L), synth_rir(u, 1500), f"u{u}.wav") for u in range(4)]
 
-    def run(sub):
-        args = compose(overrides=["tester.sampling_params.T=3", "network.nf=32", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
-                                  "tester.posterior_sampling.blind_hp.op_updates_per_step=2", f"+tester.sub_batches={sub}"])
+    def run(sub, blind):
+        ov = ["tester.sampling_params.T=3", "network.nf=32", f"+tester.sub_batches={sub}"]
+        if blind:
+            ov += ["tester.posterior_sampling.warm_initialization.mode=reverb_scaled", "tester.posterior_sampling.blind_hp.op_updates_per_step=2"]
+        args = compose(tester="blind_dereverberation_BUDDy" if blind else "informed_dereverberation_DPS", overrides=ov)
         net = instantiate(args.network)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(2, 32).items()})
         net = net.cuda().eval()
         t = Tester(args, net, instantiate(args.diff_params), test_set=items, device="cuda", in_training=True, batch_size=4)
         assert t.sub_batches == sub
         t.noise_factory = lambda names: [NoiseStream(800 + int(n[1:-4])) for n in names]
-        t.test_dereverberation("blind_dereverberation", blind=True)
+        t.test_dereverberation("blind_dereverberation" if blind else "informed_dereverberation", blind=blind)
         torch.cuda.synchronize()
+        assert (t._concurrent is not None) == (sub > 1)
         return t.gathered
 
-    one, two = run(1), run(2)
-    for (n1, a), (n2, b) in zip(one, two):
-        assert n1 == n2 and torch.isfinite(a).all()
-        err = float((a.double() - b.double()).abs().max() / b.double().abs().max())
-        assert err < 1e-3, (n1, err)
+    for blind, tol in ((False, 1e-4), (True, 5e-2)):
+        one, two = run(1, blind), run(2, blind)
+        for (n1, a), (n2, b) in zip(one, two):
+            assert n1 == n2 and torch.isfinite(a).all()
+            err = float((a.double() - b.double()).abs().max() / b.double().abs().max())
+            print("blind" if blind else "informed", n1, f"{err:.2e}")
+            assert err < tol, (blind, n1, err)
