@@ -141,6 +141,7 @@ struct Net {
   Tens* spec = nullptr; Tens* pyr0 = nullptr;
   const float* k_cin = nullptr; const float* k_cskip = nullptr; const float* k_cout = nullptr;
 
+  int rsv_B = 0, rsv_L = 0, rsv_vjp = -1;   // shape the arena was last sized for (the sizing dry run is skipped while it still fits)
   bool fir = false;            // fir=True: FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257)
   float* w4_scratch = nullptr; size_t w4_cap = 0, w4_need = 0;   // V / M buffers of the three-pass F(4x4,3x3) convolutions (floats)
   bool dry() const { return arena.dry; }
@@ -360,7 +361,7 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   return BUDDY_OK;
 }
 
-int net_set_fir(Net* N, int fir) { N->fir = fir != 0; return BUDDY_OK; }
+int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; return BUDDY_OK; }
 void net_destroy(Net* N) {
   if (!N) return;
   if (N->dparams) (void)hipFree(N->dparams);
@@ -877,6 +878,7 @@ int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes) {
     HIPCHK(hipMalloc(&N->arena.base, need));
     N->arena.cap = need;
   }
+  N->rsv_B = B; N->rsv_L = L; N->rsv_vjp = with_vjp != 0;
   return BUDDY_OK;
 }
 
@@ -885,7 +887,8 @@ int net_forward(Net* N, const float* x, const float* cnoise, const float* cin_b,
   if (B < 1 || L < N->cfg.n_fft) { set_error("bad B or L"); return BUDDY_ERR_ARG; }
   const int T = 1 + L / N->cfg.hop, Tp = (T + 15) / 16 * 16;
   if (Tp % (1 << (N->cfg.nlev - 1))) { set_error("frames not divisible"); return BUDDY_ERR_ARG; }
-  int rc = net_reserve(N, B, L, save, nullptr);
+  int rc = BUDDY_OK;
+  if (!(N->rsv_B == B && N->rsv_L == L && N->rsv_vjp >= (save != 0))) rc = net_reserve(N, B, L, save, nullptr);   // host dry run only on a new shape
   if (rc) return rc;
   rc = ensure_env(N, Tp);
   if (rc) return rc;
