@@ -36,6 +36,8 @@ def build_stack(args_ns, device, B, first_utt, net=None):
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
     from buddy_amd.testing.tester import Tester
     ov = [f"tester.sampling_params.T={args_ns.T}", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled"]
+    if getattr(args_ns, "attention", None):
+        ov.append(f"+network.attention={args_ns.attention}")
     args = compose(tester="blind_dereverberation_BUDDy", overrides=ov)
     if net is None:
         net = instantiate(args.network)
@@ -269,6 +271,8 @@ def main():
                     "times and the rocprofv3 summary attribute cleanly (co-running kernels stretch each other's durations)")
     ap.add_argument("--also-concurrent", type=int, default=2, help="after the main region, time the same workload as this many concurrent sub-batches "
                     "in a second region and report it as `concurrent_sub_batches` (0 = skip)")
+    ap.add_argument("--attention", default=None, choices=["flash", "matrix", "bf16", "f16"], help="attention core of the network (default: the library's, "
+                    "fp32 online softmax; bf16 / f16 = the opt-in fast mode that passed the 0.1 dB gate, profiles/r02_attention_modes.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
     ap.add_argument("--operator", default="hip", choices=["hip", "torch"], help="blind operator backend (torch = interim torch-op path)")
@@ -433,7 +437,7 @@ def main():
             "config": {"workload": f"blind DPS sampler step, B={B} utterances/GPU x {a.length} samples ({a.length / 16000:g} s@16 kHz), T={a.T}-step schedule, "
                                    f"NCSN++ nf=128 STFT 510/128" + (" (BASELINE.json configs[1])" if (B == 8 and a.length == 64000) else ""),
                        "batch_per_gpu": B, "length": a.length, "T": a.T, "order": 1, "op_updates_per_step": 10,
-                       "parallelism": f"utterance-sharded x{world}", "sub_batches_per_gpu": S, "attention": os.environ.get("BUDDY_ATTN", "default")},
+                       "parallelism": f"utterance-sharded x{world}", "sub_batches_per_gpu": S, "attention": a.attention or os.environ.get("BUDDY_ATTN", "flash (fp32)")},
             "score_evals_per_s": n_utt_steps / elapsed,   # order 1: one forward+VJP evaluation per utterance-step
             "network_algorithmic_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
             "gather_ms": gather_ms,

@@ -142,6 +142,7 @@ struct Net {
   const float* k_cin = nullptr; const float* k_cskip = nullptr; const float* k_cout = nullptr;
 
   int rsv_B = 0, rsv_L = 0, rsv_vjp = -1;   // shape the arena was last sized for (the sizing dry run is skipped while it still fits)
+  int attn_mode = 0;           // see attn_mode_from_env()
   bool fir = false;            // fir=True: FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257)
   float* w4_scratch = nullptr; size_t w4_cap = 0, w4_need = 0;   // V / M buffers of the three-pass F(4x4,3x3) convolutions (floats)
   bool dry() const { return arena.dry; }
@@ -198,9 +199,11 @@ static const PSpec* find_spec(const std::vector<PSpec>& v, const std::string& n)
   return nullptr;
 }
 
+static int attn_mode_from_env();
 int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   Net* N = new Net();
   N->cfg = cfg;
+  N->attn_mode = attn_mode_from_env();
   N->specs = build_specs(cfg);
   if (n != param_count(cfg)) { set_error("parameter blob size mismatch"); delete N; return BUDDY_ERR_ARG; }
   if (cfg.n_fft % 2) { set_error("n_fft must be even"); delete N; return BUDDY_ERR_ARG; }
@@ -361,6 +364,7 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   return BUDDY_OK;
 }
 
+int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 3) { set_error("attention mode must be 0..3"); return BUDDY_ERR_ARG; } N->attn_mode = mode; N->rsv_vjp = -1; return BUDDY_OK; }
 int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; return BUDDY_OK; }
 void net_destroy(Net* N) {
   if (!N) return;
@@ -544,16 +548,16 @@ static void gemm_b(Net* N, const float* A, int ldA, long long sA, bool tA, const
   launch_igemm(p, 1, tA, tB, batch, N->st);
 }
 
-// BUDDY_ATTN=matrix keeps the materialised T x T form (P in HBM: 16.8 MB / utterance at 4 s, 905 MB at 30 s); default = flash (attn.hip)
-static bool attn_use_flash(int C) {
-  static const bool want_matrix = getenv("BUDDY_ATTN") && std::string(getenv("BUDDY_ATTN")) == "matrix";
-  return !want_matrix && flash_attn_supported(C);
+// Attention mode of a handle: 0 = flash, fp32 operands (default); 1 / 2 = flash with bf16 / f16 MFMA operands (opt-in fast mode, DESIGN.md
+// section 7); 3 = the materialised T x T form (P in HBM: 16.8 MB / utterance at 4 s, 905 MB at 30 s).  Initialised from BUDDY_ATTN
+// (matrix | flash | bf16 | f16), changed per handle with buddy_ncsnpp_set_attention.
+static int attn_mode_from_env() {
+  const char* e = getenv("BUDDY_ATTN");
+  const std::string m = e ? e : "";
+  return m == "matrix" ? 3 : m == "bf16" ? 1 : m == "f16" ? 2 : 0;
 }
-// BUDDY_ATTN=bf16 | f16: 16-bit MFMA operands in the attention products (opt-in fast mode, not the reference arithmetic)
-static int attn_prec() {
-  static const int p = [] { const char* e = getenv("BUDDY_ATTN"); const std::string m = e ? e : ""; return m == "bf16" ? 1 : m == "f16" ? 2 : 0; }();
-  return p;
-}
+static bool attn_use_flash(const Net* N, int C) { return N->attn_mode != 3 && flash_attn_supported(C); }
+static int attn_prec(const Net* N) { return N->attn_mode == 1 || N->attn_mode == 2 ? N->attn_mode : 0; }
 
 static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
   const int B = x->B, H = x->H, W = x->W, C = A.C, T = H * W, G = gn_groups(C);
@@ -572,7 +576,7 @@ static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
     gemm_b(N, hn, C, 0, false, A.Wt[0], C, 0, false, q, C, 0, B * T, C, C, A.b[0], nullptr, 1.f, 0, 1);
     gemm_b(N, hn, C, 0, false, A.Wt[1], C, 0, false, k, C, 0, B * T, C, C, A.b[1], nullptr, 1.f, 0, 1);
     gemm_b(N, hn, C, 0, false, A.Wt[2], C, 0, false, v, C, 0, B * T, C, C, A.b[2], nullptr, 1.f, 0, 1);
-    launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, attn_prec(), st);
+    launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, attn_prec(N), st);
     IgemmParams p = ig_base();
     p.A0 = O; p.ldA0 = C; p.Cin = C; p.M = B * T; p.N = C; p.Bt = A.Wt[3]; p.ldB = C; p.C = out->p; p.ldC = C; p.bias_n = A.b[3];
     p.res = x->p; p.ldRes = C; p.res_mode = 1; p.out_scale = INV_SQRT2;
@@ -588,7 +592,7 @@ static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
       float* dO = n->tmp(BTC); float* dq = n->tmp(BTC); float* dk = n->tmp(BTC); float* dv = n->tmp(BTC); float* dhn = n->tmp(BTC);
       float* dl = n->tmp((long long)B * T);
       gemm_b(n, dout, C, 0, false, Ap->Wn[3], C, 0, false, dO, C, 0, B * T, C, C, nullptr, nullptr, INV_SQRT2, 0, 1);
-      if (!n->dry()) launch_flash_attn_bwd(q, k, v, O, dO, lse, dl, dq, dk, dv, B, T, C, scale, attn_prec(), s);
+      if (!n->dry()) launch_flash_attn_bwd(q, k, v, O, dO, lse, dl, dq, dk, dv, B, T, C, scale, attn_prec(n), s);
       gemm_b(n, dq, C, 0, false, Ap->Wn[0], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 0, 1);
       gemm_b(n, dk, C, 0, false, Ap->Wn[1], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);
       gemm_b(n, dv, C, 0, false, Ap->Wn[2], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);
@@ -603,7 +607,7 @@ static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
 }
 
 static Tens* attnblock(Net* N, const AttnW& A, Tens* x, bool rec) {
-  if (attn_use_flash(A.C)) return attnblock_flash(N, A, x, rec);
+  if (attn_use_flash(N, A.C)) return attnblock_flash(N, A, x, rec);
   const int B = x->B, H = x->H, W = x->W, C = A.C, T = H * W, G = gn_groups(C);
   hipStream_t st = N->st;
   const float scale = 1.f / std::sqrt((float)C);

@@ -102,6 +102,9 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
  * The transposes are the other direction times 4 resp. 1/4.  buddy_ncsnpp_set_fir switches a network handle to this resampling (no parameters). */
 int buddy_fir_resample2(const float* x, float* y, int B, int H, int W, int C, int up, float scale, int accumulate, void* stream);
 int buddy_ncsnpp_set_fir(void* handle, int fir);
+/* attention core of a network handle: 0 = online-softmax kernels, fp32 operands (default); 1 / 2 = the same with bf16 / f16 MFMA operands (opt-in
+ * fast mode, fp32 accumulate + fp32 softmax); 3 = materialised T x T matrix.  Initial value from BUDDY_ATTN = flash | bf16 | f16 | matrix. */
+int buddy_ncsnpp_set_attention(void* handle, int mode);
 
 /* single-head attention over T tokens without the T x T matrix (online softmax, fp32 MFMA), token-major q, k, v, O [B][T][C], C in {64,128,256}:
  * O = softmax(scale * q k^T) v, lse [B][T] = row log-sum-exp; replaces the einsum / softmax / einsum of AttnBlockpp.forward

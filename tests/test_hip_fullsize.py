@@ -159,6 +159,13 @@ def test_longform_blind_sampler_two_steps_vs_oracle(net):
     _two_blind_steps_vs_oracle(net, 480000, 4, 8000)
 
 
+def test_longform_f16_attention_blind_sampler_two_steps_vs_oracle():
+    """BASELINE config 5 names an fp16 MFMA attention path: the same two blind steps at 480 000 samples, B = 4, with
+    NCSNppTime(attention="f16") (16-bit MFMA operands in the attention kernels only, fp32 accumulate / softmax) against the fp32 oracle."""
+    from tests.test_hip_network import build
+    _two_blind_steps_vs_oracle(build(128, 510, 128, 0, attention="f16"), 480000, 4, 8000)
+
+
 def test_longform_chunked_policy(net):
     """testing/longform.py through the Tester: a 10 s clip as overlapping 4 s chunks sampled as one batch (informed, 2 steps) and cross-faded;
     a clip that fits one chunk takes the un-chunked path bit for bit."""

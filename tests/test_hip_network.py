@@ -18,13 +18,13 @@ def rel(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
-def build(nf, n_fft, hop, seed, fir=False):
+def build(nf, n_fft, hop, seed, fir=False, attention=None):
     from buddy_amd.config import load_yaml, CONF_DIR, AttrDict
     from buddy_amd.networks.ncsnpp import NCSNppTime
     from buddy_amd.synth import synth_state_dict
     cfg = load_yaml(os.path.join(CONF_DIR, "network", "ncsnpp.yaml"))
     cfg.pop("_target_")
-    cfg.update(nf=nf, fir=fir, stft=AttrDict(n_fft=n_fft, hop_length=hop, center=True))
+    cfg.update(nf=nf, fir=fir, attention=attention, stft=AttrDict(n_fft=n_fft, hop_length=hop, center=True))
     net = NCSNppTime(**cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(seed, nf).items()})
     return net.cuda().eval()
@@ -52,6 +52,21 @@ def test_forward_vjp_vs_golden(golden, name):
     gx, = torch.autograd.grad(y, x, torch.from_numpy(g["cot"]).cuda())
     e = rel(gx.cpu().numpy(), g["vjp"])
     assert e < TOL, f"vjp rel err {e}"
+
+
+@pytest.mark.parametrize("attention,tol", [("matrix", TOL), ("flash", TOL), ("f16", 1e-3), ("bf16", 5e-3)])
+def test_attention_modes_vs_golden(golden, attention, tol):
+    """NCSNppTime(attention=...): the materialised form and the online-softmax kernels hold the fp32 tolerance; the opt-in 16-bit-operand
+    variants are stated at 1e-3 (f16) / 5e-3 (bf16) of the output peak on the full-width fixture (one attention block in a 36-module network)."""
+    g = golden("net_full")
+    nf, n_fft, hop, L, B, seed = [int(v) for v in g["meta"]]
+    net = build(nf, n_fft, hop, seed, attention=attention)
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = net(x, torch.from_numpy(g["cnoise"]).cuda())
+    gx, = torch.autograd.grad(y, x, torch.from_numpy(g["cot"]).cuda())
+    ey, eg = rel(y.detach().cpu().numpy(), g["y"]), rel(gx.cpu().numpy(), g["vjp"])
+    print(attention, f"forward {ey:.2e} vjp {eg:.2e}")
+    assert ey < tol and eg < tol
 
 
 def test_forward_vjp_vs_oracle_batched_fused_edm():
