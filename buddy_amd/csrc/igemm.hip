@@ -16,6 +16,7 @@
 #include "common.h"
 #include <cstdio>
 #include <cstdint>
+#include <string>
 #include <vector>
 #include <cstdlib>
 
@@ -24,6 +25,38 @@ namespace buddy {
 namespace {
 constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = 36, NT = 256;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- opt-in "bf16x3" mode of the Winograd-domain GEMM (BUDDY_GEMM=bf16x3 / buddy_set_gemm_mode(1)) ----
+// Every fp32 operand is split EXACTLY into three bf16 terms by truncation, x = hi + mid + lo (8 + 8 + 8 significant bits: hi = top 16 bits of x,
+// mid = top 16 bits of x - hi, lo = x - hi - mid, each subtraction exact), and the product a*b is formed from the six largest cross terms
+// hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped terms (mid*lo, lo*mid, lo*lo)
+// are <= 2^-23 of the product, i.e. at the fp32 rounding level.  Six bf16 MFMAs (32 cycles each, 16 k) replace eight fp32 MFMAs (64 cycles each, 2 k):
+// 2.7x fewer matrix cycles per MAC.  Not the default: the reference computes in fp32 and this is an emulation of it, gated like the attention fast mode.
+struct Split3 { bf16x8 hi, mid, lo; };
+__device__ __forceinline__ Split3 split3(const float4 a, const float4 b) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned int h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned int u = __float_as_uint(x[i]);
+    h[i] = u & 0xFFFF0000u;
+    const float r = x[i] - __uint_as_float(h[i]);
+    m[i] = __float_as_uint(r) & 0xFFFF0000u;
+    l[i] = __float_as_uint(r - __uint_as_float(m[i]));          // <= 8 significant bits left: its low 16 mantissa bits are zero
+  }
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    ph[p] = (h[2 * p] >> 16) | h[2 * p + 1];
+    pm[p] = (m[2 * p] >> 16) | m[2 * p + 1];
+    pl[p] = (l[2 * p] >> 16) | (l[2 * p + 1] & 0xFFFF0000u);
+  }
+  Split3 s;
+  s.hi = __builtin_bit_cast(bf16x8, ph); s.mid = __builtin_bit_cast(bf16x8, pm); s.lo = __builtin_bit_cast(bf16x8, pl);
+  return s;
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -31,7 +64,7 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // MT = 32-row MFMA tiles per wave along M: 2 -> 128-row block tile (default), 1 -> 64-row block tile for GEMMs whose 128-row
 // tiling would leave CUs idle (the operator's 4040 x 512 x 1028 DFT GEMMs are 128 tiles on 256 CUs).
 // TAG only names an instantiation (the 36-batch GEMM of the F(4x4,3x3) convolutions shows up as its own row in rocprofv3 summaries).
-template <int TAPS, bool TA, bool TB, int V = 2, int MT = 2, int TAG = 0>
+template <int TAPS, bool TA, bool TB, int V = 2, int MT = 2, int TAG = 0, int SPLIT = 0>
 __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
   static_assert(MT == 2 || !TA, "64-row tiles are only built for row-major A");
   constexpr int NBUF = (V >= 4) ? 2 : 1;
@@ -169,7 +202,43 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
     }
   };
 
-  if (V < 4) {
+  // bf16x3 mode: one group = 16 k; lane half h = lane >> 5 supplies k = 16 G + 8 h .. + 7 of its row (two float4 LDS reads per fragment)
+  const float* Af3 = As + (wm * 32 * MT + (lane & 31)) * LDS_LD + (lane >> 5) * 8;
+  const float* Bf3 = Bs + (wn * 64 + (lane & 31)) * LDS_LD + (lane >> 5) * 8;
+  auto mfma_split_group = [&](int G) {
+    Split3 a[MT], b[2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+      a[t] = split3(*reinterpret_cast<const float4*>(Af3 + t * 32 * LDS_LD + 16 * G), *reinterpret_cast<const float4*>(Af3 + t * 32 * LDS_LD + 16 * G + 4));
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      b[t] = split3(*reinterpret_cast<const float4*>(Bf3 + t * 32 * LDS_LD + 16 * G), *reinterpret_cast<const float4*>(Bf3 + t * 32 * LDS_LD + 16 * G + 4));
+#pragma unroll
+    for (int ta = 0; ta < MT; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        f32x16 c = acc[ta][tb];          // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb].mid, a[ta].mid, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb].lo, a[ta].hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb].hi, a[ta].lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb].mid, a[ta].hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb].hi, a[ta].mid, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb].hi, a[ta].hi, c, 0, 0, 0);
+        acc[ta][tb] = c;
+      }
+  };
+
+  if (SPLIT) {
+    for (int kt = 0; kt < nk; ++kt) {
+      store_tile(As, ra, TA, AR);
+      store_tile(Bs, rb, TB);
+      __syncthreads();
+      mfma_split_group(0);
+      if (kt + 1 < nk) { loadA(kt + 1, ra); loadB(kt + 1, rb); }
+      mfma_split_group(1);
+      __syncthreads();
+    }
+  } else if (V < 4) {
     for (int kt = 0; kt < nk; ++kt) {
       store_tile(As, ra, TA, AR);
       store_tile(Bs, rb, TB);
@@ -379,6 +448,14 @@ void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st
   }
 }
 
+// 0 = exact fp32 MFMA (default), 1 = bf16x3 split for the 36-batch Winograd-domain GEMM (initial value from BUDDY_GEMM=bf16x3)
+namespace { int g_gemm_mode = -1; }
+int gemm_mode() {
+  if (g_gemm_mode < 0) { const char* e = getenv("BUDDY_GEMM"); g_gemm_mode = (e && std::string(e) == "bf16x3") ? 1 : 0; }
+  return g_gemm_mode;
+}
+void set_gemm_mode(int m) { g_gemm_mode = m ? 1 : 0; }
+
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st) {
   dim3 grid(cdiv(p.N, BN) * cdiv(p.M, BM), 1, batch), block(NT);
   // fewer than two 128-row tiles per CU: halve the tile height so the grid fills the chip (row-major A only)
@@ -412,7 +489,8 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
     else if (variant == 4) hipLaunchKernelGGL((igemm_kernel<9, false, false, 4>), grid, block, 0, st, pw);
     else hipLaunchKernelGGL((igemm_kernel<9, false, false, 2>), grid, block, 0, st, pw);
   } else if (!transA && !transB && p.tag == 36 && !small_grid) {
-    hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 2, 36>), grid, block, 0, st, pw);
+    if (gemm_mode() == 1) hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 2, 36, 1>), grid, block, 0, st, pw);
+    else hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 2, 36>), grid, block, 0, st, pw);
   } else if (!transA && !transB) {
     if (small_grid) hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 1>), grid, block, 0, st, pw);
     else hipLaunchKernelGGL((igemm_kernel<1, false, false>), grid, block, 0, st, pw);
