@@ -83,8 +83,6 @@ void launch_fir_up2(const float* x, float* y, int B, int H, int W, int C, float 
 void launch_fir_down2(const float* x, float* y, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st);
 void launch_pool2(const float* src, float* dst, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st); // (H,W)->(H/2,W/2), sum*scale
 void launch_up2_acc(const float* src, float* dst, int B, int Hs, int Ws, int C, float scale, int accumulate, hipStream_t st); // (Hs,Ws)->(2Hs,2Ws)
-int gemm_mode();
-void set_gemm_mode(int m);     // 0 exact fp32 MFMA, 1 bf16x3 split in the Winograd-domain GEMM (opt-in)
 bool flash_attn_supported(int C);
 void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, int prec, hipStream_t st);
 void launch_flash_attn_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* Lse, float* D, float* dq,

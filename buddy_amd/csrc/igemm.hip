@@ -16,7 +16,6 @@
 #include "common.h"
 #include <cstdio>
 #include <cstdint>
-#include <string>
 #include <vector>
 #include <cstdlib>
 
@@ -25,14 +24,6 @@ namespace buddy {
 namespace {
 constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = 36, NT = 256;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// ---- opt-in "bf16x3" mode of the Winograd-domain GEMM (BUDDY_GEMM=bf16x3 / buddy_set_gemm_mode(1)) ----
-// Every fp32 operand is split EXACTLY into three bf16 terms by truncation, x = hi + mid + lo (8 + 8 + 8 significant bits: hi = top 16 bits of x,
-// mid = top 16 bits of x - hi, lo = x - hi - mid, each subtraction exact), and the product a*b is formed from the six largest cross terms
-// hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped terms (mid*lo, lo*mid, lo*lo)
-// are <= 2^-23 of the product, i.e. at the fp32 rounding level.  Six bf16 MFMAs (32 cycles each, 16 k) replace eight fp32 MFMAs (64 cycles each, 2 k):
-// 2.7x fewer matrix cycles per MAC.  Not the default: the reference computes in fp32 and this is an emulation of it, gated like the attention fast mode.
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -40,15 +31,12 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // MT = 32-row MFMA tiles per wave along M: 2 -> 128-row block tile (default), 1 -> 64-row block tile for GEMMs whose 128-row
 // tiling would leave CUs idle (the operator's 4040 x 512 x 1028 DFT GEMMs are 128 tiles on 256 CUs).
 // TAG only names an instantiation (the 36-batch GEMM of the F(4x4,3x3) convolutions shows up as its own row in rocprofv3 summaries).
-// SPLIT = 1: the bf16x3 arithmetic above (operands split while they are staged into LDS).
-template <int TAPS, bool TA, bool TB, int V = 2, int MT = 2, int TAG = 0, int SPLIT = 0>
+template <int TAPS, bool TA, bool TB, int V = 2, int MT = 2, int TAG = 0>
 __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
   static_assert(MT == 2 || !TA, "64-row tiles are only built for row-major A");
   constexpr int NBUF = (V >= 4) ? 2 : 1;
   constexpr int BMt = 64 * MT, AR = BMt / 32;
-  constexpr int SPLIT_LD = BK + 8;                                     // bf16 row stride of the three split planes (80 B: conflict-free 16-B fragment reads)
-  constexpr int SM_SPLIT = SPLIT ? 3 * (BMt + BN) * SPLIT_LD / 2 : 0;  // floats
-  constexpr int SM_MAIN0 = NBUF * (BMt + BN) * LDS_LD, SM_MAIN = SM_MAIN0 > SM_SPLIT ? SM_MAIN0 : SM_SPLIT, SM_EPI = 64 * (BN + 4);
+  constexpr int SM_MAIN = NBUF * (BMt + BN) * LDS_LD, SM_EPI = 64 * (BN + 4);
   __shared__ __attribute__((aligned(16))) float smem[SM_MAIN > SM_EPI ? SM_MAIN : SM_EPI];
   float* As = smem;
   float* Bs = smem + BMt * LDS_LD;
@@ -181,69 +169,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
     }
   };
 
-  // bf16x3 mode: the tile is split ONCE while it is staged (each element is later read by two waves): three bf16 planes [row][BK + 8] per operand;
-  // a fragment = 8 consecutive k of one row = one 16-byte LDS read per plane (lane half h = lane >> 5 supplies k = 16 G + 8 h .. + 7)
-  __bf16* Pa = reinterpret_cast<__bf16*>(smem);                          // planes: A hi, A mid, A lo, B hi, B mid, B lo
-  constexpr int PA = BMt * SPLIT_LD, PB = BN * SPLIT_LD;
-  __bf16* Pb = Pa + 3 * PA;
-  auto store_split = [&](__bf16* base, int plane_sz, const float4 (&r)[4], int cnt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i >= cnt) continue;
-      const float x[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-      unsigned int h[4], m[4], l[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned int u = __float_as_uint(x[e]);
-        h[e] = u & 0xFFFF0000u;
-        const float rr = x[e] - __uint_as_float(h[e]);
-        m[e] = __float_as_uint(rr) & 0xFFFF0000u;
-        l[e] = __float_as_uint(rr - __uint_as_float(m[e]));
-      }
-      __bf16* d = base + (lr + 32 * i) * SPLIT_LD + lc4 * 4;
-      *reinterpret_cast<uint2*>(d) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-      *reinterpret_cast<uint2*>(d + plane_sz) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
-      *reinterpret_cast<uint2*>(d + 2 * plane_sz) = make_uint2((l[0] >> 16) | (l[1] & 0xFFFF0000u), (l[2] >> 16) | (l[3] & 0xFFFF0000u));
-    }
-  };
-  const __bf16* Af3 = Pa + (wm * 32 * MT + (lane & 31)) * SPLIT_LD + (lane >> 5) * 8;
-  const __bf16* Bf3 = Pb + (wn * 64 + (lane & 31)) * SPLIT_LD + (lane >> 5) * 8;
-  auto mfma_split_group = [&](int G) {
-    bf16x8 a[MT][3], b[2][3];
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) a[t][q] = *reinterpret_cast<const bf16x8*>(Af3 + q * PA + t * 32 * SPLIT_LD + 16 * G);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) b[t][q] = *reinterpret_cast<const bf16x8*>(Bf3 + q * PB + t * 32 * SPLIT_LD + 16 * G);
-#pragma unroll
-    for (int ta = 0; ta < MT; ++ta)
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        f32x16 c = acc[ta][tb];          // smallest terms first: mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi  (0 = hi, 1 = mid, 2 = lo)
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb][1], a[ta][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb][2], a[ta][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb][0], a[ta][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb][1], a[ta][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb][0], a[ta][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[tb][0], a[ta][0], c, 0, 0, 0);
-        acc[ta][tb] = c;
-      }
-  };
-
-  if (SPLIT) {
-    for (int kt = 0; kt < nk; ++kt) {
-      store_split(Pa, PA, ra, AR);
-      store_split(Pb, PB, rb, 4);
-      __syncthreads();
-      mfma_split_group(0);
-      if (kt + 1 < nk) { loadA(kt + 1, ra); loadB(kt + 1, rb); }
-      mfma_split_group(1);
-      __syncthreads();
-    }
-  } else if (V < 4) {
+  if (V < 4) {
     for (int kt = 0; kt < nk; ++kt) {
       store_tile(As, ra, TA, AR);
       store_tile(Bs, rb, TB);
@@ -453,14 +379,6 @@ void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st
   }
 }
 
-// 0 = exact fp32 MFMA (default), 1 = bf16x3 split for the 36-batch Winograd-domain GEMM (initial value from BUDDY_GEMM=bf16x3)
-namespace { int g_gemm_mode = -1; }
-int gemm_mode() {
-  if (g_gemm_mode < 0) { const char* e = getenv("BUDDY_GEMM"); g_gemm_mode = (e && std::string(e) == "bf16x3") ? 1 : 0; }
-  return g_gemm_mode;
-}
-void set_gemm_mode(int m) { g_gemm_mode = m ? 1 : 0; }
-
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st) {
   dim3 grid(cdiv(p.N, BN) * cdiv(p.M, BM), 1, batch), block(NT);
   // fewer than two 128-row tiles per CU: halve the tile height so the grid fills the chip (row-major A only)
@@ -494,8 +412,7 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
     else if (variant == 4) hipLaunchKernelGGL((igemm_kernel<9, false, false, 4>), grid, block, 0, st, pw);
     else hipLaunchKernelGGL((igemm_kernel<9, false, false, 2>), grid, block, 0, st, pw);
   } else if (!transA && !transB && p.tag == 36 && !small_grid) {
-    if (gemm_mode() == 1) hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 2, 36, 1>), grid, block, 0, st, pw);
-    else hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 2, 36>), grid, block, 0, st, pw);
+    hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 2, 36>), grid, block, 0, st, pw);
   } else if (!transA && !transB) {
     if (small_grid) hipLaunchKernelGGL((igemm_kernel<1, false, false, 2, 1>), grid, block, 0, st, pw);
     else hipLaunchKernelGGL((igemm_kernel<1, false, false>), grid, block, 0, st, pw);

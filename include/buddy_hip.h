@@ -105,11 +105,6 @@ int buddy_ncsnpp_set_fir(void* handle, int fir);
 /* attention core of a network handle: 0 = online-softmax kernels, fp32 operands (default); 1 / 2 = the same with bf16 / f16 MFMA operands (opt-in
  * fast mode, fp32 accumulate + fp32 softmax); 3 = materialised T x T matrix.  Initial value from BUDDY_ATTN = flash | bf16 | f16 | matrix. */
 int buddy_ncsnpp_set_attention(void* handle, int mode);
-/* process-wide arithmetic of the 36-batch Winograd-domain GEMM of the 3x3 convolutions: 0 = exact fp32 MFMA (default, the reference arithmetic),
- * 1 = "bf16x3": every fp32 operand split exactly into three bf16 terms, six bf16 MFMA products with fp32 accumulation (fp32-level accuracy at
- * ~2.7x fewer matrix cycles; opt-in fast mode, initial value from BUDDY_GEMM=bf16x3). */
-int buddy_set_gemm_mode(int mode);
-int buddy_get_gemm_mode(void);
 
 /* single-head attention over T tokens without the T x T matrix (online softmax, fp32 MFMA), token-major q, k, v, O [B][T][C], C in {64,128,256}:
  * O = softmax(scale * q k^T) v, lse [B][T] = row log-sum-exp; replaces the einsum / softmax / einsum of AttnBlockpp.forward

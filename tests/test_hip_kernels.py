@@ -122,40 +122,6 @@ def test_conv3x3_winograd4(lib, B, H, W, Cin, Cout):
     assert rel(y.permute(0, 3, 1, 2), ref) < 1e-4
 
 
-def test_conv3x3_winograd4_bf16x3_mode(lib):
-    """opt-in bf16x3 arithmetic of the 36-batch Winograd-domain GEMM (buddy_set_gemm_mode(1)): every fp32 operand split exactly into three bf16
-    terms, six bf16 MFMA products, fp32 accumulation.  Same stated tolerance as the exact-fp32 path (1e-4 of the abs-max against fp64), on a
-    shape large enough to take the 128-row tile kernel; the two modes must agree to 2e-5 and differ in the last bits (the mode really ran)."""
-    from buddy_amd import _lib
-    B, H, W, Cin, Cout = 2, 128, 128, 128, 256
-    g = torch.Generator(device="cpu").manual_seed(99)
-    x = torch.randn(B, Cin, H, W, generator=g).cuda()
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin))
-    b = torch.randn(Cout, generator=g).cuda()
-    ref = F.conv2d(x.double(), w.cuda().double(), b.double(), padding=1).float()
-    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().numpy()
-    U = np.empty(36 * Cin * Cout, dtype=np.float32)
-    _lib.check(lib.buddy_winograd4_transform_weights(wt.ctypes.data, Cout, Cin, U.ctypes.data))
-    Ud = torch.from_numpy(U).cuda()
-    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
-    scratch = torch.empty(36 * (B * H * W // 16) * (Cin + Cout), device="cuda")
-    out = {}
-    try:
-        for mode in (0, 1):
-            _lib.check(lib.buddy_set_gemm_mode(mode))
-            assert lib.buddy_get_gemm_mode() == mode
-            y = torch.empty(B, H, W, Cout, device="cuda")
-            _lib.check(lib.buddy_conv3x3_winograd4(P(x_nhwc), P(Ud), P(b), P(y), P(scratch), B, H, W, Cin, Cout, S()))
-            torch.cuda.synchronize()
-            out[mode] = y.permute(0, 3, 1, 2)
-    finally:
-        _lib.check(lib.buddy_set_gemm_mode(0))
-    e0, e1, d = rel(out[0], ref), rel(out[1], ref), rel(out[1], out[0])
-    print(f"fp32 MFMA {e0:.2e}, bf16x3 {e1:.2e}, between the two {d:.2e}")
-    assert e0 < 1e-4 and e1 < 1e-4 and d < 2e-5
-    assert not torch.equal(out[0], out[1])
-
-
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("C,silu", [(32, 1), (96, 1), (128, 0), (384, 1), (512, 1)])
 def test_groupnorm_act_fwd_bwd(lib, mode, C, silu):
