@@ -164,6 +164,28 @@ int buddy_conv3x3_winograd4(const float* x, const float* U4, const float* bias, 
   return finish();
 }
 
+int buddy_gn_conv3x3_winograd4(const float* x0, const float* x1, int C0, const float* gamma, const float* beta, int G, int silu, const float* U4,
+                               const float* bias, float* y, float* scratch, float* stats, double* stat_scratch, double* csum, int B, int H, int W,
+                               int Cin, int Cout, void* stream) {
+  if (!x0 || !gamma || !beta || !U4 || !y || !scratch || !stats || !stat_scratch || G < 1 || Cin % 4 || (Cin / G) % 4 || Cin > 1024 ||
+      (x1 && (C0 % 4 || C0 < 4 || C0 >= Cin))) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = y; p.ldC = Cout;
+  p.bias_n = bias; p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
+  if (!wino4_supported(p)) { set_error("shape not supported by the F(4x4,3x3) path (H, W, Cin, Cout multiples of 4)"); return BUDDY_ERR_ARG; }
+  const int sc = csum ? wino4_stat_chunks(p) : 0;
+  if (csum && (sc == 0 || (long long)sc * Cout > 256LL * 1024)) { set_error("shape not supported by the statistics epilogue"); return BUDDY_ERR_ARG; }
+  W4Gn gn;
+  gn.x.p0 = x0; gn.x.p1 = x1; gn.x.C0 = x1 ? C0 : Cin; gn.x.ld0 = x1 ? C0 : Cin; gn.x.ld1 = x1 ? Cin - C0 : 0;
+  gn.stats = stats; gn.gamma = gamma; gn.beta = beta; gn.G = G; gn.silu = silu;
+  launch_gn_stats(gn.x, B, H * W, Cin, G, 1e-6f, stat_scratch, stats, st);
+  long long vf = 0, mf = 0; wino4_scratch(p, &vf, &mf);
+  launch_wino4(p, U4, scratch, scratch + vf, st, &gn, csum ? stat_scratch : nullptr);
+  if (csum) launch_csum_collapse(stat_scratch, sc, B, Cout, csum, st);
+  return finish();
+}
+
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B, int H, int W, int C,
                         int G, int mode, int silu, void* stream) {
   if (!x || !y || !stats || !scratch || C % 4 || (C / G) % 4 || C > 1024) { set_error("bad groupnorm arguments"); return BUDDY_ERR_ARG; }

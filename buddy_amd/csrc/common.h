@@ -37,10 +37,17 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
 bool wino_supported(const IgemmParams& p);
 void launch_wino(const IgemmParams& p, const float* Uw, hipStream_t st);
 void wino_transform_weights(const float* wt_host, int Cout, int Cin, float* U_host);
+struct Src2 { const float* p0; const float* p1; int C0; int ld0; int ld1; };   // channel-concatenated input view
+struct Dst2 { float* p0; float* p1; int C0; int ld0; int ld1; int acc0; int acc1; };
 // Winograd F(4x4,3x3) in three passes (wino4.hip): weights U4[36][Cout][Cin], scratch V (36*M/16*Cin floats) and Mb (36*M/16*N floats)
+// Fusions with the GroupNorms either side of the convolution (both optional):
+//   gn   -- the input is act(GroupNorm(gn->x)) of a same-resolution (concatenated) view, applied inside the input transform (p.A0 unused)
+//   stat -- the output transform also writes per-(utterance, channel) partial (sum, sum of squares), wino4_stat_chunks(p) per utterance
+struct W4Gn { Src2 x; const float* stats; const float* gamma; const float* beta; int G; int silu; };
 bool wino4_supported(const IgemmParams& p);
 void wino4_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats);
-void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st);
+int wino4_stat_chunks(const IgemmParams& p);
+void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st, const W4Gn* gn = nullptr, double* stat = nullptr);
 void wino4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_host);
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin, double exec_ratio = 4.0 / 9.0);
 void igemm_prof_enable(int on);
@@ -61,10 +68,16 @@ void launch_conv_c2out(const float* x, int ldX, const float* w /*[taps][Cin][2]*
                        float* y, int B, int H, int W, int Cin, int taps, int accumulate, hipStream_t st);
 
 // ---- GroupNorm (+SiLU, + 2x resample) -------------------------------------------------------------------
-struct Src2 { const float* p0; const float* p1; int C0; int ld0; int ld1; };   // channel-concatenated input view
-struct Dst2 { float* p0; float* p1; int C0; int ld0; int ld1; int acc0; int acc1; };
 int  gn_num_chunks(int HW);
 void launch_gn_stats(Src2 x, int B, int HW, int C, int G, float eps, double* partial, float* stats /*[B][G][2]*/, hipStream_t st);
+// per-(utterance, channel) sums kept with a tensor (csum[b][c][2] = sum, sum of squares, fp64) so that every GroupNorm reading it -- alone or
+// as one half of a skip concatenation -- gets its statistics without another pass over the tensor:
+//   launch_chan_sums      one pass over a single-source tensor (for tensors whose producer does not leave partials)
+//   launch_csum_collapse  partial[b][chunks][C][2] (a producer's epilogue, wino4 stat) -> csum
+//   launch_gn_stats_csum  (mean, rstd) per group from the csums of the one or two sources of a view
+void launch_chan_sums(const float* x, int B, int HW, int C, double* partial, double* csum, hipStream_t st);
+void launch_csum_collapse(const double* partial, int chunks, int B, int C, double* csum, hipStream_t st);
+void launch_gn_stats_csum(const double* csum0, const double* csum1, int C0, int B, int HW, int C, int G, float eps, float* stats, hipStream_t st);
 // mode: 0 same, 1 down (2x2 mean of the activated tensor; pooled_raw gets the 2x2 mean of x itself), 2 up (nearest x2)
 void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float* beta, int B, int H, int W, int C, int G,
                      int mode, int silu, float* out, float* pooled_raw, hipStream_t st);

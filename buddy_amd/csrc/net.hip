@@ -87,6 +87,7 @@ long long param_count(const NetCfg& c) {
 struct Tens {
   float* p = nullptr; float* g = nullptr; int ginit = 0;
   int B = 0, H = 0, W = 0, C = 0;
+  double* csum = nullptr; bool has_csum = false;   // per-(utterance, channel) (sum, sum of squares) left by the producer (GroupNorm statistics)
   long long numel() const { return (long long)B * H * W * C; }
 };
 struct View { Tens* a = nullptr; Tens* b = nullptr; int C() const { return a->C + (b ? b->C : 0); } };
@@ -152,6 +153,7 @@ struct Net {
     t->B = B_; t->H = H; t->W = W; t->C = C;
     t->p = arena.f(t->numel());
     if (grad) t->g = arena.f(t->numel());
+    t->csum = (double*)arena.alloc((size_t)B_ * C * 2 * sizeof(double));
     return t;
   }
   float* tmp(long long n) { return arena.f(n); }
@@ -395,9 +397,11 @@ static IgemmParams ig_base() {
 static inline int gn_groups(int C) { int g = C / 4; return g < 32 ? g : 32; }
 
 // conv3x3 over an NHWC tensor (single source) -> out
+// gn / gn_tmp: the input is act(GroupNorm(gn->x)); the three-pass path applies it inside its input transform, any other path materialises it
+// into gn_tmp first.  stat_out: the tensor `out` belongs to -- its per-channel sums are left by the output transform where the shape allows.
 static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const float* wt, int Cout, const float* bias, const float* bias_bn,
                   int ld_bn, const float* res, int ldRes, int res_mode, float alpha, float out_scale, float* out, const float* U = nullptr,
-                  const float* U4 = nullptr) {
+                  const float* U4 = nullptr, const W4Gn* gn = nullptr, float* gn_tmp = nullptr, Tens* stat_out = nullptr) {
   // BUDDY_CONV = direct | wino2 | (default) F(4x4,3x3) three-pass where the shape allows, else fused F(2x2,3x3), else direct
   static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
   static const bool use_wino = mode != "direct", use_wino4 = mode != "direct" && mode != "wino2";
@@ -413,11 +417,20 @@ static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const fl
   p.Bt = wt; p.ldB = 9 * Cin; p.C = out; p.ldC = Cout;
   p.bias_n = bias; p.bias_bn = bias_bn; p.ld_bias_bn = ld_bn; p.rows_per_batch = H * W;
   p.res = res; p.ldRes = ldRes; p.res_mode = res_mode; p.alpha = alpha; p.out_scale = out_scale;
-  if (use_wino4 && U4 != nullptr && N->w4_scratch != nullptr && wino4_supported(p)) {
+  static const bool fuse_gn = !(getenv("BUDDY_GN_FUSE") && atoi(getenv("BUDDY_GN_FUSE")) == 0);
+  const bool w4 = use_wino4 && U4 != nullptr && N->w4_scratch != nullptr && wino4_supported(p);
+  if (gn != nullptr && !(w4 && fuse_gn)) {
+    launch_gn_apply(gn->x, gn->stats, gn->gamma, gn->beta, B, H, W, Cin, gn->G, 0, gn->silu, gn_tmp, nullptr, N->st);
+    p.A0 = gn_tmp; gn = nullptr;
+  }
+  if (w4) {
     long long vf = 0, mf = 0; wino4_scratch(p, &vf, &mf);
+    const int sc = (stat_out != nullptr && fuse_gn) ? wino4_stat_chunks(p) : 0;
+    const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;     // N->partial holds 256 x 1024 (chunk, channel) pairs per utterance
     igemm_prof_record(p, 9, 1, N->st, true, 0.25);
-    launch_wino4(p, U4, N->w4_scratch, N->w4_scratch + vf, N->st);
+    launch_wino4(p, U4, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr);
     igemm_prof_record(p, 9, 1, N->st, false, 0.25);
+    if (stat) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
   } else if (use_wino && U != nullptr && wino_supported(p)) {
     igemm_prof_record(p, 9, 1, N->st, true);
     launch_wino(p, U, N->st);
@@ -435,6 +448,15 @@ static void conv1(Net* N, Src2 a, long long M, int Cin, const float* wt, int Cou
   launch_igemm(p, 1, false, false, 1, N->st);
 }
 static Src2 single(const float* p, int C) { Src2 s; s.p0 = p; s.p1 = nullptr; s.C0 = C; s.ld0 = C; s.ld1 = 0; return s; }
+
+// GroupNorm statistics of a (concatenated) view from the per-channel sums its tensors carry; a tensor without them gets one reduction pass
+static void view_stats(Net* N, const View& x, int HW, int G, float* stats) {
+  hipStream_t st = N->st;
+  const int B = x.a->B;
+  for (Tens* t : {x.a, x.b})
+    if (t != nullptr && !t->has_csum) { launch_chan_sums(t->p, B, HW, t->C, N->partial, t->csum, st); t->has_csum = true; }
+  launch_gn_stats_csum(x.a->csum, x.b ? x.b->csum : nullptr, x.a->C, B, HW, x.C(), G, 1e-6f, stats, st);
+}
 
 // ------------------------------------------------------------------------------------------------ composite ops
 static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb_all, bool rec) {
@@ -458,16 +480,19 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
     conv3(N, nullptr, B, Ho, Wo, Cout, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c1.uf, R.c1.uf4);
   }
   if (!N->dry()) {
-    launch_gn_stats(src_of(x), B, H * W, Cin, G0, 1e-6f, N->partial, stats0, st);
+    view_stats(N, x, H * W, G0, stats0);
+    W4Gn g0{src_of(x), stats0, R.gn0.gamma, R.gn0.beta, G0, 1}, g1{single(h1->p, Cout), stats1, R.gn1.gamma, R.gn1.beta, G1, 1};
     if (firm) {
       launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, 0, 1, a0f, nullptr, st);
       if (mode == 2) { launch_fir_up2(a0f, a0, B, H, W, Cin, 1.f, 0, st); launch_fir_up2(x.a->p, xr, B, H, W, Cin, 1.f, 0, st); }
       else { launch_fir_down2(a0f, a0, B, H, W, Cin, 1.f, 0, st); launch_fir_down2(x.a->p, xr, B, H, W, Cin, 1.f, 0, st); }
-    } else
+    } else if (mode != 0)
     launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
-    conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p, R.c0.uf, R.c0.uf4);
-    launch_gn_stats(single(h1->p, Cout), B, Ho * Wo, Cout, G1, 1e-6f, N->partial, stats1, st);
-    launch_gn_apply(single(h1->p, Cout), stats1, R.gn1.gamma, R.gn1.beta, B, Ho, Wo, Cout, G1, 0, 1, a1, nullptr, st);
+    // same resolution: act(GroupNorm(.)) is applied by the convolution's input transform (a0 / a1 are only its fallback buffers)
+    conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p, R.c0.uf, R.c0.uf4,
+          mode == 0 ? &g0 : nullptr, a0, h1);
+    View vh1; vh1.a = h1;
+    view_stats(N, vh1, Ho * Wo, G1, stats1);
     const float* res; int res_mode = 1;
     if (R.has_c2) {
       if (mode == 1 || firm) conv1(N, single(xr, Cin), (long long)B * Ho * Wo, Cin, R.c2.wf, Cout, R.c2.bias, 1.f, xs, 0);
@@ -476,7 +501,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
     } else {
       res = x.a->p;   // identity skip: single source, same resolution, Cin == Cout
     }
-    conv3(N, a1, B, Ho, Wo, Cout, R.c1.wf, Cout, R.c1.bias, nullptr, 0, res, Cout, res_mode, 1.f, INV_SQRT2, out->p, R.c1.uf, R.c1.uf4);
+    conv3(N, a1, B, Ho, Wo, Cout, R.c1.wf, Cout, R.c1.bias, nullptr, 0, res, Cout, res_mode, 1.f, INV_SQRT2, out->p, R.c1.uf, R.c1.uf4, &g1, a1, out);
   }
   N->arena.off = mark;
   if (rec) {
@@ -571,7 +596,7 @@ static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
   const size_t mark = N->arena.off;
   float* hn = N->tmp(BTC);
   if (!N->dry()) {
-    launch_gn_stats(single(x->p, C), B, T, C, G, 1e-6f, N->partial, stats, st);
+    { View vx; vx.a = x; view_stats(N, vx, T, G, stats); }
     launch_gn_apply(single(x->p, C), stats, A.gn.gamma, A.gn.beta, B, H, W, C, G, 0, 0, hn, nullptr, st);
     gemm_b(N, hn, C, 0, false, A.Wt[0], C, 0, false, q, C, 0, B * T, C, C, A.b[0], nullptr, 1.f, 0, 1);
     gemm_b(N, hn, C, 0, false, A.Wt[1], C, 0, false, k, C, 0, B * T, C, C, A.b[1], nullptr, 1.f, 0, 1);
@@ -621,7 +646,7 @@ static Tens* attnblock(Net* N, const AttnW& A, Tens* x, bool rec) {
   float* hn = N->tmp((long long)B * T * C);
   float* O = N->tmp((long long)B * T * C);
   if (!N->dry()) {
-    launch_gn_stats(single(x->p, C), B, T, C, G, 1e-6f, N->partial, stats, st);
+    { View vx; vx.a = x; view_stats(N, vx, T, G, stats); }
     launch_gn_apply(single(x->p, C), stats, A.gn.gamma, A.gn.beta, B, H, W, C, G, 0, 0, hn, nullptr, st);
     gemm_b(N, hn, C, 0, false, A.Wt[0], C, 0, false, q, C, 0, B * T, C, C, A.b[0], nullptr, 1.f, 0, 1);
     gemm_b(N, hn, C, 0, false, A.Wt[1], C, 0, false, k, C, 0, B * T, C, C, A.b[1], nullptr, 1.f, 0, 1);
@@ -797,7 +822,7 @@ static void run_forward(Net* N, const float* x, const float* cnoise, const float
       float* a = N->tmp(h->numel());
       Tens* prevp = pyr; Tens* hh = h;
       if (!N->dry()) {
-        launch_gn_stats(single(h->p, C), B, Hh * Ww, C, G, 1e-6f, N->partial, stats, st);
+        { View vx; vx.a = h; view_stats(N, vx, Hh * Ww, G, stats); }
         launch_gn_apply(single(h->p, C), stats, gw.gamma, gw.beta, B, Hh, Ww, C, G, 0, 1, a, nullptr, st);
         if (N->fir) {                                      // upsample_2d of the running pyramid (layerspp.py:122) instead of nearest
           launch_conv_c2out(a, C, cw.wf, cw.bias, nullptr, np->p, B, Hh, Ww, C, 9, 0, st);

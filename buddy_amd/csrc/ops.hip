@@ -151,6 +151,48 @@ __global__ __launch_bounds__(64) void group_finalize_kernel(const double* partia
   }
 }
 
+// partial[b][chunks][C][2] -> csum[b][c][2]: block = 16 channels x 16 chunk slices, fixed summation order
+__global__ __launch_bounds__(256) void csum_collapse_kernel(const double* __restrict__ partial, int chunks, int C, double* __restrict__ csum) {
+  __shared__ double red[256 * 2];
+  const int tid = threadIdx.x, cl = tid & 15, sl = tid >> 4, b = blockIdx.y;
+  const int c = blockIdx.x * 16 + cl;
+  double s = 0, t = 0;
+  if (c < C)
+    for (int ch = sl; ch < chunks; ch += 16) {
+      const double2 v = *reinterpret_cast<const double2*>(partial + (((long long)b * chunks + ch) * C + c) * 2);
+      s += v.x; t += v.y;
+    }
+  red[tid * 2] = s; red[tid * 2 + 1] = t;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    for (int l = 1; l < 16; ++l) { s += red[(l * 16 + cl) * 2]; t += red[(l * 16 + cl) * 2 + 1]; }
+    csum[((long long)b * C + c) * 2] = s; csum[((long long)b * C + c) * 2 + 1] = t;
+  }
+}
+
+// one wave per (b, group) of a (concatenated) view: (mean, rstd) from the per-channel sums of its sources
+__global__ __launch_bounds__(64) void group_finalize_csum_kernel(const double* __restrict__ c0, const double* __restrict__ c1, int C0, int C, int G,
+                                                                 int HW, float eps, float* __restrict__ out) {
+  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int cpg = C / G;
+  double s = 0, t = 0;
+  for (int i = lane; i < cpg; i += 64) {
+    const int c = g * cpg + i;
+    const double* p = (c1 != nullptr && c >= C0) ? c1 + ((long long)b * (C - C0) + (c - C0)) * 2 : c0 + ((long long)b * C0 + c) * 2;
+    s += p[0]; t += p[1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); t += __shfl_down(t, off, 64); }
+  if (lane == 0) {
+    const double n = (double)cpg * (double)HW;
+    const double mean = s / n;
+    double var = t / n - mean * mean;
+    if (var < 0) var = 0;
+    float* o = out + ((long long)b * G + g) * 2;
+    o[0] = (float)mean; o[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 // ------------------------------------------------------------------ GroupNorm apply (+SiLU) with optional 2x resample
 __global__ __launch_bounds__(256) void gn_apply_kernel(Src2 x, const float* stats, const float* gamma, const float* beta, int B, int H,
                                                        int W, int C, int G, int mode, int silu, float* out, float* pooled_raw) {
@@ -781,6 +823,21 @@ void launch_gn_stats(Src2 x, int B, int HW, int C, int G, float eps, double* par
   hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(a.chunks, B), dim3(256), 0, st, a);
   hipLaunchKernelGGL(group_finalize_kernel<0>, dim3(G, B), dim3(64), 0, st, (const double*)partial, stats, C, G, a.chunks, HW, eps);
   prof_hbm_end(st);
+}
+
+void launch_csum_collapse(const double* partial, int chunks, int B, int C, double* csum, hipStream_t st) {
+  hipLaunchKernelGGL(csum_collapse_kernel, dim3((C + 15) / 16, B), dim3(256), 0, st, partial, chunks, C, csum);
+}
+void launch_chan_sums(const float* x, int B, int HW, int C, double* partial, double* csum, hipStream_t st) {
+  Src2 s; s.p0 = x; s.p1 = nullptr; s.C0 = C; s.ld0 = C; s.ld1 = 0;
+  RedArgs a = make_red(s, B, 1, HW, C, 1, partial);
+  prof_hbm_begin(4.0 * B * HW * C, st);                                   // one read of x
+  hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(a.chunks, B), dim3(256), 0, st, a);
+  launch_csum_collapse(partial, a.chunks, B, C, csum, st);
+  prof_hbm_end(st);
+}
+void launch_gn_stats_csum(const double* csum0, const double* csum1, int C0, int B, int HW, int C, int G, float eps, float* stats, hipStream_t st) {
+  hipLaunchKernelGGL(group_finalize_csum_kernel, dim3(G, B), dim3(64), 0, st, csum0, csum1, csum1 ? C0 : C, C, G, HW, eps, stats);
 }
 
 void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float* beta, int B, int H, int W, int C, int G, int mode, int silu,

@@ -39,10 +39,19 @@ __device__ __forceinline__ void at6(const float4 (&m)[6], float4 (&y)[4]) {
   y[3] = d12 + 8.f * d34 + m[5];
 }
 
+// SiLU on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each): the input transform evaluates it 2.25x per input value (tile halo),
+// and with the exact expf + IEEE division it became ALU-bound (measured 301 us per launch; 212 us with these, 160 us without the GroupNorm --
+// still cheaper than the 94 us apply pass + its 2 x tensor traffic that it replaces; a two-channels-per-thread form with 5 waves per SIMD
+// instead of 3 was slower, 238 us: profiles/README.md r02c)
+__device__ __forceinline__ float silu_f(float z) { return z * __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+
 // thread = (tile, channel quad); V[(pos * Mt + tile) * Cin + c]
 // tile0 / Mc: this launch covers tiles [tile0, tile0 + Mc) and V holds only that chunk (whole tensor: tile0 = 0, Mc = all tiles)
-__global__ __launch_bounds__(256) void w4_input_kernel(const float* __restrict__ x, int ldX, float* __restrict__ V, int B, int H, int W, int Cin,
-                                                       long long tile0, long long Mc) {
+// GN: the convolution's input is act(GroupNorm(x)) of a (channel-concatenated) view x (reference layerspp.py:243-245, 257-258): normalise and
+// activate on the fly while loading the tile, so the activated tensor never exists in HBM (the zero padding applies to the ACTIVATED tensor)
+template <bool GN>
+__global__ __launch_bounds__(256) void w4_input_kernel(const float* __restrict__ x, int ldX, const W4Gn gn, float* __restrict__ V, int B, int H, int W,
+                                                       int Cin, long long tile0, long long Mc) {
   const int q = Cin >> 2, TH = H >> 2, TW = W >> 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= Mc * q) return;
@@ -50,14 +59,35 @@ __global__ __launch_bounds__(256) void w4_input_kernel(const float* __restrict__
   const long long ltile = idx / q, tile = tile0 + ltile;
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
   const int gy0 = 4 * ty - 1, gx0 = 4 * tx - 1;
+  float mean = 0.f, rstd = 0.f;
+  float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), bt = gm;
+  if (GN) {
+    const int g = c / (Cin / gn.G);
+    mean = gn.stats[((long long)b * gn.G + g) * 2]; rstd = gn.stats[((long long)b * gn.G + g) * 2 + 1];
+    gm = ld4(gn.gamma + c); bt = ld4(gn.beta + c);
+    const bool second = gn.x.p1 != nullptr && c >= gn.x.C0;
+    x = second ? gn.x.p1 + (c - gn.x.C0) : gn.x.p0 + c;
+    ldX = second ? gn.x.ld1 : gn.x.ld0;
+  } else {
+    x += c;
+  }
   float4 d[6][6];
 #pragma unroll
   for (int r = 0; r < 6; ++r)
 #pragma unroll
     for (int cc = 0; cc < 6; ++cc) {
       const int gy = gy0 + r, gx = gx0 + cc;
-      d[r][cc] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? ld4(x + (((long long)b * H + gy) * W + gx) * ldX + c)
-                                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+        float4 v = ld4(x + (((long long)b * H + gy) * W + gx) * ldX);
+        if (GN) {
+          v = make_float4((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y, (v.z - mean) * rstd * gm.z + bt.z,
+                          (v.w - mean) * rstd * gm.w + bt.w);
+          if (gn.silu) v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+        }
+        d[r][cc] = v;
+      } else {
+        d[r][cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
   for (int cc = 0; cc < 6; ++cc) {                          // columns: t[:, cc] = B^T d[:, cc]
@@ -80,11 +110,18 @@ __global__ __launch_bounds__(256) void w4_input_kernel(const float* __restrict__
 }
 
 // thread = (tile, cout quad); Mb[(pos * Mt + tile) * N + n]
-__global__ __launch_bounds__(256) void w4_output_kernel(const float* __restrict__ Mb, const IgemmParams p, int B, long long tile0, long long Mc) {
+// STAT: also leave the per-(utterance, channel) sum and sum of squares of the values written (fp64), one partial per workgroup, for the
+// GroupNorm that consumes this tensor (reference layerspp.py:243, 257): stat[((b * chunks + chunk) * N + n) * 2 + {0, 1}], chunks = tiles per
+// utterance / (256 / q).  Requires 256 % q == 0 and tiles per utterance % (256 / q) == 0 (wino4_stat_chunks): a workgroup then holds whole
+// tiles of one utterance and every thread is live.
+template <bool STAT>
+__global__ __launch_bounds__(256) void w4_output_kernel(const float* __restrict__ Mb, const IgemmParams p, int B, long long tile0, long long Mc,
+                                                        double* __restrict__ stat) {
   const int H = p.H, W = p.W, N = p.N;
   const int q = N >> 2, TH = H >> 2, TW = W >> 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Mc * q) return;
+  if (!STAT && idx >= Mc * q) return;
+  double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
   const int n = (int)(idx % q) * 4;
   const long long ltile = idx / q, tile = tile0 + ltile;
   const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
@@ -119,10 +156,42 @@ __global__ __launch_bounds__(256) void w4_output_kernel(const float* __restrict_
       float* dst = p.C + pix * p.ldC + n;
       if (p.accumulate) v = v + ld4(dst);
       st4(dst, v);
+      if (STAT) {
+        ssum[0] += (double)v.x; ssum[1] += (double)v.y; ssum[2] += (double)v.z; ssum[3] += (double)v.w;
+        ssq[0] += (double)v.x * (double)v.x; ssq[1] += (double)v.y * (double)v.y; ssq[2] += (double)v.z * (double)v.z;
+        ssq[3] += (double)v.w * (double)v.w;
+      }
+    }
+  }
+  if (STAT) {
+    __shared__ double red[256 * 8];
+    const int tid = threadIdx.x, pl = 256 / q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = ssum[j]; red[tid * 8 + 4 + j] = ssq[j]; }
+    __syncthreads();
+    if (tid < q) {
+      double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int l = 0; l < pl; ++l)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += red[(l * q + tid) * 8 + j];
+      const long long tpb = (long long)TW * TH, first = (long long)blockIdx.x * pl;      // first tile of this workgroup (tile0 == 0)
+      const long long bb = first / tpb, chunk = (first % tpb) / pl, chunks = tpb / pl;
+      double* o = stat + ((bb * chunks + chunk) * N + tid * 4) * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j * 2] = r[j]; o[j * 2 + 1] = r[4 + j]; }
     }
   }
 }
 }  // namespace
+
+// partial sums per utterance the STAT epilogue writes (0: the shape does not allow it)
+int wino4_stat_chunks(const IgemmParams& p) {
+  const int q = p.N / 4;
+  if (q < 1 || q > 256 || 256 % q) return 0;
+  const long long tpb = (long long)(p.H / 4) * (p.W / 4);
+  const int pl = 256 / q;
+  return tpb % pl ? 0 : (int)(tpb / pl);
+}
 
 bool wino4_supported(const IgemmParams& p) {
   auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -136,7 +205,7 @@ void wino4_scratch(const IgemmParams& p, long long* v_floats, long long* m_float
   *v_floats = 36 * Mt * p.Cin; *m_floats = 36 * Mt * p.N;
 }
 
-void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st) {
+void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat) {
   const int B = p.M / (p.H * p.W);
   const long long Mt = (long long)p.M / 16;
   const bool prof = igemm_prof_enabled();                   // the caller brackets the three passes as ONE 3x3 convolution; passes timed here
@@ -147,7 +216,9 @@ void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hi
   if (prof) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], st); }
   for (long long t0 = 0; t0 < Mt; t0 += chunk) {
     const long long Mc = std::min(chunk, Mt - t0);
-    hipLaunchKernelGGL(w4_input_kernel, dim3((unsigned)((Mc * (p.Cin / 4) + 255) / 256)), dim3(256), 0, st, p.A0, p.ldA0, V, B, p.H, p.W, p.Cin, t0, Mc);
+    const dim3 gi((unsigned)((Mc * (p.Cin / 4) + 255) / 256));
+    if (gn) hipLaunchKernelGGL(w4_input_kernel<true>, gi, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, B, p.H, p.W, p.Cin, t0, Mc);
+    else hipLaunchKernelGGL(w4_input_kernel<false>, gi, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, B, p.H, p.W, p.Cin, t0, Mc);
     if (prof) (void)hipEventRecord(ev[1], st);
     IgemmParams g; std::memset(&g, 0, sizeof(g));
     g.A0 = V; g.ldA0 = p.Cin; g.sA = Mc * p.Cin; g.Cin = p.Cin;
@@ -159,7 +230,9 @@ void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hi
     launch_igemm(g, 1, false, false, 36, st);
     igemm_prof_enable(prof ? 1 : 0);
     if (prof) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(w4_output_kernel, dim3((unsigned)((Mc * (p.N / 4) + 255) / 256)), dim3(256), 0, st, (const float*)Mb, p, B, t0, Mc);
+    const dim3 go((unsigned)((Mc * (p.N / 4) + 255) / 256));
+    if (stat) hipLaunchKernelGGL(w4_output_kernel<true>, go, dim3(256), 0, st, (const float*)Mb, p, B, t0, Mc, stat);
+    else hipLaunchKernelGGL(w4_output_kernel<false>, go, dim3(256), 0, st, (const float*)Mb, p, B, t0, Mc, (double*)nullptr);
   }
   if (prof) {
     (void)hipEventRecord(ev[3], st);

@@ -89,6 +89,13 @@ int buddy_conv3x3_winograd(const float* x, const float* U, const float* bias, fl
 int buddy_winograd4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_host);
 int buddy_conv3x3_winograd4(const float* x, const float* U4, const float* bias, float* y, float* scratch, int B, int H, int W, int Cin, int Cout,
                             void* stream);
+/* act(GroupNorm(cat[x0, x1])) -> conv3x3 as ONE three-pass convolution: the normalisation and SiLU are applied inside the input transform
+ * (the activated tensor never reaches HBM) and, with csum != NULL, the output transform leaves the per-(utterance, channel) sum and sum of
+ * squares of y (csum[B][Cout][2], float64) -- the statistics the NEXT GroupNorm needs (layerspp.py:243-245, 257-259).  x1 may be NULL (single
+ * source; C0 ignored).  stats: [B][G][2] out.  scratch as for buddy_conv3x3_winograd4; stat_scratch: >= B*256*1024*16 bytes. */
+int buddy_gn_conv3x3_winograd4(const float* x0, const float* x1, int C0, const float* gamma, const float* beta, int G, int silu, const float* U4,
+                               const float* bias, float* y, float* scratch, float* stats, double* stat_scratch, double* csum, int B, int H, int W,
+                               int Cin, int Cout, void* stream);
 /* GroupNorm(G, C, eps=1e-6) [+SiLU] [+2x down(mode 1)/up(mode 2)] forward; replaces nn.GroupNorm + nn.SiLU +
  * naive_{up,down}sample_2d (layerspp.py:243-258). stats: [B][G][2] out; scratch: >= B*256*C*16 bytes. */
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B,

@@ -122,6 +122,48 @@ def test_conv3x3_winograd4(lib, B, H, W, Cin, Cout):
     assert rel(y.permute(0, 3, 1, 2), ref) < 1e-4
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout,silu,stat", [(2, 32, 32, 16, 0, 32, 1, 1), (1, 64, 32, 128, 0, 256, 1, 1), (3, 8, 12, 24, 16, 8, 1, 0),
+                                                       (2, 16, 16, 256, 128, 128, 1, 1), (2, 16, 32, 64, 0, 64, 0, 1)])
+def test_gn_conv3x3_winograd4_fused(lib, B, H, W, C0, C1, Cout, silu, stat):
+    """conv3x3(act(GroupNorm(cat[x0, x1]))) with the normalisation + SiLU applied inside the F(4x4,3x3) input transform and the per-channel
+    (sum, sum of squares) of the output left by the output transform (the next GroupNorm's statistics), vs fp64 torch.  1e-4 like the unfused
+    convolution; the sums are fp64 sums of the fp32 outputs: 1e-6 relative to sum |y| / sum y^2."""
+    from buddy_amd import _lib
+    Cin = C0 + C1
+    G = min(Cin // 4, 32)
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin + Cout + 7)
+    x = (torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.3).cuda()
+    gamma = (1 + 0.2 * torch.randn(Cin, generator=g)).cuda()
+    beta = (0.2 * torch.randn(Cin, generator=g)).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g).cuda()
+    z = F.group_norm(x.double(), G, gamma.double(), beta.double(), eps=1e-6)
+    if silu:
+        z = F.silu(z)
+    ref = F.conv2d(z, w.cuda().double(), b.double(), padding=1)
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().numpy()
+    U = np.empty(36 * Cin * Cout, dtype=np.float32)
+    _lib.check(lib.buddy_winograd4_transform_weights(wt.ctypes.data, Cout, Cin, U.ctypes.data))
+    Ud = torch.from_numpy(U).cuda()
+    xn = x.permute(0, 2, 3, 1)
+    x0 = xn[..., :C0].contiguous()
+    x1 = xn[..., C0:].contiguous() if C1 else None
+    y = torch.empty(B, H, W, Cout, device="cuda")
+    scratch = torch.empty(36 * (B * H * W // 16) * (Cin + Cout), device="cuda")
+    stats = torch.empty(B, G, 2, device="cuda")
+    stat_scratch = torch.empty(B * 256 * 1024 * 2, dtype=torch.float64, device="cuda")
+    csum = torch.zeros(B, Cout, 2, dtype=torch.float64, device="cuda")
+    _lib.check(lib.buddy_gn_conv3x3_winograd4(P(x0), P(x1) if C1 else None, C0, P(gamma), P(beta), G, silu, P(Ud), P(b), P(y), P(scratch), P(stats),
+                                              stat_scratch.data_ptr(), csum.data_ptr() if stat else None, B, H, W, Cin, Cout, S()))
+    torch.cuda.synchronize()
+    assert rel(y.permute(0, 3, 1, 2), ref.float()) < 1e-4
+    if stat:
+        yd = y.double()
+        s_ref, q_ref = yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))
+        assert float((csum[..., 0] - s_ref).abs().max() / yd.abs().sum(dim=(1, 2)).max()) < 1e-6
+        assert float((csum[..., 1] - q_ref).abs().max() / q_ref.max()) < 1e-6
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("C,silu", [(32, 1), (96, 1), (128, 0), (384, 1), (512, 1)])
 def test_groupnorm_act_fwd_bwd(lib, mode, C, silu):
