@@ -50,8 +50,9 @@ int wino4_stat_chunks(const IgemmParams& p);
 void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st, const W4Gn* gn = nullptr, double* stat = nullptr);
 void wino4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_host);
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin, double exec_ratio = 4.0 / 9.0);
-void igemm_prof_enable(int on);
-bool igemm_prof_enabled();
+void igemm_prof_enable(int level);   // 0 off, 1 the dominant kernel only (36 batched Winograd-domain GEMMs), 2 every instrumented class
+bool igemm_prof_enabled();           // level 2
+int igemm_prof_level();
 void prof_w4_push(hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, double gemm_flops, double bytes_in, double bytes_out, double bytes_gemm);
 int prof_w4_collect(double ms[3], double* gemm_flops, double* bytes_in, double* bytes_out, double* bytes_gemm, long long* launches);
 void prof_hbm_begin(double algorithmic_bytes, hipStream_t st);   // bracket of an HBM-bound launch group (GroupNorm kernels)

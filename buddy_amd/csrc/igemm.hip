@@ -296,11 +296,15 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const IgemmParams p) {
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg) ----
 namespace {
 struct ProfRec { hipEvent_t e0, e1; double flops, bytes, exec_flops; int taps; int M, N, K, batch, kind; };
-bool g_prof_on = false;
+// level 0: off.  1: only the dominant kernel (the 36 batched GEMMs of the three-pass convolutions, launch_wino4) -- every event pair costs a
+// dispatch bubble of several microseconds, so the timed region of bench.py brackets nothing else.  2: every class below (attribution pass).
+int g_prof_level = 0;
+bool g_prof_on = false;          // level 2
 std::vector<ProfRec> g_prof;
 }
-void igemm_prof_enable(int on) { g_prof_on = on != 0; }
+void igemm_prof_enable(int level) { g_prof_level = level < 0 ? 0 : level; g_prof_on = g_prof_level >= 2; }
 bool igemm_prof_enabled() { return g_prof_on; }
+int igemm_prof_level() { return g_prof_level; }
 // sums elapsed time / algorithmic flops / launches per class (class 0: 3x3 convs, class 1: everything else) and clears
 int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], double bytes[2], double exec_flops[2]) {
   for (int c = 0; c < 2; ++c) { ms[c] = 0; flops[c] = 0; launches[c] = 0; bytes[c] = 0; exec_flops[c] = 0; }
@@ -353,9 +357,12 @@ void prof_w4_push(hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, do
 int prof_w4_collect(double ms[3], double* gemm_flops, double* bytes_in, double* bytes_out, double* bytes_gemm, long long* launches) {
   ms[0] = ms[1] = ms[2] = 0; *gemm_flops = 0; *bytes_in = 0; *bytes_out = 0; *bytes_gemm = 0; *launches = 0;
   for (auto& r : g_prof_w4) {
-    if (hipEventSynchronize(r.e[3]) != hipSuccess) return 1;
-    for (int i = 0; i < 3; ++i) { float t = 0.f; if (hipEventElapsedTime(&t, r.e[i], r.e[i + 1]) != hipSuccess) return 1; ms[i] += t; }
-    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(r.e[i]);
+    const bool full = r.e[0] != nullptr;                     // level 1 records hold only the GEMM bracket e[1], e[2]
+    if (hipEventSynchronize(r.e[full ? 3 : 2]) != hipSuccess) return 1;
+    for (int i = full ? 0 : 1; i < (full ? 3 : 2); ++i) {
+      float t = 0.f; if (hipEventElapsedTime(&t, r.e[i], r.e[i + 1]) != hipSuccess) return 1; ms[i] += t;
+    }
+    for (int i = 0; i < 4; ++i) if (r.e[i]) (void)hipEventDestroy(r.e[i]);
     *gemm_flops += r.gemm_flops; *bytes_in += r.bytes_in; *bytes_out += r.bytes_out; *bytes_gemm += r.bytes_gemm; *launches += 1;
   }
   g_prof_w4.clear();

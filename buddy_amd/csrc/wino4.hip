@@ -208,18 +208,21 @@ void wino4_scratch(const IgemmParams& p, long long* v_floats, long long* m_float
 void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat) {
   const int B = p.M / (p.H * p.W);
   const long long Mt = (long long)p.M / 16;
-  const bool prof = igemm_prof_enabled();                   // the caller brackets the three passes as ONE 3x3 convolution; passes timed here
+  const int plevel = igemm_prof_level();
+  const bool prof = plevel >= 2;                            // the caller brackets the three passes as ONE 3x3 convolution; passes timed here
+  const bool prof_gemm = plevel == 1;                       // level 1: only the batched GEMM is bracketed
   // the passes take a tile range [t0, t0 + Mc): one range = the whole tensor.  (Running them chunk by chunk so that V / M stay in the 256 MB
   // Infinity Cache was measured and lost at every chunk size: +3...+27 % per convolution, profiles/README.md r02.)
   const long long chunk = Mt;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   if (prof) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], st); }
+  if (prof_gemm) { (void)hipEventCreate(&ev[1]); (void)hipEventCreate(&ev[2]); }
   for (long long t0 = 0; t0 < Mt; t0 += chunk) {
     const long long Mc = std::min(chunk, Mt - t0);
     const dim3 gi((unsigned)((Mc * (p.Cin / 4) + 255) / 256));
     if (gn) hipLaunchKernelGGL(w4_input_kernel<true>, gi, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, B, p.H, p.W, p.Cin, t0, Mc);
     else hipLaunchKernelGGL(w4_input_kernel<false>, gi, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, B, p.H, p.W, p.Cin, t0, Mc);
-    if (prof) (void)hipEventRecord(ev[1], st);
+    if (prof || prof_gemm) (void)hipEventRecord(ev[1], st);
     IgemmParams g; std::memset(&g, 0, sizeof(g));
     g.A0 = V; g.ldA0 = p.Cin; g.sA = Mc * p.Cin; g.Cin = p.Cin;
     g.Bt = U4; g.ldB = p.Cin; g.sB = (long long)p.N * p.Cin;
@@ -228,11 +231,15 @@ void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hi
     g.tag = 36;
     igemm_prof_enable(0);
     launch_igemm(g, 1, false, false, 36, st);
-    igemm_prof_enable(prof ? 1 : 0);
-    if (prof) (void)hipEventRecord(ev[2], st);
+    igemm_prof_enable(plevel);
+    if (prof || prof_gemm) (void)hipEventRecord(ev[2], st);
     const dim3 go((unsigned)((Mc * (p.N / 4) + 255) / 256));
     if (stat) hipLaunchKernelGGL(w4_output_kernel<true>, go, dim3(256), 0, st, (const float*)Mb, p, B, t0, Mc, stat);
     else hipLaunchKernelGGL(w4_output_kernel<false>, go, dim3(256), 0, st, (const float*)Mb, p, B, t0, Mc, (double*)nullptr);
+  }
+  if (prof_gemm) {
+    const double mt = (double)Mt;
+    prof_w4_push(nullptr, ev[1], ev[2], nullptr, 2.0 * 36.0 * mt * p.Cin * p.N, 0.0, 0.0, 4.0 * 36.0 * (mt * p.Cin + mt * p.N + (double)p.N * p.Cin));
   }
   if (prof) {
     (void)hipEventRecord(ev[3], st);

@@ -54,7 +54,10 @@ int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream);
  * the recorded events and returns, per class (index 0: 3x3 convolutions, index 1: 1x1 convs / attention / DFT GEMMs),
  * the summed kernel time [ms], the algorithmic FLOPs (2*M*N*K, zero padding counted like torch's flop counter) and
  * the number of launches since the last collect, and the algorithmic bytes (A once + weights once + C once). ---- */
-int buddy_prof_enable(int on);
+/* level: 0 off; 1 only the dominant kernel (the 36 batched GEMMs of the three-pass convolutions; collect with buddy_prof_collect_wino4, only its
+ * GEMM entries are filled) -- every event pair costs a dispatch bubble of several microseconds, so a throughput measurement brackets nothing
+ * else; 2 every instrumented class (attribution). */
+int buddy_prof_enable(int level);
 int buddy_prof_collect(double* ms /*[2]*/, double* flops /*[2]*/, long long* launches /*[2]*/, double* bytes /*[2]*/,
                        double* executed_flops /*[2]: = flops except for Winograd launches (4/9 of the direct-conv flops)*/);
 /* same for the HBM-bound GroupNorm launch groups (statistics; apply + SiLU + resample; backward sums + apply): summed time [ms],

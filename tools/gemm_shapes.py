@@ -13,7 +13,7 @@ for _ in range(2):
     y = net(x, cn); g, = torch.autograd.grad(y, x, cot)
 torch.cuda.synchronize()
 lib = _lib.load()
-lib.buddy_prof_enable(1)
+lib.buddy_prof_enable(2)
 y = net(x, cn); g, = torch.autograd.grad(y, x, cot)
 torch.cuda.synchronize()
 import ctypes as C
