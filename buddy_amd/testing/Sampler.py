@@ -22,11 +22,19 @@ class Sampler:
         self.noise = None
 
     def _randn(self, shape, device):
-        """(B, L) standard normal; with injected streams utterance b draws its own (1, L) in reference call order."""
+        """(B, L) standard normal; with injected streams utterance b draws its own (1, L) in reference call order.
+        Drawn on the CPU generator like the reference (same values for the same seed).  On a GPU the host copy is pinned and the transfer
+        asynchronous in stream order: a pageable ``.to(device)`` makes the host wait for everything queued before it, i.e. drains the GPU at
+        every step boundary (measured ~1 ms of a 107 ms step: copy + relaunch latency with an empty queue)."""
+        cuda = torch.device(device).type == "cuda"
         if self.noise is None:
-            return torch.randn(shape).to(device)
-        assert len(self.noise) == shape[0], "one noise stream per utterance"
-        return torch.cat([n.randn((1,) + tuple(shape[1:])) for n in self.noise], dim=0).to(device)
+            n = torch.randn(shape, pin_memory=cuda)
+        else:
+            assert len(self.noise) == shape[0], "one noise stream per utterance"
+            n = torch.cat([s.randn((1,) + tuple(shape[1:])) for s in self.noise], dim=0)
+            if cuda:
+                n = n.pin_memory()
+        return n.to(device, non_blocking=cuda)
 
     @abc.abstractmethod
     def predict(self, *args, **kwargs):

@@ -37,3 +37,12 @@ for g, n in gaps:
         big[k] = big.get(k, [0, 0]); big[k][0] += 1; big[k][1] += g
 for k, (c, g) in sorted(big.items(), key=lambda kv: -kv[1][1])[:12]:
     print(f"  before {k:60s} {c:5d} gaps  {g/1e6:7.2f} ms")
+
+if marker:                                   # launches per step by kernel, largest time first
+    agg = {}
+    for st, en, n in ev:
+        k = n.split("(")[0][-70:]
+        a = agg.setdefault(k, [0, 0]); a[0] += 1; a[1] += en - st
+    print("per step (launches, ms):")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[4]) if len(sys.argv) > 4 else 0]:
+        print(f"  {k:70s} {c / nsteps:8.1f} {t / 1e6 / nsteps:8.3f}")
