@@ -164,7 +164,27 @@ int buddy_conv3x3_winograd4(const float* x, const float* U4, const float* bias, 
   return finish();
 }
 
-int buddy_gn_conv3x3_winograd4(const float* x0, const float* x1, int C0, const float* gamma, const float* beta, int G, int silu, const float* U4,
+int buddy_winograd6_transform_weights(const float* wt_host, int Cout, int Cin, float* U6_host) {
+  if (!wt_host || !U6_host || Cout < 1 || Cin < 1) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  wino6_transform_weights(wt_host, Cout, Cin, U6_host);
+  return BUDDY_OK;
+}
+int buddy_conv3x3_winograd6(const float* x, const float* U6, const float* bias, float* y, float* scratch, int B, int H, int W, int Cin, int Cout,
+                            void* stream) {
+  if (!x || !U6 || !y || !scratch) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.A0 = x; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = y; p.ldC = Cout;
+  p.bias_n = bias; p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
+  if (!wino6_supported(p)) { set_error("shape not supported by the F(6x6,3x3) path (H, W >= 6; Cin, Cout multiples of 4)"); return BUDDY_ERR_ARG; }
+  long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf);
+  const double xr = wino6_exec_ratio(p);
+  igemm_prof_record(p, 9, 1, (hipStream_t)stream, true, xr);
+  launch_wino6(p, U6, scratch, scratch + vf, (hipStream_t)stream);
+  igemm_prof_record(p, 9, 1, (hipStream_t)stream, false, xr);
+  return finish();
+}
+
+static int gn_conv3x3_winograd(bool f6, const float* x0, const float* x1, int C0, const float* gamma, const float* beta, int G, int silu, const float* U4,
                                const float* bias, float* y, float* scratch, float* stats, double* stat_scratch, double* csum, int B, int H, int W,
                                int Cin, int Cout, void* stream) {
   if (!x0 || !gamma || !beta || !U4 || !y || !scratch || !stats || !stat_scratch || G < 1 || Cin % 4 || (Cin / G) % 4 || Cin > 1024 ||
@@ -173,17 +193,28 @@ int buddy_gn_conv3x3_winograd4(const float* x0, const float* x1, int C0, const f
   IgemmParams p; std::memset(&p, 0, sizeof(p));
   p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = y; p.ldC = Cout;
   p.bias_n = bias; p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
-  if (!wino4_supported(p)) { set_error("shape not supported by the F(4x4,3x3) path (H, W, Cin, Cout multiples of 4)"); return BUDDY_ERR_ARG; }
-  const int sc = csum ? wino4_stat_chunks(p) : 0;
+  if (!(f6 ? wino6_supported(p) : wino4_supported(p))) { set_error("shape not supported by this Winograd path"); return BUDDY_ERR_ARG; }
+  const int sc = csum ? (f6 ? wino6_stat_chunks(p) : wino4_stat_chunks(p)) : 0;
   if (csum && (sc == 0 || (long long)sc * Cout > 256LL * 1024)) { set_error("shape not supported by the statistics epilogue"); return BUDDY_ERR_ARG; }
   W4Gn gn;
   gn.x.p0 = x0; gn.x.p1 = x1; gn.x.C0 = x1 ? C0 : Cin; gn.x.ld0 = x1 ? C0 : Cin; gn.x.ld1 = x1 ? Cin - C0 : 0;
   gn.stats = stats; gn.gamma = gamma; gn.beta = beta; gn.G = G; gn.silu = silu;
   launch_gn_stats(gn.x, B, H * W, Cin, G, 1e-6f, stat_scratch, stats, st);
-  long long vf = 0, mf = 0; wino4_scratch(p, &vf, &mf);
-  launch_wino4(p, U4, scratch, scratch + vf, st, &gn, csum ? stat_scratch : nullptr);
+  long long vf = 0, mf = 0;
+  if (f6) { wino6_scratch(p, &vf, &mf); launch_wino6(p, U4, scratch, scratch + vf, st, &gn, csum ? stat_scratch : nullptr); }
+  else { wino4_scratch(p, &vf, &mf); launch_wino4(p, U4, scratch, scratch + vf, st, &gn, csum ? stat_scratch : nullptr); }
   if (csum) launch_csum_collapse(stat_scratch, sc, B, Cout, csum, st);
   return finish();
+}
+int buddy_gn_conv3x3_winograd4(const float* x0, const float* x1, int C0, const float* gamma, const float* beta, int G, int silu, const float* U4,
+                               const float* bias, float* y, float* scratch, float* stats, double* stat_scratch, double* csum, int B, int H, int W,
+                               int Cin, int Cout, void* stream) {
+  return gn_conv3x3_winograd(false, x0, x1, C0, gamma, beta, G, silu, U4, bias, y, scratch, stats, stat_scratch, csum, B, H, W, Cin, Cout, stream);
+}
+int buddy_gn_conv3x3_winograd6(const float* x0, const float* x1, int C0, const float* gamma, const float* beta, int G, int silu, const float* U6,
+                               const float* bias, float* y, float* scratch, float* stats, double* stat_scratch, double* csum, int B, int H, int W,
+                               int Cin, int Cout, void* stream) {
+  return gn_conv3x3_winograd(true, x0, x1, C0, gamma, beta, G, silu, U6, bias, y, scratch, stats, stat_scratch, csum, B, H, W, Cin, Cout, stream);
 }
 
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B, int H, int W, int C,

@@ -107,7 +107,8 @@ struct Arena {
 
 struct ConvW { int cin = 0, cout = 0, taps = 0; float* wf = nullptr; float* wb = nullptr; float* bias = nullptr;
                float* uf = nullptr; float* ub = nullptr;      // uf/ub: Winograd F(2x2,3x3)-domain weights (forward / data-gradient)
-               float* uf4 = nullptr; float* ub4 = nullptr; }; // F(4x4,3x3)-domain weights [36][Cout][Cin]
+               float* uf4 = nullptr; float* ub4 = nullptr;    // F(4x4,3x3)-domain weights [36][Cout][Cin]
+               float* uf6 = nullptr; float* ub6 = nullptr; }; // F(6x6,3x3)-domain weights [64][Cout][Cin]
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResW { GNW gn0, gn1; ConvW c0, c1, c2; bool has_c2 = false; int cin = 0, cout = 0, dense_off = 0; };
 struct AttnW { GNW gn; float* Wt[4]; float* Wn[4]; float* b[4]; int C = 0; };
@@ -259,6 +260,9 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
       std::vector<float> u4((size_t)36 * cin * cout);
       wino4_transform_weights(wfv.data(), cout, cin, u4.data()); packed(&c.uf4, u4);
       wino4_transform_weights(wbv.data(), cin, cout, u4.data()); packed(&c.ub4, u4);
+      std::vector<float> u6((size_t)64 * cin * cout);
+      wino6_transform_weights(wfv.data(), cout, cin, u6.data()); packed(&c.uf6, u6);
+      wino6_transform_weights(wbv.data(), cin, cout, u6.data()); packed(&c.ub6, u6);
     }
   };
   auto load_res = [&](int cin, int cout, bool resample) {
@@ -401,13 +405,18 @@ static inline int gn_groups(int C) { int g = C / 4; return g < 32 ? g : 32; }
 // into gn_tmp first.  stat_out: the tensor `out` belongs to -- its per-channel sums are left by the output transform where the shape allows.
 static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const float* wt, int Cout, const float* bias, const float* bias_bn,
                   int ld_bn, const float* res, int ldRes, int res_mode, float alpha, float out_scale, float* out, const float* U = nullptr,
-                  const float* U4 = nullptr, const W4Gn* gn = nullptr, float* gn_tmp = nullptr, Tens* stat_out = nullptr) {
-  // BUDDY_CONV = direct | wino2 | (default) F(4x4,3x3) three-pass where the shape allows, else fused F(2x2,3x3), else direct
+                  const float* U4 = nullptr, const W4Gn* gn = nullptr, float* gn_tmp = nullptr, Tens* stat_out = nullptr, const float* U6 = nullptr) {
+  // BUDDY_CONV = direct | wino2 | wino4 | (default) three-pass F(6x6,3x3) on the large layers, three-pass F(4x4,3x3) where the shape allows,
+  // else fused F(2x2,3x3), else direct
   static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
-  static const bool use_wino = mode != "direct", use_wino4 = mode != "direct" && mode != "wino2";
+  static const bool use_wino = mode != "direct", use_wino4 = mode != "direct" && mode != "wino2", use_wino6 = use_wino4 && mode != "wino4";
   if (N->dry()) {
     if (use_wino4 && U4 != nullptr && H % 4 == 0 && W % 4 == 0) {
       const size_t need = (size_t)36 * ((size_t)B * H * W / 16) * (size_t)(Cin + Cout);
+      if (need > N->w4_need) N->w4_need = need;
+    }
+    if (use_wino6 && U6 != nullptr && H >= 6 && W >= 6) {
+      const size_t need = (size_t)64 * ((size_t)B * ((H + 5) / 6) * ((W + 5) / 6)) * (size_t)(Cin + Cout);
       if (need > N->w4_need) N->w4_need = need;
     }
     return;
@@ -418,12 +427,22 @@ static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const fl
   p.bias_n = bias; p.bias_bn = bias_bn; p.ld_bias_bn = ld_bn; p.rows_per_batch = H * W;
   p.res = res; p.ldRes = ldRes; p.res_mode = res_mode; p.alpha = alpha; p.out_scale = out_scale;
   static const bool fuse_gn = !(getenv("BUDDY_GN_FUSE") && atoi(getenv("BUDDY_GN_FUSE")) == 0);
-  const bool w4 = use_wino4 && U4 != nullptr && N->w4_scratch != nullptr && wino4_supported(p);
-  if (gn != nullptr && !(w4 && fuse_gn)) {
+  const bool w6 = use_wino6 && U6 != nullptr && N->w4_scratch != nullptr && wino6_supported(p) && wino6_pays(p);
+  const bool w4 = !w6 && use_wino4 && U4 != nullptr && N->w4_scratch != nullptr && wino4_supported(p);
+  if (gn != nullptr && !((w4 || w6) && fuse_gn)) {
     launch_gn_apply(gn->x, gn->stats, gn->gamma, gn->beta, B, H, W, Cin, gn->G, 0, gn->silu, gn_tmp, nullptr, N->st);
     p.A0 = gn_tmp; gn = nullptr;
   }
-  if (w4) {
+  if (w6) {
+    long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf);
+    const int sc = (stat_out != nullptr && fuse_gn) ? wino6_stat_chunks(p) : 0;
+    const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;
+    const double xr = wino6_exec_ratio(p);
+    igemm_prof_record(p, 9, 1, N->st, true, xr);
+    launch_wino6(p, U6, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr);
+    igemm_prof_record(p, 9, 1, N->st, false, xr);
+    if (stat) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
+  } else if (w4) {
     long long vf = 0, mf = 0; wino4_scratch(p, &vf, &mf);
     const int sc = (stat_out != nullptr && fuse_gn) ? wino4_stat_chunks(p) : 0;
     const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;     // N->partial holds 256 x 1024 (chunk, channel) pairs per utterance
@@ -476,8 +495,8 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
   float* a1 = N->tmp((long long)B * Ho * Wo * Cout);
   float* a0f = firm ? N->tmp((long long)B * H * W * Cin) : nullptr;
   if (N->dry()) {                                         // sizing pass: let the convolutions note their F(4x4,3x3) scratch need
-    conv3(N, nullptr, B, Ho, Wo, Cin, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c0.uf, R.c0.uf4);
-    conv3(N, nullptr, B, Ho, Wo, Cout, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c1.uf, R.c1.uf4);
+    conv3(N, nullptr, B, Ho, Wo, Cin, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c0.uf, R.c0.uf4, nullptr, nullptr, nullptr, R.c0.uf6);
+    conv3(N, nullptr, B, Ho, Wo, Cout, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c1.uf, R.c1.uf4, nullptr, nullptr, nullptr, R.c1.uf6);
   }
   if (!N->dry()) {
     view_stats(N, x, H * W, G0, stats0);
@@ -490,7 +509,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
     launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
     // same resolution: act(GroupNorm(.)) is applied by the convolution's input transform (a0 / a1 are only its fallback buffers)
     conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p, R.c0.uf, R.c0.uf4,
-          mode == 0 ? &g0 : nullptr, a0, h1);
+          mode == 0 ? &g0 : nullptr, a0, h1, R.c0.uf6);
     View vh1; vh1.a = h1;
     view_stats(N, vh1, Ho * Wo, G1, stats1);
     const float* res; int res_mode = 1;
@@ -501,7 +520,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
     } else {
       res = x.a->p;   // identity skip: single source, same resolution, Cin == Cout
     }
-    conv3(N, a1, B, Ho, Wo, Cout, R.c1.wf, Cout, R.c1.bias, nullptr, 0, res, Cout, res_mode, 1.f, INV_SQRT2, out->p, R.c1.uf, R.c1.uf4, &g1, a1, out);
+    conv3(N, a1, B, Ho, Wo, Cout, R.c1.wf, Cout, R.c1.bias, nullptr, 0, res, Cout, res_mode, 1.f, INV_SQRT2, out->p, R.c1.uf, R.c1.uf4, &g1, a1, out, R.c1.uf6);
   }
   N->arena.off = mark;
   if (rec) {
@@ -540,12 +559,14 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       float* da1 = n->tmp((long long)B * Ho * Wo * Cout);
       float* dh1 = n->tmp((long long)B * Ho * Wo * Cout);
       float* da0 = n->tmp((long long)B * Ho * Wo * Cin);
-      conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub, Rp->c1.ub4);
+      conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub, Rp->c1.ub4, nullptr, nullptr, nullptr,
+            Rp->c1.ub6);
       Dst2 d1; d1.p0 = dh1; d1.p1 = nullptr; d1.C0 = Cout; d1.ld0 = Cout; d1.ld1 = 0; d1.acc0 = 0; d1.acc1 = 0;
       if (!n->dry())
         launch_gn_bwd(single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, da1, B, Ho, Wo, Cout, G1, 0, 1, nullptr, 0, 0.f, n->partial,
                       n->red, d1, s);
-      conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub, Rp->c0.ub4);
+      conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub, Rp->c0.ub4, nullptr, nullptr, nullptr,
+            Rp->c0.ub6);
       Dst2 d0 = gdst_of(x);
       if (firm) {
         float* da0f = n->tmp((long long)B * H * W * Cin);

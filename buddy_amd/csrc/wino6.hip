@@ -1,0 +1,294 @@
+// Winograd F(6x6, 3x3) convolution in three passes (gfx950, fp32, NHWC, stride 1, pad 1) -- the large layers of the score network.
+// Same call sites, epilogue semantics and GroupNorm fusions as the F(4x4,3x3) form (wino4.hip; reference ddpm_conv3x3,
+// networks/ncsnpp_utils/layers.py:119-126, and its data-gradient), with 64 / 36 = 1.78 multiply-adds per output and (cin, cout) pair instead
+// of 2.25, and transformed tensors V / M that are 1.78x the activation instead of 2.25x:
+//   1. input transform   V[pos][tile][cin]  = (B^T d B)[pos]      8x8 input patch per 6x6 output tile
+//   2. 64 batched GEMMs  M[pos][tile][cout] = V[pos] x U[pos]^T    igemm_kernel<1> with batch = 64 (fp32 MFMA)
+//   3. output transform  Y = A^T M A + bias / time-embedding bias / residual / scale / accumulate
+// Interpolation points {0, +-1, +-2, +-1/2, inf}.  Round-off (fp32 throughout) is about twice that of F(4x4,3x3): 1.0e-5 against 5.0e-6 of
+// the abs-max on unit-variance data with 128 input channels (direct form 3e-7); unit test tolerance 1e-4 like F(4x4,3x3).
+// H and W need not be multiples of 6: tiles overhang the image, overhanging inputs read as zero padding, overhanging outputs are not
+// written -- the caller uses this form where the overhang costs less than the transform saves (wino6_pays).
+//
+// A thread cannot hold an 8x8 patch of float4 (256 VGPRs), so both transforms are separable passes through LDS: in the first phase a
+// thread owns one COLUMN of one tile for one channel quad (8 float4), in the second one ROW.  Lanes run along the channel quads, so every
+// global access is a run of 16-byte pieces (512 B for 128 channels) and the LDS image [row][col][quad] is conflict free.  A workgroup of
+// 256 threads = 8 columns x QC channel quads x (32 / QC) tiles, QC <= 32.
+#include "common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace buddy {
+namespace {
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float silu_f(float z) { return z * __builtin_amdgcn_rcpf(1.f + __expf(-z)); }   // as wino4.hip
+
+// t = B^T d (8 -> 8)
+__device__ __forceinline__ void bt8(const float4 (&d)[8], float4 (&t)[8]) {
+  const float4 e0 = d[2] + d[6] - 4.25f * d[4], o0 = d[1] + d[5] - 4.25f * d[3];
+  const float4 e1 = d[6] + 0.25f * d[2] - 1.25f * d[4], o1 = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
+  const float4 e2 = d[6] + 4.f * d[2] - 5.f * d[4], o2 = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
+  t[0] = d[0] - d[6] + 5.25f * (d[4] - d[2]);
+  t[1] = e0 + o0; t[2] = e0 - o0;
+  t[3] = e1 + o1; t[4] = e1 - o1;
+  t[5] = e2 + o2; t[6] = e2 - o2;
+  t[7] = d[7] - d[1] + 5.25f * (d[3] - d[5]);
+}
+// y = A^T m (8 -> 6)
+__device__ __forceinline__ void at8(const float4 (&m)[8], float4 (&y)[6]) {
+  const float4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
+  y[0] = m[0] + s12 + s34 + s56;
+  y[1] = d12 + 2.f * d34 + 0.5f * d56;
+  y[2] = s12 + 4.f * s34 + 0.25f * s56;
+  y[3] = d12 + 8.f * d34 + 0.125f * d56;
+  y[4] = s12 + 16.f * s34 + 0.0625f * s56;
+  y[5] = d12 + 32.f * d34 + 0.03125f * d56 + m[7];
+}
+
+struct W6Geo { int B, H, W, TH, TW, QC, TPB; long long Mt; };   // TH x TW tiles per utterance, Mt = B * TH * TW
+
+// grid (ceil(Mt / TPB), ceil(q / QC)); V[(pos * Mt + tile) * Cin + c]
+// GN: the input is act(GroupNorm(x)) of a (channel-concatenated) view, applied while loading (zero padding applies to the ACTIVATED tensor)
+template <bool GN>
+__global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__ x, int ldX, const W4Gn gn, float* __restrict__ V, int Cin,
+                                                       const W6Geo geo) {
+  __shared__ float4 lds[32 * 64];
+  const int tid = threadIdx.x, QC = geo.QC;
+  const int ql = tid % QC, col = (tid / QC) & 7, tl = tid / (QC * 8);
+  const int quad = blockIdx.y * QC + ql, c = quad * 4;
+  const long long tile = (long long)blockIdx.x * geo.TPB + tl;
+  const bool live = tile < geo.Mt && c < Cin;
+  const int H = geo.H, W = geo.W;
+  int b = 0, ty = 0, tx = 0;
+  if (live) { tx = (int)(tile % geo.TW); ty = (int)((tile / geo.TW) % geo.TH); b = (int)(tile / ((long long)geo.TW * geo.TH)); }
+  if (live) {
+    float mean = 0.f, rstd = 0.f;
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), bt = gm;
+    if (GN) {
+      const int g = c / (Cin / gn.G);
+      mean = gn.stats[((long long)b * gn.G + g) * 2]; rstd = gn.stats[((long long)b * gn.G + g) * 2 + 1];
+      gm = ld4(gn.gamma + c); bt = ld4(gn.beta + c);
+      const bool second = gn.x.p1 != nullptr && c >= gn.x.C0;
+      x = second ? gn.x.p1 + (c - gn.x.C0) : gn.x.p0 + c;
+      ldX = second ? gn.x.ld1 : gn.x.ld0;
+    } else {
+      x += c;
+    }
+    const int gx = 6 * tx - 1 + col, gy0 = 6 * ty - 1;
+    float4 d[8], t[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int gy = gy0 + r;
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+        float4 v = ld4(x + (((long long)b * H + gy) * W + gx) * ldX);
+        if (GN) {
+          v = make_float4((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y, (v.z - mean) * rstd * gm.z + bt.z,
+                          (v.w - mean) * rstd * gm.w + bt.w);
+          if (gn.silu) v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+        }
+        d[r] = v;
+      } else {
+        d[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    bt8(d, t);                                               // column: t[:, col] = B^T d[:, col]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) lds[(tl * 64 + r * 8 + col) * QC + ql] = t[r];
+  }
+  __syncthreads();
+  if (live) {
+    const int r = col;                                       // this thread's row in the second phase
+    float4 d[8], t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = lds[(tl * 64 + r * 8 + j) * QC + ql];
+    bt8(d, t);                                               // row: v[r, :] = t[r, :] B
+    float* out = V + tile * Cin + c;
+    const long long ps = geo.Mt * Cin;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st4(out + (long long)(r * 8 + j) * ps, t[j]);
+  }
+}
+
+// grid (B * chunks, ceil(q / QC)): workgroup (b, chunk) walks tiles [chunk * TPB * TL, (chunk + 1) * TPB * TL) of utterance b, TPB at a time.
+// STAT: per-(utterance, channel) partial (sum, sum of squares) of the values written, fp64, one per workgroup:
+// stat[((b * chunks + chunk) * N + n) * 2 + {0, 1}] (the layout csum_collapse_kernel reads).
+template <bool STAT>
+__global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict__ Mb, const IgemmParams p, const W6Geo geo, int chunks, int TL,
+                                                        double* __restrict__ stat) {
+  __shared__ float4 lds[32 * 48];
+  __shared__ double red[STAT ? 256 * 8 : 1];
+  const int tid = threadIdx.x, QC = geo.QC;
+  const int ql = tid % QC, col = (tid / QC) & 7, tl = tid / (QC * 8);
+  const int N = p.N, H = geo.H, W = geo.W;
+  const int quad = blockIdx.y * QC + ql, n = quad * 4;
+  const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+  const int tpb = geo.TH * geo.TW;                            // tiles per utterance
+  const bool chan = n < N;
+  const long long ps = geo.Mt * N;
+  double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
+  float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (chan) {
+    if (p.bias_n) add = ld4(p.bias_n + n);
+    if (p.bias_bn) add = add + ld4(p.bias_bn + (long long)b * p.ld_bias_bn + n);
+  }
+  for (int it = 0; it < TL; ++it) {
+    const int lt = (chunk * TL + it) * geo.TPB + tl;          // tile within the utterance
+    const bool live = chan && lt < tpb;
+    const long long tile = (long long)b * tpb + lt;
+    if (live) {
+      const float* src = Mb + tile * N + n;
+      float4 m[8], s[6];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m[i] = ld4(src + (long long)(i * 8 + col) * ps);
+      at8(m, s);                                             // column: s[:, col] = A^T m[:, col]
+#pragma unroll
+      for (int r = 0; r < 6; ++r) lds[(tl * 48 + r * 8 + col) * QC + ql] = s[r];
+    }
+    __syncthreads();
+    if (live && col < 6) {
+      const int r = col, ty = lt / geo.TW, tx = lt - ty * geo.TW;
+      const int hh = 6 * ty + r;
+      float4 m[8], y[6];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = lds[(tl * 48 + r * 8 + j) * QC + ql];
+      at8(m, y);                                             // row: y[r, :] = s[r, :] A
+      if (hh < H) {
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) {
+          const int ww = 6 * tx + cc;
+          if (ww < W) {
+            const long long pix = ((long long)b * H + hh) * W + ww;
+            float4 v = p.alpha * y[cc] + add;
+            if (p.res_mode == 1) v = v + ld4(p.res + pix * p.ldRes + n);
+            else if (p.res_mode == 2) v = v + ld4(p.res + (((long long)b * (H >> 1) + (hh >> 1)) * (W >> 1) + (ww >> 1)) * p.ldRes + n);
+            v = p.out_scale * v;
+            float* dst = p.C + pix * p.ldC + n;
+            if (p.accumulate) v = v + ld4(dst);
+            st4(dst, v);
+            if (STAT) {
+              ssum[0] += (double)v.x; ssum[1] += (double)v.y; ssum[2] += (double)v.z; ssum[3] += (double)v.w;
+              ssq[0] += (double)v.x * (double)v.x; ssq[1] += (double)v.y * (double)v.y; ssq[2] += (double)v.z * (double)v.z;
+              ssq[3] += (double)v.w * (double)v.w;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (STAT) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = ssum[j]; red[tid * 8 + 4 + j] = ssq[j]; }
+    __syncthreads();
+    if (tid < QC && chan) {                                   // tid < QC: ql == tid, col == 0, tl == 0
+      double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int l = 0; l < 256 / QC; ++l)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += red[(l * QC + tid) * 8 + j];
+      double* o = stat + (((long long)b * chunks + chunk) * N + n) * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j * 2] = r[j]; o[j * 2 + 1] = r[4 + j]; }
+    }
+  }
+}
+
+W6Geo geometry(const IgemmParams& p, int C) {
+  W6Geo g;
+  g.H = p.H; g.W = p.W; g.B = p.M / (p.H * p.W);
+  g.TH = (p.H + 5) / 6; g.TW = (p.W + 5) / 6;
+  g.Mt = (long long)g.B * g.TH * g.TW;
+  const int q = C / 4;
+  g.QC = q >= 32 ? 32 : (q > 16 ? 32 : (q > 8 ? 16 : (q > 4 ? 8 : (q > 2 ? 4 : (q > 1 ? 2 : 1)))));
+  g.TPB = 32 / g.QC;
+  return g;
+}
+// iterations of TPB tiles a workgroup of the output transform walks: about 512 workgroups (= statistics partials) per utterance
+int out_walk(const W6Geo& g) { const int t = g.TH * g.TW, per = g.TPB * 512; return std::max(1, (t + per - 1) / per); }
+}  // namespace
+
+bool wino6_supported(const IgemmParams& p) {
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return p.H >= 6 && p.W >= 6 && p.Cin % 4 == 0 && p.N % 4 == 0 && p.A1 == nullptr && p.bias_m == nullptr && p.ldA0 % 4 == 0 && p.ldC % 4 == 0 &&
+         (p.res_mode == 0 || p.ldRes % 4 == 0) && (p.res_mode != 2 || (p.H % 2 == 0 && p.W % 2 == 0)) &&
+         (p.bias_bn == nullptr || p.ld_bias_bn % 4 == 0) && al16(p.A0) && al16(p.C) && al16(p.res) && al16(p.bias_n) && al16(p.bias_bn) &&
+         (long long)((p.H + 5) / 6) * ((p.W + 5) / 6) * (p.M / (p.H * p.W)) * 64 < (1LL << 31);
+}
+// worth it against F(4x4,3x3): executed multiply-adds 64 per 6x6 tile (overhang included) against 36 per 4x4 tile, with a margin for the
+// second LDS phase of the transforms; small layers stay with F(4x4,3x3)
+bool wino6_pays(const IgemmParams& p) {
+  const double tiles6 = (double)((p.H + 5) / 6) * ((p.W + 5) / 6), tiles4 = (double)p.H * p.W / 16.0;
+  return tiles6 * 64.0 <= 0.90 * tiles4 * 36.0 && tiles6 >= 256;
+}
+void wino6_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats) {
+  const long long Mt = (long long)(p.M / (p.H * p.W)) * ((p.H + 5) / 6) * ((p.W + 5) / 6);
+  *v_floats = 64 * Mt * p.Cin; *m_floats = 64 * Mt * p.N;
+}
+int wino6_stat_chunks(const IgemmParams& p) {
+  if (p.N % 4) return 0;
+  const W6Geo g = geometry(p, p.N);
+  const int per = g.TPB * out_walk(g);
+  return (g.TH * g.TW + per - 1) / per;
+}
+double wino6_exec_ratio(const IgemmParams& p) {               // executed / direct-convolution multiply-adds
+  const W6Geo g = geometry(p, p.N);
+  return 64.0 * (double)g.Mt / (9.0 * (double)p.M);
+}
+
+void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat) {
+  const W6Geo gi = geometry(p, p.Cin), go = geometry(p, p.N);
+  const long long Mt = gi.Mt;
+  const int plevel = igemm_prof_level();
+  const bool prof = plevel >= 2, prof_gemm = plevel == 1;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (prof) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], st); }
+  if (prof_gemm) { (void)hipEventCreate(&ev[1]); (void)hipEventCreate(&ev[2]); }
+  const dim3 grid_in((unsigned)((Mt + gi.TPB - 1) / gi.TPB), (unsigned)((p.Cin / 4 + gi.QC - 1) / gi.QC));
+  if (gn) hipLaunchKernelGGL(w6_input_kernel<true>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
+  else hipLaunchKernelGGL(w6_input_kernel<false>, grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, p.Cin, gi);
+  if (prof || prof_gemm) (void)hipEventRecord(ev[1], st);
+  IgemmParams g; std::memset(&g, 0, sizeof(g));
+  g.A0 = V; g.ldA0 = p.Cin; g.sA = Mt * p.Cin; g.Cin = p.Cin;
+  g.Bt = U6; g.ldB = p.Cin; g.sB = (long long)p.N * p.Cin;
+  g.C = Mb; g.ldC = p.N; g.sC = Mt * p.N;
+  g.M = (int)Mt; g.N = p.N; g.H = 1; g.W = 1; g.rows_per_batch = 1; g.alpha = 1.f; g.out_scale = 1.f;
+  g.tag = 36;                                                 // the Winograd-domain batched GEMM instantiation (36 or 64 positions)
+  igemm_prof_enable(0);
+  launch_igemm(g, 1, false, false, 64, st);
+  igemm_prof_enable(plevel);
+  if (prof || prof_gemm) (void)hipEventRecord(ev[2], st);
+  const int TL = out_walk(go), per = go.TPB * TL, chunks = (go.TH * go.TW + per - 1) / per;
+  const dim3 grid_out((unsigned)(go.B * chunks), (unsigned)((p.N / 4 + go.QC - 1) / go.QC));
+  if (stat) hipLaunchKernelGGL(w6_output_kernel<true>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat);
+  else hipLaunchKernelGGL(w6_output_kernel<false>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr);
+  const double mt = (double)Mt, m = (double)p.M;
+  if (prof_gemm) prof_w4_push(nullptr, ev[1], ev[2], nullptr, 2.0 * 64.0 * mt * p.Cin * p.N, 0.0, 0.0, 4.0 * 64.0 * (mt * p.Cin + mt * p.N + (double)p.N * p.Cin));
+  if (prof) {
+    (void)hipEventRecord(ev[3], st);
+    prof_w4_push(ev[0], ev[1], ev[2], ev[3], 2.0 * 64.0 * mt * p.Cin * p.N, 4.0 * (m * p.Cin + 64.0 * mt * p.Cin),
+                 4.0 * (64.0 * mt * p.N + m * p.N * (p.res_mode ? 2.0 : 1.0)), 4.0 * 64.0 * (mt * p.Cin + mt * p.N + (double)p.N * p.Cin));
+  }
+}
+
+// host: U6[pos][cout][cin] = (G g G^T)[pos] from tap-major packed weights wt[cout][(dy*3+dx)*Cin + cin]
+void wino6_transform_weights(const float* wt, int Cout, int Cin, float* U) {
+  static const double G[8][3] = {{1, 0, 0}, {-2.0 / 9, -2.0 / 9, -2.0 / 9}, {-2.0 / 9, 2.0 / 9, -2.0 / 9}, {1.0 / 90, 1.0 / 45, 2.0 / 45},
+                                 {1.0 / 90, -1.0 / 45, 2.0 / 45}, {32.0 / 45, 16.0 / 45, 8.0 / 45}, {32.0 / 45, -16.0 / 45, 8.0 / 45}, {0, 0, 1}};
+  for (int o = 0; o < Cout; ++o)
+    for (int i = 0; i < Cin; ++i) {
+      double g[3][3], t[8][3];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) g[a][b] = wt[(size_t)o * 9 * Cin + (size_t)(a * 3 + b) * Cin + i];
+      for (int xi = 0; xi < 8; ++xi) for (int b = 0; b < 3; ++b) t[xi][b] = G[xi][0] * g[0][b] + G[xi][1] * g[1][b] + G[xi][2] * g[2][b];
+      for (int xi = 0; xi < 8; ++xi) for (int nu = 0; nu < 8; ++nu) {
+        const double u = t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2];
+        U[((size_t)(xi * 8 + nu) * Cout + o) * Cin + i] = (float)u;
+      }
+    }
+}
+
+}  // namespace buddy

@@ -92,11 +92,20 @@ int buddy_conv3x3_winograd(const float* x, const float* U, const float* bias, fl
 int buddy_winograd4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_host);
 int buddy_conv3x3_winograd4(const float* x, const float* U4, const float* bias, float* y, float* scratch, int B, int H, int W, int Cin, int Cout,
                             void* stream);
+/* F(6x6,3x3) three-pass variant for the large layers (64 positions, 8x8 input patch per 6x6 output tile: 1.78 instead of 2.25 multiply-adds per
+ * output, any H, W >= 6 -- tiles may overhang): U6[64][Cout][Cin]; scratch: 64 * B * ceil(H/6) * ceil(W/6) * (Cin + Cout) floats. */
+int buddy_winograd6_transform_weights(const float* wt_host, int Cout, int Cin, float* U6_host);
+int buddy_conv3x3_winograd6(const float* x, const float* U6, const float* bias, float* y, float* scratch, int B, int H, int W, int Cin, int Cout,
+                            void* stream);
 /* act(GroupNorm(cat[x0, x1])) -> conv3x3 as ONE three-pass convolution: the normalisation and SiLU are applied inside the input transform
  * (the activated tensor never reaches HBM) and, with csum != NULL, the output transform leaves the per-(utterance, channel) sum and sum of
  * squares of y (csum[B][Cout][2], float64) -- the statistics the NEXT GroupNorm needs (layerspp.py:243-245, 257-259).  x1 may be NULL (single
  * source; C0 ignored).  stats: [B][G][2] out.  scratch as for buddy_conv3x3_winograd4; stat_scratch: >= B*256*1024*16 bytes. */
 int buddy_gn_conv3x3_winograd4(const float* x0, const float* x1, int C0, const float* gamma, const float* beta, int G, int silu, const float* U4,
+                               const float* bias, float* y, float* scratch, float* stats, double* stat_scratch, double* csum, int B, int H, int W,
+                               int Cin, int Cout, void* stream);
+/* the same through the F(6x6,3x3) passes (scratch as for buddy_conv3x3_winograd6) */
+int buddy_gn_conv3x3_winograd6(const float* x0, const float* x1, int C0, const float* gamma, const float* beta, int G, int silu, const float* U6,
                                const float* bias, float* y, float* scratch, float* stats, double* stat_scratch, double* csum, int B, int H, int W,
                                int Cin, int Cout, void* stream);
 /* GroupNorm(G, C, eps=1e-6) [+SiLU] [+2x down(mode 1)/up(mode 2)] forward; replaces nn.GroupNorm + nn.SiLU +

@@ -122,9 +122,37 @@ def test_conv3x3_winograd4(lib, B, H, W, Cin, Cout):
     assert rel(y.permute(0, 3, 1, 2), ref) < 1e-4
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 24, 16, 12), (1, 64, 32, 128, 256), (3, 8, 14, 40, 8), (2, 20, 16, 384, 128), (1, 6, 6, 8, 4),
+                                            (2, 37, 50, 96, 64)])
+def test_conv3x3_winograd6(lib, B, H, W, Cin, Cout):
+    """Three-pass Winograd F(6x6,3x3) (separable transforms through LDS, 64 batched fp32 GEMMs), H / W not multiples of 6 (overhanging
+    tiles), channel counts that do not fill a 32-quad chunk.  Stated tolerance 1e-4 of the abs-max as for F(4x4,3x3) (measured ~1e-5: about
+    twice the round-off of F(4x4,3x3))."""
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin + Cout + 6)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin))
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = F.conv2d(x.double(), w.cuda().double(), b.double(), padding=1).float()
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().numpy()
+    U = np.empty(64 * Cin * Cout, dtype=np.float32)
+    _lib.check(lib.buddy_winograd6_transform_weights(wt.ctypes.data, Cout, Cin, U.ctypes.data))
+    Ud = torch.from_numpy(U).cuda()
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    tiles = B * ((H + 5) // 6) * ((W + 5) // 6)
+    scratch = torch.empty(64 * tiles * (Cin + Cout), device="cuda")
+    _lib.check(lib.buddy_conv3x3_winograd6(P(x_nhwc), P(Ud), P(b), P(y), P(scratch), B, H, W, Cin, Cout, S()))
+    torch.cuda.synchronize()
+    e = rel(y.permute(0, 3, 1, 2), ref)
+    print(f"F(6x6,3x3) {B}x{H}x{W} {Cin}->{Cout}: {e:.2e}")
+    assert e < 1e-4
+
+
+@pytest.mark.parametrize("f6", [0, 1])
 @pytest.mark.parametrize("B,H,W,C0,C1,Cout,silu,stat", [(2, 32, 32, 16, 0, 32, 1, 1), (1, 64, 32, 128, 0, 256, 1, 1), (3, 8, 12, 24, 16, 8, 1, 0),
                                                        (2, 16, 16, 256, 128, 128, 1, 1), (2, 16, 32, 64, 0, 64, 0, 1)])
-def test_gn_conv3x3_winograd4_fused(lib, B, H, W, C0, C1, Cout, silu, stat):
+def test_gn_conv3x3_winograd_fused(lib, B, H, W, C0, C1, Cout, silu, stat, f6):
     """conv3x3(act(GroupNorm(cat[x0, x1]))) with the normalisation + SiLU applied inside the F(4x4,3x3) input transform and the per-channel
     (sum, sum of squares) of the output left by the output transform (the next GroupNorm's statistics), vs fp64 torch.  1e-4 like the unfused
     convolution; the sums are fp64 sums of the fp32 outputs: 1e-6 relative to sum |y| / sum y^2."""
@@ -142,18 +170,18 @@ def test_gn_conv3x3_winograd4_fused(lib, B, H, W, C0, C1, Cout, silu, stat):
         z = F.silu(z)
     ref = F.conv2d(z, w.cuda().double(), b.double(), padding=1)
     wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().numpy()
-    U = np.empty(36 * Cin * Cout, dtype=np.float32)
-    _lib.check(lib.buddy_winograd4_transform_weights(wt.ctypes.data, Cout, Cin, U.ctypes.data))
+    U = np.empty((64 if f6 else 36) * Cin * Cout, dtype=np.float32)
+    _lib.check((lib.buddy_winograd6_transform_weights if f6 else lib.buddy_winograd4_transform_weights)(wt.ctypes.data, Cout, Cin, U.ctypes.data))
     Ud = torch.from_numpy(U).cuda()
     xn = x.permute(0, 2, 3, 1)
     x0 = xn[..., :C0].contiguous()
     x1 = xn[..., C0:].contiguous() if C1 else None
     y = torch.empty(B, H, W, Cout, device="cuda")
-    scratch = torch.empty(36 * (B * H * W // 16) * (Cin + Cout), device="cuda")
+    scratch = torch.empty(64 * B * ((H + 5) // 6) * ((W + 5) // 6) * (Cin + Cout) if f6 else 36 * (B * H * W // 16) * (Cin + Cout), device="cuda")
     stats = torch.empty(B, G, 2, device="cuda")
     stat_scratch = torch.empty(B * 256 * 1024 * 2, dtype=torch.float64, device="cuda")
     csum = torch.zeros(B, Cout, 2, dtype=torch.float64, device="cuda")
-    _lib.check(lib.buddy_gn_conv3x3_winograd4(P(x0), P(x1) if C1 else None, C0, P(gamma), P(beta), G, silu, P(Ud), P(b), P(y), P(scratch), P(stats),
+    _lib.check((lib.buddy_gn_conv3x3_winograd6 if f6 else lib.buddy_gn_conv3x3_winograd4)(P(x0), P(x1) if C1 else None, C0, P(gamma), P(beta), G, silu, P(Ud), P(b), P(y), P(scratch), P(stats),
                                               stat_scratch.data_ptr(), csum.data_ptr() if stat else None, B, H, W, Cin, Cout, S()))
     torch.cuda.synchronize()
     assert rel(y.permute(0, 3, 1, 2), ref.float()) < 1e-4
