@@ -257,7 +257,7 @@ def conv_source_stamp():
     """sha1 over the sources of the dominant kernel group: a PMC summary is only quoted if it was measured on these exact kernels"""
     import hashlib
     h = hashlib.sha1()
-    for f in ("igemm.hip", "wino4.hip", "common.h"):
+    for f in ("igemm.hip", "wino4.hip", "wino6.hip", "common.h"):
         h.update(open(os.path.join(ROOT, "buddy_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 
@@ -471,10 +471,11 @@ def main():
             "network_algorithmic_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
             "gather_ms": gather_ms,
             # dominant kernel: the 36 batched Winograd-domain GEMMs (fp32 MFMA 32x32x2) of the 3x3 convolutions
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<1,false,false,2,2,36> -- the 36 batched GEMMs M[pos] = V[pos] U[pos]^T of the three-pass "
-                                                    "Winograd F(4x4,3x3) 3x3 convolutions (94 % of the network's algorithmic FLOPs)",
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<1,false,false,2,2,36> -- the batched GEMMs M[pos] = V[pos] U[pos]^T of the three-pass "
+                                                    "Winograd 3x3 convolutions (64 positions, F(6x6,3x3), on the large layers; 36, F(4x4,3x3), on the "
+                                                    "small ones; 94 % of the network's algorithmic FLOPs)",
                          "achieved": gemm_tf, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_FP32_MFMA,
-                         "achieved_note": "EXECUTED FLOPs per launch (2 * 36 * tiles * Cin * Cout) / average launch duration, HIP events on the launch stream inside "
+                         "achieved_note": "EXECUTED FLOPs per launch (2 * positions * tiles * Cin * Cout) / average launch duration, HIP events on the launch stream inside "
                                           "the timed region (every launch of every other step: an event pair costs a ~7 us dispatch bubble); <= 1 by construction",
                          "avg_launch_ms": dom_ms[1] / n36, "launches": n36, "sampled_steps": sampled_steps, "share_of_step": gemm_ms_per_step * 1e-3 / step_s,
                          "flops_per_launch": dom_fl.value / n36, "algorithmic_bytes_per_launch": dom_bg.value / n36,
@@ -482,14 +483,15 @@ def main():
                          "peak_measured_on_box": peaks.get("fp32_mfma_tflops"),
                          "frac_of_measured_peak": (gemm_tf / peaks["fp32_mfma_tflops"]) if peaks.get("fp32_mfma_tflops") else None},
             # the whole 3x3 convolution (three launches) and the whole step, for context
-            "conv3x3": {"algorithmic_tflops": conv_alg_tf, "algorithmic_speedup": 4.0,
-                        "note": "direct-convolution FLOPs (2*M*N*9*Cin) / time of the three-launch group; F(4x4,3x3) executes 1/4 of them, so this is NOT a "
-                                "roofline fraction -- the matrix-pipe utilisation is roofline.frac",
+            "conv3x3": {"algorithmic_tflops": conv_alg_tf, "algorithmic_speedup": (fl[0] / xf[0]) if xf[0] > 0 else None,
+                        "note": "direct-convolution FLOPs (2*M*N*9*Cin) / time of the three-launch group; the Winograd forms execute 64/(36*9) "
+                                "(F(6x6,3x3), plus tile overhang) or 1/4 (F(4x4,3x3)) of them -- algorithmic_speedup = direct / executed FLOPs over all "
+                                "convolutions -- so this is NOT a roofline fraction: the matrix-pipe utilisation is roofline.frac",
                         "avg_conv_ms": ms[0] / max(1, ln[0]), "convolutions": int(ln[0]), "share_of_step": ms[0] * 1e-3 / attr_elapsed,
                         "transform_passes": {"input_GBps": w4_bi.value / (w4_ms[0] * 1e-3) / 1e9 if w4_ms[0] > 0 else 0.0,
                                              "output_GBps": w4_bo.value / (w4_ms[2] * 1e-3) / 1e9 if w4_ms[2] > 0 else 0.0,
                                              "peak_GBps": PEAK_HBM_GBS, "share_of_step": (w4_ms[0] + w4_ms[2]) * 1e-3 / attr_elapsed,
-                                             "note": "HBM-bound: input read once + 36/16 transformed values written; 36/16 read + output (and residual) once"},
+                                             "note": "HBM-bound: input read once + 64/36 (F(6x6,3x3)) or 36/16 (F(4x4,3x3)) transformed values written; the same read + output (and residual) once"},
                         "fused_form_bytes_per_conv": by[0] / max(1, ln[0]),
                         "three_pass_bytes_per_conv": (w4_bi.value + w4_bg.value + w4_bo.value) / a36},
             "step_executed": {"tflops": exec_step_tf, "frac": exec_step_tf / PEAK_FP32_MFMA,

@@ -223,7 +223,7 @@ bool wino6_supported(const IgemmParams& p) {
 // second LDS phase of the transforms; small layers stay with F(4x4,3x3)
 bool wino6_pays(const IgemmParams& p) {
   const double tiles6 = (double)((p.H + 5) / 6) * ((p.W + 5) / 6), tiles4 = (double)p.H * p.W / 16.0;
-  return tiles6 * 64.0 <= 0.90 * tiles4 * 36.0 && tiles6 >= 256;
+  return tiles6 * 64.0 <= 0.90 * tiles4 * 36.0 && tiles6 >= 128;
 }
 void wino6_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats) {
   const long long Mt = (long long)(p.M / (p.H * p.W)) * ((p.H + 5) / 6) * ((p.W + 5) / 6);
