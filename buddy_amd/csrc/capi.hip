@@ -217,6 +217,27 @@ int buddy_gn_conv3x3_winograd6(const float* x0, const float* x1, int C0, const f
   return gn_conv3x3_winograd(true, x0, x1, C0, gamma, beta, G, silu, U6, bias, y, scratch, stats, stat_scratch, csum, B, H, W, Cin, Cout, stream);
 }
 
+int buddy_conv3x3_winograd6_gn_bwd_sums(const float* g, const float* U6, float* da, float* scratch, const float* x0, const float* x1, int C0,
+                                        const float* stats, const float* gamma, const float* beta, int G, int silu, double* stat_scratch,
+                                        double* chsum, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!g || !U6 || !da || !scratch || !x0 || !stats || !gamma || !beta || !stat_scratch || !chsum || G < 1 || Cout % 4 || (Cout / G) % 4 ||
+      Cout > 1024 || (x1 && (C0 % 4 || C0 < 4 || C0 >= Cout))) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.A0 = g; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = da; p.ldC = Cout;
+  p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
+  if (!wino6_supported(p)) { set_error("shape not supported by the F(6x6,3x3) path (H, W >= 6; Cin, Cout multiples of 4)"); return BUDDY_ERR_ARG; }
+  const int sc = wino6_stat_chunks(p);
+  if (sc == 0 || (long long)sc * Cout > 256LL * 1024) { set_error("shape not supported by the statistics epilogue"); return BUDDY_ERR_ARG; }
+  W4Gn bg;
+  bg.x.p0 = x0; bg.x.p1 = x1; bg.x.C0 = x1 ? C0 : Cout; bg.x.ld0 = x1 ? C0 : Cout; bg.x.ld1 = x1 ? Cout - C0 : 0;
+  bg.stats = stats; bg.gamma = gamma; bg.beta = beta; bg.G = G; bg.silu = silu;
+  long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf);
+  launch_wino6(p, U6, scratch, scratch + vf, st, nullptr, stat_scratch, &bg);
+  launch_csum_collapse(stat_scratch, sc, B, Cout, chsum, st);
+  return finish();
+}
+
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B, int H, int W, int C,
                         int G, int mode, int silu, void* stream) {
   if (!x || !y || !stats || !scratch || C % 4 || (C / G) % 4 || C > 1024) { set_error("bad groupnorm arguments"); return BUDDY_ERR_ARG; }

@@ -56,7 +56,10 @@ bool wino6_pays(const IgemmParams& p);
 void wino6_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats);
 int wino6_stat_chunks(const IgemmParams& p);
 double wino6_exec_ratio(const IgemmParams& p);
-void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn = nullptr, double* stat = nullptr);
+//   bwd_gn (with stat) -- data-gradient convolutions: the output is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); the partials are the two sums
+//           of that GroupNorm's backward, (dxhat, dxhat * xhat), instead of (sum, sum of squares)
+void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn = nullptr, double* stat = nullptr,
+                  const W4Gn* bwd_gn = nullptr);
 void wino6_transform_weights(const float* wt_host, int Cout, int Cin, float* U6_host);
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin, double exec_ratio = 4.0 / 9.0);
 void igemm_prof_enable(int level);   // 0 off, 1 the dominant kernel only (36 batched Winograd-domain GEMMs), 2 every instrumented class
@@ -93,9 +96,11 @@ void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float
                      int mode, int silu, float* out, float* pooled_raw, hipStream_t st);
 // backward wrt x. da: gradient of the (resampled) activated output. extra: additional gradient added to dx
 // (extra_mode 0 none, 1 same index, 2 quarter of a pooled-resolution tensor), scaled by extra_scale.
+// chsum != nullptr: the per-(utterance, channel) backward sums [B][C][2] are already there (left by the producing convolution's epilogue):
+// no reduction pass
 void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C,
                    int G, int mode, int silu, const float* extra, int extra_mode, float extra_scale, double* partial,
-                   float* red /*[B][G][2]*/, Dst2 dx, hipStream_t st);
+                   float* red /*[B][G][2]*/, Dst2 dx, hipStream_t st, const double* chsum = nullptr);
 
 // ---- misc elementwise -------------------------------------------------------------------------------------
 // WPE warm start (wpe.hip): rows x T complex128 in/out, scratch rows*T doubles

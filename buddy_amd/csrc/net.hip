@@ -403,9 +403,12 @@ static inline int gn_groups(int C) { int g = C / 4; return g < 32 ? g : 32; }
 // conv3x3 over an NHWC tensor (single source) -> out
 // gn / gn_tmp: the input is act(GroupNorm(gn->x)); the three-pass path applies it inside its input transform, any other path materialises it
 // into gn_tmp first.  stat_out: the tensor `out` belongs to -- its per-channel sums are left by the output transform where the shape allows.
-static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const float* wt, int Cout, const float* bias, const float* bias_bn,
+// bwd_gn / bwd_sums (data-gradient convolutions): `out` is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); on the F(6x6,3x3) path the output
+// transform leaves that GroupNorm's per-channel backward sums in bwd_sums[B][Cout][2] and the call returns true (else: run the reduction pass).
+static bool conv3(Net* N, const float* a, int B, int H, int W, int Cin, const float* wt, int Cout, const float* bias, const float* bias_bn,
                   int ld_bn, const float* res, int ldRes, int res_mode, float alpha, float out_scale, float* out, const float* U = nullptr,
-                  const float* U4 = nullptr, const W4Gn* gn = nullptr, float* gn_tmp = nullptr, Tens* stat_out = nullptr, const float* U6 = nullptr) {
+                  const float* U4 = nullptr, const W4Gn* gn = nullptr, float* gn_tmp = nullptr, Tens* stat_out = nullptr, const float* U6 = nullptr,
+                  const W4Gn* bwd_gn = nullptr, double* bwd_sums = nullptr) {
   // BUDDY_CONV = direct | wino2 | wino4 | (default) three-pass F(6x6,3x3) on the large layers, three-pass F(4x4,3x3) where the shape allows,
   // else fused F(2x2,3x3), else direct
   static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
@@ -419,7 +422,7 @@ static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const fl
       const size_t need = (size_t)64 * ((size_t)B * ((H + 5) / 6) * ((W + 5) / 6)) * (size_t)(Cin + Cout);
       if (need > N->w4_need) N->w4_need = need;
     }
-    return;
+    return false;
   }
   IgemmParams p = ig_base();
   p.A0 = a; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout;
@@ -435,13 +438,16 @@ static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const fl
   }
   if (w6) {
     long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf);
-    const int sc = (stat_out != nullptr && fuse_gn) ? wino6_stat_chunks(p) : 0;
+    static const bool fuse_bwd = !(getenv("BUDDY_GN_FUSE_BWD") && atoi(getenv("BUDDY_GN_FUSE_BWD")) == 0);
+    const bool want_bwd = bwd_gn != nullptr && bwd_sums != nullptr && fuse_gn && fuse_bwd;
+    const int sc = ((stat_out != nullptr && fuse_gn) || want_bwd) ? wino6_stat_chunks(p) : 0;
     const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;
     const double xr = wino6_exec_ratio(p);
     igemm_prof_record(p, 9, 1, N->st, true, xr);
-    launch_wino6(p, U6, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr);
+    launch_wino6(p, U6, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, (stat && want_bwd) ? bwd_gn : nullptr);
     igemm_prof_record(p, 9, 1, N->st, false, xr);
-    if (stat) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
+    if (stat && want_bwd) { launch_csum_collapse(N->partial, sc, B, Cout, bwd_sums, N->st); return true; }
+    if (stat && stat_out) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
   } else if (w4) {
     long long vf = 0, mf = 0; wino4_scratch(p, &vf, &mf);
     const int sc = (stat_out != nullptr && fuse_gn) ? wino4_stat_chunks(p) : 0;
@@ -457,6 +463,7 @@ static void conv3(Net* N, const float* a, int B, int H, int W, int Cin, const fl
   } else {
     launch_igemm(p, 9, false, false, 1, N->st);
   }
+  return false;
 }
 // 1x1 conv / per-pixel linear over a (possibly two-source) view
 static void conv1(Net* N, Src2 a, long long M, int Cin, const float* wt, int Cout, const float* bias, float alpha, float* out, int accumulate) {
@@ -559,14 +566,17 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       float* da1 = n->tmp((long long)B * Ho * Wo * Cout);
       float* dh1 = n->tmp((long long)B * Ho * Wo * Cout);
       float* da0 = n->tmp((long long)B * Ho * Wo * Cin);
-      conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub, Rp->c1.ub4, nullptr, nullptr, nullptr,
-            Rp->c1.ub6);
+      // on the F(6x6,3x3) path the data-gradient convolutions leave the backward sums of the GroupNorm their output feeds (same resolution)
+      double* bsum = (double*)n->arena.alloc((size_t)B * std::max(Cin, Cout) * 2 * sizeof(double));
+      const W4Gn b1{single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, G1, 1}, b0{src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, G0, 1};
+      const bool s1 = conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub, Rp->c1.ub4,
+                            nullptr, nullptr, nullptr, Rp->c1.ub6, &b1, bsum);
       Dst2 d1; d1.p0 = dh1; d1.p1 = nullptr; d1.C0 = Cout; d1.ld0 = Cout; d1.ld1 = 0; d1.acc0 = 0; d1.acc1 = 0;
       if (!n->dry())
         launch_gn_bwd(single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, da1, B, Ho, Wo, Cout, G1, 0, 1, nullptr, 0, 0.f, n->partial,
-                      n->red, d1, s);
-      conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub, Rp->c0.ub4, nullptr, nullptr, nullptr,
-            Rp->c0.ub6);
+                      n->red, d1, s, s1 ? bsum : nullptr);
+      const bool s0 = conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub, Rp->c0.ub4,
+                            nullptr, nullptr, nullptr, Rp->c0.ub6, mode == 0 ? &b0 : nullptr, bsum);
       Dst2 d0 = gdst_of(x);
       if (firm) {
         float* da0f = n->tmp((long long)B * H * W * Cin);
@@ -578,7 +588,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       } else
       if (!n->dry())
         launch_gn_bwd(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0, B, H, W, Cin, G0, mode, 1, extra, extra_mode, extra_scale,
-                      n->partial, n->red, d0, s);
+                      n->partial, n->red, d0, s, s0 ? bsum : nullptr);
       n->arena.off = mk;
     });
   }

@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256) void csum_collapse_kernel(const double* __rest
   }
 }
 
-// one wave per (b, group) of a (concatenated) view: (mean, rstd) from the per-channel sums of its sources
+// one wave per (b, group) of a (concatenated) view: (mean, rstd) from the per-channel sums of its sources (KIND 0), or the two backward
+// means from the per-channel backward sums (KIND 1)
+template <int KIND>
 __global__ __launch_bounds__(64) void group_finalize_csum_kernel(const double* __restrict__ c0, const double* __restrict__ c1, int C0, int C, int G,
                                                                  int HW, float eps, float* __restrict__ out) {
   const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
@@ -185,11 +187,15 @@ __global__ __launch_bounds__(64) void group_finalize_csum_kernel(const double* _
   for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); t += __shfl_down(t, off, 64); }
   if (lane == 0) {
     const double n = (double)cpg * (double)HW;
-    const double mean = s / n;
-    double var = t / n - mean * mean;
-    if (var < 0) var = 0;
     float* o = out + ((long long)b * G + g) * 2;
-    o[0] = (float)mean; o[1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (KIND == 0) {
+      const double mean = s / n;
+      double var = t / n - mean * mean;
+      if (var < 0) var = 0;
+      o[0] = (float)mean; o[1] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+      o[0] = (float)(s / n); o[1] = (float)(t / n);
+    }
   }
 }
 
@@ -837,7 +843,7 @@ void launch_chan_sums(const float* x, int B, int HW, int C, double* partial, dou
   prof_hbm_end(st);
 }
 void launch_gn_stats_csum(const double* csum0, const double* csum1, int C0, int B, int HW, int C, int G, float eps, float* stats, hipStream_t st) {
-  hipLaunchKernelGGL(group_finalize_csum_kernel, dim3(G, B), dim3(64), 0, st, csum0, csum1, csum1 ? C0 : C, C, G, HW, eps, stats);
+  hipLaunchKernelGGL(group_finalize_csum_kernel<0>, dim3(G, B), dim3(64), 0, st, csum0, csum1, csum1 ? C0 : C, C, G, HW, eps, stats);
 }
 
 void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float* beta, int B, int H, int W, int C, int G, int mode, int silu,
@@ -856,16 +862,21 @@ void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float
 }
 
 void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G, int mode,
-                   int silu, const float* extra, int extra_mode, float extra_scale, double* partial, float* red, Dst2 dx, hipStream_t st) {
+                   int silu, const float* extra, int extra_mode, float extra_scale, double* partial, float* red, Dst2 dx, hipStream_t st,
+                   const double* chsum) {
   RedArgs a = make_red(x, B, H, W, C, G, partial);
   a.stats = stats; a.gamma = gamma; a.beta = beta; a.da = da; a.mode = mode; a.silu = silu;
   {
     const double n_in = (double)B * H * W * C, n_da = mode == 1 ? n_in / 4 : (mode == 2 ? n_in * 4 : n_in);
-    // sums pass reads x and da, apply pass reads them again and writes dx (+ reads the extra gradient): the two-pass minimum
-    prof_hbm_begin(4.0 * (2.0 * (n_in + n_da) + n_in + (extra_mode ? (extra_mode == 2 ? n_in / 4 : n_in) : 0.0)), st);
+    // sums pass reads x and da (unless the sums came with da), apply pass reads them again and writes dx (+ reads the extra gradient)
+    prof_hbm_begin(4.0 * ((chsum ? 1.0 : 2.0) * (n_in + n_da) + n_in + (extra_mode ? (extra_mode == 2 ? n_in / 4 : n_in) : 0.0)), st);
   }
-  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(a.chunks, B), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(group_finalize_kernel<1>, dim3(G, B), dim3(64), 0, st, (const double*)partial, red, C, G, a.chunks, H * W, 0.f);
+  if (chsum) {
+    hipLaunchKernelGGL(group_finalize_csum_kernel<1>, dim3(G, B), dim3(64), 0, st, chsum, (const double*)nullptr, C, C, G, H * W, 0.f, red);
+  } else {
+    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(a.chunks, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(group_finalize_kernel<1>, dim3(G, B), dim3(64), 0, st, (const double*)partial, red, C, G, a.chunks, H * W, 0.f);
+  }
   const long long total = (long long)B * H * W * (C / 4);
   static const bool fast = !(getenv("BUDDY_GN_FAST") && atoi(getenv("BUDDY_GN_FAST")) == 0);
   if (fast && mode == 0 && extra_mode != 2 && C % 4 == 0 && C / 4 <= 256) {

@@ -28,6 +28,10 @@ __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_fl
 __device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
 __device__ __forceinline__ float silu_f(float z) { return z * __builtin_amdgcn_rcpf(1.f + __expf(-z)); }   // as wino4.hip
+__device__ __forceinline__ float dsilu_f(float z) {
+  const float s = __builtin_amdgcn_rcpf(1.f + __expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
 
 // t = B^T d (8 -> 8)
 __device__ __forceinline__ void bt8(const float4 (&d)[8], float4 (&t)[8]) {
@@ -116,11 +120,14 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
 }
 
 // grid (B * chunks, ceil(q / QC)): workgroup (b, chunk) walks tiles [chunk * TPB * TL, (chunk + 1) * TPB * TL) of utterance b, TPB at a time.
-// STAT: per-(utterance, channel) partial (sum, sum of squares) of the values written, fp64, one per workgroup:
+// STAT 1: per-(utterance, channel) partial (sum, sum of squares) of the values written, fp64, one per workgroup:
 // stat[((b * chunks + chunk) * N + n) * 2 + {0, 1}] (the layout csum_collapse_kernel reads).
-template <bool STAT>
+// STAT 2 (data-gradient convolutions): the value written is da, the gradient w.r.t. act(GroupNorm(x)) of the view bg.x; the partials are the two
+// sums that GroupNorm's backward needs, (sum dxhat, sum dxhat * xhat) with dxhat = da * act'(z) * gamma -- x is read here at the output pixels and
+// the reduction pass over (x, da) disappears.  fp32 over the (at most 36 x walk) pixels a thread sees, fp64 beyond.
+template <int STAT>
 __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict__ Mb, const IgemmParams p, const W6Geo geo, int chunks, int TL,
-                                                        double* __restrict__ stat) {
+                                                        double* __restrict__ stat, const W4Gn bg) {
   __shared__ float4 lds[32 * 48];
   __shared__ double red[STAT ? 256 * 8 : 1];
   const int tid = threadIdx.x, QC = geo.QC;
@@ -132,10 +139,22 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
   const bool chan = n < N;
   const long long ps = geo.Mt * N;
   double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
+  float fs[4] = {0.f, 0.f, 0.f, 0.f}, ft[4] = {0.f, 0.f, 0.f, 0.f};
   float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+  float mean = 0.f, rstd = 0.f;
+  float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), bt = gm;
+  const float* xsrc = nullptr; int ldx = 0;
   if (chan) {
     if (p.bias_n) add = ld4(p.bias_n + n);
     if (p.bias_bn) add = add + ld4(p.bias_bn + (long long)b * p.ld_bias_bn + n);
+    if (STAT == 2) {
+      const int g = n / (N / bg.G);
+      mean = bg.stats[((long long)b * bg.G + g) * 2]; rstd = bg.stats[((long long)b * bg.G + g) * 2 + 1];
+      gm = ld4(bg.gamma + n); bt = ld4(bg.beta + n);
+      const bool second = bg.x.p1 != nullptr && n >= bg.x.C0;
+      xsrc = second ? bg.x.p1 + (n - bg.x.C0) : bg.x.p0 + n;
+      ldx = second ? bg.x.ld1 : bg.x.ld0;
+    }
   }
   for (int it = 0; it < TL; ++it) {
     const int lt = (chunk * TL + it) * geo.TPB + tl;          // tile within the utterance
@@ -171,7 +190,18 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
             float* dst = p.C + pix * p.ldC + n;
             if (p.accumulate) v = v + ld4(dst);
             st4(dst, v);
-            if (STAT) {
+            if (STAT == 2) {
+              const float4 xv4 = ld4(xsrc + pix * ldx);
+              const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {v.x, v.y, v.z, v.w};
+              const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[j] - mean) * rstd;
+                const float dxh = dv[j] * (bg.silu ? dsilu_f(xh * gv[j] + bv[j]) : 1.f) * gv[j];
+                fs[j] += dxh; ft[j] += dxh * xh;
+              }
+            }
+            if (STAT == 1) {
               ssum[0] += (double)v.x; ssum[1] += (double)v.y; ssum[2] += (double)v.z; ssum[3] += (double)v.w;
               ssq[0] += (double)v.x * (double)v.x; ssq[1] += (double)v.y * (double)v.y; ssq[2] += (double)v.z * (double)v.z;
               ssq[3] += (double)v.w * (double)v.w;
@@ -179,6 +209,10 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
           }
         }
       }
+    }
+    if (STAT == 2) {                                          // flush the fp32 strip sums of this tile row
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ssum[j] += (double)fs[j]; ssq[j] += (double)ft[j]; fs[j] = 0.f; ft[j] = 0.f; }
     }
     __syncthreads();
   }
@@ -240,7 +274,7 @@ double wino6_exec_ratio(const IgemmParams& p) {               // executed / dire
   return 64.0 * (double)g.Mt / (9.0 * (double)p.M);
 }
 
-void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat) {
+void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat, const W4Gn* bwd_gn) {
   const W6Geo gi = geometry(p, p.Cin), go = geometry(p, p.N);
   const long long Mt = gi.Mt;
   const int plevel = igemm_prof_level();
@@ -264,8 +298,9 @@ void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hi
   if (prof || prof_gemm) (void)hipEventRecord(ev[2], st);
   const int TL = out_walk(go), per = go.TPB * TL, chunks = (go.TH * go.TW + per - 1) / per;
   const dim3 grid_out((unsigned)(go.B * chunks), (unsigned)((p.N / 4 + go.QC - 1) / go.QC));
-  if (stat) hipLaunchKernelGGL(w6_output_kernel<true>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat);
-  else hipLaunchKernelGGL(w6_output_kernel<false>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr);
+  if (stat && bwd_gn) hipLaunchKernelGGL(w6_output_kernel<2>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, *bwd_gn);
+  else if (stat) hipLaunchKernelGGL(w6_output_kernel<1>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, W4Gn{});
+  else hipLaunchKernelGGL(w6_output_kernel<0>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
   const double mt = (double)Mt, m = (double)p.M;
   if (prof_gemm) prof_w4_push(nullptr, ev[1], ev[2], nullptr, 2.0 * 64.0 * mt * p.Cin * p.N, 0.0, 0.0, 4.0 * 64.0 * (mt * p.Cin + mt * p.N + (double)p.N * p.Cin));
   if (prof) {

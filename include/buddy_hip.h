@@ -108,6 +108,13 @@ int buddy_gn_conv3x3_winograd4(const float* x0, const float* x1, int C0, const f
 int buddy_gn_conv3x3_winograd6(const float* x0, const float* x1, int C0, const float* gamma, const float* beta, int G, int silu, const float* U6,
                                const float* bias, float* y, float* scratch, float* stats, double* stat_scratch, double* csum, int B, int H, int W,
                                int Cin, int Cout, void* stream);
+/* The data-gradient side of the same fusion: da = conv3x3(g) (U6 = the transposed / flipped weights in the F(6x6,3x3) domain) is the gradient
+ * w.r.t. act(GroupNorm(cat[x0, x1])) (Cout channels); the output transform also leaves that GroupNorm's per-(utterance, channel) backward sums
+ * chsum[B][Cout][2] = (sum dxhat, sum dxhat * xhat), dxhat = da * act'(z) * gamma, float64 -- what buddy_groupnorm_act_bwd otherwise obtains
+ * with a reduction pass over (x, da).  stats: the forward (mean, rstd) [B][G][2]. */
+int buddy_conv3x3_winograd6_gn_bwd_sums(const float* g, const float* U6, float* da, float* scratch, const float* x0, const float* x1, int C0,
+                                        const float* stats, const float* gamma, const float* beta, int G, int silu, double* stat_scratch,
+                                        double* chsum, int B, int H, int W, int Cin, int Cout, void* stream);
 /* GroupNorm(G, C, eps=1e-6) [+SiLU] [+2x down(mode 1)/up(mode 2)] forward; replaces nn.GroupNorm + nn.SiLU +
  * naive_{up,down}sample_2d (layerspp.py:243-258). stats: [B][G][2] out; scratch: >= B*256*C*16 bytes. */
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B,

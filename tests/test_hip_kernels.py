@@ -192,6 +192,53 @@ def test_gn_conv3x3_winograd_fused(lib, B, H, W, C0, C1, Cout, silu, stat, f6):
         assert float((csum[..., 1] - q_ref).abs().max() / q_ref.max()) < 1e-6
 
 
+@pytest.mark.parametrize("B,H,W,Cin,C0,C1,silu", [(2, 32, 32, 16, 32, 0, 1), (1, 64, 32, 256, 128, 0, 1), (2, 20, 16, 128, 256, 128, 1),
+                                                  (2, 16, 33, 64, 64, 0, 0)])
+def test_conv3x3_winograd6_gn_bwd_sums(lib, B, H, W, Cin, C0, C1, silu):
+    """Data-gradient convolution (F(6x6,3x3) passes) whose output transform also leaves the GroupNorm-backward sums of the tensor it produces
+    the gradient for: (sum dxhat, sum dxhat * xhat) per (utterance, channel), dxhat = da * act'(z) * gamma, against fp64 torch evaluated
+    on the SAME da.  1e-5 relative to sum |dxhat| (fp32 products, v_exp_f32 / v_rcp_f32 in act', fp64 accumulation beyond one tile row)."""
+    from buddy_amd import _lib
+    Cout = C0 + C1
+    G = min(Cout // 4, 32)
+    gen = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin + Cout + 11)
+    gr = torch.randn(B, H, W, Cin, generator=gen).cuda()
+    x = (torch.randn(B, H, W, Cout, generator=gen) * 1.5 + 0.3).cuda()
+    gamma = (1 + 0.2 * torch.randn(Cout, generator=gen)).cuda()
+    beta = (0.2 * torch.randn(Cout, generator=gen)).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) / np.sqrt(9 * Cin))
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().numpy()
+    U = np.empty(64 * Cin * Cout, dtype=np.float32)
+    _lib.check(lib.buddy_winograd6_transform_weights(wt.ctypes.data, Cout, Cin, U.ctypes.data))
+    Ud = torch.from_numpy(U).cuda()
+    xd = x.double()
+    xg = xd.reshape(B, H * W, G, Cout // G)
+    mean = xg.mean(dim=(1, 3)); var = xg.var(dim=(1, 3), unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-6)
+    stats = torch.stack([mean, rstd], dim=-1).float().contiguous()
+    x0 = x[..., :C0].contiguous()
+    x1 = x[..., C0:].contiguous() if C1 else None
+    da = torch.empty(B, H, W, Cout, device="cuda")
+    scratch = torch.empty(64 * B * ((H + 5) // 6) * ((W + 5) // 6) * (Cin + Cout), device="cuda")
+    stat_scratch = torch.empty(B * 256 * 1024 * 2, dtype=torch.float64, device="cuda")
+    chsum = torch.zeros(B, Cout, 2, dtype=torch.float64, device="cuda")
+    _lib.check(lib.buddy_conv3x3_winograd6_gn_bwd_sums(P(gr), P(Ud), P(da), P(scratch), P(x0), P(x1) if C1 else None, C0, P(stats), P(gamma), P(beta),
+                                                       G, silu, stat_scratch.data_ptr(), chsum.data_ptr(), B, H, W, Cin, Cout, S()))
+    torch.cuda.synchronize()
+    ref = F.conv2d(gr.permute(0, 3, 1, 2).double(), w.cuda().double(), None, padding=1).permute(0, 2, 3, 1)
+    assert rel(da, ref.float()) < 1e-4
+    mean_c = stats[..., 0].double().repeat_interleave(Cout // G, dim=1)[:, None, None, :]
+    rstd_c = stats[..., 1].double().repeat_interleave(Cout // G, dim=1)[:, None, None, :]
+    xh = (xd - mean_c) * rstd_c
+    z = xh * gamma.double() + beta.double()
+    sg = torch.sigmoid(z)
+    dact = sg * (1 + z * (1 - sg)) if silu else torch.ones_like(z)
+    dxh = da.double() * dact * gamma.double()
+    s_ref, t_ref = dxh.sum(dim=(1, 2)), (dxh * xh).sum(dim=(1, 2))
+    assert float((chsum[..., 0] - s_ref).abs().max() / dxh.abs().sum(dim=(1, 2)).max()) < 1e-5
+    assert float((chsum[..., 1] - t_ref).abs().max() / (dxh * xh).abs().sum(dim=(1, 2)).max()) < 1e-5
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("C,silu", [(32, 1), (96, 1), (128, 0), (384, 1), (512, 1)])
 def test_groupnorm_act_fwd_bwd(lib, mode, C, silu):
