@@ -238,6 +238,26 @@ int buddy_conv3x3_winograd6_gn_bwd_sums(const float* g, const float* U6, float* 
   return finish();
 }
 
+int buddy_gnbwd_conv3x3_winograd6(const float* x, const float* gamma, const float* beta, const float* stats, const float* da, int G, int silu,
+                                  const float* U6, float* y, float* scratch, double* stat_scratch, float* red, int B, int H, int W, int C, int Cout,
+                                  void* stream) {
+  if (!x || !gamma || !beta || !stats || !da || !U6 || !y || !scratch || !stat_scratch || !red || G < 1 || C % 4 || (C / G) % 4 || C > 1024) {
+    set_error("bad arguments"); return BUDDY_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.ldA0 = C; p.Cin = C; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = y; p.ldC = Cout;
+  p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
+  if (!wino6_supported(p)) { set_error("shape not supported by the F(6x6,3x3) path (H, W >= 6; channels multiples of 4)"); return BUDDY_ERR_ARG; }
+  W4Gn gn;
+  gn.x.p0 = x; gn.x.p1 = nullptr; gn.x.C0 = C; gn.x.ld0 = C; gn.x.ld1 = 0;
+  gn.stats = stats; gn.gamma = gamma; gn.beta = beta; gn.G = G; gn.silu = silu; gn.da = da; gn.ldda = C; gn.red = red;
+  launch_gn_bwd_sums(gn.x, stats, gamma, beta, da, B, H, W, C, G, 0, silu, stat_scratch, red, st);
+  long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf);
+  launch_wino6(p, U6, scratch, scratch + vf, st, &gn);
+  return finish();
+}
+
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B, int H, int W, int C,
                         int G, int mode, int silu, void* stream) {
   if (!x || !y || !stats || !scratch || C % 4 || (C / G) % 4 || C > 1024) { set_error("bad groupnorm arguments"); return BUDDY_ERR_ARG; }

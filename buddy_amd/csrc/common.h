@@ -43,7 +43,10 @@ struct Dst2 { float* p0; float* p1; int C0; int ld0; int ld1; int acc0; int acc1
 // Fusions with the GroupNorms either side of the convolution (both optional):
 //   gn   -- the input is act(GroupNorm(gn->x)) of a same-resolution (concatenated) view, applied inside the input transform (p.A0 unused)
 //   stat -- the output transform also writes per-(utterance, channel) partial (sum, sum of squares), wino4_stat_chunks(p) per utterance
-struct W4Gn { Src2 x; const float* stats; const float* gamma; const float* beta; int G; int silu; };
+// with da != nullptr the input is instead the GroupNorm BACKWARD, d/dx of act(GroupNorm(x)) applied to the incoming gradient da (same layout as
+// x's channels, row stride ldda) with the two per-group backward means `red` -- F(6x6,3x3) input transform only
+struct W4Gn { Src2 x; const float* stats; const float* gamma; const float* beta; int G; int silu;
+              const float* da = nullptr; int ldda = 0; const float* red = nullptr; };
 bool wino4_supported(const IgemmParams& p);
 void wino4_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats);
 int wino4_stat_chunks(const IgemmParams& p);
@@ -96,6 +99,10 @@ void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float
                      int mode, int silu, float* out, float* pooled_raw, hipStream_t st);
 // backward wrt x. da: gradient of the (resampled) activated output. extra: additional gradient added to dx
 // (extra_mode 0 none, 1 same index, 2 quarter of a pooled-resolution tensor), scaled by extra_scale.
+void launch_gn_bwd_sums(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G,
+                        int mode, int silu, double* partial, float* red /*[B][G][2]*/, hipStream_t st, const double* chsum = nullptr);
+void launch_gn_bwd_apply(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G,
+                         int mode, int silu, const float* extra, int extra_mode, float extra_scale, const float* red, Dst2 dx, hipStream_t st);
 // chsum != nullptr: the per-(utterance, channel) backward sums [B][C][2] are already there (left by the producing convolution's epilogue):
 // no reduction pass
 void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C,

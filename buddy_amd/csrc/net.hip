@@ -432,7 +432,13 @@ static bool conv3(Net* N, const float* a, int B, int H, int W, int Cin, const fl
   static const bool fuse_gn = !(getenv("BUDDY_GN_FUSE") && atoi(getenv("BUDDY_GN_FUSE")) == 0);
   const bool w6 = use_wino6 && U6 != nullptr && N->w4_scratch != nullptr && wino6_supported(p) && wino6_pays(p);
   const bool w4 = !w6 && use_wino4 && U4 != nullptr && N->w4_scratch != nullptr && wino4_supported(p);
-  if (gn != nullptr && !((w4 || w6) && fuse_gn)) {
+  static const bool fuse_bwd_in = !(getenv("BUDDY_GN_FUSE_BWDIN") && atoi(getenv("BUDDY_GN_FUSE_BWDIN")) == 0);
+  if (gn != nullptr && gn->da != nullptr && !(w6 && fuse_gn && fuse_bwd_in)) {       // GroupNorm backward as the input: only F(6x6,3x3) fuses it
+    Dst2 d; d.p0 = gn_tmp; d.p1 = nullptr; d.C0 = Cin; d.ld0 = Cin; d.ld1 = 0; d.acc0 = 0; d.acc1 = 0;
+    launch_gn_bwd_apply(gn->x, gn->stats, gn->gamma, gn->beta, gn->da, B, H, W, Cin, gn->G, 0, gn->silu, nullptr, 0, 0.f, gn->red, d, N->st);
+    p.A0 = gn_tmp; gn = nullptr;
+  }
+  if (gn != nullptr && gn->da == nullptr && !((w4 || w6) && fuse_gn)) {
     launch_gn_apply(gn->x, gn->stats, gn->gamma, gn->beta, B, H, W, Cin, gn->G, 0, gn->silu, gn_tmp, nullptr, N->st);
     p.A0 = gn_tmp; gn = nullptr;
   }
@@ -571,12 +577,15 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       const W4Gn b1{single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, G1, 1}, b0{src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, G0, 1};
       const bool s1 = conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub, Rp->c1.ub4,
                             nullptr, nullptr, nullptr, Rp->c1.ub6, &b1, bsum);
-      Dst2 d1; d1.p0 = dh1; d1.p1 = nullptr; d1.C0 = Cout; d1.ld0 = Cout; d1.ld1 = 0; d1.acc0 = 0; d1.acc1 = 0;
+      // GroupNorm_1 backward: its two per-group means here, its apply pass inside the input transform of the Conv_0 data-gradient (dh1 is
+      // only that convolution's fallback buffer)
       if (!n->dry())
-        launch_gn_bwd(single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, da1, B, Ho, Wo, Cout, G1, 0, 1, nullptr, 0, 0.f, n->partial,
-                      n->red, d1, s, s1 ? bsum : nullptr);
+        launch_gn_bwd_sums(single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, da1, B, Ho, Wo, Cout, G1, 0, 1, n->partial, n->red, s,
+                           s1 ? bsum : nullptr);
+      W4Gn gb1{single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, G1, 1};
+      gb1.da = da1; gb1.ldda = Cout; gb1.red = n->red;
       const bool s0 = conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub, Rp->c0.ub4,
-                            nullptr, nullptr, nullptr, Rp->c0.ub6, mode == 0 ? &b0 : nullptr, bsum);
+                            &gb1, dh1, nullptr, Rp->c0.ub6, mode == 0 ? &b0 : nullptr, bsum);
       Dst2 d0 = gdst_of(x);
       if (firm) {
         float* da0f = n->tmp((long long)B * H * W * Cin);

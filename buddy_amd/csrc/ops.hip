@@ -861,32 +861,42 @@ void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float
   prof_hbm_end(st);
 }
 
-void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G, int mode,
-                   int silu, const float* extra, int extra_mode, float extra_scale, double* partial, float* red, Dst2 dx, hipStream_t st,
-                   const double* chsum) {
+// GroupNorm backward in two callable halves: the two per-group means of the backward (`red`), and the apply pass that needs them
+void launch_gn_bwd_sums(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G, int mode,
+                        int silu, double* partial, float* red, hipStream_t st, const double* chsum) {
+  if (chsum) {                                               // the per-channel sums came with da (data-gradient epilogue): no pass over (x, da)
+    hipLaunchKernelGGL(group_finalize_csum_kernel<1>, dim3(G, B), dim3(64), 0, st, chsum, (const double*)nullptr, C, C, G, H * W, 0.f, red);
+    return;
+  }
   RedArgs a = make_red(x, B, H, W, C, G, partial);
   a.stats = stats; a.gamma = gamma; a.beta = beta; a.da = da; a.mode = mode; a.silu = silu;
-  {
-    const double n_in = (double)B * H * W * C, n_da = mode == 1 ? n_in / 4 : (mode == 2 ? n_in * 4 : n_in);
-    // sums pass reads x and da (unless the sums came with da), apply pass reads them again and writes dx (+ reads the extra gradient)
-    prof_hbm_begin(4.0 * ((chsum ? 1.0 : 2.0) * (n_in + n_da) + n_in + (extra_mode ? (extra_mode == 2 ? n_in / 4 : n_in) : 0.0)), st);
-  }
-  if (chsum) {
-    hipLaunchKernelGGL(group_finalize_csum_kernel<1>, dim3(G, B), dim3(64), 0, st, chsum, (const double*)nullptr, C, C, G, H * W, 0.f, red);
-  } else {
-    hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(a.chunks, B), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(group_finalize_kernel<1>, dim3(G, B), dim3(64), 0, st, (const double*)partial, red, C, G, a.chunks, H * W, 0.f);
-  }
+  const double n_in = (double)B * H * W * C, n_da = mode == 1 ? n_in / 4 : (mode == 2 ? n_in * 4 : n_in);
+  prof_hbm_begin(4.0 * (n_in + n_da), st);                   // reads x and da
+  hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(a.chunks, B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(group_finalize_kernel<1>, dim3(G, B), dim3(64), 0, st, (const double*)partial, red, C, G, a.chunks, H * W, 0.f);
+  prof_hbm_end(st);
+}
+void launch_gn_bwd_apply(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G, int mode,
+                         int silu, const float* extra, int extra_mode, float extra_scale, const float* red, Dst2 dx, hipStream_t st) {
+  const double n_in = (double)B * H * W * C, n_da = mode == 1 ? n_in / 4 : (mode == 2 ? n_in * 4 : n_in);
+  // reads x and da again, writes dx (+ reads the extra gradient)
+  prof_hbm_begin(4.0 * (n_in + n_da + n_in + (extra_mode ? (extra_mode == 2 ? n_in / 4 : n_in) : 0.0)), st);
   const long long total = (long long)B * H * W * (C / 4);
   static const bool fast = !(getenv("BUDDY_GN_FAST") && atoi(getenv("BUDDY_GN_FAST")) == 0);
   if (fast && mode == 0 && extra_mode != 2 && C % 4 == 0 && C / 4 <= 256) {
     GnFast g = gn_fast(H * W, C, G);
     hipLaunchKernelGGL(gn_bwd_apply_m0_kernel, dim3((H * W + g.ppc - 1) / g.ppc, B), dim3(g.q * g.pl), 0, st, x, stats, gamma, beta, da, g, silu,
-                       extra_mode == 1 ? extra : nullptr, extra_scale, (const float*)red, dx);
+                       extra_mode == 1 ? extra : nullptr, extra_scale, red, dx);
   } else
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, da, B, H, W, C, G, mode, silu, extra,
-                     extra_mode, extra_scale, (const float*)red, dx);
+                     extra_mode, extra_scale, red, dx);
   prof_hbm_end(st);
+}
+void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G, int mode,
+                   int silu, const float* extra, int extra_mode, float extra_scale, double* partial, float* red, Dst2 dx, hipStream_t st,
+                   const double* chsum) {
+  launch_gn_bwd_sums(x, stats, gamma, beta, da, B, H, W, C, G, mode, silu, partial, red, st, chsum);
+  launch_gn_bwd_apply(x, stats, gamma, beta, da, B, H, W, C, G, mode, silu, extra, extra_mode, extra_scale, red, dx, st);
 }
 
 void launch_axpy(float* dst, const float* src, float alpha, long long n, int accumulate, hipStream_t st) {

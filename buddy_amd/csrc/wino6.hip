@@ -58,8 +58,10 @@ __device__ __forceinline__ void at8(const float4 (&m)[8], float4 (&y)[6]) {
 struct W6Geo { int B, H, W, TH, TW, QC, TPB; long long Mt; };   // TH x TW tiles per utterance, Mt = B * TH * TW
 
 // grid (ceil(Mt / TPB), ceil(q / QC)); V[(pos * Mt + tile) * Cin + c]
-// GN: the input is act(GroupNorm(x)) of a (channel-concatenated) view, applied while loading (zero padding applies to the ACTIVATED tensor)
-template <bool GN>
+// GN 1: the input is act(GroupNorm(x)) of a (channel-concatenated) view, applied while loading (zero padding applies to the ACTIVATED tensor)
+// GN 2: the input is the GroupNorm backward of the gradient gn.da: rstd * (dxhat - m1 - xhat * m2), dxhat = da * act'(z) * gamma (the tensor the
+//       separate apply pass would write and this transform read back)
+template <int GN>
 __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__ x, int ldX, const W4Gn gn, float* __restrict__ V, int Cin,
                                                        const W6Geo geo) {
   __shared__ float4 lds[32 * 64];
@@ -72,11 +74,13 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
   int b = 0, ty = 0, tx = 0;
   if (live) { tx = (int)(tile % geo.TW); ty = (int)((tile / geo.TW) % geo.TH); b = (int)(tile / ((long long)geo.TW * geo.TH)); }
   if (live) {
-    float mean = 0.f, rstd = 0.f;
+    float mean = 0.f, rstd = 0.f, m1 = 0.f, m2 = 0.f;
     float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), bt = gm;
+    const float* da = nullptr;
     if (GN) {
       const int g = c / (Cin / gn.G);
       mean = gn.stats[((long long)b * gn.G + g) * 2]; rstd = gn.stats[((long long)b * gn.G + g) * 2 + 1];
+      if (GN == 2) { m1 = gn.red[((long long)b * gn.G + g) * 2]; m2 = gn.red[((long long)b * gn.G + g) * 2 + 1]; da = gn.da + c; }
       gm = ld4(gn.gamma + c); bt = ld4(gn.beta + c);
       const bool second = gn.x.p1 != nullptr && c >= gn.x.C0;
       x = second ? gn.x.p1 + (c - gn.x.C0) : gn.x.p0 + c;
@@ -90,11 +94,25 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
     for (int r = 0; r < 8; ++r) {
       const int gy = gy0 + r;
       if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-        float4 v = ld4(x + (((long long)b * H + gy) * W + gx) * ldX);
-        if (GN) {
+        const long long pix = ((long long)b * H + gy) * W + gx;
+        float4 v = ld4(x + pix * ldX);
+        if (GN == 1) {
           v = make_float4((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y, (v.z - mean) * rstd * gm.z + bt.z,
                           (v.w - mean) * rstd * gm.w + bt.w);
           if (gn.silu) v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+        }
+        if (GN == 2) {
+          const float4 g4 = ld4(da + pix * gn.ldda);
+          const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {g4.x, g4.y, g4.z, g4.w};
+          const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xh = (xv[j] - mean) * rstd;
+            const float dxh = dv[j] * (gn.silu ? dsilu_f(xh * gv[j] + bv[j]) : 1.f) * gv[j];
+            o[j] = rstd * (dxh - m1 - xh * m2);
+          }
+          v = make_float4(o[0], o[1], o[2], o[3]);
         }
         d[r] = v;
       } else {
@@ -283,8 +301,9 @@ void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hi
   if (prof) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], st); }
   if (prof_gemm) { (void)hipEventCreate(&ev[1]); (void)hipEventCreate(&ev[2]); }
   const dim3 grid_in((unsigned)((Mt + gi.TPB - 1) / gi.TPB), (unsigned)((p.Cin / 4 + gi.QC - 1) / gi.QC));
-  if (gn) hipLaunchKernelGGL(w6_input_kernel<true>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
-  else hipLaunchKernelGGL(w6_input_kernel<false>, grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, p.Cin, gi);
+  if (gn && gn->da) hipLaunchKernelGGL(w6_input_kernel<2>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
+  else if (gn) hipLaunchKernelGGL(w6_input_kernel<1>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
+  else hipLaunchKernelGGL(w6_input_kernel<0>, grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, p.Cin, gi);
   if (prof || prof_gemm) (void)hipEventRecord(ev[1], st);
   IgemmParams g; std::memset(&g, 0, sizeof(g));
   g.A0 = V; g.ldA0 = p.Cin; g.sA = Mt * p.Cin; g.Cin = p.Cin;

@@ -115,6 +115,12 @@ int buddy_gn_conv3x3_winograd6(const float* x0, const float* x1, int C0, const f
 int buddy_conv3x3_winograd6_gn_bwd_sums(const float* g, const float* U6, float* da, float* scratch, const float* x0, const float* x1, int C0,
                                         const float* stats, const float* gamma, const float* beta, int G, int silu, double* stat_scratch,
                                         double* chsum, int B, int H, int W, int Cin, int Cout, void* stream);
+/* ... and the input side of the backward: y = conv3x3(dx), dx = the input-gradient of act(GroupNorm(x)) for the incoming gradient da, with the
+ * GroupNorm backward's apply pass evaluated inside the F(6x6,3x3) input transform (dx never reaches HBM).  stats: forward (mean, rstd) [B][G][2];
+ * red: [B][G][2] out (the two per-group backward means); stat_scratch: >= B*256*C*16 bytes. */
+int buddy_gnbwd_conv3x3_winograd6(const float* x, const float* gamma, const float* beta, const float* stats, const float* da, int G, int silu,
+                                  const float* U6, float* y, float* scratch, double* stat_scratch, float* red, int B, int H, int W, int C, int Cout,
+                                  void* stream);
 /* GroupNorm(G, C, eps=1e-6) [+SiLU] [+2x down(mode 1)/up(mode 2)] forward; replaces nn.GroupNorm + nn.SiLU +
  * naive_{up,down}sample_2d (layerspp.py:243-258). stats: [B][G][2] out; scratch: >= B*256*C*16 bytes. */
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B,

@@ -239,6 +239,44 @@ def test_conv3x3_winograd6_gn_bwd_sums(lib, B, H, W, Cin, C0, C1, silu):
     assert float((chsum[..., 1] - t_ref).abs().max() / (dxh * xh).abs().sum(dim=(1, 2)).max()) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,C,Cout,silu", [(2, 32, 32, 32, 16, 1), (1, 64, 32, 128, 256, 1), (2, 20, 16, 256, 128, 1), (2, 16, 33, 64, 64, 0)])
+def test_gnbwd_conv3x3_winograd6(lib, B, H, W, C, Cout, silu):
+    """conv3x3(dx) with dx = the input-gradient of act(GroupNorm(x)) for an incoming gradient da, the GroupNorm backward's apply pass
+    evaluated inside the F(6x6,3x3) input transform, against fp64 autograd.  2e-4 of the abs-max (the backward of a normalisation subtracts
+    the two group means from dxhat: cancellation on top of the convolution's 1e-4)."""
+    from buddy_amd import _lib
+    G = min(C // 4, 32)
+    gen = torch.Generator(device="cpu").manual_seed(B * 1000 + C + Cout + 13)
+    x = (torch.randn(B, C, H, W, generator=gen) * 1.5 + 0.3).cuda()
+    da = torch.randn(B, C, H, W, generator=gen).cuda()
+    gamma = (1 + 0.2 * torch.randn(C, generator=gen)).cuda()
+    beta = (0.2 * torch.randn(C, generator=gen)).cuda()
+    w = (torch.randn(Cout, C, 3, 3, generator=gen) / np.sqrt(9 * C))
+    xd = x.double().requires_grad_(True)
+    z = F.group_norm(xd, G, gamma.double(), beta.double(), eps=1e-6)
+    a = F.silu(z) if silu else z
+    dx, = torch.autograd.grad(a, xd, da.double())
+    ref = F.conv2d(dx, w.cuda().double(), None, padding=1)
+    xg = x.double().reshape(B, G, C // G, H * W)
+    mean = xg.mean(dim=(2, 3)); rstd = 1.0 / torch.sqrt(xg.var(dim=(2, 3), unbiased=False) + 1e-6)
+    stats = torch.stack([mean, rstd], dim=-1).float().contiguous()
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * C).contiguous().numpy()
+    U = np.empty(64 * C * Cout, dtype=np.float32)
+    _lib.check(lib.buddy_winograd6_transform_weights(wt.ctypes.data, Cout, C, U.ctypes.data))
+    Ud = torch.from_numpy(U).cuda()
+    xn, dn = x.permute(0, 2, 3, 1).contiguous(), da.permute(0, 2, 3, 1).contiguous()
+    y = torch.empty(B, H, W, Cout, device="cuda")
+    scratch = torch.empty(64 * B * ((H + 5) // 6) * ((W + 5) // 6) * (C + Cout), device="cuda")
+    stat_scratch = torch.empty(B * 256 * C * 2, dtype=torch.float64, device="cuda")
+    red = torch.empty(B, G, 2, device="cuda")
+    _lib.check(lib.buddy_gnbwd_conv3x3_winograd6(P(xn), P(gamma), P(beta), P(stats), P(dn), G, silu, P(Ud), P(y), P(scratch), stat_scratch.data_ptr(), P(red),
+                                                 B, H, W, C, Cout, S()))
+    torch.cuda.synchronize()
+    e = rel(y.permute(0, 3, 1, 2), ref.float())
+    print(f"gn-bwd + F(6x6,3x3) {B}x{H}x{W} {C}->{Cout}: {e:.2e}")
+    assert e < 2e-4
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("C,silu", [(32, 1), (96, 1), (128, 0), (384, 1), (512, 1)])
 def test_groupnorm_act_fwd_bwd(lib, mode, C, silu):
