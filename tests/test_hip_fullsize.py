@@ -76,7 +76,9 @@ def test_fullsize_adjoint_identity_and_linearity(net):
         return torch.autograd.grad(y, xg, w)[0]
 
     g1, g2, g12 = vjp(w1), vjp(w2), vjp(0.5 * w1 + w2)
-    assert rel(g12, 0.5 * g1 + g2) < 1e-5                         # linear in the cotangent
+    # linear in the cotangent: three separate VJP evaluations, each with the ~4e-6 round-off of the network backward (F(6x6,3x3) convolutions;
+    # vs the oracle 3.8e-6) -- measured 1.0e-5 ... 1.1e-5, a missing or non-linear term would show at 1e-2
+    assert rel(g12, 0.5 * g1 + g2) < 3e-5
     eps = 1e-2
     with torch.no_grad():
         jv = (net(x + eps * v, cn).double() - net(x - eps * v, cn).double()) / (2 * eps)
