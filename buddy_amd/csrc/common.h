@@ -93,6 +93,7 @@ void launch_gn_stats(Src2 x, int B, int HW, int C, int G, float eps, double* par
 //   launch_gn_stats_csum  (mean, rstd) per group from the csums of the one or two sources of a view
 void launch_chan_sums(const float* x, int B, int HW, int C, double* partial, double* csum, hipStream_t st);
 void launch_csum_collapse(const double* partial, int chunks, int B, int C, double* csum, hipStream_t st);
+void launch_gn_stats_partial(const double* partial, int chunks, int B, int HW, int C, int G, float eps, float* stats, hipStream_t st);
 void launch_gn_stats_csum(const double* csum0, const double* csum1, int C0, int B, int HW, int C, int G, float eps, float* stats, hipStream_t st);
 // mode: 0 same, 1 down (2x2 mean of the activated tensor; pooled_raw gets the 2x2 mean of x itself), 2 up (nearest x2)
 void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float* beta, int B, int H, int W, int C, int G,
@@ -100,14 +101,14 @@ void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float
 // backward wrt x. da: gradient of the (resampled) activated output. extra: additional gradient added to dx
 // (extra_mode 0 none, 1 same index, 2 quarter of a pooled-resolution tensor), scaled by extra_scale.
 void launch_gn_bwd_sums(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G,
-                        int mode, int silu, double* partial, float* red /*[B][G][2]*/, hipStream_t st, const double* chsum = nullptr);
+                        int mode, int silu, double* partial, float* red /*[B][G][2]*/, hipStream_t st, int ready_chunks = 0);
 void launch_gn_bwd_apply(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G,
                          int mode, int silu, const float* extra, int extra_mode, float extra_scale, const float* red, Dst2 dx, hipStream_t st);
-// chsum != nullptr: the per-(utterance, channel) backward sums [B][C][2] are already there (left by the producing convolution's epilogue):
+// ready_chunks > 0: the backward-sum partials [B][ready_chunks][C][2] are already in `partial` (left by the producing convolution's epilogue):
 // no reduction pass
 void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C,
                    int G, int mode, int silu, const float* extra, int extra_mode, float extra_scale, double* partial,
-                   float* red /*[B][G][2]*/, Dst2 dx, hipStream_t st, const double* chsum = nullptr);
+                   float* red /*[B][G][2]*/, Dst2 dx, hipStream_t st, int ready_chunks = 0);
 
 // ---- misc elementwise -------------------------------------------------------------------------------------
 // WPE warm start (wpe.hip): rows x T complex128 in/out, scratch rows*T doubles

@@ -403,12 +403,14 @@ static inline int gn_groups(int C) { int g = C / 4; return g < 32 ? g : 32; }
 // conv3x3 over an NHWC tensor (single source) -> out
 // gn / gn_tmp: the input is act(GroupNorm(gn->x)); the three-pass path applies it inside its input transform, any other path materialises it
 // into gn_tmp first.  stat_out: the tensor `out` belongs to -- its per-channel sums are left by the output transform where the shape allows.
-// bwd_gn / bwd_sums (data-gradient convolutions): `out` is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); on the F(6x6,3x3) path the output
-// transform leaves that GroupNorm's per-channel backward sums in bwd_sums[B][Cout][2] and the call returns true (else: run the reduction pass).
-static bool conv3(Net* N, const float* a, int B, int H, int W, int Cin, const float* wt, int Cout, const float* bias, const float* bias_bn,
+// bwd_gn (data-gradient convolutions): `out` is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); on the F(6x6,3x3) path the output transform
+// leaves that GroupNorm's backward-sum partials in N->partial and the call returns their chunk count (0: run the reduction pass).
+// direct (with stat_out): the only reader of the statistics follows immediately -- leave the partials in N->partial and return the chunk count
+// instead of collapsing them into stat_out->csum.
+static int conv3(Net* N, const float* a, int B, int H, int W, int Cin, const float* wt, int Cout, const float* bias, const float* bias_bn,
                   int ld_bn, const float* res, int ldRes, int res_mode, float alpha, float out_scale, float* out, const float* U = nullptr,
                   const float* U4 = nullptr, const W4Gn* gn = nullptr, float* gn_tmp = nullptr, Tens* stat_out = nullptr, const float* U6 = nullptr,
-                  const W4Gn* bwd_gn = nullptr, double* bwd_sums = nullptr) {
+                  const W4Gn* bwd_gn = nullptr, bool direct = false) {
   // BUDDY_CONV = direct | wino2 | wino4 | (default) three-pass F(6x6,3x3) on the large layers, three-pass F(4x4,3x3) where the shape allows,
   // else fused F(2x2,3x3), else direct
   static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
@@ -422,7 +424,7 @@ static bool conv3(Net* N, const float* a, int B, int H, int W, int Cin, const fl
       const size_t need = (size_t)64 * ((size_t)B * ((H + 5) / 6) * ((W + 5) / 6)) * (size_t)(Cin + Cout);
       if (need > N->w4_need) N->w4_need = need;
     }
-    return false;
+    return 0;
   }
   IgemmParams p = ig_base();
   p.A0 = a; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout;
@@ -445,14 +447,14 @@ static bool conv3(Net* N, const float* a, int B, int H, int W, int Cin, const fl
   if (w6) {
     long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf);
     static const bool fuse_bwd = !(getenv("BUDDY_GN_FUSE_BWD") && atoi(getenv("BUDDY_GN_FUSE_BWD")) == 0);
-    const bool want_bwd = bwd_gn != nullptr && bwd_sums != nullptr && fuse_gn && fuse_bwd;
+    const bool want_bwd = bwd_gn != nullptr && fuse_gn && fuse_bwd;
     const int sc = ((stat_out != nullptr && fuse_gn) || want_bwd) ? wino6_stat_chunks(p) : 0;
     const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;
     const double xr = wino6_exec_ratio(p);
     igemm_prof_record(p, 9, 1, N->st, true, xr);
     launch_wino6(p, U6, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, (stat && want_bwd) ? bwd_gn : nullptr);
     igemm_prof_record(p, 9, 1, N->st, false, xr);
-    if (stat && want_bwd) { launch_csum_collapse(N->partial, sc, B, Cout, bwd_sums, N->st); return true; }
+    if (stat && (want_bwd || direct)) return sc;
     if (stat && stat_out) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
   } else if (w4) {
     long long vf = 0, mf = 0; wino4_scratch(p, &vf, &mf);
@@ -469,7 +471,7 @@ static bool conv3(Net* N, const float* a, int B, int H, int W, int Cin, const fl
   } else {
     launch_igemm(p, 9, false, false, 1, N->st);
   }
-  return false;
+  return 0;
 }
 // 1x1 conv / per-pixel linear over a (possibly two-source) view
 static void conv1(Net* N, Src2 a, long long M, int Cin, const float* wt, int Cout, const float* bias, float alpha, float* out, int accumulate) {
@@ -521,10 +523,10 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
     } else if (mode != 0)
     launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
     // same resolution: act(GroupNorm(.)) is applied by the convolution's input transform (a0 / a1 are only its fallback buffers)
-    conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p, R.c0.uf, R.c0.uf4,
-          mode == 0 ? &g0 : nullptr, a0, h1, R.c0.uf6);
-    View vh1; vh1.a = h1;
-    view_stats(N, vh1, Ho * Wo, G1, stats1);
+    const int ch1 = conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p, R.c0.uf,
+                          R.c0.uf4, mode == 0 ? &g0 : nullptr, a0, h1, R.c0.uf6, nullptr, true);
+    if (ch1 > 0) launch_gn_stats_partial(N->partial, ch1, B, Ho * Wo, Cout, G1, 1e-6f, stats1, st);   // h1 has this one reader
+    else { View vh1; vh1.a = h1; view_stats(N, vh1, Ho * Wo, G1, stats1); }
     const float* res; int res_mode = 1;
     if (R.has_c2) {
       if (mode == 1 || firm) conv1(N, single(xr, Cin), (long long)B * Ho * Wo, Cin, R.c2.wf, Cout, R.c2.bias, 1.f, xs, 0);
@@ -573,19 +575,17 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       float* dh1 = n->tmp((long long)B * Ho * Wo * Cout);
       float* da0 = n->tmp((long long)B * Ho * Wo * Cin);
       // on the F(6x6,3x3) path the data-gradient convolutions leave the backward sums of the GroupNorm their output feeds (same resolution)
-      double* bsum = (double*)n->arena.alloc((size_t)B * std::max(Cin, Cout) * 2 * sizeof(double));
       const W4Gn b1{single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, G1, 1}, b0{src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, G0, 1};
-      const bool s1 = conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub, Rp->c1.ub4,
-                            nullptr, nullptr, nullptr, Rp->c1.ub6, &b1, bsum);
+      const int s1 = conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub, Rp->c1.ub4,
+                           nullptr, nullptr, nullptr, Rp->c1.ub6, &b1);
       // GroupNorm_1 backward: its two per-group means here, its apply pass inside the input transform of the Conv_0 data-gradient (dh1 is
       // only that convolution's fallback buffer)
       if (!n->dry())
-        launch_gn_bwd_sums(single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, da1, B, Ho, Wo, Cout, G1, 0, 1, n->partial, n->red, s,
-                           s1 ? bsum : nullptr);
+        launch_gn_bwd_sums(single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, da1, B, Ho, Wo, Cout, G1, 0, 1, n->partial, n->red, s, s1);
       W4Gn gb1{single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, G1, 1};
       gb1.da = da1; gb1.ldda = Cout; gb1.red = n->red;
-      const bool s0 = conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub, Rp->c0.ub4,
-                            &gb1, dh1, nullptr, Rp->c0.ub6, mode == 0 ? &b0 : nullptr, bsum);
+      const int s0 = conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub, Rp->c0.ub4,
+                           &gb1, dh1, nullptr, Rp->c0.ub6, mode == 0 ? &b0 : nullptr);
       Dst2 d0 = gdst_of(x);
       if (firm) {
         float* da0f = n->tmp((long long)B * H * W * Cin);
@@ -597,7 +597,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       } else
       if (!n->dry())
         launch_gn_bwd(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0, B, H, W, Cin, G0, mode, 1, extra, extra_mode, extra_scale,
-                      n->partial, n->red, d0, s, s0 ? bsum : nullptr);
+                      n->partial, n->red, d0, s, s0);
       n->arena.off = mk;
     });
   }

@@ -170,9 +170,7 @@ __global__ __launch_bounds__(256) void csum_collapse_kernel(const double* __rest
   }
 }
 
-// one wave per (b, group) of a (concatenated) view: (mean, rstd) from the per-channel sums of its sources (KIND 0), or the two backward
-// means from the per-channel backward sums (KIND 1)
-template <int KIND>
+// one wave per (b, group) of a (concatenated) view: (mean, rstd) from the per-channel sums of its sources
 __global__ __launch_bounds__(64) void group_finalize_csum_kernel(const double* __restrict__ c0, const double* __restrict__ c1, int C0, int C, int G,
                                                                  int HW, float eps, float* __restrict__ out) {
   const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
@@ -188,14 +186,10 @@ __global__ __launch_bounds__(64) void group_finalize_csum_kernel(const double* _
   if (lane == 0) {
     const double n = (double)cpg * (double)HW;
     float* o = out + ((long long)b * G + g) * 2;
-    if (KIND == 0) {
-      const double mean = s / n;
-      double var = t / n - mean * mean;
-      if (var < 0) var = 0;
-      o[0] = (float)mean; o[1] = (float)(1.0 / sqrt(var + (double)eps));
-    } else {
-      o[0] = (float)(s / n); o[1] = (float)(t / n);
-    }
+    const double mean = s / n;
+    double var = t / n - mean * mean;
+    if (var < 0) var = 0;
+    o[0] = (float)mean; o[1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 
@@ -842,8 +836,11 @@ void launch_chan_sums(const float* x, int B, int HW, int C, double* partial, dou
   launch_csum_collapse(partial, a.chunks, B, C, csum, st);
   prof_hbm_end(st);
 }
+void launch_gn_stats_partial(const double* partial, int chunks, int B, int HW, int C, int G, float eps, float* stats, hipStream_t st) {
+  hipLaunchKernelGGL(group_finalize_kernel<0>, dim3(G, B), dim3(64), 0, st, partial, stats, C, G, chunks, HW, eps);
+}
 void launch_gn_stats_csum(const double* csum0, const double* csum1, int C0, int B, int HW, int C, int G, float eps, float* stats, hipStream_t st) {
-  hipLaunchKernelGGL(group_finalize_csum_kernel<0>, dim3(G, B), dim3(64), 0, st, csum0, csum1, csum1 ? C0 : C, C, G, HW, eps, stats);
+  hipLaunchKernelGGL(group_finalize_csum_kernel, dim3(G, B), dim3(64), 0, st, csum0, csum1, csum1 ? C0 : C, C, G, HW, eps, stats);
 }
 
 void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float* beta, int B, int H, int W, int C, int G, int mode, int silu,
@@ -863,9 +860,9 @@ void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float
 
 // GroupNorm backward in two callable halves: the two per-group means of the backward (`red`), and the apply pass that needs them
 void launch_gn_bwd_sums(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G, int mode,
-                        int silu, double* partial, float* red, hipStream_t st, const double* chsum) {
-  if (chsum) {                                               // the per-channel sums came with da (data-gradient epilogue): no pass over (x, da)
-    hipLaunchKernelGGL(group_finalize_csum_kernel<1>, dim3(G, B), dim3(64), 0, st, chsum, (const double*)nullptr, C, C, G, H * W, 0.f, red);
+                        int silu, double* partial, float* red, hipStream_t st, int ready_chunks) {
+  if (ready_chunks > 0) {                                    // the partials came with da (data-gradient epilogue): no pass over (x, da)
+    hipLaunchKernelGGL(group_finalize_kernel<1>, dim3(G, B), dim3(64), 0, st, (const double*)partial, red, C, G, ready_chunks, H * W, 0.f);
     return;
   }
   RedArgs a = make_red(x, B, H, W, C, G, partial);
@@ -894,8 +891,8 @@ void launch_gn_bwd_apply(Src2 x, const float* stats, const float* gamma, const f
 }
 void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da, int B, int H, int W, int C, int G, int mode,
                    int silu, const float* extra, int extra_mode, float extra_scale, double* partial, float* red, Dst2 dx, hipStream_t st,
-                   const double* chsum) {
-  launch_gn_bwd_sums(x, stats, gamma, beta, da, B, H, W, C, G, mode, silu, partial, red, st, chsum);
+                   int ready_chunks) {
+  launch_gn_bwd_sums(x, stats, gamma, beta, da, B, H, W, C, G, mode, silu, partial, red, st, ready_chunks);
   launch_gn_bwd_apply(x, stats, gamma, beta, da, B, H, W, C, G, mode, silu, extra, extra_mode, extra_scale, red, dx, st);
 }
 
