@@ -324,8 +324,11 @@ void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hi
   if (prof_gemm) prof_w4_push(nullptr, ev[1], ev[2], nullptr, 2.0 * 64.0 * mt * p.Cin * p.N, 0.0, 0.0, 4.0 * 64.0 * (mt * p.Cin + mt * p.N + (double)p.N * p.Cin));
   if (prof) {
     (void)hipEventRecord(ev[3], st);
-    prof_w4_push(ev[0], ev[1], ev[2], ev[3], 2.0 * 64.0 * mt * p.Cin * p.N, 4.0 * (m * p.Cin + 64.0 * mt * p.Cin),
-                 4.0 * (64.0 * mt * p.N + m * p.N * (p.res_mode ? 2.0 : 1.0)), 4.0 * 64.0 * (mt * p.Cin + mt * p.N + (double)p.N * p.Cin));
+    // algorithmic bytes of the transform passes incl. what the fused GroupNorm work reads: the backward apply reads x AND da (input side), the
+    // backward-sum epilogue reads x at the output pixels
+    const double in_reads = (gn && gn->da) ? 2.0 : 1.0, out_extra = (stat && bwd_gn) ? 1.0 : 0.0;
+    prof_w4_push(ev[0], ev[1], ev[2], ev[3], 2.0 * 64.0 * mt * p.Cin * p.N, 4.0 * (in_reads * m * p.Cin + 64.0 * mt * p.Cin),
+                 4.0 * (64.0 * mt * p.N + m * p.N * ((p.res_mode ? 2.0 : 1.0) + out_extra)), 4.0 * 64.0 * (mt * p.Cin + mt * p.N + (double)p.N * p.Cin));
   }
 }
 
