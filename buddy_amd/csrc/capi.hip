@@ -113,7 +113,7 @@ int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, in
   IgemmParams p; std::memset(&p, 0, sizeof(p));
   p.A0 = A; p.ldA0 = ldA; p.Cin = K; p.M = M; p.N = N; p.Bt = Bt; p.ldB = ldB; p.C = C; p.ldC = ldC; p.sA = strideA; p.sB = strideB; p.sC = strideC;
   p.alpha = alpha; p.out_scale = 1.f; p.bias_n = bias_n; p.accumulate = accumulate; p.H = 1; p.W = 1; p.rows_per_batch = 1;
-  if (batch == 36) p.tag = 36;          // the Winograd-domain GEMM instantiation (same code, own name in profiles)
+  if (batch == 36 || batch == 64) p.tag = 36;          // the Winograd-domain GEMM instantiation (same code, own name in profiles)
   launch_igemm(p, 1, transA != 0, transB != 0, batch, (hipStream_t)stream);
   return finish();
 }
