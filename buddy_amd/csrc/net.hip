@@ -400,17 +400,32 @@ static IgemmParams ig_base() {
 }
 static inline int gn_groups(int C) { int g = C / 4; return g < 32 ? g : 32; }
 
-// conv3x3 over an NHWC tensor (single source) -> out
-// gn / gn_tmp: the input is act(GroupNorm(gn->x)); the three-pass path applies it inside its input transform, any other path materialises it
-// into gn_tmp first.  stat_out: the tensor `out` belongs to -- its per-channel sums are left by the output transform where the shape allows.
-// bwd_gn (data-gradient convolutions): `out` is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); on the F(6x6,3x3) path the output transform
-// leaves that GroupNorm's backward-sum partials in N->partial and the call returns their chunk count (0: run the reduction pass).
-// direct (with stat_out): the only reader of the statistics follows immediately -- leave the partials in N->partial and return the chunk count
-// instead of collapsing them into stat_out->csum.
-static int conv3(Net* N, const float* a, int B, int H, int W, int Cin, const float* wt, int Cout, const float* bias, const float* bias_bn,
-                  int ld_bn, const float* res, int ldRes, int res_mode, float alpha, float out_scale, float* out, const float* U = nullptr,
-                  const float* U4 = nullptr, const W4Gn* gn = nullptr, float* gn_tmp = nullptr, Tens* stat_out = nullptr, const float* U6 = nullptr,
-                  const W4Gn* bwd_gn = nullptr, bool direct = false) {
+// conv3x3 over an NHWC tensor -> out, with the optional GroupNorm fusions of the three-pass Winograd paths
+struct Conv3 {
+  const float* a = nullptr;                 // input (B, H, W, Cin); unused when gn describes the input
+  int B = 0, H = 0, W = 0, Cin = 0, Cout = 0;
+  const ConvW* w = nullptr; bool dgrad = false;   // weights; dgrad: the data-gradient operands (Cin / Cout are those of THIS convolution)
+  const float* bias = nullptr; const float* bias_bn = nullptr; int ld_bn = 0;   // per-channel bias, per-(utterance, channel) bias (time embedding)
+  const float* res = nullptr; int ldRes = 0; int res_mode = 0;                  // residual: 1 same pixel, 2 nearest-upsampled (H/2 x W/2)
+  float alpha = 1.f, out_scale = 1.f;
+  float* out = nullptr;
+  // gn / gn_tmp: the input is act(GroupNorm(gn->x)) -- or, with gn->da, that GroupNorm's BACKWARD applied to the gradient gn->da; the three-pass
+  // paths evaluate it inside their input transform (the backward form: F(6x6,3x3) only), any other path materialises it into gn_tmp first
+  const W4Gn* gn = nullptr; float* gn_tmp = nullptr;
+  // stat_out: the tensor `out` belongs to -- its per-channel sums are left by the output transform where the shape allows.  direct: the only
+  // reader of those statistics follows immediately: leave the partials in N->partial and return their chunk count instead of collapsing them
+  Tens* stat_out = nullptr; bool direct = false;
+  // bwd_gn (data-gradient convolutions): `out` is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); on the F(6x6,3x3) path the output transform
+  // leaves that GroupNorm's backward-sum partials in N->partial and the call returns their chunk count (0: run the reduction pass)
+  const W4Gn* bwd_gn = nullptr;
+};
+static int conv3(Net* N, const Conv3& c) {
+  const float* a = c.a; const int B = c.B, H = c.H, W = c.W, Cin = c.Cin, Cout = c.Cout;
+  const float* wt = c.w ? (c.dgrad ? c.w->wb : c.w->wf) : nullptr;
+  const float* U = c.w ? (c.dgrad ? c.w->ub : c.w->uf) : nullptr;
+  const float* U4 = c.w ? (c.dgrad ? c.w->ub4 : c.w->uf4) : nullptr;
+  const float* U6 = c.w ? (c.dgrad ? c.w->ub6 : c.w->uf6) : nullptr;
+  const W4Gn* gn = c.gn; float* gn_tmp = c.gn_tmp; Tens* stat_out = c.stat_out; const W4Gn* bwd_gn = c.bwd_gn; const bool direct = c.direct;
   // BUDDY_CONV = direct | wino2 | wino4 | (default) three-pass F(6x6,3x3) on the large layers, three-pass F(4x4,3x3) where the shape allows,
   // else fused F(2x2,3x3), else direct
   static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
@@ -428,9 +443,9 @@ static int conv3(Net* N, const float* a, int B, int H, int W, int Cin, const flo
   }
   IgemmParams p = ig_base();
   p.A0 = a; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout;
-  p.Bt = wt; p.ldB = 9 * Cin; p.C = out; p.ldC = Cout;
-  p.bias_n = bias; p.bias_bn = bias_bn; p.ld_bias_bn = ld_bn; p.rows_per_batch = H * W;
-  p.res = res; p.ldRes = ldRes; p.res_mode = res_mode; p.alpha = alpha; p.out_scale = out_scale;
+  p.Bt = wt; p.ldB = 9 * Cin; p.C = c.out; p.ldC = Cout;
+  p.bias_n = c.bias; p.bias_bn = c.bias_bn; p.ld_bias_bn = c.ld_bn; p.rows_per_batch = H * W;
+  p.res = c.res; p.ldRes = c.ldRes; p.res_mode = c.res_mode; p.alpha = c.alpha; p.out_scale = c.out_scale;
   static const bool fuse_gn = !(getenv("BUDDY_GN_FUSE") && atoi(getenv("BUDDY_GN_FUSE")) == 0);
   const bool w6 = use_wino6 && U6 != nullptr && N->w4_scratch != nullptr && wino6_supported(p) && wino6_pays(p);
   const bool w4 = !w6 && use_wino4 && U4 != nullptr && N->w4_scratch != nullptr && wino4_supported(p);
@@ -510,8 +525,8 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
   float* a1 = N->tmp((long long)B * Ho * Wo * Cout);
   float* a0f = firm ? N->tmp((long long)B * H * W * Cin) : nullptr;
   if (N->dry()) {                                         // sizing pass: let the convolutions note their F(4x4,3x3) scratch need
-    conv3(N, nullptr, B, Ho, Wo, Cin, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c0.uf, R.c0.uf4, nullptr, nullptr, nullptr, R.c0.uf6);
-    conv3(N, nullptr, B, Ho, Wo, Cout, nullptr, Cout, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, nullptr, R.c1.uf, R.c1.uf4, nullptr, nullptr, nullptr, R.c1.uf6);
+    Conv3 c; c.B = B; c.H = Ho; c.W = Wo; c.Cin = Cin; c.Cout = Cout; c.w = &R.c0; conv3(N, c);
+    c.Cin = Cout; c.w = &R.c1; conv3(N, c);
   }
   if (!N->dry()) {
     view_stats(N, x, H * W, G0, stats0);
@@ -523,8 +538,10 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
     } else if (mode != 0)
     launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
     // same resolution: act(GroupNorm(.)) is applied by the convolution's input transform (a0 / a1 are only its fallback buffers)
-    const int ch1 = conv3(N, a0, B, Ho, Wo, Cin, R.c0.wf, Cout, R.c0.bias, temb_all + R.dense_off, N->dense_total, nullptr, 0, 0, 1.f, 1.f, h1->p, R.c0.uf,
-                          R.c0.uf4, mode == 0 ? &g0 : nullptr, a0, h1, R.c0.uf6, nullptr, true);
+    Conv3 c0; c0.a = a0; c0.B = B; c0.H = Ho; c0.W = Wo; c0.Cin = Cin; c0.Cout = Cout; c0.w = &R.c0; c0.bias = R.c0.bias;
+    c0.bias_bn = temb_all + R.dense_off; c0.ld_bn = N->dense_total; c0.out = h1->p;
+    c0.gn = mode == 0 ? &g0 : nullptr; c0.gn_tmp = a0; c0.stat_out = h1; c0.direct = true;
+    const int ch1 = conv3(N, c0);
     if (ch1 > 0) launch_gn_stats_partial(N->partial, ch1, B, Ho * Wo, Cout, G1, 1e-6f, stats1, st);   // h1 has this one reader
     else { View vh1; vh1.a = h1; view_stats(N, vh1, Ho * Wo, G1, stats1); }
     const float* res; int res_mode = 1;
@@ -535,7 +552,10 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
     } else {
       res = x.a->p;   // identity skip: single source, same resolution, Cin == Cout
     }
-    conv3(N, a1, B, Ho, Wo, Cout, R.c1.wf, Cout, R.c1.bias, nullptr, 0, res, Cout, res_mode, 1.f, INV_SQRT2, out->p, R.c1.uf, R.c1.uf4, &g1, a1, out, R.c1.uf6);
+    Conv3 c1; c1.a = a1; c1.B = B; c1.H = Ho; c1.W = Wo; c1.Cin = Cout; c1.Cout = Cout; c1.w = &R.c1; c1.bias = R.c1.bias;
+    c1.res = res; c1.ldRes = Cout; c1.res_mode = res_mode; c1.out_scale = INV_SQRT2; c1.out = out->p;
+    c1.gn = &g1; c1.gn_tmp = a1; c1.stat_out = out;
+    conv3(N, c1);
   }
   N->arena.off = mark;
   if (rec) {
@@ -576,16 +596,18 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       float* da0 = n->tmp((long long)B * Ho * Wo * Cin);
       // on the F(6x6,3x3) path the data-gradient convolutions leave the backward sums of the GroupNorm their output feeds (same resolution)
       const W4Gn b1{single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, G1, 1}, b0{src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, G0, 1};
-      const int s1 = conv3(n, dout, B, Ho, Wo, Cout, Rp->c1.wb, Cout, nullptr, nullptr, 0, nullptr, 0, 0, INV_SQRT2, 1.f, da1, Rp->c1.ub, Rp->c1.ub4,
-                           nullptr, nullptr, nullptr, Rp->c1.ub6, &b1);
+      Conv3 d1c; d1c.a = dout; d1c.B = B; d1c.H = Ho; d1c.W = Wo; d1c.Cin = Cout; d1c.Cout = Cout; d1c.w = &Rp->c1; d1c.dgrad = true;
+      d1c.alpha = INV_SQRT2; d1c.out = da1; d1c.bwd_gn = &b1;
+      const int s1 = conv3(n, d1c);
       // GroupNorm_1 backward: its two per-group means here, its apply pass inside the input transform of the Conv_0 data-gradient (dh1 is
       // only that convolution's fallback buffer)
       if (!n->dry())
         launch_gn_bwd_sums(single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, da1, B, Ho, Wo, Cout, G1, 0, 1, n->partial, n->red, s, s1);
       W4Gn gb1{single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, G1, 1};
       gb1.da = da1; gb1.ldda = Cout; gb1.red = n->red;
-      const int s0 = conv3(n, dh1, B, Ho, Wo, Cout, Rp->c0.wb, Cin, nullptr, nullptr, 0, nullptr, 0, 0, 1.f, 1.f, da0, Rp->c0.ub, Rp->c0.ub4,
-                           &gb1, dh1, nullptr, Rp->c0.ub6, mode == 0 ? &b0 : nullptr);
+      Conv3 d0c; d0c.a = dh1; d0c.B = B; d0c.H = Ho; d0c.W = Wo; d0c.Cin = Cout; d0c.Cout = Cin; d0c.w = &Rp->c0; d0c.dgrad = true;
+      d0c.out = da0; d0c.gn = &gb1; d0c.gn_tmp = dh1; d0c.bwd_gn = mode == 0 ? &b0 : nullptr;
+      const int s0 = conv3(n, d0c);
       Dst2 d0 = gdst_of(x);
       if (firm) {
         float* da0f = n->tmp((long long)B * H * W * Cin);
