@@ -178,6 +178,16 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
     const int lt = (chunk * TL + it) * geo.TPB + tl;          // tile within the utterance
     const bool live = chan && lt < tpb;
     const long long tile = (long long)b * tpb + lt;
+    // STAT 2: this thread's row of x is requested now, together with the M loads of phase 1, not after the LDS exchange
+    float4 xpre[6];
+    if (STAT == 2 && live && col < 6) {
+      const int ty = lt / geo.TW, tx = lt - ty * geo.TW, hh = 6 * ty + col;
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        const int ww = 6 * tx + cc;
+        xpre[cc] = (hh < H && ww < W) ? ld4(xsrc + (((long long)b * H + hh) * W + ww) * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     if (live) {
       const float* src = Mb + tile * N + n;
       float4 m[8], s[6];
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
             if (p.accumulate) v = v + ld4(dst);
             st4(dst, v);
             if (STAT == 2) {
-              const float4 xv4 = ld4(xsrc + pix * ldx);
+              const float4 xv4 = xpre[cc];
               const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w}, dv[4] = {v.x, v.y, v.z, v.w};
               const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
 #pragma unroll
