@@ -7,9 +7,10 @@ reference testing/EulerHeunSamplerDPS.py:115-157) over one batch of B=8 syntheti
 BASELINE.json configs[1] ("Batch=8 4 s@16 kHz synthetic STFT, 50-step EulerHeun blind sampler, NCSN++ HIP on 1 MI355X").
 value = utterance-diffusion-steps per second over ALL ranks = n_gpus * B * K / max-over-ranks(elapsed).
 
-Launch: `python bench.py` (1 GPU) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
-(one process per GPU; utterances sharded across ranks, no collective inside the loop, ONE all_gather of the outputs
-at the end of the run, outside the timed region and reported as gather_ms).
+Launch: `python bench.py` (1 GPU), `python bench.py --gpus N` (re-executes itself as N ranks under torch.distributed.run) or
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (one process per GPU; utterances sharded across ranks,
+no collective inside the loop, ONE all_gather of the outputs at the end of the run, outside the timed region and reported as
+gather_ms; --gpus must equal WORLD_SIZE).
 
 Instrumentation: inside the timed region HIP events bracket only the dominant kernel (`roofline`), on every other step; the per-class
 attribution (`conv3x3`, `roofline_hbm`, `other_matrix_kernels`, `operator_update`) is measured in two fully instrumented steps AFTER the
@@ -288,11 +289,28 @@ def main():
         print(json.dumps(cpu_baseline(a.length, a.cpu_baseline_only, a.cpu_reps, a.cpu_utt)))
         return
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher -- one rank per GPU under torch.distributed.run (RCCL), same
+        # arguments; rank 0 of the children prints the ONE JSON line, which passes through this process's stdout.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sampler path has no CPU fallback")
+    if world > 1 and a.backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {torch.cuda.device_count()} (--backend gloo lets ranks share a GPU for smoke tests)")
     dev_index = local_rank % torch.cuda.device_count()     # == local_rank on a real node; lets 2 gloo ranks share one GPU in smoke tests
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -423,15 +441,20 @@ def main():
         del runs2, run2
 
     # end-of-run gather of the (B_local, L) outputs: the only collective on this path (RCCL over xGMI)
-    gather_ms = 0.0
+    gather_ms = gather_first_ms = 0.0
     out = torch.cat([r.x_den for r in runs]).contiguous()
     if dist is not None:
-        torch.cuda.synchronize(); tg = time.perf_counter()
-        out_c = out.to(coll_dev)
-        bufs = [torch.empty_like(out_c) for _ in range(world)]
-        dist.all_gather(bufs, out_c)
-        torch.cuda.synchronize(); gather_ms = (time.perf_counter() - tg) * 1e3
+        # twice: the first call carries the communicator's lazy set-up (ring / channel construction), the second is what a long-running
+        # harness pays per run; both are outside the timed region
+        for k in range(2):
+            torch.cuda.synchronize(); dist.barrier(); tg = time.perf_counter()
+            out_c = out.to(coll_dev)
+            bufs = [torch.empty_like(out_c) for _ in range(world)]
+            dist.all_gather(bufs, out_c)
+            torch.cuda.synchronize(); g = (time.perf_counter() - tg) * 1e3
+            gather_first_ms, gather_ms = (g, g) if k == 0 else (gather_first_ms, g)
         assert torch.isfinite(torch.stack(bufs)).all()
+        assert torch.equal(bufs[rank].to(out.device), out), "gather returned another rank's rows in this rank's slot"
     assert torch.isfinite(out).all(), "sampler diverged"
 
     if rank == 0:
@@ -469,7 +492,8 @@ def main():
                        "parallelism": f"utterance-sharded x{world}", "sub_batches_per_gpu": S, "attention": a.attention or os.environ.get("BUDDY_ATTN", "flash (fp32)")},
             "score_evals_per_s": n_utt_steps / elapsed,   # order 1: one forward+VJP evaluation per utterance-step
             "network_algorithmic_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
-            "gather_ms": gather_ms,
+            "gather_ms": gather_ms, "gather_first_call_ms": gather_first_ms, "gather_bytes_per_rank": int(out.numel() * 4),
+            "gather_backend": (a.backend if world > 1 else None),
             # dominant kernel: the 36 batched Winograd-domain GEMMs (fp32 MFMA 32x32x2) of the 3x3 convolutions
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel<1,false,false,2,2,36> -- the batched GEMMs M[pos] = V[pos] U[pos]^T of the three-pass "
                                                     "Winograd 3x3 convolutions (64 positions, F(6x6,3x3), on the large layers; 36, F(4x4,3x3), on the "

@@ -32,6 +32,8 @@ _SIGS = {
     "buddy_ncsnpp_tap": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int * 4)]),
     "buddy_prof_enable": (C.c_int, [C.c_int]),
     "buddy_wpe": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_wpe_workspace_bytes": (C.c_longlong, [C.c_int, C.c_int]),
+    "buddy_wpe_dereverb": (C.c_int, [_f32p, _f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_prof_collect_wino4": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_longlong)]),
     "buddy_prof_collect_hbm": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

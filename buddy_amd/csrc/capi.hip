@@ -339,6 +339,14 @@ int buddy_wpe(const double* Y, double* X, double* scratch, int rows, int T, int 
   return finish();
 }
 
+long long buddy_wpe_workspace_bytes(int B, int L) { return (B < 1 || L < 1) ? 0 : (long long)wpe_workspace_bytes(B, L); }
+
+int buddy_wpe_dereverb(const float* y, float* out, void* workspace, int B, int L, int taps, int delay, int iterations, void* stream) {
+  if (!y || !out || !workspace || B < 1 || L < 1 || taps < 1 || taps > 56 || delay < 0 || iterations < 0) { set_error("bad wpe arguments (taps <= 56)"); return BUDDY_ERR_ARG; }
+  launch_wpe_dereverb(y, out, workspace, B, L, taps, delay, iterations, (hipStream_t)stream);
+  return finish();
+}
+
 // ---- blind operator ----
 int buddy_blindop_create(int U, int L, int Nf, int E, int num_knots, const float* knots, int sample_rate, float comp, float min_decay,
                          float max_decay, float w_lo, float w_hi, int clamp_decay, int long_second, void** handle) {

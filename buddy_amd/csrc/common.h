@@ -113,6 +113,9 @@ void launch_gn_bwd(Src2 x, const float* stats, const float* gamma, const float* 
 // ---- misc elementwise -------------------------------------------------------------------------------------
 // WPE warm start (wpe.hip): rows x T complex128 in/out, scratch rows*T doubles
 void launch_wpe(const double* Y, double* X, double* inv_scratch, int rows, int T, int taps, int delay, int iters, hipStream_t st);
+size_t wpe_workspace_bytes(int B, int L);
+int wpe_frames(int L);
+void launch_wpe_dereverb(const float* y, float* out, void* work, int B, int L, int taps, int delay, int iters, hipStream_t st);
 void launch_axpy(float* dst, const float* src, float alpha, long long n, int accumulate, hipStream_t st);
 // fir=True resampling with the (1,3,3,1) kernel: (H,W)->(2H,2W) / (H,W)->(H/2,W/2); adjoints: up^T = 4 down, down^T = up / 4
 void launch_fir_up2(const float* x, float* y, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st);

@@ -106,6 +106,65 @@ __global__ __launch_bounds__(WPE_NT) void wpe_kernel(const c128* __restrict__ Y,
     __syncthreads();
   }
 }
+
+// ---- STFT / iSTFT of the warm start (nara_wpe.utils.stft / istft conventions: size 512, shift 128, periodic Blackman analysis window,
+// size - shift zeros of "fading" on both sides, tail zero-padded to a whole frame, bi-orthogonal synthesis window), complex128.
+// 512-point transforms as direct sums against a twiddle table in LDS: 0.13 GFLOP per 4 s utterance, once per run -- clarity over speed.
+constexpr int WS = 512, WH = 128, WF = WS / 2 + 1, WPAD = WS - WH;
+
+__device__ __forceinline__ double blackman_periodic(int n) {
+  const double a = 2.0 * M_PI * (double)n / (double)WS;
+  return 0.42 - 0.5 * cos(a) + 0.08 * cos(2.0 * a);
+}
+
+// Y[(b * WF + f) * T + t] = sum_n w[n] ypad[t * WH + n] e^{-2 pi i f n / WS};   grid (T, B), 256 threads
+__global__ __launch_bounds__(256) void wpe_stft_kernel(const float* __restrict__ y, c128* __restrict__ Y, int L, int T) {
+  __shared__ double xw[WS], tc[WS], ts[WS];
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  for (int n = tid; n < WS; n += 256) {
+    const long long p = (long long)t * WH + n - WPAD;                   // index into the un-padded signal
+    const double v = (p >= 0 && p < L) ? (double)y[(long long)b * L + p] : 0.0;
+    xw[n] = v * blackman_periodic(n);
+    double sn, cs; sincos(-2.0 * M_PI * (double)n / (double)WS, &sn, &cs);
+    tc[n] = cs; ts[n] = sn;
+  }
+  __syncthreads();
+  for (int f = tid; f < WF; f += 256) {
+    double re = 0.0, im = 0.0;
+    for (int n = 0; n < WS; ++n) { const int k = (f * n) & (WS - 1); re += xw[n] * tc[k]; im += xw[n] * ts[k]; }
+    Y[((long long)b * WF + f) * T + t] = {re, im};
+  }
+}
+
+// out[b][j] = sum over the (at most 4) frames covering padded position j + WPAD of wsyn[n] * irfft(Z[:, t])[n];  grid (ceil(L / WH), B), 512 threads:
+// thread (q, m) computes sample n = q * WH + m of frame h + ... so that all four land on output position h * WH + m
+__global__ __launch_bounds__(512) void wpe_istft_kernel(const c128* __restrict__ Z, float* __restrict__ out, int L, int T) {
+  __shared__ double tc[WS], ts[WS], acc[4][WH];
+  __shared__ c128 zf[4][WF];
+  const int hb = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int q = tid >> 7, m = tid & (WH - 1);
+  const int h = hb + WPAD / WH;                                         // hop index in the padded signal
+  for (int n = tid; n < WS; n += 512) { double sn, cs; sincos(2.0 * M_PI * (double)n / (double)WS, &sn, &cs); tc[n] = cs; ts[n] = sn; }
+  for (int e = tid; e < 4 * WF; e += 512) {
+    const int qq = e / WF, f = e - qq * WF, t = h - qq;
+    zf[qq][f] = (t >= 0 && t < T) ? Z[((long long)b * WF + f) * T + t] : c128{0.0, 0.0};
+  }
+  __syncthreads();
+  {
+    const int n = q * WH + m;                                           // frame t = h - q contributes its sample n to padded position h * WH + m
+    double s = zf[q][0].x + ((n & 1) ? -zf[q][WS / 2].x : zf[q][WS / 2].x);      // irfft ignores Im of the DC and Nyquist bins
+    for (int f = 1; f < WS / 2; ++f) { const int k = (f * n) & (WS - 1); s += 2.0 * (zf[q][f].x * tc[k] - zf[q][f].y * ts[k]); }
+    // synthesis window: analysis window / sum of its squares over the WS / WH overlapping positions
+    double den = 0.0;
+    for (int r = 0; r < WS / WH; ++r) { const double w = blackman_periodic(r * WH + m); den += w * w; }
+    acc[q][m] = s * (1.0 / WS) * blackman_periodic(n) / den;
+  }
+  __syncthreads();
+  if (tid < WH) {
+    const long long j = (long long)hb * WH + tid;
+    if (j < L) out[(long long)b * L + j] = (float)(((acc[3][tid] + acc[2][tid]) + acc[1][tid]) + acc[0][tid]);   // overlap-add in ascending frame order
+  }
+}
 }  // namespace
 
 size_t wpe_lds_bytes(int K) { return (size_t)(K * K + 2 * K) * sizeof(double) * 2 + WPE_NT * sizeof(double); }
@@ -113,6 +172,29 @@ size_t wpe_lds_bytes(int K) { return (size_t)(K * K + 2 * K) * sizeof(double) * 
 void launch_wpe(const double* Y, double* X, double* inv_scratch, int rows, int T, int taps, int delay, int iters, hipStream_t st) {
   hipLaunchKernelGGL(wpe_kernel, dim3(rows), dim3(WPE_NT), wpe_lds_bytes(taps), st, reinterpret_cast<const c128*>(Y), reinterpret_cast<c128*>(X),
                      inv_scratch, T, taps, delay, iters);
+}
+
+int wpe_frames(int L) {                                      // frames of nara_wpe.utils.stft(size 512, shift 128, fading, pad)
+  long long n = (long long)L + 2 * WPAD;
+  if (n < WS) n = WS;
+  else if ((n + WH - WS) % WH) n += WH - (n + WH - WS) % WH;
+  return (int)((n - WS) / WH + 1);
+}
+
+size_t wpe_workspace_bytes(int B, int L) {                   // Y, X (complex128) + inverse-power scratch
+  const size_t rows = (size_t)B * WF, T = (size_t)wpe_frames(L);
+  return rows * T * (2 * sizeof(c128) + sizeof(double));
+}
+
+void launch_wpe_dereverb(const float* y, float* out, void* work, int B, int L, int taps, int delay, int iters, hipStream_t st) {
+  const int T = wpe_frames(L);
+  const size_t rows = (size_t)B * WF;
+  c128* Y = reinterpret_cast<c128*>(work);
+  c128* X = Y + rows * T;
+  double* inv = reinterpret_cast<double*>(X + rows * T);
+  hipLaunchKernelGGL(wpe_stft_kernel, dim3(T, B), dim3(256), 0, st, y, Y, L, T);
+  hipLaunchKernelGGL(wpe_kernel, dim3((unsigned)rows), dim3(WPE_NT), wpe_lds_bytes(taps), st, Y, X, inv, T, taps, delay, iters);
+  hipLaunchKernelGGL(wpe_istft_kernel, dim3((L + WH - 1) / WH, B), dim3(512), 0, st, X, out, L, T);
 }
 
 }  // namespace buddy

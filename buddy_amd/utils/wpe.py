@@ -6,8 +6,10 @@
 is a restatement of its published algorithm (Nakatani et al. 2010; Drude et al. 2018, batch "full statistics" variant) and of
 its STFT conventions (periodic Blackman analysis window, "fading" zero padding of size-shift samples on both sides,
 bi-orthogonal synthesis window).  PARITY UNPINNED: there is no reference output to compare with.
-Runs once per utterance, outside the sampling loop.  On the GPU the iterations (inverse power, correlation matrix, Cholesky solve,
-prediction filter) are one hand-written kernel per (utterance, bin) row (``csrc/wpe.hip``); STFT / iSTFT stay torch FFTs in float64."""
+Runs once per utterance, outside the sampling loop.  On the GPU the whole estimate is ONE library call (``buddy_wpe_dereverb``,
+``csrc/wpe.hip``): hand-written complex128 STFT, the iterations (inverse power, correlation matrix, Cholesky solve, prediction filter;
+one workgroup per (utterance, bin) row) and the overlap-add iSTFT.  Checked on the GPU against ``oracle/wpe_ref.py`` (numpy, written
+independently).  The torch functions below are the ``backend="torch"`` form for CPU host-logic tests and never run on a CUDA tensor."""
 from __future__ import annotations
 
 import math
@@ -86,13 +88,22 @@ def wpe_hip(Y, taps=10, delay=3, iterations=3):
 
 
 def wpe_dereverb(y, taps=50, delay=2, iterations=5, size=512, shift=128):
-    """y (B, L) float -> (B, <=L) float32: stft -> per-utterance single-channel WPE -> istft (reference :36-51).
-    On a CUDA tensor the WPE iterations run in the HIP library (no torch fallback there); the torch form serves CPU tensors."""
+    """y (B, L) float -> (B, L) float32: stft -> per-utterance single-channel WPE -> istft (reference :36-51).
+    A CUDA tensor goes through the HIP library (one call, no torch ops, no fallback); the torch form serves CPU tensors."""
+    if y.is_cuda:
+        from .. import _lib
+        lib = _lib.require_gpu()
+        assert (size, shift) == (512, 128), "the HIP warm start is built for the reference's stft_options (size 512, shift 128)"
+        B, L = y.shape
+        yc = y.contiguous().float()
+        out = torch.empty_like(yc)
+        work = torch.empty(int(lib.buddy_wpe_workspace_bytes(B, L)) // 8, dtype=torch.float64, device=y.device)
+        _lib.check(lib.buddy_wpe_dereverb(_lib.ptr(yc), _lib.ptr(out), _lib.ptr(work), B, L, int(taps), int(delay), int(iterations), _lib.stream_ptr()))
+        return out
     out = []
     for b in range(y.shape[0]):
         Y = stft(y[b:b + 1], size, shift)                   # (1, T, F)
-        solver = wpe_hip if y.is_cuda else wpe
-        Z = solver(Y.permute(2, 0, 1).contiguous(), taps=taps, delay=delay, iterations=iterations).permute(1, 2, 0)
+        Z = wpe(Y.permute(2, 0, 1).contiguous(), taps=taps, delay=delay, iterations=iterations).permute(1, 2, 0)
         out.append(istft(Z, size, shift))
     x = torch.cat(out, dim=0).to(torch.float32)
     return x[..., :y.shape[-1]]

@@ -168,6 +168,12 @@ int buddy_fir(const float* x, const float* h, long long h_stride, float* y, int 
  * statistics_mode='full'), single channel): Y, X are (rows, T) complex128 as interleaved doubles, one row per (utterance, frequency bin);
  * scratch: rows*T doubles.  Per row and iteration: inverse power, correlation matrix/vector, Cholesky solve, prediction filter. ---- */
 int buddy_wpe(const double* Y, double* X, double* scratch, int rows, int T, int taps, int delay, int iterations, void* stream);
+/* The whole warm-start estimate of testing/EulerHeunSamplerDPS.py:36-49 in one call: y (B, L) float32 -> out (B, L) float32 =
+ * istft(wpe(stft(y)))[..., :L] with nara_wpe.utils.stft / istft conventions (size 512, shift 128, periodic Blackman window, fading,
+ * bi-orthogonal synthesis window), every utterance on its own, complex128 inside.  workspace: buddy_wpe_workspace_bytes(B, L) bytes of
+ * device memory.  The rescaling to scaling_factor / std (:51) and the noise (:52) stay with the caller. */
+long long buddy_wpe_workspace_bytes(int B, int L);
+int buddy_wpe_dereverb(const float* y, float* out, void* workspace, int B, int L, int taps, int delay, int iterations, void* stream);
 
 /* ---- blind subband-filtering reverb operator, batched over U utterances; replaces testing/operators/subband_filtering.py
  * (BlindSubbandFiltering :142-351 incl. SubbandFiltering :8-136), utils/reverb_utils.py:3-23, utils/losses.py:59-64 and the

@@ -15,6 +15,7 @@ pinned against outputs of the reference itself (fixtures under ``tests/golden/``
 tests/golden vectors of its own.  Two third-party pieces are absent from
 ``/root/reference`` and restated from their API semantics -- parity for these two is UNPINNED:
 ``torchcde`` (unpinned in reference ``requirements.txt:17``; linear interpolation in
-``operators_ref.linear_interp``) and ``nara_wpe`` (WPE warm start; the product restates it in ``buddy_amd/utils/wpe.py``, the
-oracle does not, so ``wpe_scaled`` runs have no oracle counterpart -- see DESIGN.md).
+``operators_ref.linear_interp``) and ``nara_wpe`` (WPE warm start, ``wpe_ref``: numpy complex128, written from the package's
+published algorithm and STFT conventions independently of the product's kernels, so the HIP warm start and ``wpe_scaled`` runs
+have an oracle counterpart; against nara_wpe itself parity stays unpinned -- see DESIGN.md).
 """

@@ -43,3 +43,54 @@ def run_blind(seed, L, T, nf, updates, rir_taps, fp64=False, threads=8, weight_s
         return torch.stack([t[1][0] for t in tr]).float().cpu(), c0.float().cpu(), nr.k
     finally:
         torch.set_num_threads(prev)
+
+
+def run_informed(seed, L, T, nf, rir_taps, fp64=False, threads=8, weight_seed=0, device=None, order=2):
+    """the non-chaotic chain: informed DPS (known RIR, no operator optimisation), order 2 -> (x_den per step (T, L) float32, clean, n_draws)"""
+    from buddy_amd.config import compose
+    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        args = compose(tester="informed_dereverberation_DPS", overrides=[f"tester.sampling_params.T={T}", f"network.nf={nf}",
+                                                                         f"tester.sampling_params.order={order}"])
+        with (precision.fp64(device) if fp64 else contextlib.nullcontext()):
+            dt, dev = torch.get_default_dtype(), torch.get_default_device()
+            P = ncsnpp_ref.to_torch(synth_state_dict(weight_seed, nf))
+            net = lambda z, cn: ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
+            c0 = torch.from_numpy(synth_clean(seed, L)).to(device=dev, dtype=dt)
+            c0 = 0.05 * c0 / c0.std()
+            nr = S.NoiseStream(9000 + seed)
+            ref = S.EulerHeunDPSRef(net, S.EDMRef(args.diff_params.sde_hp), args, nr)
+            oo = O.RIROperatorRef(args.tester.informed_dereverberation.op_hp)
+            oo.update_params(torch.from_numpy(synth_rir(seed, rir_taps)).to(device=dev, dtype=dt))
+            y0 = oo.degradation(c0[None])
+            tr = []
+            ref.predict_conditional(y0, oo, shape=(1, L), blind=False, trace=tr)
+        return torch.stack([t[1][0] for t in tr]).float().cpu(), c0.float().cpu(), nr.k
+    finally:
+        torch.set_num_threads(prev)
+
+
+def denoiser_eval(seed, L, nf, sigma, fp64=False, threads=8, weight_seed=0, device=None):
+    """ONE denoiser evaluation D(x; sigma) and its input-VJP for a fixed cotangent (seeded) -> (D, J^T w) float64 on the CPU"""
+    import numpy as np
+    from buddy_amd.config import compose
+    from buddy_amd.synth import synth_state_dict
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        args = compose(overrides=[f"network.nf={nf}"])
+        with (precision.fp64(device) if fp64 else contextlib.nullcontext()):
+            dt, dev = torch.get_default_dtype(), torch.get_default_device()
+            P = ncsnpp_ref.to_torch(synth_state_dict(weight_seed, nf))
+            net = lambda z, cn: ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
+            rs = np.random.RandomState(77 + seed)
+            x = torch.from_numpy((sigma * rs.standard_normal((1, L))).astype(np.float32)).to(device=dev, dtype=dt).requires_grad_(True)
+            w = torch.from_numpy(rs.standard_normal((1, L)).astype(np.float32)).to(device=dev, dtype=dt)
+            edm = S.EDMRef(args.diff_params.sde_hp)
+            d = edm.denoiser(x.unsqueeze(1), net, torch.tensor(float(sigma), dtype=dt, device=dev)).squeeze(1)
+            g, = torch.autograd.grad(d, x, w)
+        return d.detach().double().cpu(), g.double().cpu(), x.detach().float().cpu(), w.float().cpu()
+    finally:
+        torch.set_num_threads(prev)

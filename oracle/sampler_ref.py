@@ -121,7 +121,7 @@ class EulerHeunRef:
 
 
 class EulerHeunDPSRef(EulerHeunRef):
-    """EulerHeunSamplerDPS.py:25-204 (warm init none / reverb_scaled; wpe_scaled not restated)."""
+    """EulerHeunSamplerDPS.py:25-204 (warm init none / reverb_scaled / wpe_scaled)."""
 
     def __init__(self, net, edm, args, noise):
         super().__init__(net, edm, args, noise)
@@ -134,6 +134,13 @@ class EulerHeunDPSRef(EulerHeunRef):
             return t[0] * self.noise.randn(shape)
         if mode == "reverb_scaled":
             return self.ps.warm_initialization.scaling_factor * self.y.clone() / self.y.std() + t[0] * self.noise.randn(shape)
+        if mode == "wpe_scaled":      # :32-54 through the restated nara_wpe (oracle/wpe_ref.py; that package's parity is unpinned)
+            from .wpe_ref import wpe_warm_start_estimate
+            w = self.ps.warm_initialization.wpe
+            xp = wpe_warm_start_estimate(self.y.detach().cpu().numpy(), taps=w.taps, delay=w.delay, iterations=w.iterations)
+            xp = torch.from_numpy(xp).to(device=self.y.device, dtype=self.y.dtype)
+            xp = self.ps.warm_initialization.scaling_factor * xp / xp.std()
+            return xp + t[0] * self.noise.randn(shape)
         raise NotImplementedError(mode)
 
     def likelihood_score(self, x_den, x):

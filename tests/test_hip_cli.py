@@ -70,3 +70,27 @@ def test_harness_ragged_utterance_lengths(tmp_path):
         a, b = allr[f"u{i}"].double(), single.double()
         assert float((a - b).abs().max() / b.abs().max()) < 1e-3      # same bound as the batched-vs-single sampler test (guidance normalisation amplifies round-off)
         assert torch.isfinite(a).all()
+
+
+def test_bench_gpus2_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must become two ranks itself (the driver's own command for the scaling curve),
+    shard the utterances, time the end-of-run gather and print ONE line with n_gpus == 2.  One GPU here: gloo lets the two ranks share it
+    (RCCL needs one device per rank); the N-rank RCCL path differs only in the backend string."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--also-concurrent", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["config"]["batch_per_gpu"] == 2
+    assert j["gather_ms"] > 0 and j["gather_bytes_per_rank"] == 2 * 64000 * 4 and j["gather_backend"] == "gloo"
+    assert abs(j["value"] - 2 * 2 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+    # a launcher / --gpus mismatch is refused instead of silently printing n_gpus = 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

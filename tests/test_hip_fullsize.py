@@ -92,9 +92,9 @@ def test_fullsize_adjoint_identity_and_linearity(net):
     assert torch.equal(yb[:1], y0)
 
 
-def _two_blind_steps_vs_oracle(net, L, B, rir_taps):
-    """Two blind DPS steps (network forward + VJP, HIP operator optimisation, likelihood, fused update): utterance 0 of a batch of B
-    against the oracle's B=1 run (same noise draws)."""
+def _two_blind_steps_vs_oracle(net, L, B, rir_taps, updates=3, check=(0,), floor_db=40.0, rel_tol=1e-2):
+    """Two blind DPS steps (network forward + VJP, HIP operator optimisation, likelihood, fused update): utterances `check` of a batch of B
+    against the oracle's B=1 runs (same noise draws)."""
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
@@ -102,7 +102,7 @@ def _two_blind_steps_vs_oracle(net, L, B, rir_taps):
     from buddy_amd.utils.metrics import si_sdr
     from oracle import ncsnpp_ref, operators_ref as O, sampler_ref as S
     ov = ["tester.sampling_params.T=50", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
-          "tester.posterior_sampling.blind_hp.op_updates_per_step=3"]
+          f"tester.posterior_sampling.blind_hp.op_updates_per_step={updates}"]
     args = compose(overrides=ov)
     edm = instantiate(args.diff_params)
     items = [(synth_clean(u, L), synth_rir(u, rir_taps), f"u{u}.wav") for u in range(B)]
@@ -123,36 +123,44 @@ def _two_blind_steps_vs_oracle(net, L, B, rir_taps):
         x, x_den = smp.step(x, sched[i], sched[i + 1], gam[i], blind=True)
     assert torch.isfinite(x).all() and torch.isfinite(x_den).all()
     assert float((x_den.std(dim=1) - 0.05).abs().max()) < 1e-5          # constraint_speech_magnitude per utterance
-    # oracle, utterance 0
     torch.set_num_threads(32)
     P = ncsnpp_ref.to_torch(synth_state_dict(0, 128))
     onet = lambda z, cn: ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
-    nr = S.NoiseStream(70)
-    ref = S.EulerHeunDPSRef(onet, S.EDMRef(args.diff_params.sde_hp), args, nr)
-    op_hp = args.tester.informed_dereverberation.op_hp
-    oo = O.RIROperatorRef(op_hp); oo.update_params(torch.from_numpy(items[0][1]))
-    c0 = torch.from_numpy(items[0][0]); c0 = 0.05 * c0 / c0.std()
-    y0 = oo.degradation(c0[None])
-    assert rel(y[:1], y0) < 1e-4
-    bo = O.BlindSubbandFilteringRef(op_hp, 16000, nr); bo.update_H(use_noise=True, noise=nr)
-    ref.operator, ref.y = bo, y0
-    ps = args.tester.posterior_sampling
-    ref.rec_loss = O.get_loss_ref(ps.rec_loss, bo); ref.rec_loss_params = O.get_loss_ref(ps.rec_loss_params, bo)
-    ref.rir_reg_loss = O.get_loss_ref(ps.RIR_noise_regularization.loss, bo)
-    ref.optim = torch.optim.Adam(bo.params + bo.params_phases, lr=ps.blind_hp.lr_op, betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
-    ts = S.create_schedule(ref.sde_hp, ref.T); gm = S.get_gamma(ts, ref.sp)
-    xr = ref.initialize_x(y0.shape, ts)
-    for i in range(2):
-        xr, xdr = ref.step(xr, ts[i], ts[i + 1], gm[i], True)
-    assert nr.k == ns[0].k
-    s = float(si_sdr(x_den[:1].cpu(), xdr))
-    print(f"L={L} B={B}: two blind steps, SI-SDR(build; oracle) = {s:.1f} dB, rel {rel(x_den[:1], xdr):.2e}")
-    assert s > 40.0, f"SI-SDR(build; oracle) = {s:.1f} dB"
-    assert rel(x_den[:1], xdr) < 1e-2
+    for u in check:                                                     # oracle, utterance u on its own (per-utterance semantics)
+        nr = S.NoiseStream(70 + u)
+        ref = S.EulerHeunDPSRef(onet, S.EDMRef(args.diff_params.sde_hp), args, nr)
+        op_hp = args.tester.informed_dereverberation.op_hp
+        oo = O.RIROperatorRef(op_hp); oo.update_params(torch.from_numpy(items[u][1]))
+        c0 = torch.from_numpy(items[u][0]); c0 = 0.05 * c0 / c0.std()
+        y0 = oo.degradation(c0[None])
+        assert rel(y[u:u + 1], y0) < 1e-4
+        bo = O.BlindSubbandFilteringRef(op_hp, 16000, nr); bo.update_H(use_noise=True, noise=nr)
+        ref.operator, ref.y = bo, y0
+        ps = args.tester.posterior_sampling
+        ref.rec_loss = O.get_loss_ref(ps.rec_loss, bo); ref.rec_loss_params = O.get_loss_ref(ps.rec_loss_params, bo)
+        ref.rir_reg_loss = O.get_loss_ref(ps.RIR_noise_regularization.loss, bo)
+        ref.optim = torch.optim.Adam(bo.params + bo.params_phases, lr=ps.blind_hp.lr_op, betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
+        ts = S.create_schedule(ref.sde_hp, ref.T); gm = S.get_gamma(ts, ref.sp)
+        xr = ref.initialize_x(y0.shape, ts)
+        for i in range(2):
+            xr, xdr = ref.step(xr, ts[i], ts[i + 1], gm[i], True)
+        assert nr.k == ns[u].k
+        s = float(si_sdr(x_den[u:u + 1].cpu(), xdr))
+        print(f"L={L} B={B} updates={updates} utterance {u}: two blind steps, SI-SDR(build; oracle) = {s:.1f} dB, rel {rel(x_den[u:u + 1], xdr):.2e}")
+        assert s > floor_db, f"utterance {u}: SI-SDR(build; oracle) = {s:.1f} dB"
+        assert rel(x_den[u:u + 1], xdr) < rel_tol
 
 
 def test_fullsize_blind_sampler_two_steps_vs_oracle(net):
     _two_blind_steps_vs_oracle(net, 64000, 2, 4000)
+
+
+def test_fullsize_blind_configs1_B8_10updates_vs_oracle(net):
+    """BASELINE.json configs[1] as specified -- B = 8 utterances x 64 000 samples, the shipped 10 operator updates per step, T = 50
+    schedule -- two steps, first and last utterance of the batch against the oracle's single-utterance runs.  With ten scale-free Adam
+    updates per step the chain amplifies fp32 round-off by ~75 dB per step (the fp32 oracle itself sits at 53 dB of its
+    float64 trajectory after step 2, the build at 54 dB), so two fp32 executions agree to ~50 dB after two steps, not to 87 dB as with 3 updates."""
+    _two_blind_steps_vs_oracle(net, 64000, 8, 8000, updates=10, check=(0, 7), floor_db=35.0, rel_tol=3e-2)
 
 
 def test_longform_blind_sampler_two_steps_vs_oracle(net):
@@ -190,3 +198,98 @@ def test_longform_chunked_policy(net):
     direct = t.sampler.predict_conditional(yb, op, shape=(1, LL), blind=False)
     assert torch.equal(whole, direct[0])
     print(f"chunked (4 s / 0.5 s overlap) vs un-chunked, 10 s clip, 3-step informed run: SI-SDR {float(si_sdr(pred[None].cpu(), whole[None].cpu())):.1f} dB")
+
+
+def _sd(a, b):
+    from buddy_amd.utils.metrics import si_sdr
+    return float(si_sdr(torch.as_tensor(a).double().reshape(1, -1), torch.as_tensor(b).double().reshape(1, -1)))
+
+
+def test_fullsize_blind_T10_fp64_arbiter(net):
+    """The claim of profiles/r02_arbiter_L64000_T50.json under the driver: full size (L = 64 000, nf = 128), the shipped 10 updates per
+    step, T = 10, one utterance / noise seed.  Arbiter = the restated algorithm in float64 (oracle.precision; run through torch ops on the
+    GPU, the CPU has no fast fp64 convolution); the fp32 oracle runs on the CPU at two thread counts.  The build's per-step deviation
+    from the float64 trajectory must not be worse than the worse fp32 oracle's by more than 10 dB (one denoiser evaluation of the build
+    carries up to 16 dB more round-off than the oracle's, the F(6x6,3x3) convolutions, and the chain amplifies both alike until
+    saturation), and the step before any feedback must be at the fp32 round-off floor."""
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_clean, synth_rir
+    from buddy_amd.testing.tester import Tester
+    from buddy_amd.utils.losses import get_loss
+    from oracle.arbiter_runs import run_blind, overrides
+    from oracle.sampler_ref import NoiseStream
+    T, nf, up, taps, seed = 10, 128, 10, 8000, 3
+    args = compose(overrides=overrides(T, up, nf))
+    t = Tester(args, net, instantiate(args.diff_params), test_set=None, device="cuda", in_training=True)
+    ns = [NoiseStream(9000 + seed)]
+    t.sampler.noise = ns
+    seg, y, op, _ = t.prepare_batch([(synth_clean(seed, L), synth_rir(seed, taps), "u.wav")], blind=True, noise=ns)
+    smp = t.sampler
+    smp.operator, smp.y = op, y
+    smp.rec_loss = get_loss(args.tester.posterior_sampling.rec_loss, operator=op)
+    smp._hip_op = True
+    op.hip_bind(y, args.tester.posterior_sampling)
+    sched = smp.create_schedule()
+    tl, gl = sched.tolist(), smp.get_gamma(sched).tolist()
+    x = smp.initialize_x(tuple(y.shape), "cuda", sched)
+    tr = []
+    for i in range(T):
+        x, xd = smp.step(x, tl[i], tl[i + 1], gl[i], blind=True)
+        tr.append(xd[0].cpu())
+    x64, clean, k = run_blind(seed, L, T, nf, up, taps, fp64=True, device="cuda")
+    assert k == ns[0].k
+    dev = {"build": [_sd(tr[i], x64[i]) for i in range(T)]}
+    for name, th in (("fp32t16", 16), ("fp32t8", 8)):
+        dev[name] = [_sd(a, b) for a, b in zip(run_blind(seed, L, T, nf, up, taps, threads=th)[0], x64)]
+    for name, v in dev.items():
+        print(f"full size T10 seed {seed} {name:8s} SI-SDR to the fp64 trajectory per step:", [round(q, 1) for q in v])
+    assert dev["build"][0] > 105.0
+    for i in range(T):
+        assert dev["build"][i] > min(100.0, min(dev["fp32t16"][i], dev["fp32t8"][i]) - 10.0), (i, dev)
+
+
+def test_precision_budget_one_denoiser_evaluation_vs_fp64(net):
+    """Gate on the round-off the kernels may spend: ONE denoiser evaluation D(x; sigma) and its input-VJP at full
+    width / full length against the algorithm in float64.  Today: build 114 dB (F(6x6,3x3) + F(4x4,3x3) Winograd convolutions with fused
+    GroupNorms), fp32 oracle 130 dB.  A kernel change that spends more than 4 dB of it turns this red."""
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.config import compose
+    from oracle.arbiter_runs import denoiser_eval
+    args = compose()
+    edm = instantiate(args.diff_params)
+    for sigma in (0.5, 0.02):
+        d64, g64, x, w = denoiser_eval(0, L, 128, sigma, fp64=True, device="cuda")
+        xg = x.cuda().requires_grad_(True)
+        d = edm.denoiser(xg, net, sigma)
+        g, = torch.autograd.grad(d, xg, w.cuda())
+        sd_d, sd_g = _sd(d.detach().cpu(), d64), _sd(g.cpu(), g64)
+        # what the network itself contributes: D = c_skip x + c_out F, so compare F through (D - c_skip x) as well
+        print(f"sigma {sigma}: one denoiser evaluation vs float64: D {sd_d:.1f} dB, VJP {sd_g:.1f} dB")
+        assert sd_d > 110.0 and sd_g > 105.0, (sigma, sd_d, sd_g)
+
+
+def test_precision_budget_informed_T50_vs_fp64(net):
+    """The non-chaotic chain over the whole schedule: informed DPS (known RIR), order 2, T = 50 = 99 denoiser evaluations with VJP, full
+    size, against the float64 execution of the same algorithm (torch ops on the GPU).  Round 2: 66.8 dB against the fp32 oracle (70.2 dB
+    with F(4x4,3x3) convolutions only).  Floor 65 dB; |delta SI-SDR to clean| < 0.01 dB (north star: 0.1 dB)."""
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_clean, synth_rir
+    from buddy_amd.testing.tester import Tester
+    from oracle.arbiter_runs import run_informed
+    from oracle.sampler_ref import NoiseStream
+    T, seed, taps = 50, 0, 8000
+    args = compose(tester="informed_dereverberation_DPS", overrides=[f"tester.sampling_params.T={T}"])
+    t = Tester(args, net, instantiate(args.diff_params), test_set=None, device="cuda", in_training=True)
+    ns = [NoiseStream(9000 + seed)]
+    t.sampler.noise = ns
+    seg, y, op, _ = t.prepare_batch([(synth_clean(seed, L), synth_rir(seed, taps), "u.wav")], blind=False, noise=ns)
+    pred = t.sampler.predict_conditional(y, op, shape=(1, L), blind=False)
+    x64, clean, k = run_informed(seed, L, T, 128, taps, fp64=True, device="cuda")
+    assert k == ns[0].k
+    s = _sd(pred[0].cpu(), x64[-1])
+    dc = _sd(pred[0].cpu(), clean) - _sd(x64[-1], clean)
+    print(f"informed T=50 order 2, full size: SI-SDR(build; float64 run) {s:.1f} dB, delta SI-SDR to clean {dc:+.5f} dB")
+    assert s > 65.0
+    assert abs(dc) < 0.01

@@ -201,6 +201,36 @@ def test_wpe_restated_roundtrip_and_dereverb():
     assert float((z[0, gap] ** 2).mean()) < 0.5 * float((y[0, :n][gap] ** 2).mean())     # reverberant tail in the pauses at least halved
 
 
+def test_wpe_oracle_conventions_and_independent_restatements_agree():
+    """oracle/wpe_ref.py (numpy, test infrastructure) against the conventions it cites -- frame count of the fading + padded STFT, exact
+    STFT -> iSTFT round trip at ragged lengths, zero prediction filter for a white input's delayed taps within statistics -- and against
+    the product's separately written torch form of the same published algorithm (two restatements, one algorithm: 1e-6)."""
+    from buddy_amd.utils import wpe
+    from oracle import wpe_ref
+    rs = np.random.RandomState(3)
+    for n in (700, 12345, 16000, 64000):
+        x = rs.standard_normal(n)
+        X = wpe_ref.stft(x[None])
+        npad = n + 2 * 384
+        assert X.shape == (1, max(1, -(-(npad - 512) // 128) + 1), 257)
+        back = wpe_ref.istft(X)
+        assert back.shape[-1] >= n and np.abs(back[0, :n] - x).max() < 1e-12
+    # iterations = 0 is the identity; delay beyond the signal leaves it untouched
+    Y = wpe_ref.stft(rs.standard_normal((1, 4000))).transpose(2, 0, 1)
+    assert np.array_equal(wpe_ref.wpe(Y, taps=5, delay=2, iterations=0), Y)
+    # build_y_tilde: oldest frame first (nara_wpe docstring example: T = 20, D = 2, taps 4, delay 2)
+    Yd = np.arange(1, 41).reshape(20, 2).T
+    Yt = wpe_ref.build_y_tilde(Yd, 4, 2)
+    assert Yt.shape == (8, 20) and list(Yt[0, :8]) == [0, 0, 0, 0, 0, 1, 3, 5] and list(Yt[6, :5]) == [0, 0, 1, 3, 5] and list(Yt[7, :4]) == [0, 0, 2, 4]
+    from buddy_amd.synth import synth_clean, synth_rir
+    c = synth_clean(1, 16000).astype(np.float64)
+    y = np.convolve(0.05 * c / c.std(), synth_rir(1, 4000))[:16000].astype(np.float32)
+    a = wpe_ref.wpe_warm_start_estimate(y[None])
+    b = wpe.wpe_dereverb(torch.from_numpy(y)[None]).double().numpy()
+    assert a.shape == b.shape == (1, 16000)
+    assert rel(b, a) < 1e-6
+
+
 def test_cli_parser_matches_reference_command_line():
     import test as cli
     groups, ov = cli.parse(["--config-name=conf_VCTK.yaml", "tester=blind_dereverberation_BUDDy", "tester.checkpoint=x.pt",
