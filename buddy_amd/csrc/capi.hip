@@ -107,15 +107,26 @@ int buddy_prof_collect_wino4(double* ms, double* gemm_flops, double* bytes_in, d
   return BUDDY_OK;
 }
 
-int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, int transB, float* C, int ldC, int M, int N, int K, float alpha,
-               const float* bias_n, int accumulate, int batch, long long strideA, long long strideB, long long strideC, void* stream) {
+static int gemm_impl(const float* A, int ldA, int transA, const float* Bt, int ldB, int transB, float* C, int ldC, int M, int N, int K, float alpha,
+                     const float* bias_n, int accumulate, int batch, long long strideA, long long strideB, long long strideC, int tag, void* stream) {
   if (!A || !Bt || !C || K % 4 || (transA && M % 4) || (transB && N % 4)) { set_error("bad gemm arguments (K, and M/N of k-major operands, must be multiples of 4)"); return BUDDY_ERR_ARG; }
   IgemmParams p; std::memset(&p, 0, sizeof(p));
   p.A0 = A; p.ldA0 = ldA; p.Cin = K; p.M = M; p.N = N; p.Bt = Bt; p.ldB = ldB; p.C = C; p.ldC = ldC; p.sA = strideA; p.sB = strideB; p.sC = strideC;
   p.alpha = alpha; p.out_scale = 1.f; p.bias_n = bias_n; p.accumulate = accumulate; p.H = 1; p.W = 1; p.rows_per_batch = 1;
-  if (batch == 36 || batch == 64) p.tag = 36;          // the Winograd-domain GEMM instantiation (same code, own name in profiles)
+  p.tag = tag;
   launch_igemm(p, 1, transA != 0, transB != 0, batch, (hipStream_t)stream);
   return finish();
+}
+
+int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, int transB, float* C, int ldC, int M, int N, int K, float alpha,
+               const float* bias_n, int accumulate, int batch, long long strideA, long long strideB, long long strideC, void* stream) {
+  return gemm_impl(A, ldA, transA, Bt, ldB, transB, C, ldC, M, N, K, alpha, bias_n, accumulate, batch, strideA, strideB, strideC, 0, stream);
+}
+
+int buddy_gemm_winograd_domain(const float* V, const float* U, float* Mo, int tiles, int Cout, int Cin, int positions, void* stream) {
+  if (positions < 1) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  return gemm_impl(V, Cin, 0, U, Cin, 0, Mo, Cout, tiles, Cout, Cin, 1.f, nullptr, 0, positions, (long long)tiles * Cin, (long long)Cout * Cin,
+                   (long long)tiles * Cout, 36, stream);
 }
 
 int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, void* stream) {

@@ -951,7 +951,10 @@ int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes) {
   Arena saved = N->arena;
   N->w4_need = 0;
   N->arena = Arena(); N->arena.dry = true;
-  run_forward(N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, L, with_vjp != 0);
+  // the dry run takes the allocation sequence of the form with per-utterance EDM scalars (a superset of the one without): the pointers
+  // only have to be non-null, nothing is dereferenced or launched while arena.dry is set
+  static const float dry_scalars[1] = {0.f};
+  run_forward(N, nullptr, nullptr, dry_scalars, dry_scalars, dry_scalars, nullptr, B, L, with_vjp != 0);
   if (with_vjp) run_vjp(N, nullptr, nullptr);
   const size_t need = N->arena.peak + (1 << 20);
   N->arena = saved;

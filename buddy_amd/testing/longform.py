@@ -27,7 +27,9 @@ def crossfade_weights(starts, chunk, L, device=None):
     w = torch.ones(n, chunk, device=device)
     for i in range(n - 1):
         ov = starts[i] + chunk - starts[i + 1]
-        assert ov > 0, "chunks must overlap"
+        assert ov >= 0, "chunks must not leave gaps"
+        if ov == 0:                       # L an exact multiple of the chunk with overlap 0: neighbours abut, plain concatenation
+            continue
         ramp = (torch.arange(ov, device=device, dtype=torch.float32) + 0.5) / ov
         w[i, chunk - ov:] *= 1.0 - ramp
         w[i + 1, :ov] *= ramp

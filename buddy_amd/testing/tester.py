@@ -41,8 +41,10 @@ class Tester:
         self.results = []
         self.blind_backend = None      # None: HIP operator on a GPU; "torch" forces the torch-op implementation
         # a batch of >= 2 * sub_batches utterances is sampled as that many concurrent sub-batches on their own HIP streams
-        # (testing/concurrent.py; identical results, better occupancy); 1 = one batch, one stream
-        self.sub_batches = int(args.tester.get("sub_batches", 1)) if hasattr(args.tester, "get") else 1
+        # (testing/concurrent.py; identical results, better occupancy); 1 = one batch, one stream.  Default ("auto", tester.sub_batches
+        # absent): 2 whenever a group has >= 4 utterances -- the measured optimum (+5 %; 4 loses), DESIGN.md section 6
+        sb = args.tester.get("sub_batches", None) if hasattr(args.tester, "get") else None
+        self.sub_batches = None if sb in (None, "auto") else int(sb)
         self._concurrent = None
 
     # ---- checkpoints (reference :34-67): the EMA weights are what gets loaded -------------------------------------
@@ -129,8 +131,9 @@ class Tester:
                 # parity runs: one injected noise stream per utterance, shared by the sampler AND the blind operator (random phases,
                 # update_H(use_noise=True), per-step RIR-regulariser draws) in the reference's call order; otherwise the torch RNG
                 self.sampler.noise = self.noise_factory([it[2] for it in grp]) if getattr(self, "noise_factory", None) is not None else None
-                if self.sub_batches > 1 and len(grp) >= 2 * self.sub_batches and str(self.device).startswith("cuda"):
-                    seg, y, pred, est, rirs = self._sample_concurrent(grp, L, blind)
+                S = self.sub_batches if self.sub_batches is not None else (2 if len(grp) >= 4 else 1)
+                if S > 1 and len(grp) >= 2 * S and str(self.device).startswith("cuda"):
+                    seg, y, pred, est, rirs = self._sample_concurrent(grp, L, blind, S)
                 else:
                     seg, y, operator, rirs = self.prepare_batch(grp, blind, noise=self.sampler.noise)
                     pred = self.sampler.predict_conditional(y, operator, shape=(len(grp), L), blind=blind)
@@ -154,12 +157,12 @@ class Tester:
         rows = bdist.gather_ragged([local[i] for i in mine], len(self.test_set), self.rank, self.world_size, device=self.device)
         self.gathered = [(os.path.basename(self.test_set[i][2])[:-4], rows[i].detach().cpu()) for i in range(len(self.test_set))]
 
-    def _sample_concurrent(self, grp, L, blind):
-        """one equal-length group as ``sub_batches`` concurrent sub-batches (testing/concurrent.py)"""
+    def _sample_concurrent(self, grp, L, blind, S):
+        """one equal-length group as ``S`` concurrent sub-batches (testing/concurrent.py)"""
         from .concurrent import ConcurrentSampler, split_rows
-        if self._concurrent is None:
-            self._concurrent = ConcurrentSampler(self.args, self.network, self.diff_params, self.sub_batches)
-        parts = split_rows(len(grp), self.sub_batches)
+        if self._concurrent is None or self._concurrent_S != S:
+            self._concurrent, self._concurrent_S = ConcurrentSampler(self.args, self.network, self.diff_params, S), S
+        parts = split_rows(len(grp), S)
         noise = self.sampler.noise
         segs, ys, ops, rirs, noises = [], [], [], [], []
         for lo, hi in parts:

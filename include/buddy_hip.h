@@ -78,6 +78,10 @@ int buddy_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsi
 int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, int transB, float* C, int ldC, int M, int N,
                int K, float alpha, const float* bias_n, int accumulate, int batch, long long strideA, long long strideB,
                long long strideC, void* stream);
+/* The batched Winograd-domain products of the three-pass 3x3 convolutions on their own (benchmarks, tools/gemm36.py):
+ * M[p] (tiles x Cout) = V[p] (tiles x Cin) . U[p]^T (Cout x Cin), p < positions (36 = F(4x4,3x3), 64 = F(6x6,3x3)), dense strides.
+ * Same arithmetic as buddy_gemm; this entry point selects the instantiation the convolutions use (own name in profiles). */
+int buddy_gemm_winograd_domain(const float* V, const float* U, float* M, int tiles, int Cout, int Cin, int positions, void* stream);
 /* NHWC 3x3 stride-1 pad-1 conv, packed weights wt[Cout][9*Cin] (tap-major, channel-minor); replaces ddpm_conv3x3
  * (networks/ncsnpp_utils/layers.py:119-126). */
 int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,

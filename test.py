@@ -60,7 +60,9 @@ def _main(args):
                     rank=rank, world_size=world)                          # :59
     ckpt = args.tester.get("checkpoint", None)
     if ckpt is not None:
-        tester.load_checkpoint(ckpt if os.path.isabs(ckpt) or os.path.exists(ckpt) else os.path.join(args.model_dir, ckpt))   # :73-93
+        ok = tester.load_checkpoint(ckpt if os.path.isabs(ckpt) or os.path.exists(ckpt) else os.path.join(args.model_dir, ckpt))   # :73-93
+        if not ok:                                                        # load_state_dict raises on an unusable file; belt and braces
+            raise ValueError(f"checkpoint {ckpt} could not be loaded")
     elif bool(args.get("allow_random_init", False)):
         print("+allow_random_init: sampling with the randomly initialised network (synthetic runs only)")
     else:

@@ -266,7 +266,7 @@ def test_precision_budget_one_denoiser_evaluation_vs_fp64(net):
         sd_d, sd_g = _sd(d.detach().cpu(), d64), _sd(g.cpu(), g64)
         # what the network itself contributes: D = c_skip x + c_out F, so compare F through (D - c_skip x) as well
         print(f"sigma {sigma}: one denoiser evaluation vs float64: D {sd_d:.1f} dB, VJP {sd_g:.1f} dB")
-        assert sd_d > 110.0 and sd_g > 105.0, (sigma, sd_d, sd_g)
+        assert sd_d > 110.0 and sd_g > 108.0, (sigma, sd_d, sd_g)      # measured r03: 115.9 / 113.2 dB (sigma 0.5), 126.4 / 122.8 dB (0.02)
 
 
 def test_precision_budget_informed_T50_vs_fp64(net):
@@ -291,5 +291,5 @@ def test_precision_budget_informed_T50_vs_fp64(net):
     s = _sd(pred[0].cpu(), x64[-1])
     dc = _sd(pred[0].cpu(), clean) - _sd(x64[-1], clean)
     print(f"informed T=50 order 2, full size: SI-SDR(build; float64 run) {s:.1f} dB, delta SI-SDR to clean {dc:+.5f} dB")
-    assert s > 65.0
+    assert s > 68.0                                                   # measured r03: 72.7 dB, delta -0.0007 dB
     assert abs(dc) < 0.01

@@ -284,9 +284,33 @@ def test_load_checkpoint_reference_fallback_chain(tmp_path):
     fresh()
     assert t.load_checkpoint(str(p)) is True
     assert torch.equal(net.state_dict()[key], ema[key])
-    # nothing loadable
-    torch.save({"foo": 1}, p)
-    assert t.load_checkpoint(str(p)) is False
+    # 5. legacy layout: names from 'model', tensors from the LIST 'ema_weights' (reference utils/training_utils.py:103-113)
+    torch.save({"model": raw, "ema_weights": list(ema.values())}, p)
+    fresh()
+    assert t.load_checkpoint(str(p)) is True
+    assert all(torch.equal(net.state_dict()[k], ema[k]) for k in ema)
+    # 6. 'ema_weights' lists only the trainable entries of 'model' (:115-129); the frozen entry is taken from 'model'
+    frozen = "all_modules.0.W"
+    model = {k: (v.clone().requires_grad_(k != frozen)) for k, v in raw.items()}
+    torch.save({"model": model, "ema_weights": [v for k, v in ema.items() if k != frozen] + [torch.zeros(1)]}, p)   # one surplus tensor: attempt 5 cannot zip-load it
+    fresh()
+    assert t.load_checkpoint(str(p)) is True
+    sd = net.state_dict()
+    assert torch.equal(sd[key], ema[key]) and torch.equal(sd[frozen], raw[frozen])
+    # 7. 'diffusion_ema.'-prefixed names under 'state_dict' (:132-173)
+    torch.save({"state_dict": {**{"diffusion." + k: v for k, v in raw.items()}, **{"diffusion_ema." + k: v for k, v in ema.items()}}}, p)
+    fresh()
+    assert t.load_checkpoint(str(p)) is True
+    assert all(torch.equal(net.state_dict()[k], ema[k]) for k in ema)
+    # 8. a bare state dict (:174-178)
+    torch.save(ema, p)
+    fresh()
+    assert t.load_checkpoint(str(p)) is True
+    assert all(torch.equal(net.state_dict()[k], ema[k]) for k in ema)
+    # nothing loadable: the final strict load RAISES (the sampler never runs on random weights by accident)
+    torch.save({"foo": torch.zeros(1)}, p)
+    with pytest.raises(RuntimeError):
+        t.load_checkpoint(str(p))
     # load_latest_checkpoint: highest iteration wins; no file -> ValueError("No checkpoint found")
     with pytest.raises(ValueError, match="No checkpoint found"):
         t.load_latest_checkpoint()

@@ -8,7 +8,7 @@ lib = _lib.require_gpu()
 P = _lib.ptr; S = _lib.stream_ptr
 def run(Mt, N, K, reps=5, nb=36):
     A = torch.randn(nb, Mt, K, device="cuda"); Bt = torch.randn(nb, N, K, device="cuda"); Cm = torch.empty(nb, Mt, N, device="cuda")
-    f = lambda: _lib.check(lib.buddy_gemm(P(A), K, 0, P(Bt), K, 0, P(Cm), N, Mt, N, K, 1.0, None, 0, nb, Mt * K, N * K, Mt * N, S()))
+    f = lambda: _lib.check(lib.buddy_gemm_winograd_domain(P(A), P(Bt), P(Cm), Mt, N, K, nb, S()))
     f(); f(); torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(reps): f()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps

@@ -7,7 +7,7 @@ lib = _lib.require_gpu()
 P = _lib.ptr; S = _lib.stream_ptr
 Mt, N, K = (int(v) for v in sys.argv[1:4]); reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 A = torch.randn(36, Mt, K, device="cuda"); Bt = torch.randn(36, N, K, device="cuda"); Cm = torch.empty(36, Mt, N, device="cuda")
-f = lambda: _lib.check(lib.buddy_gemm(P(A), K, 0, P(Bt), K, 0, P(Cm), N, Mt, N, K, 1.0, None, 0, 36, Mt * K, N * K, Mt * N, S()))
+f = lambda: _lib.check(lib.buddy_gemm_winograd_domain(P(A), P(Bt), P(Cm), Mt, N, K, 36, S()))
 f(); torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(reps): f()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps

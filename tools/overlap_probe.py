@@ -14,7 +14,7 @@ s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 def gemm(n):
     with torch.cuda.stream(s1):
         for _ in range(n):
-            _lib.check(lib.buddy_gemm(P(A), K, 0, P(Bt), K, 0, P(Cm), N, Mt, N, K, 1.0, None, 0, 36, Mt * K, N * K, Mt * N, s1.cuda_stream))
+            _lib.check(lib.buddy_gemm_winograd_domain(P(A), P(Bt), P(Cm), Mt, N, K, 36, s1.cuda_stream))
 def mem(n):
     with torch.cuda.stream(s2):
         for _ in range(n):
