@@ -43,6 +43,9 @@ _SIGS = {
     "buddy_gemm": (C.c_int, [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                              _f32p, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_void_p]),
     "buddy_gemm_winograd_domain": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_wgemm_packed_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "buddy_wgemm_pack_weights": (C.c_int, [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_gemm_winograd_domain_bf16x3": (C.c_int, [_f32p, C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_conv3x3": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_winograd_transform_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "buddy_winograd4_transform_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

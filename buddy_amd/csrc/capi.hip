@@ -129,6 +129,22 @@ int buddy_gemm_winograd_domain(const float* V, const float* U, float* Mo, int ti
                    (long long)tiles * Cout, 36, stream);
 }
 
+long long buddy_wgemm_packed_bytes(int positions, int Cout, int Cin) {
+  return (positions < 1 || !wgemm_supported(Cout, Cin)) ? 0 : (long long)wgemm_packed_bytes(positions, Cout, Cin);
+}
+
+int buddy_wgemm_pack_weights(const float* U, void* U3, int positions, int Cout, int Cin, void* stream) {
+  if (!U || !U3 || positions < 1 || !wgemm_supported(Cout, Cin)) { set_error("bad arguments (Cout % 128, Cin % 32)"); return BUDDY_ERR_ARG; }
+  wgemm_pack_weights(U, U3, positions, Cout, Cin, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_gemm_winograd_domain_bf16x3(const float* V, const void* U3, float* Mo, int tiles, int Cout, int Cin, int positions, void* stream) {
+  if (!V || !U3 || !Mo || tiles < 1 || positions < 1 || !wgemm_supported(Cout, Cin)) { set_error("bad arguments (Cout % 128, Cin % 32)"); return BUDDY_ERR_ARG; }
+  launch_wgemm_bf16x3(V, U3, Mo, tiles, Cout, Cin, positions, (hipStream_t)stream);
+  return finish();
+}
+
 int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, void* stream) {
   if (!x || !wt || !y || Cin % 4) { set_error("bad conv arguments"); return BUDDY_ERR_ARG; }
   IgemmParams p; std::memset(&p, 0, sizeof(p));

@@ -33,6 +33,11 @@ struct IgemmParams {
   int tag;                 // 36: the batched GEMM of a F(4x4,3x3) convolution (own kernel instantiation, profiling only)
 };
 void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int batch, hipStream_t st);
+// bf16x3 form of the Winograd-domain batched GEMM (wgemm.hip): weights pre-split into the LDS stage image, V / M dense fp32
+bool wgemm_supported(int Cout, int Cin);
+size_t wgemm_packed_bytes(int P, int Cout, int Cin);
+void wgemm_pack_weights(const float* U_dev, void* U3_dev, int P, int Cout, int Cin, hipStream_t st);
+void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st);
 // Winograd F(2x2,3x3) variant of the 3x3 conv (wino.hip): same IgemmParams, pre-transformed weights U[Cin/16][16][Cout][16]
 bool wino_supported(const IgemmParams& p);
 void launch_wino(const IgemmParams& p, const float* Uw, hipStream_t st);

@@ -1,0 +1,194 @@
+// Winograd-domain batched GEMM  M[p] (tiles x Cout) = V[p] (tiles x Cin) . U[p]^T (Cout x Cin),  p < positions,  in "bf16x3" arithmetic:
+// the middle pass of the three-pass 3x3 convolutions (reference ddpm_conv3x3, networks/ncsnpp_utils/layers.py:119-126) -- 94 % of the
+// score network's FLOPs.
+//
+// Arithmetic.  Every fp32 operand is split EXACTLY into three bf16 terms by truncation, x = hi + mid + lo (8 + 8 + 8 significant bits), and
+// the product is accumulated in fp32 as  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are
+// exact in fp32; the dropped terms mid*lo, lo*mid, lo*lo are <= 2^-23 of a product, the fp32 rounding level).  Six bf16 MFMAs (32 cycles, 16 k)
+// replace eight fp32 MFMAs (64 cycles, 2 k each): 2.67x fewer matrix-pipe cycles per multiply-add at the accuracy of the fp32 path
+// (unit test vs fp64: the same 1e-4 bound as the fp32 kernel; measured in profiles/README.md).
+//
+// Structure (round 2's drop-in variant of the fp32 loop lost to LDS latency and two barriers per 48 MFMAs; this loop is built for the split):
+//  * workgroup = 4 waves x 32 rows of V, all 128 columns (output channels) of one channel block: a wave's A operand (V rows) is PRIVATE, so it
+//    goes global -> registers in MFMA fragment order, is split in registers (5.5 VALU per element, once) and never touches LDS;
+//  * the k index an MFMA lane holds is free as long as A and B agree: lane (row r, half h) takes k = 32 s + 16 h + 0..15 of K-stage s, i.e. 64
+//    contiguous bytes per lane, a whole 128-byte line per row and stage;
+//  * the weights are split once, at handle creation (wgemm_pack_weights), into the exact LDS image of a stage: [k chunk][column block][plane][lane]
+//    x 16 B, so a stage is a linear 24 KB copy and every fragment read is one conflict-free ds_read_b128;
+//  * LDS is double-buffered: ONE barrier per K-stage of 48 MFMAs per wave; global loads for stage s + 1 are issued before the MFMAs of stage s;
+//  * the accumulator is C^T (weights as the MFMA's first operand): a lane holds 4 consecutive output channels of one row -> 16-byte stores.
+#include "common.h"
+#include <cstdint>
+
+namespace buddy {
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WBM = 128, WBN = 128, WKS = 32, WNT = 256;
+constexpr int STAGE_BYTES = WBN * WKS * 6;                    // 24 KB: 2 k-chunks x 4 column blocks x 3 planes x 1 KB
+constexpr int FRAG = 1024;                                    // bytes of one (chunk, column block, plane) fragment block: 64 lanes x 16 B
+
+struct Split3 { bf16x8 p[3]; };
+// exact three-way split of 8 fp32 values by truncation (hi = top 16 bits; mid = top 16 bits of x - hi; lo = x - hi - mid, <= 8 significant bits)
+__device__ __forceinline__ Split3 split3(const float4 a, const float4 b) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned int h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned int u = __float_as_uint(x[i]);
+    h[i] = u;
+    const float r = x[i] - __uint_as_float(u & 0xFFFF0000u);
+    m[i] = __float_as_uint(r);
+    l[i] = __float_as_uint(r - __uint_as_float(m[i] & 0xFFFF0000u));
+  }
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                               // v_perm_b32: the high halves of two dwords -> one packed pair
+    ph[q] = __builtin_amdgcn_perm(h[2 * q + 1], h[2 * q], 0x07060302u);
+    pm[q] = __builtin_amdgcn_perm(m[2 * q + 1], m[2 * q], 0x07060302u);
+    pl[q] = __builtin_amdgcn_perm(l[2 * q + 1], l[2 * q], 0x07060302u);
+  }
+  Split3 s;
+  s.p[0] = (bf16x8)ph; s.p[1] = (bf16x8)pm; s.p[2] = (bf16x8)pl;
+  return s;
+}
+
+// U fp32 [P][Cout][Cin] -> stage images [P][Cout/128][Cin/32][2][4][3][64] x 16 B; one thread per 16-byte element
+__global__ __launch_bounds__(256) void wgemm_pack_kernel(const float* __restrict__ U, u32x4* __restrict__ out, int P, int Cout, int Cin) {
+  const long long n16 = (long long)P * Cout * Cin * 6 / 16;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n16) return;
+  const int lane = (int)(i & 63);
+  long long r = i >> 6;
+  const int q = (int)(r % 3); r /= 3;
+  const int cb = (int)(r & 3); r >>= 2;
+  const int kc = (int)(r & 1); r >>= 1;
+  const int S = Cin / WKS, NB = Cout / WBN;
+  const int s = (int)(r % S); r /= S;
+  const int nb = (int)(r % NB); r /= NB;
+  const int p = (int)r;
+  const int n = nb * WBN + cb * 32 + (lane & 31), k = s * WKS + 16 * (lane >> 5) + 8 * kc;
+  const float* src = U + ((long long)p * Cout + n) * Cin + k;
+  const Split3 sp = split3(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4));
+  out[i] = (u32x4)sp.p[q];
+}
+
+struct WgemmArgs {
+  const float* V; const unsigned char* U3; float* M;
+  int Mt, Cin, Cout, S, NB;                                    // rows per position, K, N, K-stages, column blocks
+  long long sV, sM;                                            // strides between positions (floats)
+};
+
+__global__ __launch_bounds__(WNT, 2) void wgemm_bf16x3_kernel(const WgemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // XCD-aware order (hardware places block b on XCD b % 8): each XCD gets a contiguous range of logical tiles, the column blocks of one row
+  // tile adjacent, so the second column block finds its V rows in the same L2
+  int lid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int nb = lid % a.NB, m0 = (lid / a.NB) * WBM;
+  const int p = blockIdx.z;
+  const float* __restrict__ V = a.V + (long long)p * a.sV;
+  const unsigned char* __restrict__ U3 = a.U3 + ((long long)p * a.NB + nb) * a.S * STAGE_BYTES;
+  const int S = a.S;
+
+  // A: lane (row r = lane & 31, half h = lane >> 5) reads 16 consecutive floats per stage; rows past M are clamped (never stored)
+  int row = m0 + wid * 32 + (lane & 31);
+  const bool row_ok = row < a.Mt;
+  if (!row_ok) row = a.Mt - 1;
+  const float* Ap = V + (long long)row * a.Cin + 16 * (lane >> 5);
+  // B: the stage image is copied linearly, 6 x 16 B per thread (thread t moves bytes 16 t + 4096 j)
+  const u32x4* Bg = reinterpret_cast<const u32x4*>(U3) + tid;
+  u32x4* Bs = reinterpret_cast<u32x4*>(smem) + tid;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  float4 ra[4];
+  u32x4 rb[6];
+  auto loadA = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(Ap + s * WKS + 4 * j);
+  };
+  auto loadB = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) rb[j] = Bg[(long long)s * (STAGE_BYTES / 16) + j * WNT];
+  };
+  auto storeB = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Bs[buf * (STAGE_BYTES / 16) + j * WNT] = rb[j];
+  };
+
+  loadA(0);
+  loadB(0);
+  storeB(0);
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    const float4 ca[4] = {ra[0], ra[1], ra[2], ra[3]};
+    if (s + 1 < S) { loadA(s + 1); loadB(s + 1); }
+    const unsigned char* Bcur = smem + (s & 1) * STAGE_BYTES + lane * 16;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      const Split3 av = split3(ca[2 * kc], ca[2 * kc + 1]);
+      bf16x8 b[4][3];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[cb][q] = *reinterpret_cast<const bf16x8*>(Bcur + ((kc * 4 + cb) * 3 + q) * FRAG);
+      // smallest terms first; the four column blocks interleaved so that consecutive MFMAs never share an accumulator
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][1], av.p[1], acc[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][2], av.p[0], acc[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][0], av.p[2], acc[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][1], av.p[0], acc[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][0], av.p[1], acc[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][0], av.p[0], acc[cb], 0, 0, 0);
+    }
+    if (s + 1 < S) storeB((s + 1) & 1);                        // that buffer was last read in stage s - 1: every wave is past its barrier
+    __syncthreads();
+  }
+
+  // epilogue: accumulator = C^T tile, lane (row = lane & 31, h = lane >> 5) holds channels 8 g + 4 h + 0..3 of each 32-channel block
+  if (row_ok) {
+    float* dst = a.M + (long long)p * a.sM + (long long)row * a.Cout + nb * WBN + 4 * (lane >> 5);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + cb * 32 + 8 * g) = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+  }
+}
+}  // namespace
+
+bool wgemm_supported(int Cout, int Cin) { return Cout % WBN == 0 && Cin % WKS == 0; }
+size_t wgemm_packed_bytes(int P, int Cout, int Cin) { return (size_t)P * Cout * Cin * 6; }
+
+void wgemm_pack_weights(const float* U_dev, void* U3_dev, int P, int Cout, int Cin, hipStream_t st) {
+  const long long n16 = (long long)P * Cout * Cin * 6 / 16;
+  hipLaunchKernelGGL(wgemm_pack_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, U_dev, reinterpret_cast<u32x4*>(U3_dev), P, Cout, Cin);
+}
+
+void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st) {
+  WgemmArgs a;
+  a.V = V; a.U3 = reinterpret_cast<const unsigned char*>(U3); a.M = M;
+  a.Mt = (int)Mt; a.Cin = Cin; a.Cout = Cout; a.S = Cin / WKS; a.NB = Cout / WBN;
+  a.sV = Mt * Cin; a.sM = Mt * Cout;
+  const dim3 grid((unsigned)(cdiv((int)Mt, WBM) * a.NB), 1, (unsigned)P);
+  hipLaunchKernelGGL(wgemm_bf16x3_kernel, grid, dim3(WNT), 0, st, a);
+}
+
+}  // namespace buddy

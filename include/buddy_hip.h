@@ -82,6 +82,13 @@ int buddy_gemm(const float* A, int ldA, int transA, const float* Bt, int ldB, in
  * M[p] (tiles x Cout) = V[p] (tiles x Cin) . U[p]^T (Cout x Cin), p < positions (36 = F(4x4,3x3), 64 = F(6x6,3x3)), dense strides.
  * Same arithmetic as buddy_gemm; this entry point selects the instantiation the convolutions use (own name in profiles). */
 int buddy_gemm_winograd_domain(const float* V, const float* U, float* M, int tiles, int Cout, int Cin, int positions, void* stream);
+/* The same products in "bf16x3" arithmetic (csrc/wgemm.hip): every fp32 operand split exactly into three bf16 terms, six bf16 MFMA products,
+ * fp32 accumulation -- the accuracy of the fp32 kernel at 2.67x fewer matrix-pipe cycles.  The weights are split once into the kernel's LDS
+ * stage image: U3 = buddy_wgemm_packed_bytes(...) bytes of device memory filled by buddy_wgemm_pack_weights from U [positions][Cout][Cin]
+ * (device).  Cout % 128 == 0, Cin % 32 == 0 (packed_bytes returns 0 otherwise). */
+long long buddy_wgemm_packed_bytes(int positions, int Cout, int Cin);
+int buddy_wgemm_pack_weights(const float* U, void* U3, int positions, int Cout, int Cin, void* stream);
+int buddy_gemm_winograd_domain_bf16x3(const float* V, const void* U3, float* M, int tiles, int Cout, int Cin, int positions, void* stream);
 /* NHWC 3x3 stride-1 pad-1 conv, packed weights wt[Cout][9*Cin] (tap-major, channel-minor); replaces ddpm_conv3x3
  * (networks/ncsnpp_utils/layers.py:119-126). */
 int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,

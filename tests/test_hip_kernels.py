@@ -52,6 +52,48 @@ def test_gemm(lib, tA, tB, M, N, K, batch):
     assert rel(Cc, 2 * ref - bias) < 2e-5
 
 
+@pytest.mark.parametrize("tiles,Cout,Cin,P_", [(300, 128, 128, 3), (1000, 256, 384, 2), (129, 256, 32, 5), (4096, 128, 512, 2)])
+def test_winograd_domain_gemm_bf16x3(lib, tiles, Cout, Cin, P_):
+    """buddy_gemm_winograd_domain_bf16x3 (exact three-way bf16 split, six bf16 MFMA products, fp32 accumulate; csrc/wgemm.hip) against fp64:
+    the SAME bound as the fp32-MFMA GEMM (2e-5 of the abs-max), measured next to it; ragged row counts, both column-block counts.  Values
+    with a wide dynamic range (the Winograd-domain operands span ~4 decades) so that a dropped low-order term would show."""
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(tiles + Cout + Cin)
+    V = (torch.randn(P_, tiles, Cin, generator=g) * torch.exp(2.0 * torch.randn(P_, tiles, 1, generator=g))).cuda()
+    U = (torch.randn(P_, Cout, Cin, generator=g) * torch.exp(1.5 * torch.randn(P_, 1, Cin, generator=g))).cuda()
+    ref = torch.einsum("pmk,pnk->pmn", V.double(), U.double())
+    nbytes = int(lib.buddy_wgemm_packed_bytes(P_, Cout, Cin))
+    assert nbytes == P_ * Cout * Cin * 6
+    U3 = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda")
+    _lib.check(lib.buddy_wgemm_pack_weights(P(U), U3.data_ptr(), P_, Cout, Cin, S()))
+    M3 = torch.full((P_, tiles, Cout), 7.0, device="cuda")
+    _lib.check(lib.buddy_gemm_winograd_domain_bf16x3(P(V), U3.data_ptr(), P(M3), tiles, Cout, Cin, P_, S()))
+    M1 = torch.empty(P_, tiles, Cout, device="cuda")
+    _lib.check(lib.buddy_gemm_winograd_domain(P(V), P(U), P(M1), tiles, Cout, Cin, P_, S()))
+    torch.cuda.synchronize()
+    e3, e1 = rel(M3, ref), rel(M1, ref)
+    # relative to the row-wise scale as well (rows span decades): the worst row
+    rr = lambda X: float(((X.double() - ref).abs().amax(dim=2) / ref.abs().amax(dim=2)).max())
+    print(f"tiles={tiles} Cout={Cout} Cin={Cin}: bf16x3 {e3:.2e} (worst row {rr(M3):.2e}), fp32 MFMA {e1:.2e} (worst row {rr(M1):.2e})")
+    assert e3 < 2e-5 and rr(M3) < 2e-5
+    assert lib.buddy_wgemm_packed_bytes(2, 96, 128) == 0 and lib.buddy_wgemm_packed_bytes(2, 128, 48) == 0
+
+
+def test_winograd_domain_gemm_bf16x3_layout(lib):
+    """V = I-like selector against asymmetric weights: every (row, channel, k) lands where it should (exactly representable values)."""
+    from buddy_amd import _lib
+    tiles, Cout, Cin = 128, 256, 128
+    V = torch.zeros(1, tiles, Cin, device="cuda")
+    V[0, torch.arange(tiles), (torch.arange(tiles) * 37) % Cin] = 1.0
+    U = ((torch.arange(Cout * Cin, device="cuda", dtype=torch.float32).reshape(1, Cout, Cin) % 251) + 0.5)
+    U3 = torch.empty(Cout * Cin * 6 // 4, dtype=torch.int32, device="cuda")
+    _lib.check(lib.buddy_wgemm_pack_weights(P(U), U3.data_ptr(), 1, Cout, Cin, S()))
+    Mo = torch.empty(1, tiles, Cout, device="cuda")
+    _lib.check(lib.buddy_gemm_winograd_domain_bf16x3(P(V), U3.data_ptr(), P(Mo), tiles, Cout, Cin, 1, S()))
+    torch.cuda.synchronize()
+    assert torch.equal(Mo[0], U[0][:, (torch.arange(tiles) * 37) % Cin].t().contiguous())
+
+
 def test_gemm_asymmetric_layout(lib):
     """A = I against an asymmetric B catches a transposed C write (guide rule: always A=I with asymmetric B)."""
     from buddy_amd import _lib
