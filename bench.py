@@ -33,6 +33,7 @@ U_FWD = 1.2501e12   # algorithmic FLOPs of one score-network forward for a 4 s u
                     # torch.utils.flop_counter on the reference); forward + input-VJP = 2 * U_FWD
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E, MI355X_MICROARCH.md
 PEAK_FP32_MFMA = 157.3   # TFLOP/s, MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA = 2500.0  # TFLOP/s, MI355X dense bf16 matrix peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 
 
 def build_stack(args_ns, device, B, first_utt, net=None):
@@ -43,6 +44,8 @@ def build_stack(args_ns, device, B, first_utt, net=None):
     ov = [f"tester.sampling_params.T={args_ns.T}", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled"]
     if getattr(args_ns, "attention", None):
         ov.append(f"+network.attention={args_ns.attention}")
+    if getattr(args_ns, "gemm", None):
+        ov.append(f"+network.gemm={args_ns.gemm}")
     args = compose(tester="blind_dereverberation_BUDDy", overrides=ov)
     if net is None:
         net = instantiate(args.network)
@@ -258,7 +261,7 @@ def conv_source_stamp():
     """sha1 over the sources of the dominant kernel group: a PMC summary is only quoted if it was measured on these exact kernels"""
     import hashlib
     h = hashlib.sha1()
-    for f in ("igemm.hip", "wino4.hip", "wino6.hip", "common.h"):
+    for f in ("igemm.hip", "wgemm.hip", "wino4.hip", "wino6.hip", "common.h"):
         h.update(open(os.path.join(ROOT, "buddy_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 
@@ -278,6 +281,8 @@ def main():
                     "in a second region and report it as `concurrent_sub_batches` (0 = skip)")
     ap.add_argument("--attention", default=None, choices=["flash", "matrix", "bf16", "f16"], help="attention core of the network (default: the library's, "
                     "fp32 online softmax; bf16 / f16 = the opt-in fast mode that passed the 0.1 dB gate, profiles/r02_attention_modes.json)")
+    ap.add_argument("--gemm", default=None, choices=["bf16x3", "fp32"], help="arithmetic of the Winograd-domain GEMMs (default: the library's, bf16x3 = exact "
+                    "three-way bf16 split of the fp32 operands, six bf16 MFMA products, fp32 accumulate; fp32 = v_mfma_f32_32x32x2_f32, the reference run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
     ap.add_argument("--operator", default="hip", choices=["hip", "torch"], help="blind operator backend (torch = interim torch-op path)")
@@ -469,14 +474,16 @@ def main():
         a36 = max(1, int(w4_n.value))
         # HBM bytes of the dominant kernel: separate rocprofv3 --pmc passes of this same command (counters cannot be read in-process),
         # summarised by tools/pmc_summary.py; quoted only if measured on the kernels that are running now (source stamp)
-        traffic, traffic_src = None, "no PMC summary for the current kernel sources (tools/pmc_summary.py writes profiles/conv_traffic_pmc.json)"
+        gemm_mode = a.gemm or ("fp32" if os.environ.get("BUDDY_GEMM", "") == "fp32" else "bf16x3")
+        traffic, traffic_group, traffic_src = None, None, "no PMC summary for the current kernel sources (tools/pmc_summary.py writes profiles/conv_traffic_pmc.json)"
         tp = os.path.join(ROOT, "profiles", "conv_traffic_pmc.json")
         stamp = conv_source_stamp()
         if os.path.exists(tp) and B == 8 and a.length == 64000:
             pj = json.load(open(tp))
             if pj.get("source_stamp") == stamp:
-                k36 = [v for k, v in pj["per_kernel_bytes_per_convolution"].items() if "36>" in k][0]
+                k36 = [v for k, v in pj["per_kernel_bytes_per_convolution"].items() if "GEMM" in k or "36>" in k][0]
                 traffic = k36["fetch"] + k36["write"]
+                traffic_group = pj.get("hbm_bytes_per_launch")
                 traffic_src = f"profiles/conv_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction; source stamp {stamp})"
             else:
                 traffic_src = f"profiles/conv_traffic_pmc.json is stale (stamp {pj.get('source_stamp')} != {stamp} of the current igemm.hip / wino4.hip): not quoted"
@@ -485,7 +492,7 @@ def main():
             "metric": f"diffusion steps/sec ({a.length / 16000:g} s@16 kHz utterance, blind Euler-Heun DPS, order 1, 10 operator updates/step)",
             "value": n_utt_steps / elapsed, "unit": "utterance-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded clean/RIR/weights; random-init NCSN++ 27.7 M params)",
+            "dtype": ("f32 (bf16x3 exact split in the Winograd-domain GEMMs)" if gemm_mode == "bf16x3" else "f32"), "data": "synthetic (seeded clean/RIR/weights; random-init NCSN++ 27.7 M params)",
             "config": {"workload": f"blind DPS sampler step, B={B} utterances/GPU x {a.length} samples ({a.length / 16000:g} s@16 kHz), T={a.T}-step schedule, "
                                    f"NCSN++ nf=128 STFT 510/128" + (" (BASELINE.json configs[1])" if (B == 8 and a.length == 64000) else ""),
                        "batch_per_gpu": B, "length": a.length, "T": a.T, "order": 1, "op_updates_per_step": 10,
@@ -494,18 +501,31 @@ def main():
             "network_algorithmic_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
             "gather_ms": gather_ms, "gather_first_call_ms": gather_first_ms, "gather_bytes_per_rank": int(out.numel() * 4),
             "gather_backend": (a.backend if world > 1 else None),
-            # dominant kernel: the 36 batched Winograd-domain GEMMs (fp32 MFMA 32x32x2) of the 3x3 convolutions
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel<1,false,false,2,2,36> -- the batched GEMMs M[pos] = V[pos] U[pos]^T of the three-pass "
-                                                    "Winograd 3x3 convolutions (64 positions, F(6x6,3x3), on the large layers; 36, F(4x4,3x3), on the "
-                                                    "small ones; 94 % of the network's algorithmic FLOPs)",
-                         "achieved": gemm_tf, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_FP32_MFMA,
-                         "achieved_note": "EXECUTED FLOPs per launch (2 * positions * tiles * Cin * Cout) / average launch duration, HIP events on the launch stream inside "
-                                          "the timed region (every launch of every other step: an event pair costs a ~7 us dispatch bubble); <= 1 by construction",
-                         "avg_launch_ms": dom_ms[1] / n36, "launches": n36, "sampled_steps": sampled_steps, "share_of_step": gemm_ms_per_step * 1e-3 / step_s,
-                         "flops_per_launch": dom_fl.value / n36, "algorithmic_bytes_per_launch": dom_bg.value / n36,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "peak_measured_on_box": peaks.get("fp32_mfma_tflops"),
-                         "frac_of_measured_peak": (gemm_tf / peaks["fp32_mfma_tflops"]) if peaks.get("fp32_mfma_tflops") else None},
+            # dominant kernel: the batched Winograd-domain GEMMs of the 3x3 convolutions.  bf16x3 (default): every fp32 multiply-add is SIX bf16 MFMA
+            # multiply-adds -> achieved = 6 x the fp32-equivalent rate, against the bf16 matrix peak; the fp32-equivalent rate against the fp32 matrix
+            # peak is beside it (the kernel replaces v_mfma_f32_32x32x2_f32 at equal accuracy; --gemm fp32 is the reference run)
+            "roofline": ({"bound": "mfma", "kernel": "wgemm_bf16x3_kernel -- the batched GEMMs M[pos] = V[pos] U[pos]^T of the three-pass Winograd 3x3 convolutions "
+                                                     "(64 positions, F(6x6,3x3), on the large layers; 36, F(4x4,3x3), on the small ones; 94 % of the network's "
+                                                     "algorithmic FLOPs) in bf16x3 arithmetic: exact three-way bf16 split of both fp32 operands, six "
+                                                     "v_mfma_f32_32x32x16_bf16 products per 16 k, fp32 accumulate",
+                          "achieved": 6.0 * gemm_tf, "peak": PEAK_BF16_MFMA, "unit": "TFLOP/s", "frac": 6.0 * gemm_tf / PEAK_BF16_MFMA,
+                          "achieved_note": "EXECUTED bf16 MFMA FLOPs per launch (6 x 2 * positions * tiles * Cin * Cout) / average launch duration, HIP events on the "
+                                           "launch stream inside the timed region (every launch of every other step)",
+                          "fp32_equivalent_tflops": gemm_tf, "frac_of_fp32_matrix_peak": gemm_tf / PEAK_FP32_MFMA,
+                          "fp32_equivalent_note": "the same launches counted as the fp32 multiply-adds they replace (2 * positions * tiles * Cin * Cout) against the "
+                                                  "157.3 TFLOP/s fp32 matrix peak: what an exact-fp32 GEMM could reach at most on v_mfma_f32_32x32x2_f32",
+                          "hbm_side": {"achieved_GBps": dom_bg.value / (dom_ms[1] * 1e-3) / 1e9 if dom_ms[1] > 0 else 0.0, "peak_GBps": PEAK_HBM_GBS,
+                                       "frac": (dom_bg.value / (dom_ms[1] * 1e-3) / 1e9 / PEAK_HBM_GBS) if dom_ms[1] > 0 else 0.0,
+                                       "note": "algorithmic bytes (V read once, M written once, weights once) / time: the K = 128 layers of level 0 sit nearer this roofline "
+                                               "than the matrix one (192 bf16 FLOP per byte)"}}
+                         if gemm_mode == "bf16x3" else
+                         {"bound": "mfma", "kernel": "igemm_kernel<1,false,false,2,2,36> -- the batched GEMMs M[pos] = V[pos] U[pos]^T of the three-pass "
+                                                     "Winograd 3x3 convolutions on v_mfma_f32_32x32x2_f32 (--gemm fp32: the reference run)",
+                          "achieved": gemm_tf, "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_FP32_MFMA,
+                          "achieved_note": "EXECUTED FLOPs per launch (2 * positions * tiles * Cin * Cout) / average launch duration, HIP events on the launch stream inside "
+                                           "the timed region (every launch of every other step: an event pair costs a ~7 us dispatch bubble); <= 1 by construction",
+                          "peak_measured_on_box": peaks.get("fp32_mfma_tflops"),
+                          "frac_of_measured_peak": (gemm_tf / peaks["fp32_mfma_tflops"]) if peaks.get("fp32_mfma_tflops") else None}),
             # the whole 3x3 convolution (three launches) and the whole step, for context
             "conv3x3": {"algorithmic_tflops": conv_alg_tf, "algorithmic_speedup": (fl[0] / xf[0]) if xf[0] > 0 else None,
                         "note": "direct-convolution FLOPs (2*M*N*9*Cin) / time of the three-launch group; the Winograd forms execute 64/(36*9) "
@@ -537,6 +557,13 @@ def main():
                                          "steps run right after the timed region (shares are of THIS pass's time); value, ms_per_step and roofline from the timed region"},
             "peaks": {"nominal": {"fp32_mfma_tflops": PEAK_FP32_MFMA, "hbm_GBps": PEAK_HBM_GBS}, "measured_on_this_box": peaks},
         }
+        res["roofline"].update({"avg_launch_ms": dom_ms[1] / n36, "launches": n36, "sampled_steps": sampled_steps, "share_of_step": gemm_ms_per_step * 1e-3 / step_s,
+                                "flops_per_launch_fp32_equivalent": dom_fl.value / n36, "algorithmic_bytes_per_launch": dom_bg.value / n36,
+                                "traffic": traffic, "traffic_source": traffic_src,
+                                # the whole three-launch convolution against the bytes a fused form would move: what the three-pass structure costs
+                                "traffic_conv_group": traffic_group, "fused_form_bytes_per_conv": by[0] / max(1, ln[0]),
+                                "traffic_conv_group_over_fused_form": (traffic_group / (by[0] / max(1, ln[0]))) if (traffic_group and ln[0]) else None})
+        res["config"]["gemm"] = gemm_mode
         if conc is not None:
             res["concurrent_sub_batches"] = conc
         if world == 1 and not a.no_cpu_baseline:

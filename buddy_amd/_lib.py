@@ -67,6 +67,7 @@ _SIGS = {
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_fir_resample2": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "buddy_ncsnpp_set_fir": (C.c_int, [C.c_void_p, C.c_int]),
+    "buddy_ncsnpp_set_gemm": (C.c_int, [C.c_void_p, C.c_int]),
     "buddy_ncsnpp_set_attention": (C.c_int, [C.c_void_p, C.c_int]),
     "buddy_flash_attention_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "buddy_flash_attention_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,

@@ -303,6 +303,7 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
   return finish();
 }
 
+int buddy_ncsnpp_set_gemm(void* h, int mode) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_set_gemm((Net*)h, mode); }
 int buddy_ncsnpp_set_attention(void* h, int mode) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_set_attention((Net*)h, mode); }
 int buddy_ncsnpp_set_fir(void* h, int fir) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_set_fir((Net*)h, fir); }
 int buddy_fir_resample2(const float* x, float* y, int B, int H, int W, int C, int up, float scale, int accumulate, void* stream) {

@@ -55,7 +55,8 @@ struct W4Gn { Src2 x; const float* stats; const float* gamma; const float* beta;
 bool wino4_supported(const IgemmParams& p);
 void wino4_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats);
 int wino4_stat_chunks(const IgemmParams& p);
-void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st, const W4Gn* gn = nullptr, double* stat = nullptr);
+void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st, const W4Gn* gn = nullptr, double* stat = nullptr,
+                  const void* U4x = nullptr);   // U4x: the same weights in the bf16x3 stage image (wgemm.hip) -> the GEMM pass runs in bf16x3
 void wino4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_host);
 // Winograd F(6x6,3x3) in three passes (wino6.hip): weights U6[64][Cout][Cin], 64 * tiles * (Cin + N) floats of scratch, any H, W >= 6 (tiles
 // overhang); same fusions.  wino6_pays: executed work incl. the overhang is at least 10 % below F(4x4,3x3)'s (the large layers).
@@ -67,7 +68,7 @@ double wino6_exec_ratio(const IgemmParams& p);
 //   bwd_gn (with stat) -- data-gradient convolutions: the output is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); the partials are the two sums
 //           of that GroupNorm's backward, (dxhat, dxhat * xhat), instead of (sum, sum of squares)
 void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn = nullptr, double* stat = nullptr,
-                  const W4Gn* bwd_gn = nullptr);
+                  const W4Gn* bwd_gn = nullptr, const void* U6x = nullptr);
 void wino6_transform_weights(const float* wt_host, int Cout, int Cin, float* U6_host);
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin, double exec_ratio = 4.0 / 9.0);
 void igemm_prof_enable(int level);   // 0 off, 1 the dominant kernel only (36 batched Winograd-domain GEMMs), 2 every instrumented class

@@ -13,6 +13,7 @@ const char* last_error();
 long long param_count(const NetCfg& c);
 int net_create(const float* host_params, long long n, const NetCfg& cfg, Net** out);
 void net_destroy(Net* N);
+int net_set_gemm(Net* N, int mode);        // Winograd-domain GEMM arithmetic: 1 bf16x3 exact split (default), 0 fp32 MFMA
 int net_set_attention(Net* N, int mode);   // 0 flash fp32 (default), 1 bf16 / 2 f16 MFMA operands, 3 materialised T x T
 int net_set_fir(Net* N, int fir);     // fir=True resampling (reference up_or_down_sampling.py:195-257), set before the first forward
 int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes);

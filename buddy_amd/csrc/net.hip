@@ -108,7 +108,8 @@ struct Arena {
 struct ConvW { int cin = 0, cout = 0, taps = 0; float* wf = nullptr; float* wb = nullptr; float* bias = nullptr;
                float* uf = nullptr; float* ub = nullptr;      // uf/ub: Winograd F(2x2,3x3)-domain weights (forward / data-gradient)
                float* uf4 = nullptr; float* ub4 = nullptr;    // F(4x4,3x3)-domain weights [36][Cout][Cin]
-               float* uf6 = nullptr; float* ub6 = nullptr; }; // F(6x6,3x3)-domain weights [64][Cout][Cin]
+               float* uf6 = nullptr; float* ub6 = nullptr;    // F(6x6,3x3)-domain weights [64][Cout][Cin]
+               void* uf4x = nullptr; void* ub4x = nullptr; void* uf6x = nullptr; void* ub6x = nullptr; };   // ... in the bf16x3 stage image (wgemm.hip)
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResW { GNW gn0, gn1; ConvW c0, c1, c2; bool has_c2 = false; int cin = 0, cout = 0, dense_off = 0; };
 struct AttnW { GNW gn; float* Wt[4]; float* Wn[4]; float* b[4]; int C = 0; };
@@ -145,6 +146,8 @@ struct Net {
 
   int rsv_B = 0, rsv_L = 0, rsv_vjp = -1;   // shape the arena was last sized for (the sizing dry run is skipped while it still fits)
   int attn_mode = 0;           // see attn_mode_from_env()
+  int gemm_mode = 1;           // Winograd-domain GEMM arithmetic: 1 = bf16x3 (exact three-way split, default), 0 = fp32 MFMA; BUDDY_GEMM=fp32|bf16x3
+  unsigned char* dpacked3 = nullptr;   // bf16x3 stage images of the F(4x4) / F(6x6) weights
   bool fir = false;            // fir=True: FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257)
   float* w4_scratch = nullptr; size_t w4_cap = 0, w4_need = 0;   // V / M buffers of the three-pass F(4x4,3x3) convolutions (floats)
   bool dry() const { return arena.dry; }
@@ -207,6 +210,7 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   Net* N = new Net();
   N->cfg = cfg;
   N->attn_mode = attn_mode_from_env();
+  if (const char* g = getenv("BUDDY_GEMM")) N->gemm_mode = std::string(g) == "fp32" ? 0 : 1;
   N->specs = build_specs(cfg);
   if (n != param_count(cfg)) { set_error("parameter blob size mismatch"); delete N; return BUDDY_ERR_ARG; }
   if (cfg.n_fft % 2) { set_error("n_fft must be even"); delete N; return BUDDY_ERR_ARG; }
@@ -233,6 +237,14 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   Packer pk;
   struct Fix { float** dst; long long off; };
   std::vector<Fix> fixes;
+  struct Pack3 { float** src; void** dst; int P, cout, cin; size_t off; };   // bf16x3 images, built on the device after the upload
+  std::vector<Pack3> pack3;
+  size_t pack3_bytes = 0;
+  auto want3 = [&](float** src, void** dst, int P, int cout, int cin) {
+    if (!wgemm_supported(cout, cin)) return;
+    pack3.push_back({src, dst, P, cout, cin, pack3_bytes});
+    pack3_bytes += (wgemm_packed_bytes(P, cout, cin) + 255) / 256 * 256;
+  };
   auto raw = [&](const std::string& name) -> float* {
     for (size_t i = 0; i < N->specs.size(); ++i) if (N->specs[i].name == name) return N->dparams + doff[i];
     return nullptr;
@@ -258,11 +270,11 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
       wino_transform_weights(wfv.data(), cout, cin, u.data()); packed(&c.uf, u);
       wino_transform_weights(wbv.data(), cin, cout, u.data()); packed(&c.ub, u);
       std::vector<float> u4((size_t)36 * cin * cout);
-      wino4_transform_weights(wfv.data(), cout, cin, u4.data()); packed(&c.uf4, u4);
-      wino4_transform_weights(wbv.data(), cin, cout, u4.data()); packed(&c.ub4, u4);
+      wino4_transform_weights(wfv.data(), cout, cin, u4.data()); packed(&c.uf4, u4); want3(&c.uf4, &c.uf4x, 36, cout, cin);
+      wino4_transform_weights(wbv.data(), cin, cout, u4.data()); packed(&c.ub4, u4); want3(&c.ub4, &c.ub4x, 36, cin, cout);
       std::vector<float> u6((size_t)64 * cin * cout);
-      wino6_transform_weights(wfv.data(), cout, cin, u6.data()); packed(&c.uf6, u6);
-      wino6_transform_weights(wbv.data(), cin, cout, u6.data()); packed(&c.ub6, u6);
+      wino6_transform_weights(wfv.data(), cout, cin, u6.data()); packed(&c.uf6, u6); want3(&c.uf6, &c.uf6x, 64, cout, cin);
+      wino6_transform_weights(wbv.data(), cin, cout, u6.data()); packed(&c.ub6, u6); want3(&c.ub6, &c.ub6x, 64, cin, cout);
     }
   };
   auto load_res = [&](int cin, int cout, bool resample) {
@@ -366,16 +378,23 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   HIPCHK(hipMalloc(&N->dpacked, pk.buf.size() * 4));
   HIPCHK(hipMemcpy(N->dpacked, pk.buf.data(), pk.buf.size() * 4, hipMemcpyHostToDevice));
   for (auto& f : fixes) *f.dst = N->dpacked + f.off;
+  if (pack3_bytes) {     // the Winograd-domain weights once more, split into three bf16 planes in the GEMM's LDS stage order
+    HIPCHK(hipMalloc(&N->dpacked3, pack3_bytes));
+    for (auto& j : pack3) { *j.dst = N->dpacked3 + j.off; wgemm_pack_weights(*j.src, *j.dst, j.P, j.cout, j.cin, nullptr); }
+    HIPCHK(hipDeviceSynchronize());
+  }
   *out = N;
   return BUDDY_OK;
 }
 
 int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 3) { set_error("attention mode must be 0..3"); return BUDDY_ERR_ARG; } N->attn_mode = mode; N->rsv_vjp = -1; return BUDDY_OK; }
+int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 1) { set_error("gemm mode must be 0 (fp32 MFMA) or 1 (bf16x3)"); return BUDDY_ERR_ARG; } N->gemm_mode = mode; return BUDDY_OK; }
 int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; return BUDDY_OK; }
 void net_destroy(Net* N) {
   if (!N) return;
   if (N->dparams) (void)hipFree(N->dparams);
   if (N->dpacked) (void)hipFree(N->dpacked);
+  if (N->dpacked3) (void)hipFree(N->dpacked3);
   if (N->w4_scratch) (void)hipFree(N->w4_scratch);
   if (N->arena.base) (void)hipFree(N->arena.base);
   if (N->inv_env) (void)hipFree(N->inv_env);
@@ -425,6 +444,8 @@ static int conv3(Net* N, const Conv3& c) {
   const float* U = c.w ? (c.dgrad ? c.w->ub : c.w->uf) : nullptr;
   const float* U4 = c.w ? (c.dgrad ? c.w->ub4 : c.w->uf4) : nullptr;
   const float* U6 = c.w ? (c.dgrad ? c.w->ub6 : c.w->uf6) : nullptr;
+  const void* U4x = (c.w && N->gemm_mode == 1) ? (c.dgrad ? c.w->ub4x : c.w->uf4x) : nullptr;
+  const void* U6x = (c.w && N->gemm_mode == 1) ? (c.dgrad ? c.w->ub6x : c.w->uf6x) : nullptr;
   const W4Gn* gn = c.gn; float* gn_tmp = c.gn_tmp; Tens* stat_out = c.stat_out; const W4Gn* bwd_gn = c.bwd_gn; const bool direct = c.direct;
   // BUDDY_CONV = direct | wino2 | wino4 | (default) three-pass F(6x6,3x3) on the large layers, three-pass F(4x4,3x3) where the shape allows,
   // else fused F(2x2,3x3), else direct
@@ -467,7 +488,7 @@ static int conv3(Net* N, const Conv3& c) {
     const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;
     const double xr = wino6_exec_ratio(p);
     igemm_prof_record(p, 9, 1, N->st, true, xr);
-    launch_wino6(p, U6, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, (stat && want_bwd) ? bwd_gn : nullptr);
+    launch_wino6(p, U6, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, (stat && want_bwd) ? bwd_gn : nullptr, U6x);
     igemm_prof_record(p, 9, 1, N->st, false, xr);
     if (stat && (want_bwd || direct)) return sc;
     if (stat && stat_out) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
@@ -476,7 +497,7 @@ static int conv3(Net* N, const Conv3& c) {
     const int sc = (stat_out != nullptr && fuse_gn) ? wino4_stat_chunks(p) : 0;
     const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;     // N->partial holds 256 x 1024 (chunk, channel) pairs per utterance
     igemm_prof_record(p, 9, 1, N->st, true, 0.25);
-    launch_wino4(p, U4, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr);
+    launch_wino4(p, U4, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, U4x);
     igemm_prof_record(p, 9, 1, N->st, false, 0.25);
     if (stat) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
   } else if (use_wino && U != nullptr && wino_supported(p)) {

@@ -205,7 +205,7 @@ void wino4_scratch(const IgemmParams& p, long long* v_floats, long long* m_float
   *v_floats = 36 * Mt * p.Cin; *m_floats = 36 * Mt * p.N;
 }
 
-void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat) {
+void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat, const void* U4x) {
   const int B = p.M / (p.H * p.W);
   const long long Mt = (long long)p.M / 16;
   const int plevel = igemm_prof_level();
@@ -230,7 +230,8 @@ void launch_wino4(const IgemmParams& p, const float* U4, float* V, float* Mb, hi
     g.M = (int)Mc; g.N = p.N; g.H = 1; g.W = 1; g.rows_per_batch = 1; g.alpha = 1.f; g.out_scale = 1.f;
     g.tag = 36;
     igemm_prof_enable(0);
-    launch_igemm(g, 1, false, false, 36, st);
+    if (U4x != nullptr && wgemm_supported(p.N, p.Cin)) launch_wgemm_bf16x3(V, U4x, Mb, Mc, p.N, p.Cin, 36, st);
+    else launch_igemm(g, 1, false, false, 36, st);
     igemm_prof_enable(plevel);
     if (prof || prof_gemm) (void)hipEventRecord(ev[2], st);
     const dim3 go((unsigned)((Mc * (p.N / 4) + 255) / 256));

@@ -302,7 +302,8 @@ double wino6_exec_ratio(const IgemmParams& p) {               // executed / dire
   return 64.0 * (double)g.Mt / (9.0 * (double)p.M);
 }
 
-void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat, const W4Gn* bwd_gn) {
+void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat, const W4Gn* bwd_gn,
+                  const void* U6x) {
   const W6Geo gi = geometry(p, p.Cin), go = geometry(p, p.N);
   const long long Mt = gi.Mt;
   const int plevel = igemm_prof_level();
@@ -322,7 +323,8 @@ void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hi
   g.M = (int)Mt; g.N = p.N; g.H = 1; g.W = 1; g.rows_per_batch = 1; g.alpha = 1.f; g.out_scale = 1.f;
   g.tag = 36;                                                 // the Winograd-domain batched GEMM instantiation (36 or 64 positions)
   igemm_prof_enable(0);
-  launch_igemm(g, 1, false, false, 64, st);
+  if (U6x != nullptr && wgemm_supported(p.N, p.Cin)) launch_wgemm_bf16x3(V, U6x, Mb, Mt, p.N, p.Cin, 64, st);
+  else launch_igemm(g, 1, false, false, 64, st);
   igemm_prof_enable(plevel);
   if (prof || prof_gemm) (void)hipEventRecord(ev[2], st);
   const int TL = out_walk(go), per = go.TPB * TL, chunks = (go.TH * go.TW + per - 1) / per;

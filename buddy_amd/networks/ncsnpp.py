@@ -64,13 +64,14 @@ class _NetFn(torch.autograd.Function):
 
 class NCSNppTime(nn.Module):
     ATTENTION_MODES = {"flash": 0, "bf16": 1, "f16": 2, "matrix": 3}
+    GEMM_MODES = {"fp32": 0, "bf16x3": 1}
 
     def __init__(self, stft=None, nonlinearity="swish", nf=128, ch_mult=(1, 2, 2, 2), num_res_blocks=1,
                  attn_resolutions=(0,), resamp_with_conv=True, time_conditional=True, fir=False,
                  fir_kernel=(1, 3, 3, 1), skip_rescale=True, resblock_type="biggan", progressive="output_skip",
                  progressive_input="input_skip", progressive_combine="sum", init_scale=0.0, fourier_scale=16,
                  image_size=256, embedding_type="fourier", input_channels=2, spatial_channels=1, dropout=0.0,
-                 centered=True, discriminative=False, attention=None, **kwargs):
+                 centered=True, discriminative=False, attention=None, gemm=None, **kwargs):
         super().__init__()
         self._init_kwargs = dict(stft=stft, nonlinearity=nonlinearity, nf=nf, ch_mult=ch_mult, num_res_blocks=num_res_blocks,
                                  attn_resolutions=attn_resolutions, resamp_with_conv=resamp_with_conv, time_conditional=time_conditional,
@@ -78,7 +79,7 @@ class NCSNppTime(nn.Module):
                                  progressive=progressive, progressive_input=progressive_input, progressive_combine=progressive_combine,
                                  init_scale=init_scale, fourier_scale=fourier_scale, image_size=image_size, embedding_type=embedding_type,
                                  input_channels=input_channels, spatial_channels=spatial_channels, dropout=dropout, centered=centered,
-                                 discriminative=discriminative, attention=attention)
+                                 discriminative=discriminative, attention=attention, gemm=gemm)
         assert stft is not None, "stft must be provided"          # reference ncsnpp.py:459
         unsupported = []
         if nonlinearity != "swish": unsupported.append("nonlinearity")
@@ -107,6 +108,11 @@ class NCSNppTime(nn.Module):
         if attention is not None and attention not in self.ATTENTION_MODES:
             raise NotImplementedError(f"attention must be one of {sorted(self.ATTENTION_MODES)}")
         self.attention = attention
+        # arithmetic of the Winograd-domain GEMMs (build extension): None = library default (BUDDY_GEMM, else "bf16x3": exact three-way bf16
+        # split of the fp32 operands, fp32-equal accuracy); "fp32" = v_mfma_f32_32x32x2_f32
+        if gemm is not None and gemm not in self.GEMM_MODES:
+            raise NotImplementedError(f"gemm must be one of {sorted(self.GEMM_MODES)}")
+        self.gemm = gemm
         self.fir = bool(fir)            # FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257); no parameters
         self._specs = module_specs(self.nf, self.ch_mult, self.num_res_blocks)
         # parameter containers under the reference names
@@ -166,6 +172,8 @@ class NCSNppTime(nn.Module):
                 _lib.check(lib.buddy_ncsnpp_set_fir(h, 1))
             if self.attention is not None:
                 _lib.check(lib.buddy_ncsnpp_set_attention(h, self.ATTENTION_MODES[self.attention]))
+            if self.gemm is not None:
+                _lib.check(lib.buddy_ncsnpp_set_gemm(h, self.GEMM_MODES[self.gemm]))
             self._handle = h
         return self._handle
 

@@ -148,6 +148,10 @@ int buddy_ncsnpp_set_fir(void* handle, int fir);
 /* attention core of a network handle: 0 = online-softmax kernels, fp32 operands (default); 1 / 2 = the same with bf16 / f16 MFMA operands (opt-in
  * fast mode, fp32 accumulate + fp32 softmax); 3 = materialised T x T matrix.  Initial value from BUDDY_ATTN = flash | bf16 | f16 | matrix. */
 int buddy_ncsnpp_set_attention(void* handle, int mode);
+/* Arithmetic of the Winograd-domain GEMMs of the 3x3 convolutions (94 % of the FLOPs): 1 (default) = "bf16x3" -- every fp32 operand split
+ * exactly into three bf16 terms, six bf16 MFMA products, fp32 accumulation: the fp32 kernel's accuracy against float64 (unit test) at
+ * 2.67x fewer matrix-pipe cycles; 0 = v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains).  Env BUDDY_GEMM=fp32|bf16x3 sets the default. */
+int buddy_ncsnpp_set_gemm(void* handle, int mode);
 
 /* single-head attention over T tokens without the T x T matrix (online softmax, fp32 MFMA), token-major q, k, v, O [B][T][C], C in {64,128,256}:
  * O = softmax(scale * q k^T) v, lse [B][T] = row log-sum-exp; replaces the einsum / softmax / einsum of AttnBlockpp.forward

@@ -18,13 +18,13 @@ def rel(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
-def build(nf, n_fft, hop, seed, fir=False, attention=None):
+def build(nf, n_fft, hop, seed, fir=False, attention=None, gemm=None):
     from buddy_amd.config import load_yaml, CONF_DIR, AttrDict
     from buddy_amd.networks.ncsnpp import NCSNppTime
     from buddy_amd.synth import synth_state_dict
     cfg = load_yaml(os.path.join(CONF_DIR, "network", "ncsnpp.yaml"))
     cfg.pop("_target_")
-    cfg.update(nf=nf, fir=fir, attention=attention, stft=AttrDict(n_fft=n_fft, hop_length=hop, center=True))
+    cfg.update(nf=nf, fir=fir, attention=attention, gemm=gemm, stft=AttrDict(n_fft=n_fft, hop_length=hop, center=True))
     net = NCSNppTime(**cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(seed, nf).items()})
     return net.cuda().eval()
@@ -110,3 +110,18 @@ def test_batch_independence_and_determinism():
         y1 = torch.cat([net(x[b:b + 1], cn[b:b + 1]) for b in range(4)])
     assert torch.equal(y, y2)
     assert torch.equal(y, y1)
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "fp32"])
+def test_gemm_modes_vs_golden(golden, gemm):
+    """NCSNppTime(gemm=...): the Winograd-domain GEMMs in bf16x3 arithmetic (default: exact three-way bf16 split, six bf16 MFMA products) and on
+    the fp32 MFMA hold the SAME tolerance against the full-width reference fixture; both errors are printed side by side."""
+    g = golden("net_full")
+    nf, n_fft, hop, L, B, seed = [int(v) for v in g["meta"]]
+    net = build(nf, n_fft, hop, seed, gemm=gemm)
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = net(x, torch.from_numpy(g["cnoise"]).cuda())
+    gx, = torch.autograd.grad(y, x, torch.from_numpy(g["cot"]).cuda())
+    ey, eg = rel(y.detach().cpu().numpy(), g["y"]), rel(gx.cpu().numpy(), g["vjp"])
+    print(f"gemm={gemm}: forward {ey:.2e} vjp {eg:.2e}")
+    assert ey < TOL and eg < TOL

@@ -5,8 +5,9 @@ w4_output_kernel); their counters are summed and divided by the number of convol
 bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> doubled here."""
 import csv, hashlib, json, os, sys
 
-GROUP = ("input transform (w6_input_kernel, w4_input_kernel)", "2, 2, 36>", "output transform (w6_output_kernel, w4_output_kernel)")
-MATCH = {GROUP[0]: ("w6_input_kernel", "w4_input_kernel"), GROUP[1]: ("2, 2, 36>",), GROUP[2]: ("w6_output_kernel", "w4_output_kernel")}
+GROUP = ("input transform (w6_input_kernel, w4_input_kernel)", "batched GEMM (wgemm_bf16x3_kernel / igemm_kernel<...,36>)",
+         "output transform (w6_output_kernel, w4_output_kernel)")
+MATCH = {GROUP[0]: ("w6_input_kernel", "w4_input_kernel"), GROUP[1]: ("2, 2, 36>", "wgemm_bf16x3_kernel"), GROUP[2]: ("w6_output_kernel", "w4_output_kernel")}
 
 
 def per_kernel(path, counter):
@@ -22,12 +23,13 @@ def per_kernel(path, counter):
 
 f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 nconv = f[GROUP[0]][1]
-out = {"kernel_group": "3x3 convolution = input transform + igemm_kernel<1,false,false,2,2,36> (64 / 36 batched GEMMs: F(6x6,3x3) / F(4x4,3x3)) + output transform",
+out = {"kernel_group": "3x3 convolution = input transform + batched Winograd-domain GEMM (64 / 36 positions: F(6x6,3x3) / F(4x4,3x3); wgemm_bf16x3_kernel, or "
+                       "igemm_kernel<1,false,false,2,2,36> with BUDDY_GEMM=fp32) + output transform",
        "convolutions_in_fetch_pass": nconv, "convolutions_in_write_pass": w[GROUP[0]][1],
        "per_kernel_bytes_per_convolution": {k: {"fetch": 2 * f[k][0] * 1024 / nconv, "write": w[k][0] * 1024 / max(1, w[GROUP[0]][1])} for k in GROUP},
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --also-concurrent 0`; FETCH_SIZE x2 (gfx950 correction)"}
 _h = hashlib.sha1()
-for _f in ("igemm.hip", "wino4.hip", "wino6.hip", "common.h"):        # same stamp as bench.py conv_source_stamp(): the summary is tied to these kernels
+for _f in ("igemm.hip", "wgemm.hip", "wino4.hip", "wino6.hip", "common.h"):        # same stamp as bench.py conv_source_stamp(): the summary is tied to these kernels
     _h.update(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "buddy_amd", "csrc", _f), "rb").read())
 out["source_stamp"] = _h.hexdigest()[:12]
 out["fetch_bytes_per_launch"] = sum(v["fetch"] for v in out["per_kernel_bytes_per_convolution"].values())
