@@ -19,6 +19,7 @@
 //  * the accumulator is C^T (weights as the MFMA's first operand): a lane holds 4 consecutive output channels of one row -> 16-byte stores.
 #include "common.h"
 #include <cstdint>
+#include <cstdlib>
 
 namespace buddy {
 namespace {
@@ -81,7 +82,8 @@ struct WgemmArgs {
   long long sV, sM;                                            // strides between positions (floats)
 };
 
-__global__ __launch_bounds__(WNT, 2) void wgemm_bf16x3_kernel(const WgemmArgs a) {
+template <int OCC, int PF>
+__global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // XCD-aware order (hardware places block b on XCD b % 8): each XCD gets a contiguous range of logical tiles, the column blocks of one row
@@ -113,11 +115,11 @@ __global__ __launch_bounds__(WNT, 2) void wgemm_bf16x3_kernel(const WgemmArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-  float4 ra[4];
+  float4 ra[PF][4];                                           // ring of PF stages of A in flight (PF = 2: the loads of stage s + 2 are issued in stage s)
   u32x4 rb[6];
-  auto loadA = [&](int s) {
+  auto loadA = [&](int s, int slot) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(Ap + s * WKS + 4 * j);
+    for (int j = 0; j < 4; ++j) ra[slot][j] = *reinterpret_cast<const float4*>(Ap + s * WKS + 4 * j);
   };
   auto loadB = [&](int s) {
 #pragma unroll
@@ -128,13 +130,19 @@ __global__ __launch_bounds__(WNT, 2) void wgemm_bf16x3_kernel(const WgemmArgs a)
     for (int j = 0; j < 6; ++j) Bs[buf * (STAGE_BYTES / 16) + j * WNT] = rb[j];
   };
 
-  loadA(0);
+  loadA(0, 0);
   loadB(0);
+  if (PF == 2 && S > 1) loadA(1, 1);
   storeB(0);
   __syncthreads();
   for (int s = 0; s < S; ++s) {
-    const float4 ca[4] = {ra[0], ra[1], ra[2], ra[3]};
-    if (s + 1 < S) { loadA(s + 1); loadB(s + 1); }
+    const float4 ca[4] = {ra[0][0], ra[0][1], ra[0][2], ra[0][3]};
+    if (PF == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ra[0][j] = ra[1][j];
+      if (s + 2 < S) loadA(s + 2, 1);
+      if (s + 1 < S) loadB(s + 1);
+    } else if (s + 1 < S) { loadA(s + 1, 0); loadB(s + 1); }
     const unsigned char* Bcur = smem + (s & 1) * STAGE_BYTES + lane * 16;
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
@@ -188,7 +196,12 @@ void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt,
   a.Mt = (int)Mt; a.Cin = Cin; a.Cout = Cout; a.S = Cin / WKS; a.NB = Cout / WBN;
   a.sV = Mt * Cin; a.sM = Mt * Cout;
   const dim3 grid((unsigned)(cdiv((int)Mt, WBM) * a.NB), 1, (unsigned)P);
-  hipLaunchKernelGGL(wgemm_bf16x3_kernel, grid, dim3(WNT), 0, st, a);
+  // variants measured on one box (profiles/README.md r03): 3 workgroups per CU (<= 168 VGPRs) +2...4 % over 2; a second stage of A in flight
+  // (PF = 2: 190 VGPRs) -3 %; both at once spills.  BUDDY_WGEMM_VARIANT=2|3 keep the losers runnable.
+  static const int variant = getenv("BUDDY_WGEMM_VARIANT") ? atoi(getenv("BUDDY_WGEMM_VARIANT")) : 1;
+  if (variant == 2) hipLaunchKernelGGL((wgemm_bf16x3_kernel<2, 1>), grid, dim3(WNT), 0, st, a);
+  else if (variant == 3) hipLaunchKernelGGL((wgemm_bf16x3_kernel<2, 2>), grid, dim3(WNT), 0, st, a);
+  else hipLaunchKernelGGL((wgemm_bf16x3_kernel<3, 1>), grid, dim3(WNT), 0, st, a);
 }
 
 }  // namespace buddy

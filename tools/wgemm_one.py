@@ -1,0 +1,18 @@
+"""ONE shape of the bf16x3 Winograd-domain GEMM (csrc/wgemm.hip), a few launches (for rocprofv3 --pmc passes and kernel experiments).
+usage: python tools/wgemm_one.py Mt N K [positions] [reps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from buddy_amd import _lib
+lib = _lib.require_gpu()
+P = _lib.ptr; S = _lib.stream_ptr
+Mt, N, K = (int(v) for v in sys.argv[1:4]); nb = int(sys.argv[4]) if len(sys.argv) > 4 else 64; reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+A = torch.randn(nb, Mt, K, device="cuda"); Bt = torch.randn(nb, N, K, device="cuda"); Cm = torch.empty(nb, Mt, N, device="cuda")
+U3 = torch.empty(nb * N * K * 6 // 4, dtype=torch.int32, device="cuda")
+_lib.check(lib.buddy_wgemm_pack_weights(P(Bt), U3.data_ptr(), nb, N, K, S()))
+f = lambda: _lib.check(lib.buddy_gemm_winograd_domain_bf16x3(P(A), U3.data_ptr(), P(Cm), Mt, N, K, nb, S()))
+f(); f(); torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(reps): f()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
+print(f"wgemm v{os.environ.get('BUDDY_WGEMM_VARIANT', '0')} P={nb} Mt={Mt} N={N} K={K}: {dt*1e3:.3f} ms {2.0*nb*Mt*N*K/dt/1e12:.1f} TF-eq {12.0*nb*Mt*N*K/dt/1e12:.0f} TF bf16 "
+      f"{(Mt*K+Mt*N)*nb*4/dt/1e9:.0f} GB/s", flush=True)
