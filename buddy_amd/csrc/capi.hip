@@ -145,6 +145,15 @@ int buddy_gemm_winograd_domain_bf16x3(const float* V, const void* U3, float* Mo,
   return finish();
 }
 
+int buddy_gemm_bf16x3(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W3, float* Cm, int ldC, long long M, int N, int K,
+                      const float* bias_n, float alpha, int accumulate, void* stream) {
+  if (!A0 || !W3 || !Cm || M < 1 || !wgemm_general_supported(N, K, A1 ? C0 : 0, ldA0, A1 ? ldA1 : 0, ldC, A0, A1, Cm, bias_n)) {
+    set_error("bad arguments (N % 128, K % 32, C0 % 32, 16-byte aligned rows)"); return BUDDY_ERR_ARG;
+  }
+  launch_wgemm_bf16x3_general(A0, ldA0, A1, ldA1, C0, W3, Cm, ldC, M, N, K, bias_n, alpha, accumulate, (hipStream_t)stream);
+  return finish();
+}
+
 int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, void* stream) {
   if (!x || !wt || !y || Cin % 4) { set_error("bad conv arguments"); return BUDDY_ERR_ARG; }
   IgemmParams p; std::memset(&p, 0, sizeof(p));

@@ -38,6 +38,9 @@ bool wgemm_supported(int Cout, int Cin);
 size_t wgemm_packed_bytes(int P, int Cout, int Cin);
 void wgemm_pack_weights(const float* U_dev, void* U3_dev, int P, int Cout, int Cin, hipStream_t st);
 void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st);
+bool wgemm_general_supported(int N, int K, int C0, int ldA0, int ldA1, int ldC, const void* A0, const void* A1, const void* C, const void* bias);
+void launch_wgemm_bf16x3_general(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W3, float* C, int ldC, long long M, int N, int K,
+                                 const float* bias_n, float alpha, int accumulate, hipStream_t st);
 // Winograd F(2x2,3x3) variant of the 3x3 conv (wino.hip): same IgemmParams, pre-transformed weights U[Cin/16][16][Cout][16]
 bool wino_supported(const IgemmParams& p);
 void launch_wino(const IgemmParams& p, const float* Uw, hipStream_t st);

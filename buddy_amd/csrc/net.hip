@@ -13,6 +13,7 @@
 #include <functional>
 #include <string>
 #include <vector>
+#include <unordered_map>
 
 namespace buddy {
 
@@ -148,6 +149,7 @@ struct Net {
   int attn_mode = 0;           // see attn_mode_from_env()
   int gemm_mode = 1;           // Winograd-domain GEMM arithmetic: 1 = bf16x3 (exact three-way split, default), 0 = fp32 MFMA; BUDDY_GEMM=fp32|bf16x3
   unsigned char* dpacked3 = nullptr;   // bf16x3 stage images of the F(4x4) / F(6x6) weights
+  std::unordered_map<const float*, const void*> w3;   // 1x1 / NIN weights [N][K] (fp32, device) -> their bf16x3 stage image
   bool fir = false;            // fir=True: FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257)
   float* w4_scratch = nullptr; size_t w4_cap = 0, w4_need = 0;   // V / M buffers of the three-pass F(4x4,3x3) convolutions (floats)
   bool dry() const { return arena.dry; }
@@ -238,6 +240,7 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   struct Fix { float** dst; long long off; };
   std::vector<Fix> fixes;
   struct Pack3 { float** src; void** dst; int P, cout, cin; size_t off; };   // bf16x3 images, built on the device after the upload
+  std::vector<std::pair<float**, std::pair<int, int>>> plain3;               // 1x1 / NIN weights [N][K]: registered in N->w3 by pointer
   std::vector<Pack3> pack3;
   size_t pack3_bytes = 0;
   auto want3 = [&](float** src, void** dst, int P, int cout, int cin) {
@@ -294,6 +297,7 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
       R.c2.cin = cin; R.c2.cout = cout; R.c2.taps = 1; R.c2.bias = raw(p + "Conv_2.bias");
       R.c2.wf = raw(p + "Conv_2.weight");                                  // [cout][cin] already k-contiguous
       packed(&R.c2.wb, transpose2(host(p + "Conv_2.weight"), cout, cin));  // [cin][cout]
+      plain3.push_back({&R.c2.wf, {cout, cin}}); plain3.push_back({&R.c2.wb, {cin, cout}});
     }
     ++idx;
   };
@@ -332,6 +336,7 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
     for (int k = 0; k < 4; ++k) {
       a.Wn[k] = raw(p + "NIN_" + std::to_string(k) + ".W"); a.b[k] = raw(p + "NIN_" + std::to_string(k) + ".b");
       packed(&a.Wt[k], transpose2(host(p + "NIN_" + std::to_string(k) + ".W"), ch, ch));
+      plain3.push_back({&a.Wt[k], {ch, ch}}); plain3.push_back({&a.Wn[k], {ch, ch}});
     }
     ++idx;
   }
@@ -378,9 +383,20 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   HIPCHK(hipMalloc(&N->dpacked, pk.buf.size() * 4));
   HIPCHK(hipMemcpy(N->dpacked, pk.buf.data(), pk.buf.size() * 4, hipMemcpyHostToDevice));
   for (auto& f : fixes) *f.dst = N->dpacked + f.off;
+  std::vector<size_t> plain_off;
+  for (auto& j : plain3) {
+    plain_off.push_back(pack3_bytes);
+    if (wgemm_supported(j.second.first, j.second.second)) pack3_bytes += (wgemm_packed_bytes(1, j.second.first, j.second.second) + 255) / 256 * 256;
+  }
   if (pack3_bytes) {     // the Winograd-domain weights once more, split into three bf16 planes in the GEMM's LDS stage order
     HIPCHK(hipMalloc(&N->dpacked3, pack3_bytes));
     for (auto& j : pack3) { *j.dst = N->dpacked3 + j.off; wgemm_pack_weights(*j.src, *j.dst, j.P, j.cout, j.cin, nullptr); }
+    for (size_t i = 0; i < plain3.size(); ++i) {
+      const int n = plain3[i].second.first, k = plain3[i].second.second;
+      if (!wgemm_supported(n, k) || *plain3[i].first == nullptr) continue;
+      wgemm_pack_weights(*plain3[i].first, N->dpacked3 + plain_off[i], 1, n, k, nullptr);
+      N->w3[*plain3[i].first] = N->dpacked3 + plain_off[i];
+    }
     HIPCHK(hipDeviceSynchronize());
   }
   *out = N;
@@ -509,12 +525,24 @@ static int conv3(Net* N, const Conv3& c) {
   }
   return 0;
 }
+// a plain row-major GEMM against a registered [N][K] weight (1x1 convolution, NIN) in bf16x3 arithmetic when the handle's mode asks for it
+static bool try_wgemm(Net* N, const IgemmParams& p) {
+  if (N->gemm_mode != 1 || p.bias_m || p.bias_bn || p.res_mode || p.out_scale != 1.f || p.sA || p.sC) return false;
+  const auto it = N->w3.find(p.Bt);
+  if (it == N->w3.end() || p.ldB != p.Cin) return false;
+  if (!wgemm_general_supported(p.N, p.Cin, p.A1 ? p.C0 : 0, p.ldA0, p.A1 ? p.ldA1 : 0, p.ldC, p.A0, p.A1, p.C, p.bias_n)) return false;
+  igemm_prof_record(p, 1, 1, N->st, true, 1.0);
+  launch_wgemm_bf16x3_general(p.A0, p.ldA0, p.A1, p.ldA1, p.C0, it->second, p.C, p.ldC, p.M, p.N, p.Cin, p.bias_n, p.alpha, p.accumulate, N->st);
+  igemm_prof_record(p, 1, 1, N->st, false, 1.0);
+  return true;
+}
 // 1x1 conv / per-pixel linear over a (possibly two-source) view
 static void conv1(Net* N, Src2 a, long long M, int Cin, const float* wt, int Cout, const float* bias, float alpha, float* out, int accumulate) {
   if (N->dry()) return;
   IgemmParams p = ig_base();
   p.A0 = a.p0; p.A1 = a.p1; p.C0 = a.C0; p.ldA0 = a.ld0; p.ldA1 = a.ld1; p.Cin = Cin; p.M = (int)M; p.N = Cout;
   p.Bt = wt; p.ldB = Cin; p.C = out; p.ldC = Cout; p.bias_n = bias; p.alpha = alpha; p.accumulate = accumulate;
+  if (try_wgemm(N, p)) return;
   launch_igemm(p, 1, false, false, 1, N->st);
 }
 static Src2 single(const float* p, int C) { Src2 s; s.p0 = p; s.p1 = nullptr; s.C0 = C; s.ld0 = C; s.ld1 = 0; return s; }
@@ -653,6 +681,7 @@ static void gemm_b(Net* N, const float* A, int ldA, long long sA, bool tA, const
   IgemmParams p = ig_base();
   p.A0 = A; p.ldA0 = ldA; p.sA = sA; p.Bt = Bt; p.ldB = ldB; p.sB = sB; p.C = C; p.ldC = ldC; p.sC = sC;
   p.M = M; p.N = Nn; p.Cin = K; p.bias_n = bias_n; p.bias_m = bias_m; p.alpha = alpha; p.accumulate = accumulate;
+  if (!tA && !tB && batch == 1 && try_wgemm(N, p)) return;
   launch_igemm(p, 1, tA, tB, batch, N->st);
 }
 

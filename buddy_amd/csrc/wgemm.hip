@@ -80,9 +80,12 @@ struct WgemmArgs {
   const float* V; const unsigned char* U3; float* M;
   int Mt, Cin, Cout, S, NB;                                    // rows per position, K, N, K-stages, column blocks
   long long sV, sM;                                            // strides between positions (floats)
+  // general form (GEN = true; 1x1 convolutions, NIN): A from up to two sources (channel concatenation, split at C0), row strides, C = alpha * A W^T
+  // + bias [+ C]
+  const float* A1; int C0, ldA0, ldA1, ldC; const float* bias_n; float alpha; int accumulate;
 };
 
-template <int OCC, int PF>
+template <int OCC, int PF, bool GEN = false>
 __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -104,7 +107,8 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
   int row = m0 + wid * 32 + (lane & 31);
   const bool row_ok = row < a.Mt;
   if (!row_ok) row = a.Mt - 1;
-  const float* Ap = V + (long long)row * a.Cin + 16 * (lane >> 5);
+  const float* Ap = V + (long long)row * (GEN ? a.ldA0 : a.Cin) + 16 * (lane >> 5);
+  const float* Ap1 = (GEN && a.A1) ? a.A1 + (long long)row * a.ldA1 + 16 * (lane >> 5) - a.C0 : nullptr;   // channels >= C0 come from the second source
   // B: the stage image is copied linearly, 6 x 16 B per thread (thread t moves bytes 16 t + 4096 j)
   const u32x4* Bg = reinterpret_cast<const u32x4*>(U3) + tid;
   u32x4* Bs = reinterpret_cast<u32x4*>(smem) + tid;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
   u32x4 rb[6];
   auto loadA = [&](int s, int slot) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ra[slot][j] = *reinterpret_cast<const float4*>(Ap + s * WKS + 4 * j);
+    for (int j = 0; j < 4; ++j) ra[slot][j] = *reinterpret_cast<const float4*>(((GEN && Ap1 && s * WKS >= a.C0) ? Ap1 : Ap) + s * WKS + 4 * j);
   };
   auto loadB = [&](int s) {
 #pragma unroll
@@ -172,12 +176,19 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
 
   // epilogue: accumulator = C^T tile, lane (row = lane & 31, h = lane >> 5) holds channels 8 g + 4 h + 0..3 of each 32-channel block
   if (row_ok) {
-    float* dst = a.M + (long long)p * a.sM + (long long)row * a.Cout + nb * WBN + 4 * (lane >> 5);
+    float* dst = a.M + (long long)p * a.sM + (long long)row * (GEN ? a.ldC : a.Cout) + nb * WBN + 4 * (lane >> 5);
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(dst + cb * 32 + 8 * g) = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+        if (GEN) {     // same operation order as the fp32 kernel's epilogue: alpha * acc, + bias, + C
+          v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+          if (a.bias_n) { const float4 t = *reinterpret_cast<const float4*>(a.bias_n + nb * WBN + 4 * (lane >> 5) + cb * 32 + 8 * g); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+          if (a.accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst + cb * 32 + 8 * g); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        }
+        *reinterpret_cast<float4*>(dst + cb * 32 + 8 * g) = v;
+      }
   }
 }
 }  // namespace
@@ -190,8 +201,24 @@ void wgemm_pack_weights(const float* U_dev, void* U3_dev, int P, int Cout, int C
   hipLaunchKernelGGL(wgemm_pack_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, U_dev, reinterpret_cast<u32x4*>(U3_dev), P, Cout, Cin);
 }
 
+// general form: C (M x N, row stride ldC) = alpha * [A0 | A1] (M x K) . W^T + bias_n (+ C), W pre-split by wgemm_pack_weights(W, ., 1, N, K)
+bool wgemm_general_supported(int N, int K, int C0, int ldA0, int ldA1, int ldC, const void* A0, const void* A1, const void* C, const void* bias) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return wgemm_supported(N, K) && C0 % WKS == 0 && ldA0 % 4 == 0 && ldA1 % 4 == 0 && ldC % 4 == 0 && al16(A0) && al16(A1) && al16(C) && al16(bias);
+}
+void launch_wgemm_bf16x3_general(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W3, float* C, int ldC, long long M, int N, int K,
+                                 const float* bias_n, float alpha, int accumulate, hipStream_t st) {
+  WgemmArgs a;
+  a.V = A0; a.U3 = reinterpret_cast<const unsigned char*>(W3); a.M = C;
+  a.Mt = (int)M; a.Cin = K; a.Cout = N; a.S = K / WKS; a.NB = N / WBN; a.sV = 0; a.sM = 0;
+  a.A1 = A1; a.C0 = A1 ? C0 : K; a.ldA0 = ldA0; a.ldA1 = ldA1; a.ldC = ldC; a.bias_n = bias_n; a.alpha = alpha; a.accumulate = accumulate;
+  const dim3 grid((unsigned)(cdiv((int)M, WBM) * a.NB), 1, 1);
+  hipLaunchKernelGGL((wgemm_bf16x3_kernel<3, 1, true>), grid, dim3(WNT), 0, st, a);
+}
+
 void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st) {
   WgemmArgs a;
+  a.A1 = nullptr; a.C0 = Cin; a.ldA0 = Cin; a.ldA1 = 0; a.ldC = Cout; a.bias_n = nullptr; a.alpha = 1.f; a.accumulate = 0;
   a.V = V; a.U3 = reinterpret_cast<const unsigned char*>(U3); a.M = M;
   a.Mt = (int)Mt; a.Cin = Cin; a.Cout = Cout; a.S = Cin / WKS; a.NB = Cout / WBN;
   a.sV = Mt * Cin; a.sM = Mt * Cout;

@@ -89,6 +89,11 @@ int buddy_gemm_winograd_domain(const float* V, const float* U, float* M, int til
 long long buddy_wgemm_packed_bytes(int positions, int Cout, int Cin);
 int buddy_wgemm_pack_weights(const float* U, void* U3, int positions, int Cout, int Cin, void* stream);
 int buddy_gemm_winograd_domain_bf16x3(const float* V, const void* U3, float* M, int tiles, int Cout, int Cin, int positions, void* stream);
+/* The 1x1 convolutions / NIN layers (layers.py:100-106, 548-557) on the same kernel: C (M x N, row stride ldC) = alpha * [A0 | A1] W^T + bias_n
+ * (+ C if accumulate); the K input channels come from A0 (first C0, row stride ldA0) and, if A1 != NULL, A1 (the rest, ldA1) -- the U-Net's
+ * channel concatenation is never materialised.  W3 = buddy_wgemm_pack_weights(W [N][K], ., 1, N, K).  N % 128, K % 32, C0 % 32 == 0. */
+int buddy_gemm_bf16x3(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W3, float* C, int ldC, long long M, int N, int K,
+                      const float* bias_n, float alpha, int accumulate, void* stream);
 /* NHWC 3x3 stride-1 pad-1 conv, packed weights wt[Cout][9*Cin] (tap-major, channel-minor); replaces ddpm_conv3x3
  * (networks/ncsnpp_utils/layers.py:119-126). */
 int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,

@@ -79,6 +79,29 @@ def test_winograd_domain_gemm_bf16x3(lib, tiles, Cout, Cin, P_):
     assert lib.buddy_wgemm_packed_bytes(2, 96, 128) == 0 and lib.buddy_wgemm_packed_bytes(2, 128, 48) == 0
 
 
+@pytest.mark.parametrize("M,N,K,C0", [(1000, 128, 384, 256), (4097, 256, 256, 0), (300, 128, 64, 32)])
+def test_gemm_bf16x3_general_form(lib, M, N, K, C0):
+    """buddy_gemm_bf16x3 (the 1x1 convolutions / NINs on the bf16x3 kernel): two-source A (channel concatenation split at C0; 0 = one source), bias,
+    alpha, accumulate, ragged M -- against fp64, the fp32 GEMM's bound."""
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = torch.randn(N, K, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    W3 = torch.empty(N * K * 6 // 4, dtype=torch.int32, device="cuda")
+    _lib.check(lib.buddy_wgemm_pack_weights(P(W), W3.data_ptr(), 1, N, K, S()))
+    A0 = A[:, :C0].contiguous() if C0 else A
+    A1 = A[:, C0:].contiguous() if C0 else None
+    Cc = torch.full((M, N), 3.0, device="cuda")
+    ref = 0.5 * (A.double() @ W.double().t()).float() + bias
+    _lib.check(lib.buddy_gemm_bf16x3(P(A0), A0.shape[1], P(A1), A1.shape[1] if C0 else 0, C0, W3.data_ptr(), P(Cc), N, M, N, K, P(bias), 0.5, 0, S()))
+    torch.cuda.synchronize()
+    assert rel(Cc, ref) < 2e-5
+    _lib.check(lib.buddy_gemm_bf16x3(P(A0), A0.shape[1], P(A1), A1.shape[1] if C0 else 0, C0, W3.data_ptr(), P(Cc), N, M, N, K, None, 0.5, 1, S()))
+    torch.cuda.synchronize()
+    assert rel(Cc, 2 * ref - bias) < 2e-5
+
+
 def test_winograd_domain_gemm_bf16x3_layout(lib):
     """V = I-like selector against asymmetric weights: every (row, channel, k) lands where it should (exactly representable values)."""
     from buddy_amd import _lib
