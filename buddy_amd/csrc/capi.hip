@@ -14,6 +14,7 @@ void launch_perturb(const float* x, const float* eps, float scale, float* out, l
 void launch_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* den_scale_b, const float* base, const float* d_prev,
                        float t, float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, hipStream_t st);
 void launch_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st);
+void launch_mfma_ubench_bf16(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st);
 void launch_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, hipStream_t st);
 }
 
@@ -85,6 +86,12 @@ int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream) {
 int buddy_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, void* stream) {
   if (!seed || !out || !clk) { set_error("null argument"); return BUDDY_ERR_ARG; }
   launch_mfma_ubench(seed, out, blocks, iters, clk, (hipStream_t)stream);
+  return finish();
+}
+
+int buddy_mfma_ubench_bf16(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, void* stream) {
+  if (!seed || !out || !clk) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  launch_mfma_ubench_bf16(seed, out, blocks, iters, clk, (hipStream_t)stream);
   return finish();
 }
 

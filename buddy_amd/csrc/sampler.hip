@@ -149,7 +149,42 @@ __global__ __launch_bounds__(256) void mfma_ubench_kernel(const float* seed, flo
   out[blockIdx.x * 256 + tid] = s;
   if (blockIdx.x == 0 && tid == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
+// the same for v_mfma_f32_32x32x16_bf16 on random bf16 operand bits (three "planes" per side, rotated like the bf16x3 GEMM does): what the matrix
+// pipe sustains on THIS box for bf16 under its power budget, with no memory traffic at all
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_ubench_bf16_kernel(const float* seed, float* out, int iters, unsigned long long* clk) {
+  const int tid = threadIdx.x;
+  bf16x8_t a[3], b[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    u32x4_t ua, ub;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // two bf16 per dword, exponents kept near 1 so the accumulators stay finite: sign/mantissa bits from the seed
+      const unsigned int r = __float_as_uint(seed[(tid * 7 + q * 4 + j) & 1023]), t = __float_as_uint(seed[(tid * 13 + q * 4 + j + 512) & 1023]);
+      ua[j] = (r & 0x807F807Fu) | 0x3F003F00u; ub[j] = (t & 0x807F807Fu) | 0x3F003F00u;
+    }
+    a[q] = (bf16x8_t)ua; b[q] = (bf16x8_t)ub;
+  }
+  f32x16_t c[4];
+  for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) c[k][r] = 0.f;
+  const unsigned long long t0 = clock64(), w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(q + k) % 3], b[q], c[k], 0, 0, 0);
+  }
+  const unsigned long long t1 = clock64(), w1 = wall_clock64();
+  float s = 0.f;
+  for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) s += c[k][r];
+  out[blockIdx.x * 256 + tid] = s;
+  if (blockIdx.x == 0 && tid == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
 }  // namespace
+void launch_mfma_ubench_bf16(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_ubench_bf16_kernel, dim3(blocks), dim3(256), 0, st, seed, out, iters, clk);
+}
 void launch_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st) {
   hipLaunchKernelGGL(mfma_ubench_kernel, dim3(blocks), dim3(256), 0, st, seed, out, iters, clk);
 }

@@ -85,8 +85,10 @@ struct WgemmArgs {
   const float* A1; int C0, ldA0, ldA1, ldC; const float* bias_n; float alpha; int accumulate;
 };
 
-template <int OCC, int PF, bool GEN = false>
+// RM = 32-row blocks per wave (workgroup tile = 128 RM rows x 128 columns): RM = 2 halves the LDS reads and the weight traffic per MFMA
+template <int OCC, int PF, bool GEN = false, int RM = 1>
 __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs a) {
+  static_assert(PF == 1 || RM == 1, "the two-stage A ring is only built for RM = 1");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // XCD-aware order (hardware places block b on XCD b % 8): each XCD gets a contiguous range of logical tiles, the column blocks of one row
@@ -97,33 +99,43 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  const int nb = lid % a.NB, m0 = (lid / a.NB) * WBM;
+  const int nb = lid % a.NB, m0 = (lid / a.NB) * (WBM * RM);
   const int p = blockIdx.z;
   const float* __restrict__ V = a.V + (long long)p * a.sV;
   const unsigned char* __restrict__ U3 = a.U3 + ((long long)p * a.NB + nb) * a.S * STAGE_BYTES;
   const int S = a.S;
 
   // A: lane (row r = lane & 31, half h = lane >> 5) reads 16 consecutive floats per stage; rows past M are clamped (never stored)
-  int row = m0 + wid * 32 + (lane & 31);
-  const bool row_ok = row < a.Mt;
-  if (!row_ok) row = a.Mt - 1;
-  const float* Ap = V + (long long)row * (GEN ? a.ldA0 : a.Cin) + 16 * (lane >> 5);
-  const float* Ap1 = (GEN && a.A1) ? a.A1 + (long long)row * a.ldA1 + 16 * (lane >> 5) - a.C0 : nullptr;   // channels >= C0 come from the second source
+  int row[RM]; bool row_ok[RM];
+  const float* Ap[RM]; const float* Ap1[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    row[r] = m0 + (wid * RM + r) * 32 + (lane & 31);
+    row_ok[r] = row[r] < a.Mt;
+    if (!row_ok[r]) row[r] = a.Mt - 1;
+    Ap[r] = V + (long long)row[r] * (GEN ? a.ldA0 : a.Cin) + 16 * (lane >> 5);
+    Ap1[r] = (GEN && a.A1) ? a.A1 + (long long)row[r] * a.ldA1 + 16 * (lane >> 5) - a.C0 : nullptr;   // channels >= C0 come from the second source
+  }
   // B: the stage image is copied linearly, 6 x 16 B per thread (thread t moves bytes 16 t + 4096 j)
   const u32x4* Bg = reinterpret_cast<const u32x4*>(U3) + tid;
   u32x4* Bs = reinterpret_cast<u32x4*>(smem) + tid;
 
-  f32x16 acc[4];
+  f32x16 acc[RM][4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int m = 0; m < RM; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][c][r] = 0.f;
 
-  float4 ra[PF][4];                                           // ring of PF stages of A in flight (PF = 2: the loads of stage s + 2 are issued in stage s)
+  float4 ra[PF * RM][4];                                           // ring of PF stages of A in flight (PF = 2: the loads of stage s + 2 are issued in stage s)
   u32x4 rb[6];
   auto loadA = [&](int s, int slot) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ra[slot][j] = *reinterpret_cast<const float4*>(((GEN && Ap1 && s * WKS >= a.C0) ? Ap1 : Ap) + s * WKS + 4 * j);
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ra[slot * RM + r][j] = *reinterpret_cast<const float4*>(((GEN && Ap1[r] && s * WKS >= a.C0) ? Ap1[r] : Ap[r]) + s * WKS + 4 * j);
   };
   auto loadB = [&](int s) {
 #pragma unroll
@@ -140,7 +152,11 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
   storeB(0);
   __syncthreads();
   for (int s = 0; s < S; ++s) {
-    const float4 ca[4] = {ra[0][0], ra[0][1], ra[0][2], ra[0][3]};
+    float4 ca[RM][4];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ca[r][j] = ra[r][j];
     if (PF == 2) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) ra[0][j] = ra[1][j];
@@ -150,38 +166,38 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
     const unsigned char* Bcur = smem + (s & 1) * STAGE_BYTES + lane * 16;
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
-      const Split3 av = split3(ca[2 * kc], ca[2 * kc + 1]);
+      Split3 av[RM];
+#pragma unroll
+      for (int r = 0; r < RM; ++r) av[r] = split3(ca[r][2 * kc], ca[r][2 * kc + 1]);
       bf16x8 b[4][3];
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int q = 0; q < 3; ++q) b[cb][q] = *reinterpret_cast<const bf16x8*>(Bcur + ((kc * 4 + cb) * 3 + q) * FRAG);
-      // smallest terms first; the four column blocks interleaved so that consecutive MFMAs never share an accumulator
+      // smallest terms first (mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi; B plane, A plane); the accumulators interleaved so that consecutive
+      // MFMAs never share one
+      constexpr int PB[6] = {1, 2, 0, 1, 0, 0}, PA[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][1], av.p[1], acc[cb], 0, 0, 0);
+      for (int t = 0; t < 6; ++t)
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][2], av.p[0], acc[cb], 0, 0, 0);
+        for (int r = 0; r < RM; ++r)
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][0], av.p[2], acc[cb], 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][1], av.p[0], acc[cb], 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][0], av.p[1], acc[cb], 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][0], av.p[0], acc[cb], 0, 0, 0);
+          for (int cb = 0; cb < 4; ++cb) acc[r][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][PB[t]], av[r].p[PA[t]], acc[r][cb], 0, 0, 0);
     }
     if (s + 1 < S) storeB((s + 1) & 1);                        // that buffer was last read in stage s - 1: every wave is past its barrier
     __syncthreads();
   }
 
   // epilogue: accumulator = C^T tile, lane (row = lane & 31, h = lane >> 5) holds channels 8 g + 4 h + 0..3 of each 32-channel block
-  if (row_ok) {
-    float* dst = a.M + (long long)p * a.sM + (long long)row * (GEN ? a.ldC : a.Cout) + nb * WBN + 4 * (lane >> 5);
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    if (!row_ok[r]) continue;
+    float* dst = a.M + (long long)p * a.sM + (long long)row[r] * (GEN ? a.ldC : a.Cout) + nb * WBN + 4 * (lane >> 5);
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float4 v = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+        float4 v = make_float4(acc[r][cb][4 * g], acc[r][cb][4 * g + 1], acc[r][cb][4 * g + 2], acc[r][cb][4 * g + 3]);
         if (GEN) {     // same operation order as the fp32 kernel's epilogue: alpha * acc, + bias, + C
           v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
           if (a.bias_n) { const float4 t = *reinterpret_cast<const float4*>(a.bias_n + nb * WBN + 4 * (lane >> 5) + cb * 32 + 8 * g); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
@@ -222,12 +238,14 @@ void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt,
   a.V = V; a.U3 = reinterpret_cast<const unsigned char*>(U3); a.M = M;
   a.Mt = (int)Mt; a.Cin = Cin; a.Cout = Cout; a.S = Cin / WKS; a.NB = Cout / WBN;
   a.sV = Mt * Cin; a.sM = Mt * Cout;
-  const dim3 grid((unsigned)(cdiv((int)Mt, WBM) * a.NB), 1, (unsigned)P);
+  dim3 grid((unsigned)(cdiv((int)Mt, WBM) * a.NB), 1, (unsigned)P);
   // variants measured on one box (profiles/README.md r03): 3 workgroups per CU (<= 168 VGPRs) +2...4 % over 2; a second stage of A in flight
   // (PF = 2: 190 VGPRs) -3 %; both at once spills.  BUDDY_WGEMM_VARIANT=2|3 keep the losers runnable.
   static const int variant = getenv("BUDDY_WGEMM_VARIANT") ? atoi(getenv("BUDDY_WGEMM_VARIANT")) : 1;
   if (variant == 2) hipLaunchKernelGGL((wgemm_bf16x3_kernel<2, 1>), grid, dim3(WNT), 0, st, a);
   else if (variant == 3) hipLaunchKernelGGL((wgemm_bf16x3_kernel<2, 2>), grid, dim3(WNT), 0, st, a);
+  // (64 rows per wave, RM = 2 -- half the LDS reads and weight traffic per MFMA -- needs 256+ VGPRs: 108 TF-equivalent at 2 workgroups per CU
+  //  with spills, 131 at one; 147 for this form on the same box)
   else hipLaunchKernelGGL((wgemm_bf16x3_kernel<3, 1>), grid, dim3(WNT), 0, st, a);
 }
 

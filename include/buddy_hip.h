@@ -71,6 +71,9 @@ int buddy_prof_collect_wino4(double* ms /*[3]*/, double* gemm_flops, double* byt
  * memory traffic; out[blocks*256] keeps the result live; clk[0] = shader clocks, clk[1] = 100 MHz wall ticks of block 0.
  * FLOPs = blocks * 4 waves * 4 * iters * 4096. */
 int buddy_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, void* stream);
+/* the same loop on v_mfma_f32_32x32x16_bf16 with random operand bits (12 MFMAs = 393 216 FLOP per wave and iteration): the bf16 matrix rate this box
+ * sustains under its power budget, the ceiling of the bf16x3 GEMM */
+int buddy_mfma_ubench_bf16(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, void* stream);
 
 /* ---- unit-level kernels (the pieces the network is made of; used by the parity tests) ---- */
 /* C[b] = alpha * op(A[b]) op(Bt[b])^T (+ bias_n), row-major; transX = operand stored k-major. replaces torch.einsum/bmm
