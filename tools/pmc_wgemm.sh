@@ -7,5 +7,5 @@ rm -rf $OUT/pmcW
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmcW -o m -- python $R/tools/wgemm_one.py $1 $2 $3 ${4:-64} 3 > /dev/null 2> $OUT/pmcW.err
 cd $R
 M=$(find $OUT/pmcW -name "*counter_collection.csv" | head -1)
-python tools/pmc_mfma_summary.py $M $OUT/pmcW_$1_$2_$3.json wgemm_bf16x3
+python tools/pmc_mfma_summary.py $M $OUT/pmcW_$1_$2_$3.json wgemm_bf16x3_kernel
 rm -rf $OUT/pmcW

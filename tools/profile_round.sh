@@ -15,4 +15,6 @@ F=$(find $OUT/pmcF_$TAG -name "*counter_collection.csv" | head -1); W=$(find $OU
 python tools/pmc_summary.py $F $W $OUT/${TAG}_conv_traffic_pmc.json | head -c 400; echo
 rm -rf $OUT/pmcF_$TAG $OUT/pmcW_$TAG $OUT/prof_$TAG
 python bench.py --length 480000 --batch 4 --steps 3 --warmup 1 --no-cpu-baseline --also-concurrent 0 > $OUT/${TAG}_bench_longform_480000_B4.json 2> $OUT/${TAG}_longform.err; tail -c 300 $OUT/${TAG}_bench_longform_480000_B4.json; echo
+python bench.py --gemm fp32 --no-cpu-baseline --also-concurrent 0 > $OUT/${TAG}_bench_N1_gemm_fp32.json 2> /dev/null; tail -c 200 $OUT/${TAG}_bench_N1_gemm_fp32.json; echo
+bash tools/pmc_mfma.sh $TAG > /dev/null 2>&1
 python tools/stats_table.py $OUT/${TAG}_bench_kernel_stats.csv | head -40
