@@ -152,6 +152,136 @@ __global__ __launch_bounds__(256) void fir_gradh_kernel(const float* X, long lon
   }
 }
 
+// ---- LDS-staged forms of the two FIR kernels of the optimisation loop (round 3).  The register-tiled kernels above re-load every X / H value
+// from L2 once per 4 complex MACs and sit at 12 % of the VALU rate on dependent loads (8 frames per thread instead of 4 changed nothing: latency, not
+// bytes); here a workgroup stages its (frames x 32 bins) slab once, the tap loop reads LDS only (two conflict-free ds_read_b64 per 8 complex MACs).
+constexpr int FL_BINS = 32, FL_FT = 8, FL_TB = 64;           // bins per workgroup, frames per thread, frames per workgroup (8 frame groups)
+// Y[u][t][f] = sum_k H[u][k][f] X[u][t + 1 - k][f]; grid (ceil(T / 64), ceil(FB / 32), U), 256 threads; LDS (64 + 2 Nf - 1) x 32 complex
+__global__ __launch_bounds__(256) void fir_sb_lds_kernel(const float* __restrict__ X, long long xs, const float* __restrict__ H, float* __restrict__ Y,
+                                                         int T, int Nf) {
+  extern __shared__ float2 fl_smem[];
+  const int nx = FL_TB + Nf - 1;                             // frames t0 - Nf + 2 ... t0 + 64
+  float2* Xs = fl_smem;                                      // [nx][32]
+  float2* Hs = fl_smem + nx * FL_BINS;                       // [Nf][32]
+  const int u = blockIdx.z, f0 = blockIdx.y * FL_BINS, t0 = blockIdx.x * FL_TB;
+  const int tid = threadIdx.x, b = tid & 31, g = tid >> 5;
+  const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs);
+  const float2* Hu = reinterpret_cast<const float2*>(H + (long long)u * Nf * LDSP);
+  const bool fok = f0 + b < FB;
+  const int xbase = t0 - Nf + 2;
+  {   // all global loads of the slab are issued before the first LDS store (a load -> store loop would pay one L2 round trip per row)
+    constexpr int NXR = (FL_TB + 128 - 1 + 7) / 8, NHR = 128 / 8;        // Nf <= 128
+    float2 vx[NXR], vh[NHR];
+#pragma unroll
+    for (int i = 0; i < NXR; ++i) {
+      const int r = g + 8 * i, tt = xbase + r;
+      vx[i] = (r < nx && fok && tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NHR; ++i) {
+      const int k = g + 8 * i;
+      vh[i] = (k < Nf && fok) ? Hu[(long long)k * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NXR; ++i) { const int r = g + 8 * i; if (r < nx) Xs[r * FL_BINS + b] = vx[i]; }
+#pragma unroll
+    for (int i = 0; i < NHR; ++i) { const int k = g + 8 * i; if (k < Nf) Hs[k * FL_BINS + b] = vh[i]; }
+  }
+  __syncthreads();
+  const int tg = g * FL_FT;                                  // this thread's outputs: t0 + tg + j
+  float ar[FL_FT], ai[FL_FT];
+  float2 w[FL_FT];                                           // w[j] = X[t0 + tg + j + 1 - k]  -> Xs row (tg + j + 1 - k) - (2 - Nf)
+#pragma unroll
+  for (int j = 0; j < FL_FT; ++j) { ar[j] = 0.f; ai[j] = 0.f; w[j] = Xs[(tg + j + Nf - 1) * FL_BINS + b]; }
+#pragma unroll 4
+  for (int k = 0; k < Nf; ++k) {                             // k ascending per output, as in the register-tiled kernel
+    const float2 h = Hs[k * FL_BINS + b];
+#pragma unroll
+    for (int j = 0; j < FL_FT; ++j) { ar[j] += h.x * w[j].x - h.y * w[j].y; ai[j] += h.x * w[j].y + h.y * w[j].x; }
+#pragma unroll
+    for (int j = FL_FT - 1; j > 0; --j) w[j] = w[j - 1];
+    const int r = tg + Nf - 2 - k;                           // row of X[t0 + tg - k]
+    w[0] = r >= 0 ? Xs[r * FL_BINS + b] : make_float2(0.f, 0.f);
+  }
+  if (fok) {
+#pragma unroll
+    for (int j = 0; j < FL_FT; ++j)
+      if (t0 + tg + j < T) reinterpret_cast<float2*>(Y + ((long long)u * T + t0 + tg + j) * LDSP)[f0 + b] = make_float2(ar[j], ai[j]);
+  }
+}
+// GH[u][k][f] (+)= sum_t conj(X[u][t + 1 - k][f]) GY[u][t][f]; grid (ceil(Nf / 16), ceil(FB / 32), U), 256 threads = 32 bins x 2 tap groups of 8 x 4
+// frame slots; frames in chunks of 64 (slot s takes frames 16 s ... 16 s + 15 of each chunk); the four slot sums are added in fixed order
+constexpr int GL_TAPS = 16, GL_CH = 64, GL_SLOT = 16;
+__global__ __launch_bounds__(256) void fir_gradh_lds_kernel(const float* __restrict__ X, long long xs, const float* __restrict__ GY, float* __restrict__ GH,
+                                                            int T, int Nf, int accumulate) {
+  __shared__ float2 Xs[(GL_CH + GL_TAPS - 1) * FL_BINS];     // frames c0 + 1 - (k0 + 15) ... c0 + 64 - k0
+  __shared__ float2 Gs[GL_CH * FL_BINS];
+  __shared__ float2 red[4][GL_TAPS][FL_BINS];
+  const int u = blockIdx.z, f0 = blockIdx.y * FL_BINS, k0 = blockIdx.x * GL_TAPS;
+  const int tid = threadIdx.x, b = tid & 31, kg = (tid >> 5) & 1, sl = tid >> 6;
+  const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs);
+  const float2* Gu = reinterpret_cast<const float2*>(GY + (long long)u * T * LDSP);
+  const bool fok = f0 + b < FB;
+  const int kk = k0 + 8 * kg;                                // this thread's taps kk ... kk + 7
+  float ar[8], ai[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ar[j] = 0.f; ai[j] = 0.f; }
+  for (int c0 = 0; c0 < T; c0 += GL_CH) {
+    __syncthreads();
+    const int xb = c0 + 1 - (k0 + GL_TAPS - 1);
+    {
+      constexpr int NXR = (GL_CH + GL_TAPS - 1 + 7) / 8, NGR = GL_CH / 8;
+      const int g = tid >> 5;
+      float2 vx[NXR], vg[NGR];
+#pragma unroll
+      for (int i = 0; i < NXR; ++i) {
+        const int r = g + 8 * i, tt = xb + r;
+        vx[i] = (r < GL_CH + GL_TAPS - 1 && fok && tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NGR; ++i) {
+        const int tt = c0 + g + 8 * i;
+        vg[i] = (fok && tt < T) ? Gu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NXR; ++i) { const int r = g + 8 * i; if (r < GL_CH + GL_TAPS - 1) Xs[r * FL_BINS + b] = vx[i]; }
+#pragma unroll
+      for (int i = 0; i < NGR; ++i) Gs[(g + 8 * i) * FL_BINS + b] = vg[i];
+    }
+    __syncthreads();
+    // frame t = c0 + 16 sl + q: X[t + 1 - kk - j] = Xs row (16 sl + q + GL_TAPS - 1 - 8 kg - j)
+    const int base = GL_SLOT * sl + GL_TAPS - 1 - 8 * kg;
+    float2 w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = Xs[(base - j) * FL_BINS + b];
+#pragma unroll 4
+    for (int q = 0; q < GL_SLOT; ++q) {
+      const float2 gy = Gs[(GL_SLOT * sl + q) * FL_BINS + b];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ar[j] += w[j].x * gy.x + w[j].y * gy.y; ai[j] += w[j].x * gy.y - w[j].y * gy.x; }
+#pragma unroll
+      for (int j = 7; j > 0; --j) w[j] = w[j - 1];
+      if (q + 1 < GL_SLOT) w[0] = Xs[(base + q + 1) * FL_BINS + b];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[sl][8 * kg + j][b] = make_float2(ar[j], ai[j]);
+  __syncthreads();
+  if (sl == 0 && fok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kk + j;
+      if (k >= Nf) continue;
+      float r = red[0][8 * kg + j][b].x, im = red[0][8 * kg + j][b].y;
+#pragma unroll
+      for (int sg = 1; sg < 4; ++sg) { r += red[sg][8 * kg + j][b].x; im += red[sg][8 * kg + j][b].y; }
+      float2* o = reinterpret_cast<float2*>(GH + ((long long)u * Nf + k) * LDSP) + f0 + b;
+      if (accumulate) { r += o->x; im += o->y; }
+      *o = make_float2(r, im);
+    }
+  }
+}
+
 // compressed spectrum: Xc = (|X| + 1e-8)^p * exp(j angle X)   (reference losses.py:59-64)
 __device__ __forceinline__ float2 compress(float2 x, float p) {
   const float r = sqrtf(x.x * x.x + x.y * x.y);
@@ -776,7 +906,20 @@ struct BlindOp {
   }
   void update_H() { design(); cons_forward(); }
   void fir(const float* X, long long xs, int Tn, float* Y) {
-    hipLaunchKernelGGL(fir_kernel_sb, dim3(gridf((long long)U * ((Tn + FT - 1) / FT) * FB)), dim3(256), 0, st, X, xs, (const float*)H, Y, U, Tn, Nf);
+    static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
+    const size_t sm = (size_t)(FL_TB + 2 * Nf - 1) * FL_BINS * sizeof(float2);
+    static const bool big_lds = hipFuncSetAttribute((const void*)fir_sb_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    if (lds && big_lds && sm <= 96 * 1024 && Nf <= 128)
+      hipLaunchKernelGGL(fir_sb_lds_kernel, dim3((Tn + FL_TB - 1) / FL_TB, (FB + FL_BINS - 1) / FL_BINS, U), dim3(256), sm, st, X, xs, (const float*)H, Y, Tn, Nf);
+    else
+      hipLaunchKernelGGL(fir_kernel_sb, dim3(gridf((long long)U * ((Tn + FT - 1) / FT) * FB)), dim3(256), 0, st, X, xs, (const float*)H, Y, U, Tn, Nf);
+  }
+  void gradh(const float* X, long long xs, const float* GY, int Tn, int accumulate) {
+    static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
+    if (lds)
+      hipLaunchKernelGGL(fir_gradh_lds_kernel, dim3((Nf + GL_TAPS - 1) / GL_TAPS, (FB + FL_BINS - 1) / FL_BINS, U), dim3(256), 0, st, X, xs, GY, GH, Tn, Nf, accumulate);
+    else
+      hipLaunchKernelGGL(fir_gradh_kernel, dim3(U * ((Nf + FT - 1) / FT) * ((FB + GH_F - 1) / GH_F)), dim3(256), 0, st, X, xs, GY, GH, U, Tn, Nf, accumulate);
   }
   // loss_u (+)= kappa * sum |Rc - comp(Xh)|^2, G optional
   void comp_loss(const float* Rcx, const float* Xh, float* G, int Tn, float weight, float* out, int accumulate) {
@@ -1069,7 +1212,7 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
   o->comp_loss(o->Yc, o->X2, o->X3, T, w_rec, o->losses, 0);
   o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, o->sig2);
   o->istft_adj(o->sig2, T, WIN + WIN / 2, o->env_T, L, o->norm, o->X2);
-  hipLaunchKernelGGL(fir_gradh_kernel, dim3(U * ((Nf + FT - 1) / FT) * ((FB + GH_F - 1) / GH_F)), dim3(256), 0, st, (const float*)o->X1, (long long)T * LDSP, (const float*)o->X2, o->GH, U, T, Nf, 0);
+  o->gradh(o->X1, (long long)T * LDSP, o->X2, T, 0);
   // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach())
   if (noise) {
     o->time_rir(o->rir);                                                     // Ybuf = FIR(Xdelta, H) consumed inside
@@ -1079,7 +1222,7 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
     o->comp_loss(o->Rc, o->X2, o->X3, Td, w_reg, o->losses + U, 0);
     o->stft_adj(o->X3, o->Lr, WIN, Td, 1.f / o->norm, o->sig2);
     o->istft_adj(o->sig2, Td, WIN + WIN / 2, o->env_d, o->Lr, o->norm, o->X2);
-    hipLaunchKernelGGL(fir_gradh_kernel, dim3(U * ((Nf + FT - 1) / FT) * ((FB + GH_F - 1) / GH_F)), dim3(256), 0, st, (const float*)o->Xdelta, 0LL, (const float*)o->X2, o->GH, U, Td, Nf, 1);
+    o->gradh(o->Xdelta, 0LL, o->X2, Td, 1);
   }
   o->cons_backward(o->GH);
   hipLaunchKernelGGL(h0_bwd_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->GFin, (const float*)o->A, (const float*)o->phi, o->gA, o->gphi, U, Nf);
