@@ -799,6 +799,15 @@ struct BlindOp {
   float *H = nullptr, *Yc = nullptr, *Xdelta = nullptr;
   // work buffers
   float *sp = nullptr, *frames = nullptr, *X1 = nullptr, *X2 = nullptr, *X3 = nullptr, *Ybuf = nullptr, *sig1 = nullptr, *sig2 = nullptr;
+  // second scratch set + stream + events: inside the captured graph the RIR-regulariser chain of an iteration (14 nodes) runs as a parallel branch
+  // beside the reconstruction chain (12 nodes); both only read H and meet again at the accumulating tap-gradient
+  float *sp_b = nullptr, *frames_b = nullptr, *X2_b = nullptr, *X3_b = nullptr, *Ybuf_b = nullptr, *sig2_b = nullptr; double* partial_b = nullptr;
+  bool big_lds = false;              // fir_sb_lds_kernel may take > 64 KB of dynamic LDS (set once at creation, outside any stream capture)
+  hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool fork_ok = false;
+  void swap_scratch() {
+    std::swap(sp, sp_b); std::swap(frames, frames_b); std::swap(X2, X2_b); std::swap(X3, X3_b); std::swap(Ybuf, Ybuf_b); std::swap(sig2, sig2_b);
+    std::swap(partial, partial_b);
+  }
   float *A = nullptr, *Apre = nullptr, *logdm = nullptr, *dmv = nullptr, *gdm = nullptr, *Fin = nullptr, *GFin = nullptr, *GH = nullptr;
   float *gA = nullptr, *gphi = nullptr, *gdecay = nullptr, *gw = nullptr, *h0 = nullptr, *hm = nullptr, *ghm = nullptr, *gh0 = nullptr;
   float2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr, *Hf = nullptr;
@@ -816,6 +825,9 @@ struct BlindOp {
   ~BlindOp() {
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     for (void* q : allocs) (void)hipFree(q);
   }
 
@@ -908,7 +920,6 @@ struct BlindOp {
   void fir(const float* X, long long xs, int Tn, float* Y) {
     static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
     const size_t sm = (size_t)(FL_TB + 2 * Nf - 1) * FL_BINS * sizeof(float2);
-    static const bool big_lds = hipFuncSetAttribute((const void*)fir_sb_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     if (lds && big_lds && sm <= 96 * 1024 && Nf <= 128)
       hipLaunchKernelGGL(fir_sb_lds_kernel, dim3((Tn + FL_TB - 1) / FL_TB, (FB + FL_BINS - 1) / FL_BINS, U), dim3(256), sm, st, X, xs, (const float*)H, Y, Tn, Nf);
     else
@@ -1028,6 +1039,12 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
   DA(c1, (size_t)U_ * N2); DA(c2, (size_t)U_ * N2); DA(c3, (size_t)U_ * N2); DA(Hf, (size_t)U_ * N2);
   DA(Mabs, (size_t)U_ * N2); DA(phim, (size_t)U_ * N2); DA(gM, (size_t)U_ * N2);
   DA(partial, (size_t)U_ * 64); DA(losses, (size_t)U_ * 4);
+  o->big_lds = hipFuncSetAttribute((const void*)fir_sb_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+  {
+    const size_t specD = (size_t)U_ * Td * LDSP + 8;
+    DA(sp_b, (size_t)U_ * ((size_t)(Td + 4) * HOP + NFFT)); DA(frames_b, (size_t)U_ * (Td + 2) * WIN);
+    DA(X2_b, specD); DA(X3_b, specD); DA(Ybuf_b, specD); DA(sig2_b, (size_t)U_ * (o->Lr + 8)); DA(partial_b, (size_t)U_ * 64);
+  }
   DA(rir, (size_t)U_ * o->Lr); DA(Rc, (size_t)U_ * Td * LDSP + 8);
   DA(dpm, (size_t)Nf * FB);
   DA(d_step, 4); DA(d_scal, 4); DA(bc_tab, BlindOp::MAXSTEP); DA(xden_buf, (size_t)U_ * L);
@@ -1204,6 +1221,21 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
   const int U = o->U, T = o->T, Td = o->Td, L = o->L, Nf = o->Nf;
   hipStream_t st = o->st;
   o->update_H();
+  if (noise && t_op_dev != nullptr && o->side_stream != nullptr && o->fork_ok) {
+    // fork: the regulariser chain only needs H (and this iteration's noise): run it on the side stream with its own scratch set
+    (void)hipEventRecord(o->ev_fork, st);
+    (void)hipStreamWaitEvent(o->side_stream, o->ev_fork, 0);
+    o->swap_scratch(); o->st = o->side_stream;
+    o->time_rir(o->rir);
+    o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X3, noise, t_op, t_op_dev);
+    hipLaunchKernelGGL(compress_kernel, dim3(gridf((long long)U * Td * FB)), dim3(256), 0, o->st, (const float*)o->X3, o->Rc, (long long)U * Td, o->c.comp);
+    o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X2);
+    o->comp_loss(o->Rc, o->X2, o->X3, Td, w_reg, o->losses + U, 0);
+    o->stft_adj(o->X3, o->Lr, WIN, Td, 1.f / o->norm, o->sig2);
+    o->istft_adj(o->sig2, Td, WIN + WIN / 2, o->env_d, o->Lr, o->norm, o->X2);
+    (void)hipEventRecord(o->ev_join, o->side_stream);
+    o->swap_scratch(); o->st = st;
+  }
   if (!have_Xd) o->stft(x_den, L, WIN, T, 1.f / o->norm, o->X1);          // X1 = STFT(x_den) stays valid across the iterations
   // reconstruction term
   o->fir(o->X1, (long long)T * LDSP, T, o->Ybuf);
@@ -1215,14 +1247,24 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
   o->gradh(o->X1, (long long)T * LDSP, o->X2, T, 0);
   // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach())
   if (noise) {
-    o->time_rir(o->rir);                                                     // Ybuf = FIR(Xdelta, H) consumed inside
-    o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X3, noise, t_op, t_op_dev);      // STFT(rir + t n)
-    hipLaunchKernelGGL(compress_kernel, dim3(gridf((long long)U * Td * FB)), dim3(256), 0, st, (const float*)o->X3, o->Rc, (long long)U * Td, o->c.comp);
-    o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X2);
-    o->comp_loss(o->Rc, o->X2, o->X3, Td, w_reg, o->losses + U, 0);
-    o->stft_adj(o->X3, o->Lr, WIN, Td, 1.f / o->norm, o->sig2);
-    o->istft_adj(o->sig2, Td, WIN + WIN / 2, o->env_d, o->Lr, o->norm, o->X2);
-    o->gradh(o->Xdelta, 0LL, o->X2, Td, 1);
+    const bool fork = t_op_dev != nullptr && o->side_stream != nullptr && o->fork_ok;     // captured-graph mode: a parallel branch
+    auto chain = [&]() {
+      o->time_rir(o->rir);                                                     // Ybuf = FIR(Xdelta, H) consumed inside
+      o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X3, noise, t_op, t_op_dev);      // STFT(rir + t n)
+      hipLaunchKernelGGL(compress_kernel, dim3(gridf((long long)U * Td * FB)), dim3(256), 0, o->st, (const float*)o->X3, o->Rc, (long long)U * Td, o->c.comp);
+      o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X2);
+      o->comp_loss(o->Rc, o->X2, o->X3, Td, w_reg, o->losses + U, 0);
+      o->stft_adj(o->X3, o->Lr, WIN, Td, 1.f / o->norm, o->sig2);
+      o->istft_adj(o->sig2, Td, WIN + WIN / 2, o->env_d, o->Lr, o->norm, o->X2);
+    };
+    if (fork) {
+      // the branch was forked right after update_H (below); it used the second scratch set and left its gradient in X2_b
+      (void)hipStreamWaitEvent(st, o->ev_join, 0);
+      o->gradh(o->Xdelta, 0LL, o->X2_b, Td, 1);
+    } else {
+      chain();
+      o->gradh(o->Xdelta, 0LL, o->X2, Td, 1);
+    }
   }
   o->cons_backward(o->GH);
   hipLaunchKernelGGL(h0_bwd_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->GFin, (const float*)o->A, (const float*)o->phi, o->gA, o->gphi, U, Nf);
@@ -1297,6 +1339,12 @@ int blindop_optimize(BlindOp* o, const float* x_den, const float* noise, float t
   if (!o->gexec || o->g_iters != n_iters || std::memcmp(hp, o->g_hp, sizeof(hp)) != 0) {
     if (o->gexec) { (void)hipGraphExecDestroy(o->gexec); o->gexec = nullptr; }
     if (!o->cap_stream) HIPCHK(hipStreamCreateWithFlags(&o->cap_stream, hipStreamNonBlocking));
+    static const bool want_fork = !(getenv("BUDDY_OP_FORK") && atoi(getenv("BUDDY_OP_FORK")) == 0);
+    if (want_fork && !o->side_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&o->side_stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&o->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&o->ev_join, hipEventDisableTiming));
+    }
+    o->fork_ok = want_fork;
     const bool prof = igemm_prof_enabled();
     igemm_prof_enable(0);                                // no event records inside the captured region
     const int step0 = o->adam_step;
@@ -1306,7 +1354,7 @@ int blindop_optimize(BlindOp* o, const float* x_den, const float* noise, float t
       optimize_iteration(o, o->xden_buf, noise ? o->noise_buf + (long long)it * U * o->Lr : nullptr, t_op, w_rec, w_reg, lr, b1, b2, wd, it > 0, true);
     hipGraph_t graph = nullptr;
     const hipError_t ce = hipStreamEndCapture(o->cap_stream, &graph);
-    o->st = st; o->adam_step = step0;
+    o->st = st; o->adam_step = step0; o->fork_ok = false;
     igemm_prof_enable(prof ? 1 : 0);
     if (ce != hipSuccess || !graph) { set_error(std::string("optimize_op graph capture failed: ") + hipGetErrorString(ce)); return BUDDY_ERR_HIP; }
     const hipError_t ie = hipGraphInstantiate(&o->gexec, graph, nullptr, nullptr, 0);
