@@ -55,7 +55,17 @@ def merge(parts, starts, L):
     return out
 
 
-def predict_chunked(sample_batch, y, chunk, overlap):
-    """``sample_batch``: (n, chunk) reverberant chunks -> (n, chunk) estimates (one sampler call, chunks = utterances)."""
+def predict_chunked(sample_batch, y, chunk, overlap, level_match=False):
+    """``sample_batch``: (n, chunk) reverberant chunks -> (n, chunk) estimates (one sampler call, chunks = utterances).
+
+    ``level_match``: the blind configuration rescales every utterance's estimate to a fixed standard deviation
+    (``constraint_speech_magnitude``, reference EulerHeunSamplerDPS.py:127-129) -- per CHUNK here, so a chunk that is mostly a pause would come
+    back as loud as a chunk of running speech and the cross-fade would mix segments of different gains.  With ``level_match`` each chunk's
+    estimate is scaled by std(y_chunk) / std(y_clip) (the observation's own level profile) before the merge, which restores one gain for the clip;
+    what remains chunk-specific is the RIR estimate (one operator per chunk), see DESIGN.md section 5."""
     parts, starts = split(y, chunk, overlap)
-    return merge(sample_batch(parts), starts, y.reshape(-1).shape[-1])
+    est = sample_batch(parts)
+    if level_match and parts.shape[0] > 1:
+        g = parts.std(dim=1, keepdim=True) / (y.reshape(-1).std() + 1e-12)
+        est = est * g.to(est.dtype)
+    return merge(est, starts, y.reshape(-1).shape[-1])

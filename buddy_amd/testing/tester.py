@@ -198,7 +198,9 @@ class Tester:
                 op.update_params(torch.as_tensor(rir, dtype=torch.float32))
             return self.sampler.predict_conditional(parts.contiguous(), op, shape=(n, clen), blind=blind)
 
-        pred = longform.predict_chunked(sample_batch, y[0], chunk, overlap)
+        csm = ps.get("constraint_speech_magnitude", None) if hasattr(ps, "get") else None
+        level = bool(blind and csm is not None and csm.get("use", False))      # per-chunk magnitude constraint -> restore one gain for the clip
+        pred = longform.predict_chunked(sample_batch, y[0], chunk, overlap, level_match=level)
         return seg[0], y[0], pred
 
     def prepare_directories(self, mode, unconditional=False, blind=False):

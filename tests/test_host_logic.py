@@ -231,6 +231,23 @@ def test_wpe_oracle_conventions_and_independent_restatements_agree():
     assert rel(b, a) < 1e-6
 
 
+def test_longform_chunking_edge_cases_and_level_match():
+    """chunk_plan / merge: overlap 0 with L an exact multiple of the chunk is plain concatenation, the identity sampler returns the clip
+    exactly for any overlap, and level_match undoes a per-chunk normalisation (every chunk rescaled to one std, as the blind configuration's
+    magnitude constraint does) up to the clip's overall gain."""
+    from buddy_amd.testing import longform
+    y = torch.from_numpy(np.random.RandomState(0).standard_normal(128000).astype(np.float32))
+    y[40000:90000] *= 0.05                                           # a long pause
+    for chunk, ov in ((64000, 0), (64000, 1), (50000, 8000), (200000, 100)):
+        out = longform.predict_chunked(lambda p: p.clone(), y, chunk, ov)
+        assert out.shape == y.shape and float((out - y).abs().max()) < 1e-6, (chunk, ov)
+    norm = lambda p: 0.05 * p / p.std(dim=1, keepdim=True)           # what constraint_speech_magnitude does to every chunk
+    flat = longform.predict_chunked(norm, y, 32000, 4000)
+    matched = longform.predict_chunked(norm, y, 32000, 4000, level_match=True)
+    ratio = lambda z: float(z[50000:80000].std() / z[:30000].std())  # pause level relative to speech level
+    assert abs(ratio(y) - 0.05) < 0.01 and ratio(flat) > 0.5 and abs(ratio(matched) - ratio(y)) < 0.02
+
+
 def test_cli_parser_matches_reference_command_line():
     import test as cli
     groups, ov = cli.parse(["--config-name=conf_VCTK.yaml", "tester=blind_dereverberation_BUDDy", "tester.checkpoint=x.pt",
