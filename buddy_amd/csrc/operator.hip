@@ -343,9 +343,10 @@ __global__ void loss_finalize_kernel(const double* partial, int nblk, float kapp
 // ---- filter design (reference :212-251) ----
 struct DesignTabs { const int* idx; const float* frac; const float* corr; const float* dpm; };   // per-bin knot index / fraction; OLA corr[Nf]; dpm[Nf][FB]
 // dm[u][n][j], j = 0..K-1 knots (rows 0 and K-1 are zero): sum_e w[e][j-1] * exp(decay[e][j-1])^(-n)
-__global__ void design_dm_kernel(const float* decay, const float* wts, float* logdm, float* dmv, int U, int E, int NB, int Nf) {
+__global__ void design_dm_kernel(const float* decay, const float* wts, float* logdm, float* dmv, int U, int E, int NB, int Nf, int* step_inc) {
   const int K = NB + 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (step_inc && i == 0) *step_inc += 1;                  // captured loop: the Adam step counter advances with the first kernel of an iteration
   if (i >= U * Nf * K) return;
   const int j = i % K, n = (i / K) % Nf, u = i / (K * Nf);
   float v = 0.f;
@@ -424,13 +425,24 @@ __global__ void design_bwd_params_kernel(const float* gdm, const float* decay, c
 // stage 1: Y1[u][n2][k1] = tw(n2 k1) * sum_{n1} x[256 n1 + n2] W101^(n1 k1).  101 is prime: a naive 101-point DFT per column n2, but a block
 // parks its S1_COLS columns of x (101 x 4 complex) and the twiddles in LDS first, so the inner loop is two LDS reads and a complex FMA.
 constexpr int S1_COLS = 4;
-__global__ __launch_bounds__(256) void fft_stage1_kernel(const float2* x, float2* y1, const float2* w101, const float2* twN, int sign) {
+// Input forms folded into the load (each was a kernel of its own, and every node of the captured loop costs ~5 us): IN 0 = complex array x;
+// IN 1 = x times the Hilbert window (2 on the first half, 0 on the second; mp_window); IN 2 = a REAL signal xr[u][0..Lr) zero-padded to N2
+// (mp_pack); IN 3 = the same with sample 0 forced to zero (mpb_pack: hm[0] is a constant of the projection).
+struct S1In { const float2* x; const float* xr; int Lr; };
+template <int IN>
+__global__ __launch_bounds__(256) void fft_stage1_kernel(S1In in, float2* y1, const float2* w101, const float2* twN, int sign) {
   __shared__ float2 W[F1];
   __shared__ float2 X[F1 * S1_COLS];
   const int u = blockIdx.y, n20 = blockIdx.x * S1_COLS;
-  const float2* xu = x + (long long)u * N2;
+  const float2* xu = in.x + (long long)u * N2;
   for (int i = threadIdx.x; i < F1; i += 256) W[i] = make_float2(w101[i].x, sign * w101[i].y);
-  for (int i = threadIdx.x; i < F1 * S1_COLS; i += 256) { const int n1 = i / S1_COLS, c = i - n1 * S1_COLS; X[i] = xu[F2 * n1 + n20 + c]; }
+  for (int i = threadIdx.x; i < F1 * S1_COLS; i += 256) {
+    const int n1 = i / S1_COLS, c = i - n1 * S1_COLS, n = F2 * n1 + n20 + c;
+    float2 v;
+    if (IN >= 2) v = make_float2((n < in.Lr && (IN == 2 || n > 0)) ? in.xr[(long long)u * in.Lr + n] : 0.f, 0.f);
+    else { v = xu[n]; if (IN == 1) { const float w = n < N2 / 2 ? 2.f : 0.f; v.x *= w; v.y *= w; } }
+    X[i] = v;
+  }
   __syncthreads();
   for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
     const int c = o / F1, k1 = o - c * F1;                  // consecutive threads: consecutive k1 of one column (coalesced store)
@@ -493,9 +505,11 @@ __device__ __forceinline__ void dft16(float2 (&x)[16]) {
     x[12 + b0] = make_float2(d02.x - jd.x, d02.y - jd.y);
   }
 }
+// Output forms: OUT 0 = complex X; OUT 1 = the first Lo REAL parts to xr[u][0..Lo) (mpb_out); OUT 2 = the same with sample 0 := first (mp_out)
+struct S2Out { float2* X; float* xr; int Lo; float first; };
 constexpr int S2_COLS = 16, S2_PITCH = 16 * S2_COLS + 4;
-template <int SGN>
-__global__ __launch_bounds__(256) void fft_stage2_kernel(const float2* y1, float2* X, const float2* w256, float scale) {
+template <int SGN, int OUT>
+__global__ __launch_bounds__(256) void fft_stage2_kernel(const float2* y1, S2Out out, const float2* w256, float scale) {
   __shared__ float2 S[16 * S2_PITCH];
   __shared__ float2 W[F2];
   for (int i = threadIdx.x; i < F2; i += 256) W[i] = make_float2(w256[i].x, SGN * w256[i].y);
@@ -517,9 +531,17 @@ __global__ __launch_bounds__(256) void fft_stage2_kernel(const float2* y1, float
   for (int rr = 0; rr < 16; ++rr) v[rr] = S[b * S2_PITCH + rr * S2_COLS + col];
   dft16<SGN>(v);
   if (ok) {
-    float2* Xu = X + (long long)u * N2 + k1;
+    if (OUT == 0) {
+      float2* Xu = out.X + (long long)u * N2 + k1;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) Xu[(long long)F1 * (b + 16 * c)] = make_float2(v[c].x * scale, v[c].y * scale);
+      for (int c = 0; c < 16; ++c) Xu[(long long)F1 * (b + 16 * c)] = make_float2(v[c].x * scale, v[c].y * scale);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int n = k1 + F1 * (b + 16 * c);
+        if (n < out.Lo) out.xr[(long long)u * out.Lo + n] = (OUT == 2 && n == 0) ? out.first : v[c].x * scale;
+      }
+    }
   }
 }
 
@@ -722,6 +744,47 @@ __global__ void project_kernel(float* decay, float* wts, int U, int E, int NB, f
     else *w = fminf(fmaxf(*w, wlo), w0);
   }
 }
+// One launch for the whole parameter update of an iteration of the captured loop (was step_inc + 3 x adam + project = 5 nodes): blocks
+// [0, pb) take the phases, the rest one (utterance, band) pair per thread -- Adam on its E decays and E weights, then the projection of exactly
+// those values (project_params reads nothing else).  Same per-element arithmetic as adam_kernel / project_kernel.  The step counter is advanced
+// by the FIRST kernel of the iteration (design_dm_kernel), so every block here reads the same value.
+__device__ __forceinline__ float adam_one(float p, float gi, float* m, float* v, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  if (wd != 0.f) gi += wd * p;
+  const float mi = *m + (gi - *m) * (1.f - b1);
+  const float vi = *v * b2 + (1.f - b2) * gi * gi;
+  *m = mi; *v = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  return p - (lr / bc1) * (mi / denom);
+}
+struct AdamAll { float *decay, *wts, *phi; const float *gdecay, *gw, *gphi; float *m_d, *v_d, *m_w, *v_w, *m_p, *v_p; };
+__global__ __launch_bounds__(256) void adam_all_kernel(AdamAll a, long long np, int pb, int U, int E, int NB, float lr, float b1, float b2, float eps, float wd,
+                                                       const int* step_dev, const float2* bc_tab, float dmin, float dmax, float wlo, float whi,
+                                                       int clamp_decay, int long2nd) {
+  const float2 bc = bc_tab[*step_dev];
+  if ((int)blockIdx.x < pb) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < np; i += (long long)pb * 256)
+      a.phi[i] = adam_one(a.phi[i], a.gphi[i], a.m_p + i, a.v_p + i, lr, b1, b2, eps, wd, bc.x, bc.y);
+    return;
+  }
+  const int i = ((int)blockIdx.x - pb) * 256 + threadIdx.x;
+  if (i >= U * NB) return;
+  const int b = i % NB, u = i / NB;
+  float d0 = 0.f, w0 = 0.f;
+  for (int e = 0; e < E; ++e) {
+    const long long q = ((long long)u * E + e) * NB + b;
+    float d = adam_one(a.decay[q], a.gdecay[q], a.m_d + q, a.v_d + q, lr, b1, b2, eps, wd, bc.x, bc.y);
+    float w = adam_one(a.wts[q], a.gw[q], a.m_w + q, a.v_w + q, lr, b1, b2, eps, wd, bc.x, bc.y);
+    if (clamp_decay) {
+      float hi = dmax;
+      if (e > 0 && long2nd) hi = fminf(d0 / 1.01f, dmax);
+      d = fminf(fmaxf(d, dmin), hi);
+      if (e == 0) d0 = d;
+    }
+    if (e == 0) { w = fminf(fmaxf(w, wlo), whi); w0 = w; }
+    else w = fminf(fmaxf(w, wlo), w0);
+    a.decay[q] = d; a.wts[q] = w;
+  }
+}
 // reference layout (U, F, Nf) <-> frame-major (U, Nf, F)
 __global__ __launch_bounds__(256) void transpose_fk_kernel(const float* src, float* dst, int U, int Nf, int to_frame_major) {
   const long long total = (long long)U * Nf * FB;
@@ -802,6 +865,7 @@ struct BlindOp {
   // second scratch set + stream + events: inside the captured graph the RIR-regulariser chain of an iteration (14 nodes) runs as a parallel branch
   // beside the reconstruction chain (12 nodes); both only read H and meet again at the accumulating tap-gradient
   float *sp_b = nullptr, *frames_b = nullptr, *X2_b = nullptr, *X3_b = nullptr, *Ybuf_b = nullptr, *sig2_b = nullptr; double* partial_b = nullptr;
+  bool fused_loop = false;           // inside the captured optimisation loop: step counter in design_dm, no loss finalisation, one Adam launch
   bool big_lds = false;              // fir_sb_lds_kernel may take > 64 KB of dynamic LDS (set once at creation, outside any stream capture)
   hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool fork_ok = false;
   void swap_scratch() {
@@ -870,50 +934,60 @@ struct BlindOp {
     if (use_fft) r2c(frames, 0, WIN, U * Tn, (long long)U * Tn, GY, scale / NFFT, 1);
     else gemm(frames, WIN, 0, BiT, WIN, false, GY, LDSP, 0, U * Tn, LDSP, WIN, scale, 1);
   }
-  void fft(const float2* x, float2* tmp, float2* X, int sign, float scale) {
-    hipLaunchKernelGGL(fft_stage1_kernel, dim3(F2 / S1_COLS, U), dim3(256), 0, st, x, tmp, (const float2*)w101, (const float2*)twN, sign);
-    if (sign > 0) hipLaunchKernelGGL(fft_stage2_kernel<1>, dim3(cdiv(F1, S2_COLS), U), dim3(256), 0, st, (const float2*)tmp, X, (const float2*)w256, scale);
-    else hipLaunchKernelGGL(fft_stage2_kernel<-1>, dim3(cdiv(F1, S2_COLS), U), dim3(256), 0, st, (const float2*)tmp, X, (const float2*)w256, scale);
+  // in_mode / out_mode: the elementwise neighbours of the transform folded into its first load / last store (S1In / S2Out above)
+  void fft(const float2* x, float2* tmp, float2* X, int sign, float scale, int in_mode = 0, const float* xr = nullptr, int Lr_ = 0, int out_mode = 0,
+           float* yr = nullptr, int Lo = 0, float first = 0.f) {
+    const S1In in{x, xr, Lr_};
+    const dim3 g1(F2 / S1_COLS, U), g2(cdiv(F1, S2_COLS), U);
+    if (in_mode == 1) hipLaunchKernelGGL(fft_stage1_kernel<1>, g1, dim3(256), 0, st, in, tmp, (const float2*)w101, (const float2*)twN, sign);
+    else if (in_mode == 2) hipLaunchKernelGGL(fft_stage1_kernel<2>, g1, dim3(256), 0, st, in, tmp, (const float2*)w101, (const float2*)twN, sign);
+    else if (in_mode == 3) hipLaunchKernelGGL(fft_stage1_kernel<3>, g1, dim3(256), 0, st, in, tmp, (const float2*)w101, (const float2*)twN, sign);
+    else hipLaunchKernelGGL(fft_stage1_kernel<0>, g1, dim3(256), 0, st, in, tmp, (const float2*)w101, (const float2*)twN, sign);
+    const S2Out o{X, yr, Lo, first};
+    if (sign > 0) {
+      if (out_mode == 1) hipLaunchKernelGGL((fft_stage2_kernel<1, 1>), g2, dim3(256), 0, st, (const float2*)tmp, o, (const float2*)w256, scale);
+      else if (out_mode == 2) hipLaunchKernelGGL((fft_stage2_kernel<1, 2>), g2, dim3(256), 0, st, (const float2*)tmp, o, (const float2*)w256, scale);
+      else hipLaunchKernelGGL((fft_stage2_kernel<1, 0>), g2, dim3(256), 0, st, (const float2*)tmp, o, (const float2*)w256, scale);
+    } else {
+      hipLaunchKernelGGL((fft_stage2_kernel<-1, 0>), g2, dim3(256), 0, st, (const float2*)tmp, o, (const float2*)w256, scale);
+    }
   }
   DesignTabs tabs() const { DesignTabs t; t.idx = idx; t.frac = frac; t.corr = corr; t.dpm = dpm; return t; }
 
   void design() {
-    hipLaunchKernelGGL(design_dm_kernel, dim3(cdiv(U * Nf * K, 256)), dim3(256), 0, st, (const float*)decay, (const float*)wts, logdm, dmv, U, E, NB, Nf);
+    hipLaunchKernelGGL(design_dm_kernel, dim3(cdiv(U * Nf * K, 256)), dim3(256), 0, st, (const float*)decay, (const float*)wts, logdm, dmv, U, E, NB, Nf,
+                       fused_loop ? d_step : (int*)nullptr);
     hipLaunchKernelGGL(design_A_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)logdm, tabs(), A, Apre, U, K, Nf);
   }
   // minimum_phase_version (reference reverb_utils.py:9-23) of hin (U, Lin <= Lm samples, zero-padded to N2): result (complex, real part = signal) in c1
-  void minphase_core(const float* hin, int Lin) {
+  // out_real != nullptr: the last transform writes Re(.)[:Lo] there (sample 0 := first when first_set) instead of the complex c1
+  void minphase_core(const float* hin, int Lin, float* out_real = nullptr, int Lo = 0, bool first_set = false, float first = 0.f) {
     const long long tot = (long long)U * N2;
-    hipLaunchKernelGGL(mp_pack_kernel, dim3(gridf(tot)), dim3(256), 0, st, hin, Lin, c1, U);
-    fft(c1, c2, Hf, -1, 1.f);
+    fft(nullptr, c2, Hf, -1, 1.f, 2, hin, Lin);                                        // FFT of [hin, zeros]
     hipLaunchKernelGGL(mp_logabs_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)Hf, Mabs, c1, tot);
     fft(c1, c2, c3, -1, 1.f);
-    hipLaunchKernelGGL(mp_window_kernel, dim3(gridf(tot)), dim3(256), 0, st, c3, tot);
-    fft(c3, c2, c1, +1, 1.f / N2);
+    fft(c3, c2, c1, +1, 1.f / N2, 1);                                                  // Hilbert window folded into the load
     hipLaunchKernelGGL(mp_phase_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)c1, (const float*)Mabs, phim, c3, tot);
-    fft(c3, c2, c1, +1, 1.f / N2);
+    if (out_real) fft(c3, c2, c1, +1, 1.f / N2, 0, nullptr, 0, first_set ? 2 : 1, out_real, Lo, first);
+    else fft(c3, c2, c1, +1, 1.f / N2);
   }
   // H = cons(A * exp(j phi))   (reference :333-351)
   void cons_forward() {
     hipLaunchKernelGGL(h0_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)A, (const float*)phi, Fin, U, Nf);
     istft(Fin, Nf + 2, WIN, env_c, Lh, 1.f, h0);
-    minphase_core(h0, Lh);
-    hipLaunchKernelGGL(mp_out_kernel, dim3(gridf((long long)U * Lm)), dim3(256), 0, st, (const float2*)c1, hm, Lm, U, (float)(WIN / (HOP * 2.0)));
+    minphase_core(h0, Lh, hm, Lm, true, (float)(WIN / (HOP * 2.0)));
     stft(hm, Lm, WIN - HOP, Nf, 1.f, H);          // frames 1..Nf of the centred STFT: frame k starts at 128 (k+1) - 512
   }
   // G_Fin from G_H
   void cons_backward(const float* GHin) {
     stft_adj(GHin, Lm, WIN - HOP, Nf, 1.f, ghm);
     const long long tot = (long long)U * N2;
-    hipLaunchKernelGGL(mpb_pack_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float*)ghm, Lm, c1, U);
-    fft(c1, c2, c3, -1, 1.f / N2);                                   // GZ
+    fft(nullptr, c2, c3, -1, 1.f / N2, 3, ghm, Lm);                  // GZ = FFT([0, ghm[1:], zeros]) / N2
     hipLaunchKernelGGL(mpb_z_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)c3, (const float*)Mabs, (const float*)phim, gM, c1, tot);
     fft(c1, c2, c3, -1, 1.f);
-    hipLaunchKernelGGL(mp_window_kernel, dim3(gridf(tot)), dim3(256), 0, st, c3, tot);
-    fft(c3, c2, c1, +1, 1.f / N2);                                   // hilbert(g_phi)
+    fft(c3, c2, c1, +1, 1.f / N2, 1);                                // hilbert(g_phi), window folded into the load
     hipLaunchKernelGGL(mpb_h_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)c1, (const float*)Mabs, (const float*)gM, (const float2*)Hf, c3, tot);
-    fft(c3, c2, c1, +1, 1.f);                                        // N2 * IFFT(GH)
-    hipLaunchKernelGGL(mpb_out_kernel, dim3(gridf((long long)U * Lh)), dim3(256), 0, st, (const float2*)c1, gh0, Lh, U);
+    fft(c3, c2, c1, +1, 1.f, 0, nullptr, 0, 1, gh0, Lh);             // g_h0 = Re(N2 * IFFT(GH))[:Lh]
     istft_adj(gh0, Nf + 2, WIN, env_c, Lh, 1.f, GFin);
   }
   void update_H() { design(); cons_forward(); }
@@ -937,7 +1011,8 @@ struct BlindOp {
     const float kappa = weight / (float)Tn;
     const int nblk = 64;
     hipLaunchKernelGGL(comp_loss_kernel, dim3(nblk, U), dim3(256), 0, st, Rcx, Xh, G, partial, Tn, kappa, c.comp);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(U), dim3(32), 0, st, (const double*)partial, nblk, kappa, out, accumulate);
+    if (!fused_loop)        // the loop only needs the gradient; the loss VALUES are read through buddy_blindop_param_grads / rec_loss_grad
+      hipLaunchKernelGGL(loss_finalize_kernel, dim3(U), dim3(32), 0, st, (const double*)partial, nblk, kappa, out, accumulate);
   }
   void degrade(const float* x, float* y) {
     stft(x, L, WIN, T, 1.f / norm, X1);
@@ -1292,11 +1367,20 @@ static void optimize_iteration(BlindOp* o, const float* x_den, const float* nois
   const int U = o->U;
   hipStream_t st = o->st;
   const long long nb = (long long)U * o->E * o->NB, np = (long long)U * o->Nf * FB;
+  o->fused_loop = dev;
   param_grads(o, x_den, noise, t_op, w_rec, w_reg, have_Xd, dev ? o->d_scal : nullptr);
-  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, o->d_step);
+  o->fused_loop = false;
   o->adam_step += 1;
+  if (dev) {
+    const AdamAll a{o->decay, o->wts, o->phi, o->gdecay, o->gw, o->gphi, o->m_d, o->v_d, o->m_w, o->v_w, o->m_p, o->v_p};
+    const int pb = (int)std::min<long long>((np + 255) / 256, 2048), db = cdiv(U * o->NB, 256);
+    hipLaunchKernelGGL(adam_all_kernel, dim3(pb + db), dim3(256), 0, st, a, np, pb, U, o->E, o->NB, lr, b1, b2, 1e-8f, wd, (const int*)o->d_step,
+                       (const float2*)o->bc_tab, o->c.min_decay, o->c.max_decay, o->c.w_lo, o->c.w_hi, o->c.clamp_decay, o->c.long2nd);
+    return;
+  }
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, o->d_step);
   const float bc1 = 1.f - std::pow(b1, (float)o->adam_step), bc2s = std::sqrt(1.f - std::pow(b2, (float)o->adam_step));
-  const int* sd = dev ? o->d_step : nullptr;
+  const int* sd = nullptr;
   hipLaunchKernelGGL(adam_kernel, dim3(gridf(nb)), dim3(256), 0, st, o->decay, (const float*)o->gdecay, o->m_d, o->v_d, nb, lr, b1, b2, 1e-8f, wd, bc1, bc2s, sd, (const float2*)o->bc_tab);
   hipLaunchKernelGGL(adam_kernel, dim3(gridf(nb)), dim3(256), 0, st, o->wts, (const float*)o->gw, o->m_w, o->v_w, nb, lr, b1, b2, 1e-8f, wd, bc1, bc2s, sd, (const float2*)o->bc_tab);
   hipLaunchKernelGGL(adam_kernel, dim3(gridf(np)), dim3(256), 0, st, o->phi, (const float*)o->gphi, o->m_p, o->v_p, np, lr, b1, b2, 1e-8f, wd, bc1, bc2s, sd, (const float2*)o->bc_tab);
