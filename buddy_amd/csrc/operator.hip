@@ -1423,7 +1423,9 @@ int blindop_optimize(BlindOp* o, const float* x_den, const float* noise, float t
   if (!o->gexec || o->g_iters != n_iters || std::memcmp(hp, o->g_hp, sizeof(hp)) != 0) {
     if (o->gexec) { (void)hipGraphExecDestroy(o->gexec); o->gexec = nullptr; }
     if (!o->cap_stream) HIPCHK(hipStreamCreateWithFlags(&o->cap_stream, hipStreamNonBlocking));
-    static const bool want_fork = !(getenv("BUDDY_OP_FORK") && atoi(getenv("BUDDY_OP_FORK")) == 0);
+    // OFF by default: a captured graph with a parallel branch gains 0.2 ms per call on its own, but its replay no longer overlaps with the other
+    // sub-batch's stream (two concurrent sub-batches: 77.4 ms/step with the branch, 71.1 without -- profiles/README.md r03b)
+    static const bool want_fork = getenv("BUDDY_OP_FORK") && atoi(getenv("BUDDY_OP_FORK")) == 1;
     if (want_fork && !o->side_stream) {
       HIPCHK(hipStreamCreateWithFlags(&o->side_stream, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&o->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&o->ev_join, hipEventDisableTiming));
