@@ -606,6 +606,7 @@ constexpr int C2O_TH = 8, C2O_TW = 32, C2O_CK = 32, C2O_PITCH = C2O_CK + 4;
 __global__ __launch_bounds__(256) void conv_c2out_tiled_kernel(const float* __restrict__ x, int ldX, const float* __restrict__ w, const float* bias,
                                                                const float* up_add, float* y, int B, int H, int W, int Cin, int accumulate) {
   __shared__ __attribute__((aligned(16))) float tile[(C2O_TH + 2) * (C2O_TW + 2) * C2O_PITCH];
+  __shared__ __attribute__((aligned(16))) float wsh[9 * C2O_CK * 2];     // this chunk's weights: [tap][channel][2] (was 576 scalar loads per thread and chunk)
   const int tid = threadIdx.x;
   const int tx = tid & (C2O_TW - 1), ty = tid / C2O_TW;
   const int nbx = (W + C2O_TW - 1) / C2O_TW, nby = (H + C2O_TH - 1) / C2O_TH;
@@ -616,25 +617,39 @@ __global__ __launch_bounds__(256) void conv_c2out_tiled_kernel(const float* __re
   const int h = h0 + ty, wq = w0 + tx;
   float s0 = 0.f, s1 = 0.f;
   constexpr int NPX = (C2O_TH + 2) * (C2O_TW + 2);        // 340 halo pixels, 8 float4 each
+  constexpr int NLD = (NPX * (C2O_CK / 4) + 255) / 256;    // 11 float4 per thread
   for (int c0 = 0; c0 < Cin; c0 += C2O_CK) {
-    for (int e = tid; e < NPX * (C2O_CK / 4); e += 256) {
+    float4 v[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {                        // all global loads of the slab in flight before the first LDS store
+      const int e = tid + 256 * i;
       const int px = e >> 3, c4 = (e & 7) * 4;
       const int hr = px / (C2O_TW + 2), wc = px - hr * (C2O_TW + 2);
       const int gh = h0 - 1 + hr, gw = w0 - 1 + wc;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) v = ld4(x + (((long long)b * H + gh) * W + gw) * ldX + c0 + c4);
-      *reinterpret_cast<float4*>(tile + px * C2O_PITCH + c4) = v;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < NPX * (C2O_CK / 4) && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) v[i] = ld4(x + (((long long)b * H + gh) * W + gw) * ldX + c0 + c4);
     }
+    float wv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int e = tid + 256 * i; wv[i] = e < 9 * C2O_CK * 2 ? w[((long long)(e / (C2O_CK * 2)) * Cin + c0) * 2 + e % (C2O_CK * 2)] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i;
+      if (e < NPX * (C2O_CK / 4)) *reinterpret_cast<float4*>(tile + (e >> 3) * C2O_PITCH + (e & 7) * 4) = v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int e = tid + 256 * i; if (e < 9 * C2O_CK * 2) wsh[e] = wv[i]; }
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const float* src = tile + ((ty + t / 3) * (C2O_TW + 2) + tx + t % 3) * C2O_PITCH;
-      const float* wt = w + ((long long)t * Cin + c0) * 2;
+      const float* wt = wsh + t * C2O_CK * 2;
 #pragma unroll
       for (int c4 = 0; c4 < C2O_CK; c4 += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(src + c4);
-        s0 += v.x * wt[c4 * 2 + 0] + v.y * wt[c4 * 2 + 2] + v.z * wt[c4 * 2 + 4] + v.w * wt[c4 * 2 + 6];
-        s1 += v.x * wt[c4 * 2 + 1] + v.y * wt[c4 * 2 + 3] + v.z * wt[c4 * 2 + 5] + v.w * wt[c4 * 2 + 7];
+        const float4 vv = *reinterpret_cast<const float4*>(src + c4);
+        const float4 wa = *reinterpret_cast<const float4*>(wt + c4 * 2), wb = *reinterpret_cast<const float4*>(wt + c4 * 2 + 4);
+        s0 += vv.x * wa.x + vv.y * wa.z + vv.z * wb.x + vv.w * wb.z;
+        s1 += vv.x * wa.y + vv.y * wa.w + vv.z * wb.y + vv.w * wb.w;
       }
     }
     __syncthreads();
