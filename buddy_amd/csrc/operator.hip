@@ -405,20 +405,25 @@ __global__ void design_bwd_knots_kernel(const float* gA, const float* Apre, Desi
   }
   gdm[i] = acc / tb.corr[n] / (dmv[i] + 1e-6f);      // d/d dm of log(dm + 1e-6)
 }
-__global__ void design_bwd_params_kernel(const float* gdm, const float* decay, const float* wts, float* gdecay, float* gw, int U, int E, int NB, int Nf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one WAVE per parameter (u, e, b): lanes take the frames n = lane, lane + 64, ...; fixed-order butterfly sum (one thread per parameter looping
+// over the Nf frames with a powf each took 35 us on a single workgroup, ten times per sampler step)
+__global__ __launch_bounds__(256) void design_bwd_params_kernel(const float* gdm, const float* decay, const float* wts, float* gdecay, float* gw, int U, int E,
+                                                                int NB, int Nf) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= U * E * NB) return;
   const int b = i % NB, u = i / (E * NB);
   const int K = NB + 2;
   const float base = expf(decay[i]), w = wts[i];
   float gd = 0.f, gwv = 0.f;
-  for (int n = 0; n < Nf; ++n) {
+  for (int n = lane; n < Nf; n += 64) {
     const float pw = powf(base, -(float)n);
     const float g = gdm[((long long)u * Nf + n) * K + b + 1];
     gwv += g * pw;
     gd += g * w * (-(float)n) * pw;
   }
-  gdecay[i] = gd; gw[i] = gwv;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { gd += __shfl_xor(gd, off, 64); gwv += __shfl_xor(gwv, off, 64); }
+  if (lane == 0) { gdecay[i] = gd; gw[i] = gwv; }
 }
 
 // ---- 25856-point complex FFT, two stages (N2 = 101 * 256): n = 256 n1 + n2, k = k1 + 101 k2 ----
@@ -1344,7 +1349,7 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
   o->cons_backward(o->GH);
   hipLaunchKernelGGL(h0_bwd_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->GFin, (const float*)o->A, (const float*)o->phi, o->gA, o->gphi, U, Nf);
   hipLaunchKernelGGL(design_bwd_knots_kernel, dim3(cdiv(U * Nf * o->K, 256)), dim3(256), 0, st, (const float*)o->gA, (const float*)o->Apre, o->tabs(), (const float*)o->dmv, o->gdm, U, o->K, Nf);
-  hipLaunchKernelGGL(design_bwd_params_kernel, dim3(cdiv(U * o->E * o->NB, 256)), dim3(256), 0, st, (const float*)o->gdm, (const float*)o->decay, (const float*)o->wts, o->gdecay, o->gw, U, o->E, o->NB, Nf);
+  hipLaunchKernelGGL(design_bwd_params_kernel, dim3(cdiv(U * o->E * o->NB, 4)), dim3(256), 0, st, (const float*)o->gdm, (const float*)o->decay, (const float*)o->wts, o->gdecay, o->gw, U, o->E, o->NB, Nf);
   return BUDDY_OK;
 }
 
