@@ -555,6 +555,60 @@ __global__ __launch_bounds__(256) void conv_c2in_reg_kernel(const float* x, cons
   }
 }
 
+// 3x3 form of the same op with FOUR consecutive pixels (along W) per thread: the 3 x 6 input neighbourhood is loaded once (18 float2 loads for four
+// outputs instead of 36) and the row / column predicates and address arithmetic are shared (the one-pixel form spends more issue slots on those than
+// on its 72 FMAs).  W % 4 == 0.
+__global__ __launch_bounds__(256) void conv_c2in_reg4_kernel(const float* x, const float* w, const float* bias, const float* add, int add_ld,
+                                                             float* y, int ldY, int B, int H, int W, int Cout, int accumulate) {
+  const int q = Cout >> 2;
+  const int quad = threadIdx.x % q, c = quad * 4;
+  float2 wr[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[t][j] = *reinterpret_cast<const float2*>(w + ((long long)(c + j) * 9 + t) * 2);
+  float b4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b4[j] = bias ? bias[c + j] : 0.f;
+  const int ppb = 256 / q;                                  // pixel groups per block iteration
+  const int W4 = W >> 2;
+  const long long ngrp = (long long)B * H * W4;
+  for (long long gi = (long long)blockIdx.x * ppb + threadIdx.x / q; gi < ngrp; gi += (long long)gridDim.x * ppb) {
+    const int wg = (int)(gi % W4) * 4; const int h = (int)((gi / W4) % H);
+    const long long p0 = (gi / W4) * W + wg;                 // pixel index of the first of the four outputs
+    float2 in[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const bool rok = (unsigned)(h + r - 1) < (unsigned)H;
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        const int wx = wg + cc - 1;
+        in[r][cc] = (rok && (unsigned)wx < (unsigned)W) ? reinterpret_cast<const float2*>(x)[p0 + (long long)(r - 1) * W + cc - 1] : make_float2(0.f, 0.f);
+      }
+    }
+    float4 ad[4], pr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ad[u] = add ? ld4(add + (p0 + u) * add_ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pr[u] = accumulate ? ld4(y + (p0 + u) * ldY + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {                          // tap order as in the one-pixel kernel (out-of-image taps contribute exact zeros)
+        const float2 v = in[t / 3][u + t % 3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += wr[t][j].x * v.x + wr[t][j].y * v.y;
+      }
+      float4 r = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (add) r = add4(r, ad[u]);
+      if (accumulate) r = add4(r, pr[u]);
+      st4(y + (p0 + u) * ldY + c, r);
+    }
+  }
+}
+
 // x [B][H][W][Cin] (ldX) -> y [B][H][W][2]; w [TAPS][Cin][2]; LPP = Cin/4 lanes cooperate on one pixel
 template <int TAPS>
 __global__ __launch_bounds__(256) void conv_c2out_kernel(const float* x, int ldX, const float* w, const float* bias, const float* up_add,
@@ -966,7 +1020,12 @@ void launch_conv_c2in(const float* x, const float* w, const float* bias, const f
     const int ppb = 256 / (Cout / 4);
     long long g = ((long long)B * H * W + ppb - 1) / ppb;
     if (g > 256 * 8) g = 256 * 8;
-    if (taps == 9)
+    static const bool four = !(getenv("BUDDY_C2IN4") && atoi(getenv("BUDDY_C2IN4")) == 0);
+    if (taps == 9 && four && W % 4 == 0) {
+      long long g4 = ((long long)B * H * (W / 4) + ppb - 1) / ppb;
+      if (g4 > 256 * 16) g4 = 256 * 16;
+      hipLaunchKernelGGL(conv_c2in_reg4_kernel, dim3((int)g4), dim3(256), 0, st, x, w, bias, add, add_ld, y, ldY, B, H, W, Cout, accumulate);
+    } else if (taps == 9)
       hipLaunchKernelGGL(conv_c2in_reg_kernel<9>, dim3((int)g), dim3(256), 0, st, x, w, bias, add, add_ld, y, ldY, B, H, W, Cout, accumulate);
     else
       hipLaunchKernelGGL(conv_c2in_reg_kernel<1>, dim3((int)g), dim3(256), 0, st, x, w, bias, add, add_ld, y, ldY, B, H, W, Cout, accumulate);
