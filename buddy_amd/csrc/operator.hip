@@ -155,6 +155,17 @@ __global__ __launch_bounds__(256) void fir_gradh_kernel(const float* X, long lon
 // ---- LDS-staged forms of the two FIR kernels of the optimisation loop (round 3).  The register-tiled kernels above re-load every X / H value
 // from L2 once per 4 complex MACs and sit at 12 % of the VALU rate on dependent loads (8 frames per thread instead of 4 changed nothing: latency, not
 // bytes); here a workgroup stages its (frames x 32 bins) slab once, the tap loop reads LDS only (two conflict-free ds_read_b64 per 8 complex MACs).
+typedef float v2f __attribute__((ext_vector_type(2)));
+// complex multiply-accumulate as TWO packed fmas (v_pk_fma_f32): acc += h.x * (w.x, w.y); acc += h.y * (-w.y, w.x)   [h * w]
+__device__ __forceinline__ v2f cmac(v2f acc, float2 h, float2 w) {
+  acc = __builtin_elementwise_fma(v2f{h.x, h.x}, v2f{w.x, w.y}, acc);
+  return __builtin_elementwise_fma(v2f{-h.y, h.y}, v2f{w.y, w.x}, acc);
+}
+// acc += conj(w) * g:  (w.x g.x + w.y g.y,  w.x g.y - w.y g.x)
+__device__ __forceinline__ v2f cmac_conj(v2f acc, float2 w, float2 g) {
+  acc = __builtin_elementwise_fma(v2f{w.x, w.x}, v2f{g.x, g.y}, acc);
+  return __builtin_elementwise_fma(v2f{w.y, -w.y}, v2f{g.y, g.x}, acc);
+}
 constexpr int FL_BINS = 32, FL_FT = 8, FL_TB = 64;           // bins per workgroup, frames per thread, frames per workgroup (8 frame groups)
 // Y[u][t][f] = sum_k H[u][k][f] X[u][t + 1 - k][f]; grid (ceil(T / 64), ceil(FB / 32), U), 256 threads; LDS (64 + 2 Nf - 1) x 32 complex
 __global__ __launch_bounds__(256) void fir_sb_lds_kernel(const float* __restrict__ X, long long xs, const float* __restrict__ H, float* __restrict__ Y,
@@ -189,15 +200,15 @@ __global__ __launch_bounds__(256) void fir_sb_lds_kernel(const float* __restrict
   }
   __syncthreads();
   const int tg = g * FL_FT;                                  // this thread's outputs: t0 + tg + j
-  float ar[FL_FT], ai[FL_FT];
+  v2f ac[FL_FT];
   float2 w[FL_FT];                                           // w[j] = X[t0 + tg + j + 1 - k]  -> Xs row (tg + j + 1 - k) - (2 - Nf)
 #pragma unroll
-  for (int j = 0; j < FL_FT; ++j) { ar[j] = 0.f; ai[j] = 0.f; w[j] = Xs[(tg + j + Nf - 1) * FL_BINS + b]; }
-#pragma unroll 4
-  for (int k = 0; k < Nf; ++k) {                             // k ascending per output, as in the register-tiled kernel
+  for (int j = 0; j < FL_FT; ++j) { ac[j] = v2f{0.f, 0.f}; w[j] = Xs[(tg + j + Nf - 1) * FL_BINS + b]; }
+#pragma unroll 8
+  for (int k = 0; k < Nf; ++k) {                             // k ascending per output, as in the register-tiled kernel (unroll = window depth: the shift is renaming)
     const float2 h = Hs[k * FL_BINS + b];
 #pragma unroll
-    for (int j = 0; j < FL_FT; ++j) { ar[j] += h.x * w[j].x - h.y * w[j].y; ai[j] += h.x * w[j].y + h.y * w[j].x; }
+    for (int j = 0; j < FL_FT; ++j) ac[j] = cmac(ac[j], h, w[j]);
 #pragma unroll
     for (int j = FL_FT - 1; j > 0; --j) w[j] = w[j - 1];
     const int r = tg + Nf - 2 - k;                           // row of X[t0 + tg - k]
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(256) void fir_sb_lds_kernel(const float* __restrict
   if (fok) {
 #pragma unroll
     for (int j = 0; j < FL_FT; ++j)
-      if (t0 + tg + j < T) reinterpret_cast<float2*>(Y + ((long long)u * T + t0 + tg + j) * LDSP)[f0 + b] = make_float2(ar[j], ai[j]);
+      if (t0 + tg + j < T) reinterpret_cast<float2*>(Y + ((long long)u * T + t0 + tg + j) * LDSP)[f0 + b] = make_float2(ac[j].x, ac[j].y);
   }
 }
 // GH[u][k][f] (+)= sum_t conj(X[u][t + 1 - k][f]) GY[u][t][f]; grid (ceil(Nf / 16), ceil(FB / 32), U), 256 threads = 32 bins x 2 tap groups of 8 x 4
@@ -223,49 +234,52 @@ __global__ __launch_bounds__(256) void fir_gradh_lds_kernel(const float* __restr
   const float2* Gu = reinterpret_cast<const float2*>(GY + (long long)u * T * LDSP);
   const bool fok = f0 + b < FB;
   const int kk = k0 + 8 * kg;                                // this thread's taps kk ... kk + 7
-  float ar[8], ai[8];
+  v2f ac[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { ar[j] = 0.f; ai[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) ac[j] = v2f{0.f, 0.f};
+  // the next chunk's slab is requested before the arithmetic of the current one (registers), stored to LDS after it
+  constexpr int NXR = (GL_CH + GL_TAPS - 1 + 7) / 8, NGR = GL_CH / 8;
+  const int g8 = tid >> 5;
+  float2 vx[NXR], vg[NGR];
+  auto fetch = [&](int c0) {
+    const int xb = c0 + 1 - (k0 + GL_TAPS - 1);
+#pragma unroll
+    for (int i = 0; i < NXR; ++i) {
+      const int r = g8 + 8 * i, tt = xb + r;
+      vx[i] = (r < GL_CH + GL_TAPS - 1 && fok && tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NGR; ++i) {
+      const int tt = c0 + g8 + 8 * i;
+      vg[i] = (fok && tt < T) ? Gu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+    }
+  };
+  fetch(0);
   for (int c0 = 0; c0 < T; c0 += GL_CH) {
     __syncthreads();
-    const int xb = c0 + 1 - (k0 + GL_TAPS - 1);
-    {
-      constexpr int NXR = (GL_CH + GL_TAPS - 1 + 7) / 8, NGR = GL_CH / 8;
-      const int g = tid >> 5;
-      float2 vx[NXR], vg[NGR];
 #pragma unroll
-      for (int i = 0; i < NXR; ++i) {
-        const int r = g + 8 * i, tt = xb + r;
-        vx[i] = (r < GL_CH + GL_TAPS - 1 && fok && tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
-      }
+    for (int i = 0; i < NXR; ++i) { const int r = g8 + 8 * i; if (r < GL_CH + GL_TAPS - 1) Xs[r * FL_BINS + b] = vx[i]; }
 #pragma unroll
-      for (int i = 0; i < NGR; ++i) {
-        const int tt = c0 + g + 8 * i;
-        vg[i] = (fok && tt < T) ? Gu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < NXR; ++i) { const int r = g + 8 * i; if (r < GL_CH + GL_TAPS - 1) Xs[r * FL_BINS + b] = vx[i]; }
-#pragma unroll
-      for (int i = 0; i < NGR; ++i) Gs[(g + 8 * i) * FL_BINS + b] = vg[i];
-    }
+    for (int i = 0; i < NGR; ++i) Gs[(g8 + 8 * i) * FL_BINS + b] = vg[i];
     __syncthreads();
+    if (c0 + GL_CH < T) fetch(c0 + GL_CH);
     // frame t = c0 + 16 sl + q: X[t + 1 - kk - j] = Xs row (16 sl + q + GL_TAPS - 1 - 8 kg - j)
     const int base = GL_SLOT * sl + GL_TAPS - 1 - 8 * kg;
     float2 w[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) w[j] = Xs[(base - j) * FL_BINS + b];
-#pragma unroll 4
+#pragma unroll
     for (int q = 0; q < GL_SLOT; ++q) {
       const float2 gy = Gs[(GL_SLOT * sl + q) * FL_BINS + b];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { ar[j] += w[j].x * gy.x + w[j].y * gy.y; ai[j] += w[j].x * gy.y - w[j].y * gy.x; }
+      for (int j = 0; j < 8; ++j) ac[j] = cmac_conj(ac[j], w[j], gy);
 #pragma unroll
       for (int j = 7; j > 0; --j) w[j] = w[j - 1];
       if (q + 1 < GL_SLOT) w[0] = Xs[(base + q + 1) * FL_BINS + b];
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) red[sl][8 * kg + j][b] = make_float2(ar[j], ai[j]);
+  for (int j = 0; j < 8; ++j) red[sl][8 * kg + j][b] = make_float2(ac[j].x, ac[j].y);
   __syncthreads();
   if (sl == 0 && fok) {
 #pragma unroll
