@@ -465,6 +465,8 @@ __global__ __launch_bounds__(256) void fft_stage1_kernel(S1In in, float2* y1, co
   __syncthreads();
   for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
     const int c = o / F1, k1 = o - c * F1;                  // consecutive threads: consecutive k1 of one column (coalesced store)
+    const int n2 = n20 + c;
+    const float2 t = twN[(long long)n2 * F1 + k1];           // requested before the 101-term sum, needed after it
     float ar = 0.f, ai = 0.f;
     int idx = 0;
     int n1 = 0;
@@ -480,8 +482,6 @@ __global__ __launch_bounds__(256) void fft_stage1_kernel(S1In in, float2* y1, co
       ar += v.x * w.x - v.y * w.y; ai += v.x * w.y + v.y * w.x;
       idx += k1; if (idx >= F1) idx -= F1;
     }
-    const int n2 = n20 + c;
-    const float2 t = twN[(long long)n2 * F1 + k1];
     const float tr = t.x, ti = sign * t.y;
     y1[(long long)u * N2 + (long long)n2 * F1 + k1] = make_float2(ar * tr - ai * ti, ar * ti + ai * tr);
   }
