@@ -85,12 +85,12 @@ struct WgemmArgs {
   const float* A1; int C0, ldA0, ldA1, ldC; const float* bias_n; float alpha; int accumulate;
 };
 
-// RM = 32-row blocks per wave (workgroup tile = 128 RM rows x 128 columns): RM = 2 halves the LDS reads and the weight traffic per MFMA
-// EPI: the accumulator tile goes through a wave-private LDS slab (the weight buffers are free after the last stage) and leaves as 256-byte row
-// pieces (full 128-byte lines per 8 lanes) instead of 32-byte pieces per lane pair
-template <int OCC, int PF, bool GEN = false, int RM = 1, bool EPI = false>
-__global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs a) {
-  static_assert(PF == 1 || RM == 1, "the two-stage A ring is only built for RM = 1");
+// GEN: the general form (two-source A, row strides, alpha / bias / accumulate epilogue).  EPI: the accumulator tile goes through a wave-private LDS
+// slab (the weight buffers are free after the last stage) and leaves as 256-byte row pieces instead of 32-byte pieces per lane pair.
+// Measured and rejected (profiles/README.md r03a): a second stage of A in flight (190 VGPRs: -3 %), 64 rows per wave (256+ VGPRs: -25 %), two
+// instead of three workgroups per CU (-2...4 %).
+template <bool GEN, bool EPI>
+__global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // XCD-aware order (hardware places block b on XCD b % 8): each XCD gets a contiguous range of logical tiles, the column blocks of one row
@@ -101,43 +101,33 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  const int nb = lid % a.NB, m0 = (lid / a.NB) * (WBM * RM);
+  const int nb = lid % a.NB, m0 = (lid / a.NB) * WBM;
   const int p = blockIdx.z;
   const float* __restrict__ V = a.V + (long long)p * a.sV;
   const unsigned char* __restrict__ U3 = a.U3 + ((long long)p * a.NB + nb) * a.S * STAGE_BYTES;
   const int S = a.S;
 
   // A: lane (row r = lane & 31, half h = lane >> 5) reads 16 consecutive floats per stage; rows past M are clamped (never stored)
-  int row[RM]; bool row_ok[RM];
-  const float* Ap[RM]; const float* Ap1[RM];
-#pragma unroll
-  for (int r = 0; r < RM; ++r) {
-    row[r] = m0 + (wid * RM + r) * 32 + (lane & 31);
-    row_ok[r] = row[r] < a.Mt;
-    if (!row_ok[r]) row[r] = a.Mt - 1;
-    Ap[r] = V + (long long)row[r] * (GEN ? a.ldA0 : a.Cin) + 16 * (lane >> 5);
-    Ap1[r] = (GEN && a.A1) ? a.A1 + (long long)row[r] * a.ldA1 + 16 * (lane >> 5) - a.C0 : nullptr;   // channels >= C0 come from the second source
-  }
+  int row = m0 + wid * 32 + (lane & 31);
+  const bool row_ok = row < a.Mt;
+  if (!row_ok) row = a.Mt - 1;
+  const float* Ap = V + (long long)row * (GEN ? a.ldA0 : a.Cin) + 16 * (lane >> 5);
+  const float* Ap1 = (GEN && a.A1) ? a.A1 + (long long)row * a.ldA1 + 16 * (lane >> 5) - a.C0 : nullptr;   // channels >= C0 come from the second source
   // B: the stage image is copied linearly, 6 x 16 B per thread (thread t moves bytes 16 t + 4096 j)
   const u32x4* Bg = reinterpret_cast<const u32x4*>(U3) + tid;
   u32x4* Bs = reinterpret_cast<u32x4*>(smem) + tid;
 
-  f32x16 acc[RM][4];
+  f32x16 acc[4];
 #pragma unroll
-  for (int m = 0; m < RM; ++m)
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][c][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-  float4 ra[PF * RM][4];                                           // ring of PF stages of A in flight (PF = 2: the loads of stage s + 2 are issued in stage s)
+  float4 ra[4];
   u32x4 rb[6];
-  auto loadA = [&](int s, int slot) {
+  auto loadA = [&](int s) {
 #pragma unroll
-    for (int r = 0; r < RM; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        ra[slot * RM + r][j] = *reinterpret_cast<const float4*>(((GEN && Ap1[r] && s * WKS >= a.C0) ? Ap1[r] : Ap[r]) + s * WKS + 4 * j);
+    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(((GEN && Ap1 && s * WKS >= a.C0) ? Ap1 : Ap) + s * WKS + 4 * j);
   };
   auto loadB = [&](int s) {
 #pragma unroll
@@ -148,29 +138,17 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
     for (int j = 0; j < 6; ++j) Bs[buf * (STAGE_BYTES / 16) + j * WNT] = rb[j];
   };
 
-  loadA(0, 0);
+  loadA(0);
   loadB(0);
-  if (PF == 2 && S > 1) loadA(1, 1);
   storeB(0);
   __syncthreads();
   for (int s = 0; s < S; ++s) {
-    float4 ca[RM][4];
-#pragma unroll
-    for (int r = 0; r < RM; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ca[r][j] = ra[r][j];
-    if (PF == 2) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ra[0][j] = ra[1][j];
-      if (s + 2 < S) loadA(s + 2, 1);
-      if (s + 1 < S) loadB(s + 1);
-    } else if (s + 1 < S) { loadA(s + 1, 0); loadB(s + 1); }
+    const float4 ca[4] = {ra[0], ra[1], ra[2], ra[3]};
+    if (s + 1 < S) { loadA(s + 1); loadB(s + 1); }           // stage s + 1 is in flight under the 48 MFMAs of stage s
     const unsigned char* Bcur = smem + (s & 1) * STAGE_BYTES + lane * 16;
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
-      Split3 av[RM];
-#pragma unroll
-      for (int r = 0; r < RM; ++r) av[r] = split3(ca[r][2 * kc], ca[r][2 * kc + 1]);
+      const Split3 av = split3(ca[2 * kc], ca[2 * kc + 1]);
       bf16x8 b[4][3];
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
@@ -182,18 +160,16 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
-        for (int r = 0; r < RM; ++r)
-#pragma unroll
-          for (int cb = 0; cb < 4; ++cb) acc[r][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][PB[t]], av[r].p[PA[t]], acc[r][cb], 0, 0, 0);
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][PB[t]], av.p[PA[t]], acc[cb], 0, 0, 0);
     }
     if (s + 1 < S) storeB((s + 1) & 1);                        // that buffer was last read in stage s - 1: every wave is past its barrier
     __syncthreads();
   }
 
   // epilogue: accumulator = C^T tile, lane (row = lane & 31, h = lane >> 5) holds channels 8 g + 4 h + 0..3 of each 32-channel block
-  if (EPI && !GEN && RM == 1) {
+  if (EPI && !GEN) {
     constexpr int SP = 68;                                   // floats per staged row (64 columns + 4: conflict-free 16-byte writes down a column)
-    float* S = reinterpret_cast<float*>(smem) + wid * (32 * SP);
+    float* St = reinterpret_cast<float*>(smem) + wid * (32 * SP);
     const int rr = lane >> 4, c4 = (lane & 15) * 4;
     float* Mrow = a.M + (long long)p * a.sM + (long long)(m0 + wid * 32) * a.Cout + nb * WBN;
 #pragma unroll
@@ -202,14 +178,14 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
       for (int cl = 0; cl < 2; ++cl)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(S + (lane & 31) * SP + cl * 32 + 8 * g + 4 * (lane >> 5)) =
-              make_float4(acc[0][2 * hb + cl][4 * g], acc[0][2 * hb + cl][4 * g + 1], acc[0][2 * hb + cl][4 * g + 2], acc[0][2 * hb + cl][4 * g + 3]);
+          *reinterpret_cast<float4*>(St + (lane & 31) * SP + cl * 32 + 8 * g + 4 * (lane >> 5)) =
+              make_float4(acc[2 * hb + cl][4 * g], acc[2 * hb + cl][4 * g + 1], acc[2 * hb + cl][4 * g + 2], acc[2 * hb + cl][4 * g + 3]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int r = 4 * it + rr;
-        const float4 v = *reinterpret_cast<const float4*>(S + r * SP + c4);
+        const float4 v = *reinterpret_cast<const float4*>(St + r * SP + c4);
         if (m0 + wid * 32 + r < a.Mt) *reinterpret_cast<float4*>(Mrow + (long long)r * a.Cout + hb * 64 + c4) = v;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -217,23 +193,20 @@ __global__ __launch_bounds__(WNT, OCC) void wgemm_bf16x3_kernel(const WgemmArgs 
     }
     return;
   }
+  if (!row_ok) return;
+  float* dst = a.M + (long long)p * a.sM + (long long)row * (GEN ? a.ldC : a.Cout) + nb * WBN + 4 * (lane >> 5);
 #pragma unroll
-  for (int r = 0; r < RM; ++r) {
-    if (!row_ok[r]) continue;
-    float* dst = a.M + (long long)p * a.sM + (long long)row[r] * (GEN ? a.ldC : a.Cout) + nb * WBN + 4 * (lane >> 5);
+  for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 v = make_float4(acc[r][cb][4 * g], acc[r][cb][4 * g + 1], acc[r][cb][4 * g + 2], acc[r][cb][4 * g + 3]);
-        if (GEN) {     // same operation order as the fp32 kernel's epilogue: alpha * acc, + bias, + C
-          v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
-          if (a.bias_n) { const float4 t = *reinterpret_cast<const float4*>(a.bias_n + nb * WBN + 4 * (lane >> 5) + cb * 32 + 8 * g); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-          if (a.accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst + cb * 32 + 8 * g); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-        }
-        *reinterpret_cast<float4*>(dst + cb * 32 + 8 * g) = v;
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+      if (GEN) {     // same operation order as the fp32 kernel's epilogue: alpha * acc, + bias, + C
+        v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+        if (a.bias_n) { const float4 t = *reinterpret_cast<const float4*>(a.bias_n + nb * WBN + 4 * (lane >> 5) + cb * 32 + 8 * g); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (a.accumulate) { const float4 t = *reinterpret_cast<const float4*>(dst + cb * 32 + 8 * g); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
       }
-  }
+      *reinterpret_cast<float4*>(dst + cb * 32 + 8 * g) = v;
+    }
 }
 }  // namespace
 
@@ -257,7 +230,7 @@ void launch_wgemm_bf16x3_general(const float* A0, int ldA0, const float* A1, int
   a.Mt = (int)M; a.Cin = K; a.Cout = N; a.S = K / WKS; a.NB = N / WBN; a.sV = 0; a.sM = 0;
   a.A1 = A1; a.C0 = A1 ? C0 : K; a.ldA0 = ldA0; a.ldA1 = ldA1; a.ldC = ldC; a.bias_n = bias_n; a.alpha = alpha; a.accumulate = accumulate;
   const dim3 grid((unsigned)(cdiv((int)M, WBM) * a.NB), 1, 1);
-  hipLaunchKernelGGL((wgemm_bf16x3_kernel<3, 1, true>), grid, dim3(WNT), 0, st, a);
+  hipLaunchKernelGGL((wgemm_bf16x3_kernel<true, false>), grid, dim3(WNT), 0, st, a);
 }
 
 void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st) {
@@ -266,16 +239,10 @@ void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt,
   a.V = V; a.U3 = reinterpret_cast<const unsigned char*>(U3); a.M = M;
   a.Mt = (int)Mt; a.Cin = Cin; a.Cout = Cout; a.S = Cin / WKS; a.NB = Cout / WBN;
   a.sV = Mt * Cin; a.sM = Mt * Cout;
-  dim3 grid((unsigned)(cdiv((int)Mt, WBM) * a.NB), 1, (unsigned)P);
-  // variants measured on one box (profiles/README.md r03): 3 workgroups per CU (<= 168 VGPRs) +2...4 % over 2; a second stage of A in flight
-  // (PF = 2: 190 VGPRs) -3 %; both at once spills.  BUDDY_WGEMM_VARIANT=2|3 keep the losers runnable.
-  static const int variant = getenv("BUDDY_WGEMM_VARIANT") ? atoi(getenv("BUDDY_WGEMM_VARIANT")) : 1;
-  if (variant == 2) hipLaunchKernelGGL((wgemm_bf16x3_kernel<2, 1>), grid, dim3(WNT), 0, st, a);
-  else if (variant == 3) hipLaunchKernelGGL((wgemm_bf16x3_kernel<2, 2>), grid, dim3(WNT), 0, st, a);
-  // (64 rows per wave, RM = 2 -- half the LDS reads and weight traffic per MFMA -- needs 256+ VGPRs: 108 TF-equivalent at 2 workgroups per CU
-  //  with spills, 131 at one; 147 for this form on the same box)
-  else if (variant == 6) hipLaunchKernelGGL((wgemm_bf16x3_kernel<3, 1>), grid, dim3(WNT), 0, st, a);      // direct 32-byte-piece stores
-  else hipLaunchKernelGGL((wgemm_bf16x3_kernel<3, 1, false, 1, true>), grid, dim3(WNT), 0, st, a);          // LDS-staged epilogue: +0.3 ... 1.9 %
+  const dim3 grid((unsigned)(cdiv((int)Mt, WBM) * a.NB), 1, (unsigned)P);
+  static const bool direct_store = getenv("BUDDY_WGEMM_EPI") && atoi(getenv("BUDDY_WGEMM_EPI")) == 0;      // A/B switch: 32-byte-piece stores (+0.3 ... 1.9 % slower)
+  if (direct_store) hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, false>), grid, dim3(WNT), 0, st, a);
+  else hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true>), grid, dim3(WNT), 0, st, a);
 }
 
 }  // namespace buddy

@@ -14,5 +14,5 @@ f = lambda: _lib.check(lib.buddy_gemm_winograd_domain_bf16x3(P(A), U3.data_ptr()
 f(); f(); torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(reps): f()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
-print(f"wgemm v{os.environ.get('BUDDY_WGEMM_VARIANT', '0')} P={nb} Mt={Mt} N={N} K={K}: {dt*1e3:.3f} ms {2.0*nb*Mt*N*K/dt/1e12:.1f} TF-eq {12.0*nb*Mt*N*K/dt/1e12:.0f} TF bf16 "
+print(f"wgemm P={nb} Mt={Mt} N={N} K={K}: {dt*1e3:.3f} ms {2.0*nb*Mt*N*K/dt/1e12:.1f} TF-eq {12.0*nb*Mt*N*K/dt/1e12:.0f} TF bf16 "
       f"{(Mt*K+Mt*N)*nb*4/dt/1e9:.0f} GB/s", flush=True)
