@@ -94,3 +94,29 @@ def test_bench_gpus2_launches_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300,
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_longform_chunked_blind_keeps_the_level_profile():
+    """blind chunked sampling rescales every chunk to one standard deviation (constraint_speech_magnitude acts per utterance = per chunk), which
+    would bring a pause back as loud as speech.  Tester.dereverberate_long(blind=True) level-matches the chunks to the observation before the cross-fade:
+    on a clip whose middle third is 26 dB quieter, the estimate's pause-to-speech level ratio follows the input's (small network, 3 steps)."""
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
+    from buddy_amd.testing.tester import Tester
+    args = compose(tester="blind_dereverberation_BUDDy", overrides=["tester.sampling_params.T=3", "network.nf=32",
+                                                                      "tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+                                                                      "tester.posterior_sampling.blind_hp.op_updates_per_step=2"])
+    net = instantiate(args.network)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(3, 32).items()})
+    net = net.cuda().eval()
+    t = Tester(args, net, instantiate(args.diff_params), test_set=None, device="cuda", in_training=True)
+    L = 96000
+    clean = synth_clean(2, L).copy()
+    clean[32000:64000] *= 0.05
+    seg, y, pred = t.dereverberate_long(clean, synth_rir(2, 2000), blind=True, chunk_seconds=2.0, overlap_seconds=0.25)
+    assert pred.shape == (L,) and torch.isfinite(pred).all()
+    ratio = lambda z: float(z[36000:60000].std() / (z[:28000].std() + 1e-12))
+    ry, rp = ratio(y), ratio(pred)
+    print(f"pause / speech level: observation {ry:.3f}, blind chunked estimate {rp:.3f}")
+    assert rp < 3.0 * ry + 0.05          # without the level match every chunk comes back at std 0.05: ratio ~ 1
