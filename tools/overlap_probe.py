@@ -9,12 +9,16 @@ lib = _lib.require_gpu()
 P = _lib.ptr
 Mt, N, K = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (65536, 256, 256)
 A = torch.randn(36, Mt, K, device="cuda"); Bt = torch.randn(36, N, K, device="cuda"); Cm = torch.empty(36, Mt, N, device="cuda")
+U3 = torch.empty(36 * N * K * 6 // 4, dtype=torch.int32, device="cuda")
+_lib.check(lib.buddy_wgemm_pack_weights(P(Bt), U3.data_ptr(), 36, N, K, _lib.stream_ptr()))
+BF = os.environ.get("BUDDY_GEMM", "bf16x3") != "fp32"
 x = torch.randn(128 * 2 ** 20 // 4 * 4, device="cuda"); y = torch.empty_like(x)       # 512 MB streaming operands
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 def gemm(n):
     with torch.cuda.stream(s1):
         for _ in range(n):
-            _lib.check(lib.buddy_gemm_winograd_domain(P(A), P(Bt), P(Cm), Mt, N, K, 36, s1.cuda_stream))
+            if BF: _lib.check(lib.buddy_gemm_winograd_domain_bf16x3(P(A), U3.data_ptr(), P(Cm), Mt, N, K, 36, s1.cuda_stream))
+            else: _lib.check(lib.buddy_gemm_winograd_domain(P(A), P(Bt), P(Cm), Mt, N, K, 36, s1.cuda_stream))
 def mem(n):
     with torch.cuda.stream(s2):
         for _ in range(n):
