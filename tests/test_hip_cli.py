@@ -120,3 +120,32 @@ def test_longform_chunked_blind_keeps_the_level_profile():
     ry, rp = ratio(y), ratio(pred)
     print(f"pause / speech level: observation {ry:.3f}, blind chunked estimate {rp:.3f}")
     assert rp < 3.0 * ry + 0.05          # without the level match every chunk comes back at std 0.05: ratio ~ 1
+
+
+def test_bench_line_contract():
+    """The ONE JSON line `python bench.py` prints (driver contract): metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /
+    scaling / vs_baseline / dtype / data / config.workload naming BASELINE.json configs[1], and the `roofline` object of the dominant kernel with
+    bound / achieved / peak / unit / frac / traffic; value consistent with ms_per_step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--also-concurrent", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert "configs[1]" in j["config"]["workload"] and j["config"]["batch_per_gpu"] == 8 and j["config"]["gemm"] in ("bf16x3", "fp32")
+    assert abs(j["value"] - 8 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+    rf = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches"):
+        assert k in rf, k
+    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] == "TFLOP/s" and 0.0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["launches"] == 80                      # all 80 launches of the dominant kernel on the one sampled step
+    if rf["traffic"] is not None:                    # quoted only when the stamped PMC summary matches the kernel sources
+        assert 0.5e9 < rf["traffic"] < 3e9 and rf["traffic_conv_group_over_fused_form"] > 1.0
