@@ -604,19 +604,64 @@ __device__ __forceinline__ void fft1024_core(float2 (&v)[16], float2* S, const f
 }
 // rows of real, windowed 512-sample frames -> [rows][1028] one-sided spectra.  frame (row) starts at src[(row / Tn) * sA + (row % Tn) * hop];
 // out[k] = fac * (cf ? cf(k) : 1) * sum_n src[n] win[n] exp(-2 pi i k n / 1024)
-__global__ __launch_bounds__(256) void fft1024_r2c_kernel(const float* __restrict__ src, long long sA, int hop, int Tn, long long rows,
-                                                          const float* __restrict__ win, const float2* __restrict__ Wg, float* __restrict__ out,
-                                                          float fac, int cf) {
+//
+// Where the frames come from (R2cSrc): every elementwise / gather neighbour of the transform is folded into its first load, because each node
+// of the captured optimisation loop costs ~5 us whatever it does.  Frame t of utterance u covers the samples s = 128 t + n - P, n < 512, of
+//   GATHER = false: the signal sig[u][0..Ls)                                                        (was: pad_const_kernel -> sp)
+//   GATHER = true : the overlap-add of fr[u][0..Tsrc)[512] at j = s + Q, times envA[j]              (was: ola_kernel -> signal -> pad_const)
+// zero outside [0, Ls); then (+ add_scale * add[u][s]) and (* envB[128 t + n]) when given           (was: pad_const's noise term / ola_adj_kernel)
+// Every product is formed in the order the separate kernels formed it, so the results are bit-identical to the unfused chain.
+struct R2cSrc {
+  const float* sig; const float* fr; int Ls, P, Tsrc, Q; const float* envA; const float* envB;
+  const float* add; float add_scale; const float* add_scale_dev;
+};
+template <bool GATHER>
+__global__ __launch_bounds__(256) void fft1024_r2c_kernel(R2cSrc sc, int Tn, long long rows, const float* __restrict__ win,
+                                                          const float2* __restrict__ Wg, float* __restrict__ out, float fac, int cf) {
   __shared__ float2 W[1024];
   __shared__ float2 S[4][16 * FLD];
   for (int i = threadIdx.x; i < 1024; i += 256) W[i] = Wg[i];
   const int w = threadIdx.x >> 6, r = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + w;
   const bool ok = row < rows;
-  const float* f = src + (ok ? (row / Tn) * sA + (row % Tn) * (long long)hop : 0);
+  const int u = ok ? (int)(row / Tn) : 0, t = ok ? (int)(row % Tn) : 0;
+  const float add_scale = sc.add ? (sc.add_scale_dev ? *sc.add_scale_dev : sc.add_scale) : 0.f;
   float2 v[16];
 #pragma unroll
-  for (int a = 0; a < 16; ++a) v[a] = (a < 8 && ok) ? make_float2(f[64 * a + r] * win[64 * a + r], 0.f) : make_float2(0.f, 0.f);
+  for (int a = 0; a < 16; ++a) v[a] = make_float2(0.f, 0.f);
+  if (ok) {
+    // all loads of the wave's 8 x 64 samples are issued before the first use (a load -> use loop would pay one L2 round trip per sample);
+    // sample j of the overlap-add has exactly four candidate frames j / 128 - 3 .. j / 128, summed in ascending frame order as ola_kernel does
+    float fv[8][GATHER ? 4 : 1], ea[8], eb[8], ad[8];
+    bool in[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int n = 64 * a + r, s = HOP * t + n - sc.P;
+      in[a] = s >= 0 && s < sc.Ls;
+      const int sc_s = in[a] ? s : 0;
+      if (GATHER) {
+        const int j = sc_s + sc.Q, tq = j >> 7, m0 = j & (HOP - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int tt = tq - 3 + k;
+          fv[a][k] = (in[a] && tt >= 0 && tt < sc.Tsrc) ? sc.fr[((long long)u * sc.Tsrc + tt) * WIN + m0 + HOP * (3 - k)] : 0.f;
+        }
+        ea[a] = in[a] ? sc.envA[j] : 0.f;
+      } else {
+        fv[a][0] = in[a] ? sc.sig[(long long)u * sc.Ls + sc_s] : 0.f;
+      }
+      ad[a] = (in[a] && sc.add) ? sc.add[(long long)u * sc.Ls + sc_s] : 0.f;
+      eb[a] = (in[a] && sc.envB) ? sc.envB[HOP * t + n] : 1.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      float val = fv[a][0];
+      if (GATHER) { val = 0.f; for (int k = 0; k < 4; ++k) val += fv[a][k]; val *= ea[a]; }
+      if (sc.add) val += add_scale * ad[a];
+      if (sc.envB) val = val * eb[a];
+      v[a].x = (in[a] ? val : 0.f) * win[64 * a + r];
+    }
+  }
   __syncthreads();
   fft1024_core<-1>(v, S[w], W, r);
   if (!ok) return;
@@ -922,24 +967,38 @@ struct BlindOp {
     launch_igemm(p, 1, false, tB, batch, st);
   }
   // the four STFT-type transforms: 1024-point FFT kernels (default) or DFT-as-GEMM on the matrix cores (BUDDY_OP_FFT=0)
-  void r2c(const float* src, long long sA, int hop, int Tn, long long rows, float* out, float fac, int cf) {
-    hipLaunchKernelGGL(fft1024_r2c_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, src, sA, hop, Tn, rows, (const float*)win, (const float2*)w1024, out, fac, cf);
+  void r2c(const R2cSrc& sc, int Tn, float* out, float fac, int cf) {
+    const long long rows = (long long)U * Tn;
+    if (sc.fr) hipLaunchKernelGGL(fft1024_r2c_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sc, Tn, rows, (const float*)win, (const float2*)w1024, out, fac, cf);
+    else hipLaunchKernelGGL(fft1024_r2c_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sc, Tn, rows, (const float*)win, (const float2*)w1024, out, fac, cf);
   }
   void c2r(const float* in, long long rows, float* fr, float fac, int cf) {
     hipLaunchKernelGGL(fft1024_c2r_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, in, rows, (const float*)win, (const float2*)w1024, fr, fac, cf);
   }
   // X[u][t][:] = scale * STFT frames of s (frame t starts at sample 128 t - P), Tn frames
   void stft(const float* s, int Ls, int P, int Tn, float scale, float* X, const float* add = nullptr, float add_scale = 0.f, const float* add_scale_dev = nullptr) {
+    if (use_fft) { r2c(R2cSrc{s, nullptr, Ls, P, 0, 0, nullptr, nullptr, add, add_scale, add_scale_dev}, Tn, X, scale, 0); return; }
     const int Lpad = ((Tn - 1) * HOP + WIN + 3) / 4 * 4;
     hipLaunchKernelGGL(pad_const_kernel, dim3(gridf((long long)U * Lpad)), dim3(256), 0, st, s, sp, U, Ls, P, Lpad, add, add_scale, add_scale_dev);
-    if (use_fft) r2c(sp, Lpad, HOP, Tn, (long long)U * Tn, X, scale, 0);
-    else gemm(sp, HOP, Lpad, Bf, WIN, false, X, LDSP, (long long)Tn * LDSP, Tn, LDSP, WIN, scale, U);
+    gemm(sp, HOP, Lpad, Bf, WIN, false, X, LDSP, (long long)Tn * LDSP, Tn, LDSP, WIN, scale, U);
   }
   // y[u][s] = sum_t frames_t[s + Q - 128 t] * inv_env[s + Q],  frames = scale * iDFT(Y) * window
   void istft(const float* Y, int Tn, int Q, const float* inv_env, int Ls, float scale, float* y) {
     if (use_fft) c2r(Y, (long long)U * Tn, frames, scale / NFFT, 1);
     else gemm(Y, LDSP, 0, Bi, LDSP, false, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
     launch_ola(frames, WIN, Tn, WIN, HOP, inv_env, y, U, Ls, Q, nullptr, nullptr, nullptr, st);
+  }
+  // X = sx * STFT(istft(Y) (+ add_scale * add)) without the signal in between: the overlap-add happens in the load of the second transform.
+  // The frames buffer stays valid afterwards (stft_of_frames below repeats the second half on it, e.g. with and without the noise term).
+  void istft_stft(const float* Y, int Tn, int Q, const float* inv_env, int Ls, float si, int P, int Tx, float sx, float* X, const float* add = nullptr,
+                  float add_scale = 0.f, const float* add_scale_dev = nullptr, float* sig_scratch = nullptr) {
+    if (!use_fft) { istft(Y, Tn, Q, inv_env, Ls, si, sig_scratch); stft(sig_scratch, Ls, P, Tx, sx, X, add, add_scale, add_scale_dev); return; }
+    c2r(Y, (long long)U * Tn, frames, si / NFFT, 1);
+    stft_of_frames(Tn, Q, inv_env, Ls, P, Tx, sx, X, add, add_scale, add_scale_dev);
+  }
+  void stft_of_frames(int Tn, int Q, const float* inv_env, int Ls, int P, int Tx, float sx, float* X, const float* add = nullptr, float add_scale = 0.f,
+                      const float* add_scale_dev = nullptr) {
+    r2c(R2cSrc{nullptr, frames, Ls, P, Tn, Q, inv_env, nullptr, add, add_scale, add_scale_dev}, Tx, X, sx, 0);
   }
   // adjoint of stft: g_s from G_X
   void stft_adj(const float* GX, int Ls, int P, int Tn, float scale, float* gs) {
@@ -949,9 +1008,15 @@ struct BlindOp {
   }
   // adjoint of istft: G_Y from g_y
   void istft_adj(const float* gy, int Tn, int Q, const float* inv_env, int Ls, float scale, float* GY) {
+    if (use_fft) { r2c(R2cSrc{gy, nullptr, Ls, Q, 0, 0, nullptr, inv_env, nullptr, 0.f, nullptr}, Tn, GY, scale / NFFT, 1); return; }
     launch_ola_adj(gy, U, Ls, Q, Tn, WIN, HOP, inv_env, nullptr, frames, WIN, st);
-    if (use_fft) r2c(frames, 0, WIN, U * Tn, (long long)U * Tn, GY, scale / NFFT, 1);
-    else gemm(frames, WIN, 0, BiT, WIN, false, GY, LDSP, 0, U * Tn, LDSP, WIN, scale, 1);
+    gemm(frames, WIN, 0, BiT, WIN, false, GY, LDSP, 0, U * Tn, LDSP, WIN, scale, 1);
+  }
+  // G_Y = istft_adj(stft_adj(G_X)) without the signal in between (both adjoints act on the same Ls samples)
+  void stft_adj_istft_adj(const float* GX, int Ls, int P, int Tx, float sx, int Tn, int Q, const float* inv_env, float si, float* GY, float* sig_scratch) {
+    if (!use_fft) { stft_adj(GX, Ls, P, Tx, sx, sig_scratch); istft_adj(sig_scratch, Tn, Q, inv_env, Ls, si, GY); return; }
+    c2r(GX, (long long)U * Tx, frames, sx, 0);
+    r2c(R2cSrc{nullptr, frames, Ls, Q, Tx, P, ones, inv_env, nullptr, 0.f, nullptr}, Tn, GY, si / NFFT, 1);
   }
   // in_mode / out_mode: the elementwise neighbours of the transform folded into its first load / last store (S1In / S2Out above)
   void fft(const float2* x, float2* tmp, float2* X, int sign, float scale, int in_mode = 0, const float* xr = nullptr, int Lr_ = 0, int out_mode = 0,
@@ -1032,6 +1097,16 @@ struct BlindOp {
     hipLaunchKernelGGL(comp_loss_kernel, dim3(nblk, U), dim3(256), 0, st, Rcx, Xh, G, partial, Tn, kappa, c.comp);
     if (!fused_loop)        // the loop only needs the gradient; the loss VALUES are read through buddy_blindop_param_grads / rec_loss_grad
       hipLaunchKernelGGL(loss_finalize_kernel, dim3(U), dim3(32), 0, st, (const double*)partial, nblk, kappa, out, accumulate);
+  }
+  // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach()), gradient w.r.t. the subband filter's output left in X2
+  void reg_chain(const float* noise, float t_op, const float* t_op_dev, float w_reg) {
+    fir(Xdelta, 0, Td, Ybuf);                                                                       // rir = istft(FIR(Xdelta, H)), never materialised:
+    istft_stft(Ybuf, Td, WIN + WIN / 2, env_d, Lr, norm, WIN, Td, 1.f / norm, X3, noise, t_op, t_op_dev, rir);   // STFT(rir + t n)
+    hipLaunchKernelGGL(compress_kernel, dim3(gridf((long long)U * Td * FB)), dim3(256), 0, st, (const float*)X3, Rc, (long long)U * Td, c.comp);
+    if (use_fft) stft_of_frames(Td, WIN + WIN / 2, env_d, Lr, WIN, Td, 1.f / norm, X2);              // STFT(rir) from the same frames
+    else stft(rir, Lr, WIN, Td, 1.f / norm, X2);
+    comp_loss(Rc, X2, X3, Td, w_reg, losses + U, 0);
+    stft_adj_istft_adj(X3, Lr, WIN, Td, 1.f / norm, Td, WIN + WIN / 2, env_d, norm, X2, sig2);
   }
   void degrade(const float* x, float* y) {
     stft(x, L, WIN, T, 1.f / norm, X1);
@@ -1278,12 +1353,10 @@ int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* l
   const int U = o->U, T = o->T, L = o->L;
   o->stft(x_den, L, WIN, T, 1.f / o->norm, o->X1);
   o->fir(o->X1, (long long)T * LDSP, T, o->Ybuf);
-  o->istft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, o->norm, o->sig1);
-  o->stft(o->sig1, L, WIN, T, 1.f / o->norm, o->X2);
+  o->istft_stft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, o->norm, WIN, T, 1.f / o->norm, o->X2, nullptr, 0.f, nullptr, o->sig1);
   o->comp_loss(o->Yc, o->X2, g_x ? o->X3 : nullptr, T, weight, loss, 0);
   if (g_x) {
-    o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, o->sig2);
-    o->istft_adj(o->sig2, T, WIN + WIN / 2, o->env_T, L, o->norm, o->X2);
+    o->stft_adj_istft_adj(o->X3, L, WIN, T, 1.f / o->norm, T, WIN + WIN / 2, o->env_T, o->norm, o->X2, o->sig2);
     hipLaunchKernelGGL(fir_adjx_kernel, dim3(gridf((long long)U * T * FB)), dim3(256), 0, st, (const float*)o->X2, (const float*)o->H, o->X3, U, T, o->Nf);
     o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, g_x);
   }
@@ -1320,37 +1393,21 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
     (void)hipEventRecord(o->ev_fork, st);
     (void)hipStreamWaitEvent(o->side_stream, o->ev_fork, 0);
     o->swap_scratch(); o->st = o->side_stream;
-    o->time_rir(o->rir);
-    o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X3, noise, t_op, t_op_dev);
-    hipLaunchKernelGGL(compress_kernel, dim3(gridf((long long)U * Td * FB)), dim3(256), 0, o->st, (const float*)o->X3, o->Rc, (long long)U * Td, o->c.comp);
-    o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X2);
-    o->comp_loss(o->Rc, o->X2, o->X3, Td, w_reg, o->losses + U, 0);
-    o->stft_adj(o->X3, o->Lr, WIN, Td, 1.f / o->norm, o->sig2);
-    o->istft_adj(o->sig2, Td, WIN + WIN / 2, o->env_d, o->Lr, o->norm, o->X2);
+    o->reg_chain(noise, t_op, t_op_dev, w_reg);
     (void)hipEventRecord(o->ev_join, o->side_stream);
     o->swap_scratch(); o->st = st;
   }
   if (!have_Xd) o->stft(x_den, L, WIN, T, 1.f / o->norm, o->X1);          // X1 = STFT(x_den) stays valid across the iterations
   // reconstruction term
   o->fir(o->X1, (long long)T * LDSP, T, o->Ybuf);
-  o->istft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, o->norm, o->sig1);
-  o->stft(o->sig1, L, WIN, T, 1.f / o->norm, o->X2);
+  o->istft_stft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, o->norm, WIN, T, 1.f / o->norm, o->X2, nullptr, 0.f, nullptr, o->sig1);
   o->comp_loss(o->Yc, o->X2, o->X3, T, w_rec, o->losses, 0);
-  o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, o->sig2);
-  o->istft_adj(o->sig2, T, WIN + WIN / 2, o->env_T, L, o->norm, o->X2);
+  o->stft_adj_istft_adj(o->X3, L, WIN, T, 1.f / o->norm, T, WIN + WIN / 2, o->env_T, o->norm, o->X2, o->sig2);
   o->gradh(o->X1, (long long)T * LDSP, o->X2, T, 0);
   // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach())
   if (noise) {
     const bool fork = t_op_dev != nullptr && o->side_stream != nullptr && o->fork_ok;     // captured-graph mode: a parallel branch
-    auto chain = [&]() {
-      o->time_rir(o->rir);                                                     // Ybuf = FIR(Xdelta, H) consumed inside
-      o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X3, noise, t_op, t_op_dev);      // STFT(rir + t n)
-      hipLaunchKernelGGL(compress_kernel, dim3(gridf((long long)U * Td * FB)), dim3(256), 0, o->st, (const float*)o->X3, o->Rc, (long long)U * Td, o->c.comp);
-      o->stft(o->rir, o->Lr, WIN, Td, 1.f / o->norm, o->X2);
-      o->comp_loss(o->Rc, o->X2, o->X3, Td, w_reg, o->losses + U, 0);
-      o->stft_adj(o->X3, o->Lr, WIN, Td, 1.f / o->norm, o->sig2);
-      o->istft_adj(o->sig2, Td, WIN + WIN / 2, o->env_d, o->Lr, o->norm, o->X2);
-    };
+    auto chain = [&]() { o->reg_chain(noise, t_op, t_op_dev, w_reg); };
     if (fork) {
       // the branch was forked right after update_H (below); it used the second scratch set and left its gradient in X2_b
       (void)hipStreamWaitEvent(st, o->ev_join, 0);
