@@ -326,14 +326,15 @@ __global__ __launch_bounds__(256) void comp_loss_kernel(const float* Rc, const f
     if (r == 0.f) {
       xc = make_float2(powf(1e-8f, p), 0.f);
     } else {
-      const float cr = x.x / r, ci = x.y / r;               // e^{j theta}
-      const float rho = powf(r + 1e-8f, p);
+      const float ir = 1.f / r, re = r + 1e-8f;
+      const float cr = x.x * ir, ci = x.y * ir;             // e^{j theta}
+      const float rho = powf(re, p);
       xc = make_float2(rho * cr, rho * ci);
       const float dr = xc.x - rc.x, di = xc.y - rc.y;       // D = Xc_hat - Rc
       const float a = dr * cr + di * ci;                    // Re(conj(D) e^{j theta})
       const float b = dr * ci - di * cr;                    // Im(conj(D) e^{j theta})
-      const float gr = 2.f * kappa * a * p * powf(r + 1e-8f, p - 1.f);
-      const float gt = -2.f * kappa * rho * b / r;          // (1/r) dL/dtheta
+      const float gr = 2.f * kappa * a * p * (rho / re);    // d rho / d r = p (r + eps)^(p - 1): one powf and a division instead of two powf
+      const float gt = -2.f * kappa * rho * b * ir;         // (1/r) dL/dtheta
       g = make_float2(gr * cr - gt * ci, gr * ci + gt * cr);
     }
     const float dr = xc.x - rc.x, di = xc.y - rc.y;
@@ -355,7 +356,7 @@ __global__ void loss_finalize_kernel(const double* partial, int nblk, float kapp
 }
 
 // ---- filter design (reference :212-251) ----
-struct DesignTabs { const int* idx; const float* frac; const float* corr; const float* dpm; };   // per-bin knot index / fraction; OLA corr[Nf]; dpm[Nf][FB]
+struct DesignTabs { const int* idx; const float* frac; const float* corr; const float* dpm; const int* fge; };   // per-bin knot index / fraction; OLA corr[Nf]; dpm[Nf][FB]
 // dm[u][n][j], j = 0..K-1 knots (rows 0 and K-1 are zero): sum_e w[e][j-1] * exp(decay[e][j-1])^(-n)
 __global__ void design_dm_kernel(const float* decay, const float* wts, float* logdm, float* dmv, int U, int E, int NB, int Nf, int* step_inc) {
   const int K = NB + 2;
@@ -381,43 +382,61 @@ __global__ __launch_bounds__(256) void design_A_kernel(const float* logdm, Desig
     A[i] = (e + 1e-6f) / tb.corr[n] + tb.dpm[(long long)n * FB + f];
   }
 }
-// H0 frames: Fin[u][k+1][f] = A[u][k][f] * exp(j phi[u][k][f]); rows 0 and Nf+1 stay zero
-__global__ __launch_bounds__(256) void h0_kernel(const float* A, const float* phi, float* Fin, int U, int Nf) {
+// design_A_kernel plus the H0 frames Fin[u][k+1][f] = A[u][k][f] * exp(j phi[u][k][f]) (rows 0 and Nf+1 stay zero) in one pass: same index space,
+// one node less in the captured loop
+__global__ __launch_bounds__(256) void design_A_h0_kernel(const float* logdm, DesignTabs tb, const float* phi, float* A, float* Apre, float* Fin, int U, int K,
+                                                          int Nf) {
   const long long total = (long long)U * Nf * FB;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int f = (int)(i % FB), k = (int)((i / FB) % Nf), u = (int)(i / ((long long)FB * Nf));
-    float s, c; sincosf(phi[i], &s, &c);
-    reinterpret_cast<float2*>(Fin + ((long long)u * (Nf + 2) + k + 1) * LDSP)[f] = make_float2(A[i] * c, A[i] * s);
+    const int f = (int)(i % FB), n = (int)((i / FB) % Nf), u = (int)(i / ((long long)FB * Nf));
+    const float* l = logdm + ((long long)u * Nf + n) * K;
+    const int j = tb.idx[f];
+    const float v0 = l[j], v1 = l[j + 1];
+    const float e = expf(v0 + tb.frac[f] * (v1 - v0));
+    const float a = (e + 1e-6f) / tb.corr[n] + tb.dpm[(long long)n * FB + f];
+    Apre[i] = e;
+    A[i] = a;
+    float sn, cs; sincosf(phi[i], &sn, &cs);
+    reinterpret_cast<float2*>(Fin + ((long long)u * (Nf + 2) + n + 1) * LDSP)[f] = make_float2(a * cs, a * sn);
   }
 }
-// gA, gphi from G_Fin (rows 1..Nf)
-__global__ __launch_bounds__(256) void h0_bwd_kernel(const float* GFin, const float* A, const float* phi, float* gA, float* gphi, int U, int Nf) {
-  const long long total = (long long)U * Nf * FB;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int f = (int)(i % FB), k = (int)((i / FB) % Nf), u = (int)(i / ((long long)FB * Nf));
-    const float2 g = reinterpret_cast<const float2*>(GFin + ((long long)u * (Nf + 2) + k + 1) * LDSP)[f];
-    float s, c; sincosf(phi[i], &s, &c);
-    gA[i] = g.x * c + g.y * s;
-    gphi[i] = A[i] * (-g.x * s + g.y * c);
+// backward of the H0 frames and of the knot interpolation in one pass
+//   gA = Re(conj(e^{j phi}) G_Fin), gphi = A Im(...);  g_logdm[u][n][j] = sum_f [idx(f) == j] (1 - frac) gi + [idx(f) + 1 == j] frac gi,  gi = gA / corr[n] * Apre
+// a block owns one (utterance, frame) row of 513 bins.  Phase 1 forms gphi and
+// gi = gA * Apre per bin (gi parked in LDS, gA never reaches memory); phase 2: wave w reduces the knots j = w, w + 4, ... -- lanes stride over the
+// contiguous bins with idx in {j - 1, j} (idx[] is non-decreasing), fixed-order butterfly.  The one-thread-per-knot form walked ~50 dependent
+// loads per thread (28 us per call).
+__global__ __launch_bounds__(256) void h0_bwd_knots_kernel(const float* GFin, const float* A, const float* Apre, const float* phi, DesignTabs tb, const float* dmv,
+                                                           float* gphi, float* gdm, int U, int K, int Nf) {
+  __shared__ float gi[FB + 3];
+  __shared__ int id_s[FB + 3];
+  __shared__ float fr_s[FB + 3];
+  const int n = blockIdx.x % Nf, u = blockIdx.x / Nf;
+  const long long row = ((long long)u * Nf + n) * FB;
+  const float2* G = reinterpret_cast<const float2*>(GFin + ((long long)u * (Nf + 2) + n + 1) * LDSP);
+  for (int f = threadIdx.x; f < FB; f += 256) {
+    const float2 g = G[f];
+    const float a = A[row + f], ap = Apre[row + f];
+    float sn, cs; sincosf(phi[row + f], &sn, &cs);
+    gphi[row + f] = a * (-g.x * sn + g.y * cs);
+    gi[f] = (g.x * cs + g.y * sn) * ap;
+    id_s[f] = tb.idx[f]; fr_s[f] = tb.frac[f];
   }
-}
-// g_logdm[u][n][j] = sum_f [idx(f) == j] (1 - frac) gi + [idx(f) + 1 == j] frac gi,  gi = gA / corr[n] * Apre
-__global__ void design_bwd_knots_kernel(const float* gA, const float* Apre, DesignTabs tb, const float* dmv, float* gdm, int U, int K, int Nf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= U * Nf * K) return;
-  const int j = i % K, n = (i / K) % Nf, u = i / (K * Nf);
-  const float* g = gA + ((long long)u * Nf + n) * FB;
-  const float* ap = Apre + ((long long)u * Nf + n) * FB;
-  float acc = 0.f;
-  // idx[] is non-decreasing in f (bin -> knot interval), so only the contiguous bins with idx in {j-1, j} contribute
-  auto first_ge = [&](int v) { int lo = 0, hi = FB; while (lo < hi) { const int mid = (lo + hi) >> 1; if (tb.idx[mid] >= v) hi = mid; else lo = mid + 1; } return lo; };
-  const int f_lo = first_ge(j - 1), f_hi = first_ge(j + 1);
-  for (int f = f_lo; f < f_hi; ++f) {
-    const int id = tb.idx[f];
-    if (id == j) acc += (1.f - tb.frac[f]) * g[f] * ap[f];
-    else if (id + 1 == j) acc += tb.frac[f] * g[f] * ap[f];
+  __syncthreads();
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = w; j < K; j += 4) {
+    const int f_lo = tb.fge[j], f_hi = tb.fge[j + 2];          // first bins with idx >= j - 1 and idx >= j + 1
+    float acc = 0.f;
+    for (int f = f_lo + lane; f < f_hi; f += 64) {
+      const int id = id_s[f];
+      if (id == j) acc += (1.f - fr_s[f]) * gi[f];
+      else if (id + 1 == j) acc += fr_s[f] * gi[f];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    const long long o = ((long long)u * Nf + n) * K + j;
+    if (lane == 0) gdm[o] = acc / tb.corr[n] / (dmv[o] + 1e-6f);      // d/d dm of log(dm + 1e-6)
   }
-  gdm[i] = acc / tb.corr[n] / (dmv[i] + 1e-6f);      // d/d dm of log(dm + 1e-6)
 }
 // one WAVE per parameter (u, e, b): lanes take the frames n = lane, lane + 64, ...; fixed-order butterfly sum (one thread per parameter looping
 // over the Nf frames with a powf each took 35 us on a single workgroup, ten times per sampler step)
@@ -524,43 +543,164 @@ __device__ __forceinline__ void dft16(float2 (&x)[16]) {
     x[12 + b0] = make_float2(d02.x - jd.x, d02.y - jd.y);
   }
 }
-// Output forms: OUT 0 = complex X; OUT 1 = the first Lo REAL parts to xr[u][0..Lo) (mpb_out); OUT 2 = the same with sample 0 := first (mp_out)
-struct S2Out { float2* X; float* xr; int Lo; float first; };
-constexpr int S2_COLS = 16, S2_PITCH = 16 * S2_COLS + 4;
-template <int SGN, int OUT>
-__global__ __launch_bounds__(256) void fft_stage2_kernel(const float2* y1, S2Out out, const float2* w256, float scale) {
+// ---- the chain of four transforms of the minimum-phase projection (and of its backward), five kernels -------------------------------------------
+// Consecutive transforms alternate between the two index splittings of N2 = 101 * 256, so that the LAST stage of one and the FIRST stage of the
+// next work on the same data in the same workgroup, with the elementwise step between them applied in registers:
+//   form I  (above):  n = 256 n1 + n2, k = k1 + 101 k2:   [101-point over n1, twiddle]  ->  [256-point over n2]
+//   form II        :  n = m1 + 101 m2, k = 256 q1 + q2:   [256-point over m2, twiddle W_N^(m1 q2)]  ->  [101-point over m1]
+// (both take and deliver NATURAL order).  FFT_1 (I) | pw | FFT_2 (II) | pw | FFT_3 (I) | pw | FFT_4 (II)  becomes
+//   stage1  ->  [256 . pw . 256]  ->  [101 . pw . 101]  ->  [256 . pw . 256]  ->  stageB
+// instead of 8 stage kernels + 2 elementwise ones; the intermediate images are y1[u][n2][k1] (after a 101-point stage) and z[u][q2][m1] (after a
+// 256-point stage of form II) -- the same [256][101] shape, so twN[q2 * 101 + m1] serves both twiddles.
+constexpr int S2_COLS = 8, S2_SHIFT = 3, S2_PITCH = 16 * S2_COLS + 4, S2_THREADS = 16 * S2_COLS;
+// 256-point DFT of v over the index held as (register a, thread r): in  v[a] = x[16 a + r];  out v[c] = X[b + 16 c] with b = r
+template <int SGN>
+__device__ __forceinline__ void dft256(float2 (&v)[16], float2* S, const float2* W, int col, int r) {
+  dft16<SGN>(v);
+#pragma unroll
+  for (int b = 0; b < 16; ++b) S[b * S2_PITCH + r * S2_COLS + col] = cmul(v[b], W[(r * b) & (F2 - 1)]);
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) v[rr] = S[r * S2_PITCH + rr * S2_COLS + col];
+  dft16<SGN>(v);
+}
+// the elementwise steps (reference reverb_utils.py:9-23 and their adjoints), on element k of utterance u:
+//   PW 0  X = FFT([h, 0]):          Hf = X, M = |X|,                          x' = log(M + 1e-8)
+//   PW 1  X = hilbert(log M):       phim = -Im X,                             x' = M e^{j phim}
+//   PW 2  X = FFT(g) / N2 (= G_Z):  gM = Re(conj(X) e^{j phim}),              x' = -M Im(conj(X) e^{j phim})
+//   PW 3  X = hilbert(g_phi):       g = gM + Im X / (M + 1e-8),               x' = g Hf / M   (0 where M = 0)
+struct MpArrays { float2* Hf; float* M; float* phim; float* gM; };
+struct MpIn { float m, ph, g; float2 h; };            // what the step reads of the stored arrays (loaded for all 16 elements of a thread up front:
+                                                      // behind the step's own stores the compiler may not hoist them, and each would cost a round trip)
+template <int PW>
+__device__ __forceinline__ MpIn mp_load(long long i, const MpArrays& A) {
+  MpIn r; r.m = 0.f; r.ph = 0.f; r.g = 0.f; r.h = make_float2(0.f, 0.f);
+  if (PW >= 1) r.m = A.M[i];
+  if (PW == 2) r.ph = A.phim[i];
+  if (PW == 3) { r.g = A.gM[i]; r.h = A.Hf[i]; }
+  return r;
+}
+template <int PW>
+__device__ __forceinline__ float2 mp_pointwise(float2 X, long long i, const MpIn& in, const MpArrays& A) {
+  if (PW == 0) {
+    const float m = sqrtf(X.x * X.x + X.y * X.y);
+    A.Hf[i] = X; A.M[i] = m;
+    return make_float2(logf(m + 1e-8f), 0.f);
+  } else if (PW == 1) {
+    const float ph = -X.y;
+    A.phim[i] = ph;
+    float sn, cs; sincosf(ph, &sn, &cs);
+    return make_float2(in.m * cs, in.m * sn);
+  } else if (PW == 2) {
+    float sn, cs; sincosf(in.ph, &sn, &cs);
+    const float a = X.x * cs + X.y * sn, b = X.x * sn - X.y * cs;
+    A.gM[i] = a;
+    return make_float2(-in.m * b, 0.f);
+  } else {
+    const float m = in.m;
+    const float g = in.g + X.y / (m + 1e-8f);
+    return m > 0.f ? make_float2(g * in.h.x / m, g * in.h.y / m) : make_float2(0.f, 0.f);
+  }
+}
+// [256-point stage of form I] . pw . [256-point stage of form II + twiddle]: y1[u][n2][k1] -> z[u][q2][m1], m1 = k1.  A block owns 16 columns k1.
+template <int SGN, int PW>
+__global__ __launch_bounds__(S2_THREADS) void fft_mid256_kernel(const float2* y1, float2* z, const float2* w256, const float2* twN, float scale, MpArrays A) {
   __shared__ float2 S[16 * S2_PITCH];
   __shared__ float2 W[F2];
-  for (int i = threadIdx.x; i < F2; i += 256) W[i] = make_float2(w256[i].x, SGN * w256[i].y);
+  for (int i = threadIdx.x; i < F2; i += S2_THREADS) W[i] = make_float2(w256[i].x, SGN * w256[i].y);
   const int u = blockIdx.y;
-  const int col = threadIdx.x & (S2_COLS - 1), r = threadIdx.x >> 4;
+  const int col = threadIdx.x & (S2_COLS - 1), r = threadIdx.x >> S2_SHIFT;
   const int k1 = blockIdx.x * S2_COLS + col;
   const bool ok = k1 < F1;
   const float2* yu = y1 + (long long)u * N2;
   float2 v[16];
+  MpIn in[16];
 #pragma unroll
   for (int a = 0; a < 16; ++a) v[a] = ok ? yu[(16 * a + r) * F1 + k1] : make_float2(0.f, 0.f);
-  dft16<SGN>(v);
-  __syncthreads();
+  const long long e0 = (long long)u * N2 + (ok ? k1 : 0) + (long long)F1 * r;       // element c of this thread: e0 + 101 * 16 c
 #pragma unroll
-  for (int b = 0; b < 16; ++b) S[b * S2_PITCH + r * S2_COLS + col] = cmul(v[b], W[(r * b) & (F2 - 1)]);
+  for (int c = 0; c < 16; ++c) in[c] = mp_load<PW>(e0 + (long long)F1 * 16 * c, A);
   __syncthreads();
-  const int b = r;                                          // second role of this thread: output residue b
-#pragma unroll
-  for (int rr = 0; rr < 16; ++rr) v[rr] = S[b * S2_PITCH + rr * S2_COLS + col];
-  dft16<SGN>(v);
+  dft256<SGN>(v, S, W, col, r);                             // v[c] = X[k1 + 101 (r + 16 c)]
   if (ok) {
-    if (OUT == 0) {
-      float2* Xu = out.X + (long long)u * N2 + k1;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) Xu[(long long)F1 * (b + 16 * c)] = make_float2(v[c].x * scale, v[c].y * scale);
-    } else {
+    for (int c = 0; c < 16; ++c) v[c] = mp_pointwise<PW>(make_float2(v[c].x * scale, v[c].y * scale), e0 + (long long)F1 * 16 * c, in[c], A);
+  }
+  __syncthreads();                                          // S is reused
+  dft256<SGN>(v, S, W, col, r);                             // m2 = r + 16 c was (thread r, register c): v[c'] = sum over m2, q2 = r + 16 c'
+  if (ok) {
+    float2* zu = z + (long long)u * N2;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int n = k1 + F1 * (b + 16 * c);
-        if (n < out.Lo) out.xr[(long long)u * out.Lo + n] = (OUT == 2 && n == 0) ? out.first : v[c].x * scale;
-      }
+    for (int c = 0; c < 16; ++c) {
+      const int q2 = r + 16 * c;
+      const float2 t = twN[q2 * F1 + k1];
+      zu[q2 * F1 + k1] = cmul(v[c], make_float2(t.x, SGN * t.y));
     }
+  }
+}
+// 101-point DFT of the S1_COLS columns parked in X[n1 * S1_COLS + c] (twiddles W, sign applied), outputs o = tid, tid + 256 -> (c, k1) = (o / 101, o % 101)
+__device__ __forceinline__ float2 dft101(const float2* X, const float2* W, int c, int k1) {
+  float ar = 0.f, ai = 0.f;
+  int idx = 0, n1 = 0;
+  for (; n1 + 8 <= F1; n1 += 8) {                          // eight LDS pairs in flight per trip
+    float2 v[8], w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = X[(n1 + j) * S1_COLS + c]; w[j] = W[idx]; idx += k1; if (idx >= F1) idx -= F1; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ar += v[j].x * w[j].x - v[j].y * w[j].y; ai += v[j].x * w[j].y + v[j].y * w[j].x; }
+  }
+  for (; n1 < F1; ++n1) {
+    const float2 v = X[n1 * S1_COLS + c], w = W[idx];
+    ar += v.x * w.x - v.y * w.y; ai += v.x * w.y + v.y * w.x;
+    idx += k1; if (idx >= F1) idx -= F1;
+  }
+  return make_float2(ar, ai);
+}
+// [101-point stage of form II, sign -] . Hilbert window . [101-point stage of form I + twiddle, sign +]: z[u][q2][m1] -> y1[u][n2][k1], n2 = q2
+__global__ __launch_bounds__(256) void fft_mid101_kernel(const float2* z, float2* y1, const float2* w101, const float2* twN) {
+  __shared__ float2 Wm[F1], Wp[F1];
+  __shared__ float2 X[F1 * S1_COLS], X2[F1 * S1_COLS];
+  const int u = blockIdx.y, n20 = blockIdx.x * S1_COLS;
+  for (int i = threadIdx.x; i < F1; i += 256) { const float2 w = w101[i]; Wm[i] = make_float2(w.x, -w.y); Wp[i] = w; }
+  const float2* zu = z + (long long)u * N2 + (long long)n20 * F1;
+  for (int i = threadIdx.x; i < F1 * S1_COLS; i += 256) { const int c = i / F1, m1 = i - c * F1; X[m1 * S1_COLS + c] = zu[i]; }
+  __syncthreads();
+  for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
+    const int c = o / F1, q1 = o - c * F1;
+    const float2 x = dft101(X, Wm, c, q1);                  // element n = 256 q1 + n2 of the inner spectrum
+    const float w = (F2 * q1 + n20 + c) < N2 / 2 ? 2.f : 0.f;
+    X2[q1 * S1_COLS + c] = make_float2(x.x * w, x.y * w);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
+    const int c = o / F1, k1 = o - c * F1, n2 = n20 + c;
+    const float2 t = twN[(long long)n2 * F1 + k1];
+    const float2 x = dft101(X2, Wp, c, k1);
+    y1[(long long)u * N2 + (long long)n2 * F1 + k1] = cmul(x, t);
+  }
+}
+// last stage of a form-II transform with REAL output: xr[u][n] = scale * Re sum_{m1} z[u][q2][m1] W101^(sign m1 q1), n = 256 q1 + q2 < Lo;
+// first_set: sample 0 := first (the minimum-phase filter's leading tap is a constant of the projection)
+__global__ __launch_bounds__(256) void fft_stageB_real_kernel(const float2* z, float* xr, int Lo, const float2* w101, int sign, float scale, int first_set, float first) {
+  __shared__ float2 W[F1];
+  __shared__ float2 X[F1 * S1_COLS];
+  const int u = blockIdx.y, n20 = blockIdx.x * S1_COLS;
+  for (int i = threadIdx.x; i < F1; i += 256) W[i] = make_float2(w101[i].x, sign * w101[i].y);
+  const float2* zu = z + (long long)u * N2 + (long long)n20 * F1;
+  for (int i = threadIdx.x; i < F1 * S1_COLS; i += 256) { const int c = i / F1, m1 = i - c * F1; X[m1 * S1_COLS + c] = zu[i]; }
+  __syncthreads();
+  for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
+    const int q1 = o / S1_COLS, c = o - q1 * S1_COLS;     // consecutive threads: the block's S1_COLS consecutive samples of one q1
+    const int n = F2 * q1 + n20 + c;
+    if (n >= Lo) continue;
+    float ar = 0.f;
+    int idx = 0;
+    for (int m1 = 0; m1 < F1; ++m1) {
+      const float2 v = X[m1 * S1_COLS + c], w = W[idx];
+      ar += v.x * w.x - v.y * w.y;
+      idx += q1; if (idx >= F1) idx -= F1;
+    }
+    xr[(long long)u * Lo + n] = (first_set && n == 0) ? first : ar * scale;
   }
 }
 
@@ -911,7 +1051,7 @@ struct BlindOp {
   // tables
   float *Bf = nullptr, *Bi = nullptr, *BfT = nullptr, *BiT = nullptr, *ones = nullptr, *env_T = nullptr, *env_d = nullptr, *env_c = nullptr;
   float norm = 1.f;
-  int* idx = nullptr; float *frac = nullptr, *corr = nullptr, *dpm = nullptr;
+  int *idx = nullptr, *fge = nullptr; float *frac = nullptr, *corr = nullptr, *dpm = nullptr;
   float2 *w101 = nullptr, *w256 = nullptr, *twN = nullptr, *w1024 = nullptr; float* win = nullptr; bool use_fft = true;
   // parameters + Adam state
   float *decay = nullptr, *wts = nullptr, *phi = nullptr;
@@ -937,7 +1077,7 @@ struct BlindOp {
     std::swap(partial, partial_b);
   }
   float *A = nullptr, *Apre = nullptr, *logdm = nullptr, *dmv = nullptr, *gdm = nullptr, *Fin = nullptr, *GFin = nullptr, *GH = nullptr;
-  float *gA = nullptr, *gphi = nullptr, *gdecay = nullptr, *gw = nullptr, *h0 = nullptr, *hm = nullptr, *ghm = nullptr, *gh0 = nullptr;
+  float *gphi = nullptr, *gdecay = nullptr, *gw = nullptr, *h0 = nullptr, *hm = nullptr, *ghm = nullptr, *gh0 = nullptr;
   float2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr, *Hf = nullptr;
   float *Mabs = nullptr, *phim = nullptr, *gM = nullptr;
   double* partial = nullptr; float* losses = nullptr;
@@ -1018,46 +1158,45 @@ struct BlindOp {
     c2r(GX, (long long)U * Tx, frames, sx, 0);
     r2c(R2cSrc{nullptr, frames, Ls, Q, Tx, P, ones, inv_env, nullptr, 0.f, nullptr}, Tn, GY, si / NFFT, 1);
   }
-  // in_mode / out_mode: the elementwise neighbours of the transform folded into its first load / last store (S1In / S2Out above)
-  void fft(const float2* x, float2* tmp, float2* X, int sign, float scale, int in_mode = 0, const float* xr = nullptr, int Lr_ = 0, int out_mode = 0,
-           float* yr = nullptr, int Lo = 0, float first = 0.f) {
-    const S1In in{x, xr, Lr_};
-    const dim3 g1(F2 / S1_COLS, U), g2(cdiv(F1, S2_COLS), U);
-    if (in_mode == 1) hipLaunchKernelGGL(fft_stage1_kernel<1>, g1, dim3(256), 0, st, in, tmp, (const float2*)w101, (const float2*)twN, sign);
-    else if (in_mode == 2) hipLaunchKernelGGL(fft_stage1_kernel<2>, g1, dim3(256), 0, st, in, tmp, (const float2*)w101, (const float2*)twN, sign);
-    else if (in_mode == 3) hipLaunchKernelGGL(fft_stage1_kernel<3>, g1, dim3(256), 0, st, in, tmp, (const float2*)w101, (const float2*)twN, sign);
-    else hipLaunchKernelGGL(fft_stage1_kernel<0>, g1, dim3(256), 0, st, in, tmp, (const float2*)w101, (const float2*)twN, sign);
-    const S2Out o{X, yr, Lo, first};
-    if (sign > 0) {
-      if (out_mode == 1) hipLaunchKernelGGL((fft_stage2_kernel<1, 1>), g2, dim3(256), 0, st, (const float2*)tmp, o, (const float2*)w256, scale);
-      else if (out_mode == 2) hipLaunchKernelGGL((fft_stage2_kernel<1, 2>), g2, dim3(256), 0, st, (const float2*)tmp, o, (const float2*)w256, scale);
-      else hipLaunchKernelGGL((fft_stage2_kernel<1, 0>), g2, dim3(256), 0, st, (const float2*)tmp, o, (const float2*)w256, scale);
-    } else {
-      hipLaunchKernelGGL((fft_stage2_kernel<-1, 0>), g2, dim3(256), 0, st, (const float2*)tmp, o, (const float2*)w256, scale);
-    }
+  // first stage (form I) of a transform of the REAL signal xr[u][0..Lr_) zero-padded to N2 (zero0: sample 0 forced to zero) -> c2
+  void fft_first(const float* xr, int Lr_, bool zero0, int sign) {
+    const S1In in{nullptr, xr, Lr_};
+    const dim3 g1(F2 / S1_COLS, U);
+    if (zero0) hipLaunchKernelGGL(fft_stage1_kernel<3>, g1, dim3(256), 0, st, in, c2, (const float2*)w101, (const float2*)twN, sign);
+    else hipLaunchKernelGGL(fft_stage1_kernel<2>, g1, dim3(256), 0, st, in, c2, (const float2*)w101, (const float2*)twN, sign);
   }
-  DesignTabs tabs() const { DesignTabs t; t.idx = idx; t.frac = frac; t.corr = corr; t.dpm = dpm; return t; }
+  template <int SGN, int PW> void fft_mid256(float scale) {           // c2 -> c1
+    const MpArrays a{Hf, Mabs, phim, gM};
+    hipLaunchKernelGGL((fft_mid256_kernel<SGN, PW>), dim3(cdiv(F1, S2_COLS), U), dim3(S2_THREADS), 0, st, (const float2*)c2, c1, (const float2*)w256, (const float2*)twN, scale, a);
+  }
+  void fft_mid101() {                                                  // c1 -> c2
+    hipLaunchKernelGGL(fft_mid101_kernel, dim3(F2 / S1_COLS, U), dim3(256), 0, st, (const float2*)c1, c2, (const float2*)w101, (const float2*)twN);
+  }
+  void fft_last_real(float* out, int Lo, int sign, float scale, bool first_set, float first) {       // c1 -> out
+    hipLaunchKernelGGL(fft_stageB_real_kernel, dim3(F2 / S1_COLS, U), dim3(256), 0, st, (const float2*)c1, out, Lo, (const float2*)w101, sign, scale, first_set ? 1 : 0, first);
+  }
+  DesignTabs tabs() const { DesignTabs t; t.idx = idx; t.frac = frac; t.corr = corr; t.dpm = dpm; t.fge = fge; return t; }
 
-  void design() {
+  void design_dm() {
     hipLaunchKernelGGL(design_dm_kernel, dim3(cdiv(U * Nf * K, 256)), dim3(256), 0, st, (const float*)decay, (const float*)wts, logdm, dmv, U, E, NB, Nf,
                        fused_loop ? d_step : (int*)nullptr);
+  }
+  void design() {              // the filter magnitudes alone (buddy_blindop_design_filter)
+    design_dm();
     hipLaunchKernelGGL(design_A_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)logdm, tabs(), A, Apre, U, K, Nf);
   }
-  // minimum_phase_version (reference reverb_utils.py:9-23) of hin (U, Lin <= Lm samples, zero-padded to N2): result (complex, real part = signal) in c1
-  // out_real != nullptr: the last transform writes Re(.)[:Lo] there (sample 0 := first when first_set) instead of the complex c1
-  void minphase_core(const float* hin, int Lin, float* out_real = nullptr, int Lo = 0, bool first_set = false, float first = 0.f) {
-    const long long tot = (long long)U * N2;
-    fft(nullptr, c2, Hf, -1, 1.f, 2, hin, Lin);                                        // FFT of [hin, zeros]
-    hipLaunchKernelGGL(mp_logabs_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)Hf, Mabs, c1, tot);
-    fft(c1, c2, c3, -1, 1.f);
-    fft(c3, c2, c1, +1, 1.f / N2, 1);                                                  // Hilbert window folded into the load
-    hipLaunchKernelGGL(mp_phase_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)c1, (const float*)Mabs, phim, c3, tot);
-    if (out_real) fft(c3, c2, c1, +1, 1.f / N2, 0, nullptr, 0, first_set ? 2 : 1, out_real, Lo, first);
-    else fft(c3, c2, c1, +1, 1.f / N2);
+  // minimum_phase_version (reference reverb_utils.py:9-23) of hin (U, Lin <= Lm samples, zero-padded to N2): out[u][0..Lo) = its real part
+  // (sample 0 := first when first_set).  Leaves Hf = FFT([hin, 0]), Mabs = |Hf| and phim for the backward pass.
+  void minphase_core(const float* hin, int Lin, float* out, int Lo, bool first_set = false, float first = 0.f) {
+    fft_first(hin, Lin, false, -1);                  // FFT([hin, zeros]) ...
+    fft_mid256<-1, 0>(1.f);                          // ... | log |.| | FFT ...
+    fft_mid101();                                    // ... | Hilbert window | IFFT ...
+    fft_mid256<1, 1>(1.f / N2);                      // ... | M exp(-j Im .) | IFFT ...
+    fft_last_real(out, Lo, +1, 1.f / N2, first_set, first);
   }
-  // H = cons(A * exp(j phi))   (reference :333-351)
+  // A = design(logdm) and H = cons(A * exp(j phi))   (reference :333-351); needs design_dm() first
   void cons_forward() {
-    hipLaunchKernelGGL(h0_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)A, (const float*)phi, Fin, U, Nf);
+    hipLaunchKernelGGL(design_A_h0_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)logdm, tabs(), (const float*)phi, A, Apre, Fin, U, K, Nf);
     istft(Fin, Nf + 2, WIN, env_c, Lh, 1.f, h0);
     minphase_core(h0, Lh, hm, Lm, true, (float)(WIN / (HOP * 2.0)));
     stft(hm, Lm, WIN - HOP, Nf, 1.f, H);          // frames 1..Nf of the centred STFT: frame k starts at 128 (k+1) - 512
@@ -1065,16 +1204,14 @@ struct BlindOp {
   // G_Fin from G_H
   void cons_backward(const float* GHin) {
     stft_adj(GHin, Lm, WIN - HOP, Nf, 1.f, ghm);
-    const long long tot = (long long)U * N2;
-    fft(nullptr, c2, c3, -1, 1.f / N2, 3, ghm, Lm);                  // GZ = FFT([0, ghm[1:], zeros]) / N2
-    hipLaunchKernelGGL(mpb_z_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)c3, (const float*)Mabs, (const float*)phim, gM, c1, tot);
-    fft(c1, c2, c3, -1, 1.f);
-    fft(c3, c2, c1, +1, 1.f / N2, 1);                                // hilbert(g_phi), window folded into the load
-    hipLaunchKernelGGL(mpb_h_kernel, dim3(gridf(tot)), dim3(256), 0, st, (const float2*)c1, (const float*)Mabs, (const float*)gM, (const float2*)Hf, c3, tot);
-    fft(c3, c2, c1, +1, 1.f, 0, nullptr, 0, 1, gh0, Lh);             // g_h0 = Re(N2 * IFFT(GH))[:Lh]
+    fft_first(ghm, Lm, true, -1);                    // GZ = FFT([0, ghm[1:], zeros]) / N2 ...
+    fft_mid256<-1, 2>(1.f / N2);                     // ... | gM, g_phi | FFT ...
+    fft_mid101();                                    // ... | Hilbert window | IFFT ...
+    fft_mid256<1, 3>(1.f / N2);                      // ... | G_H | N2 * IFFT
+    fft_last_real(gh0, Lh, +1, 1.f, false, 0.f);     // g_h0 = Re(N2 * IFFT(GH))[:Lh]
     istft_adj(gh0, Nf + 2, WIN, env_c, Lh, 1.f, GFin);
   }
-  void update_H() { design(); cons_forward(); }
+  void update_H() { design_dm(); cons_forward(); }
   void fir(const float* X, long long xs, int Tn, float* Y) {
     static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
     const size_t sm = (size_t)(FL_TB + 2 * Nf - 1) * FL_BINS * sizeof(float2);
@@ -1174,6 +1311,9 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
     idx[f] = i0; frac[f] = (q - cfg.knots[i0]) / (cfg.knots[i0 + 1] - cfg.knots[i0]);
   }
   UP(idx, idx); UP(frac, frac);
+  std::vector<int> fge((size_t)o->K + 3);                                    // fge[v + 1] = first bin with idx >= v, v = -1 .. K + 1 (idx is non-decreasing)
+  for (int v = -1; v <= o->K + 1; ++v) { int f = 0; while (f < FB && idx[f] < v) ++f; fge[v + 1] = f; }
+  UP(fge, fge);
   std::vector<float> corr(cfg.Nf, 1.f);
   { const int Kc = WIN / HOP - 1; double ws = 0; for (int n = 0; n < WIN; ++n) ws += w[n];
     for (int k = 0; k < Kc; ++k) { double s = 0; for (int n = (Kc - k) * HOP; n < WIN; ++n) s += w[n]; corr[k] = (float)((float)ws / (float)s); } }
@@ -1202,7 +1342,7 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
   DA(sp, (size_t)U_ * ((size_t)(T + 4) * HOP + NFFT)); DA(frames, (size_t)U_ * (T + 2) * WIN);
   DA(X1, specT); DA(X2, specT); DA(X3, specT); DA(Ybuf, specT); DA(sig1, (size_t)U_ * (Lmax + 8)); DA(sig2, (size_t)U_ * (Lmax + 8));
   DA(A, (size_t)U_ * Nf * FB); DA(Apre, (size_t)U_ * Nf * FB); DA(logdm, U_ * Nf * o->K); DA(dmv, U_ * Nf * o->K); DA(gdm, U_ * Nf * o->K);
-  DA(Fin, specH); DA(GFin, specH); DA(GH, specH); DA(gA, (size_t)U_ * Nf * FB); DA(gphi, (size_t)U_ * Nf * FB);
+  DA(Fin, specH); DA(GFin, specH); DA(GH, specH); DA(gphi, (size_t)U_ * Nf * FB);
   DA(gdecay, U_ * o->E * o->NB); DA(gw, U_ * o->E * o->NB);
   DA(h0, (size_t)U_ * o->Lh); DA(hm, (size_t)U_ * o->Lm); DA(ghm, (size_t)U_ * o->Lm); DA(gh0, (size_t)U_ * o->Lh);
   DA(c1, (size_t)U_ * N2); DA(c2, (size_t)U_ * N2); DA(c3, (size_t)U_ * N2); DA(Hf, (size_t)U_ * N2);
@@ -1318,8 +1458,7 @@ int blindop_apply_stft(BlindOp* o, const float* x, float* X_ref, hipStream_t st)
 // minimum_phase_version (reverb_utils.py:9-23) of h (U, 128 * (Nf + 1)) -- the size cons() uses; no direct-path override
 int blindop_minphase(BlindOp* o, const float* h, float* out, hipStream_t st) {
   o->st = st;
-  o->minphase_core(h, o->Lm);
-  hipLaunchKernelGGL(mp_out_plain_kernel, dim3(gridf((long long)o->U * o->Lm)), dim3(256), 0, st, (const float2*)o->c1, out, o->Lm, o->U);
+  o->minphase_core(h, o->Lm, out, o->Lm);
   HIPCHK(hipGetLastError());
   return BUDDY_OK;
 }
@@ -1418,8 +1557,8 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
     }
   }
   o->cons_backward(o->GH);
-  hipLaunchKernelGGL(h0_bwd_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->GFin, (const float*)o->A, (const float*)o->phi, o->gA, o->gphi, U, Nf);
-  hipLaunchKernelGGL(design_bwd_knots_kernel, dim3(cdiv(U * Nf * o->K, 256)), dim3(256), 0, st, (const float*)o->gA, (const float*)o->Apre, o->tabs(), (const float*)o->dmv, o->gdm, U, o->K, Nf);
+  hipLaunchKernelGGL(h0_bwd_knots_kernel, dim3(U * Nf), dim3(256), 0, st, (const float*)o->GFin, (const float*)o->A, (const float*)o->Apre, (const float*)o->phi, o->tabs(),
+                     (const float*)o->dmv, o->gphi, o->gdm, U, o->K, Nf);
   hipLaunchKernelGGL(design_bwd_params_kernel, dim3(cdiv(U * o->E * o->NB, 4)), dim3(256), 0, st, (const float*)o->gdm, (const float*)o->decay, (const float*)o->wts, o->gdecay, o->gw, U, o->E, o->NB, Nf);
   return BUDDY_OK;
 }
