@@ -167,14 +167,22 @@ __device__ __forceinline__ v2f cmac_conj(v2f acc, float2 w, float2 g) {
   return __builtin_elementwise_fma(v2f{w.y, -w.y}, v2f{g.y, g.x}, acc);
 }
 constexpr int FL_BINS = 32, FL_FT = 8, FL_TB = 64;           // bins per workgroup, frames per thread, frames per workgroup (8 frame groups)
-// Y[u][t][f] = sum_k H[u][k][f] X[u][t + 1 - k][f]; grid (ceil(T / 64), ceil(FB / 32), U), 256 threads; LDS (64 + 2 Nf - 1) x 32 complex
-__global__ __launch_bounds__(256) void fir_sb_lds_kernel(const float* __restrict__ X, long long xs, const float* __restrict__ H, float* __restrict__ Y,
-                                                         int T, int Nf) {
+// Y[u][t][f] = sum_k H[u][k][f] X[u][t + 1 - k][f]; grid (ceil(T / 64), ceil(FB / 32), U), 256 threads; LDS (64 + 2 Nf - 1) x 32 complex.
+// One launch filters up to TWO independent inputs with the same H (FirSegs: the reconstruction term's STFT(x_den) and the regulariser's STFT(delta));
+// the x tiles of the second follow those of the first.  Every launch of the captured loop costs ~5 us on top of its work.
+struct FirSeg { const float* X; long long xs; float* Y; int T; int tiles; };
+struct FirSegs { FirSeg s[2]; };
+__global__ __launch_bounds__(256) void fir_sb_lds_kernel(FirSegs segs, const float* __restrict__ H, int Nf) {
   extern __shared__ float2 fl_smem[];
   const int nx = FL_TB + Nf - 1;                             // frames t0 - Nf + 2 ... t0 + 64
   float2* Xs = fl_smem;                                      // [nx][32]
   float2* Hs = fl_smem + nx * FL_BINS;                       // [Nf][32]
-  const int u = blockIdx.z, f0 = blockIdx.y * FL_BINS, t0 = blockIdx.x * FL_TB;
+  const bool second = (int)blockIdx.x >= segs.s[0].tiles;
+  const float* __restrict__ X = second ? segs.s[1].X : segs.s[0].X;
+  float* __restrict__ Y = second ? segs.s[1].Y : segs.s[0].Y;
+  const long long xs = second ? segs.s[1].xs : segs.s[0].xs;
+  const int T = second ? segs.s[1].T : segs.s[0].T;
+  const int u = blockIdx.z, f0 = blockIdx.y * FL_BINS, t0 = ((int)blockIdx.x - (second ? segs.s[0].tiles : 0)) * FL_TB;
   const int tid = threadIdx.x, b = tid & 31, g = tid >> 5;
   const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs);
   const float2* Hu = reinterpret_cast<const float2*>(H + (long long)u * Nf * LDSP);
@@ -223,73 +231,90 @@ __global__ __launch_bounds__(256) void fir_sb_lds_kernel(const float* __restrict
 // GH[u][k][f] (+)= sum_t conj(X[u][t + 1 - k][f]) GY[u][t][f]; grid (ceil(Nf / 16), ceil(FB / 32), U), 256 threads = 32 bins x 2 tap groups of 8 x 4
 // frame slots; frames in chunks of 64 (slot s takes frames 16 s ... 16 s + 15 of each chunk); the four slot sums are added in fixed order
 constexpr int GL_TAPS = 16, GL_CH = 64, GL_SLOT = 16;
-__global__ __launch_bounds__(256) void fir_gradh_lds_kernel(const float* __restrict__ X, long long xs, const float* __restrict__ GY, float* __restrict__ GH,
-                                                            int T, int Nf, int accumulate) {
+struct GradSeg { const float* X; long long xs; const float* GY; int T; };
+struct GradSegs { GradSeg s[2]; int n; };
+// one launch sums the tap gradients of up to two (X, GY) pairs; each pair is accumulated from zero and reduced on its own, the second sum is added to
+// the first (exactly what two launches, the second accumulating into GH, did)
+__global__ __launch_bounds__(256) void fir_gradh_lds_kernel(GradSegs segs, float* __restrict__ GH, int Nf, int accumulate) {
   __shared__ float2 Xs[(GL_CH + GL_TAPS - 1) * FL_BINS];     // frames c0 + 1 - (k0 + 15) ... c0 + 64 - k0
   __shared__ float2 Gs[GL_CH * FL_BINS];
   __shared__ float2 red[4][GL_TAPS][FL_BINS];
   const int u = blockIdx.z, f0 = blockIdx.y * FL_BINS, k0 = blockIdx.x * GL_TAPS;
   const int tid = threadIdx.x, b = tid & 31, kg = (tid >> 5) & 1, sl = tid >> 6;
-  const float2* Xu = reinterpret_cast<const float2*>(X + (long long)u * xs);
-  const float2* Gu = reinterpret_cast<const float2*>(GY + (long long)u * T * LDSP);
   const bool fok = f0 + b < FB;
   const int kk = k0 + 8 * kg;                                // this thread's taps kk ... kk + 7
-  v2f ac[8];
+  float2 tot[8];                                             // (sl == 0 threads) the sums of the segments done so far
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ac[j] = v2f{0.f, 0.f};
-  // the next chunk's slab is requested before the arithmetic of the current one (registers), stored to LDS after it
-  constexpr int NXR = (GL_CH + GL_TAPS - 1 + 7) / 8, NGR = GL_CH / 8;
-  const int g8 = tid >> 5;
-  float2 vx[NXR], vg[NGR];
-  auto fetch = [&](int c0) {
-    const int xb = c0 + 1 - (k0 + GL_TAPS - 1);
+  for (int j = 0; j < 8; ++j) tot[j] = make_float2(0.f, 0.f);
+  for (int sg_i = 0; sg_i < segs.n; ++sg_i) {
+    const int T = segs.s[sg_i].T;
+    const float2* Xu = reinterpret_cast<const float2*>(segs.s[sg_i].X + (long long)u * segs.s[sg_i].xs);
+    const float2* Gu = reinterpret_cast<const float2*>(segs.s[sg_i].GY + (long long)u * T * LDSP);
+    v2f ac[8];
 #pragma unroll
-    for (int i = 0; i < NXR; ++i) {
-      const int r = g8 + 8 * i, tt = xb + r;
-      vx[i] = (r < GL_CH + GL_TAPS - 1 && fok && tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+    for (int j = 0; j < 8; ++j) ac[j] = v2f{0.f, 0.f};
+    // the next chunk's slab is requested before the arithmetic of the current one (registers), stored to LDS after it
+    constexpr int NXR = (GL_CH + GL_TAPS - 1 + 7) / 8, NGR = GL_CH / 8;
+    const int g8 = tid >> 5;
+    float2 vx[NXR], vg[NGR];
+    auto fetch = [&](int c0) {
+      const int xb = c0 + 1 - (k0 + GL_TAPS - 1);
+#pragma unroll
+      for (int i = 0; i < NXR; ++i) {
+        const int r = g8 + 8 * i, tt = xb + r;
+        vx[i] = (r < GL_CH + GL_TAPS - 1 && fok && tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NGR; ++i) {
+        const int tt = c0 + g8 + 8 * i;
+        vg[i] = (fok && tt < T) ? Gu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+      }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < T; c0 += GL_CH) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NXR; ++i) { const int r = g8 + 8 * i; if (r < GL_CH + GL_TAPS - 1) Xs[r * FL_BINS + b] = vx[i]; }
+#pragma unroll
+      for (int i = 0; i < NGR; ++i) Gs[(g8 + 8 * i) * FL_BINS + b] = vg[i];
+      __syncthreads();
+      if (c0 + GL_CH < T) fetch(c0 + GL_CH);
+      // frame t = c0 + 16 sl + q: X[t + 1 - kk - j] = Xs row (16 sl + q + GL_TAPS - 1 - 8 kg - j)
+      const int base = GL_SLOT * sl + GL_TAPS - 1 - 8 * kg;
+      float2 w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = Xs[(base - j) * FL_BINS + b];
+#pragma unroll
+      for (int q = 0; q < GL_SLOT; ++q) {
+        const float2 gy = Gs[(GL_SLOT * sl + q) * FL_BINS + b];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ac[j] = cmac_conj(ac[j], w[j], gy);
+#pragma unroll
+        for (int j = 7; j > 0; --j) w[j] = w[j - 1];
+        if (q + 1 < GL_SLOT) w[0] = Xs[(base + q + 1) * FL_BINS + b];
+      }
     }
+    __syncthreads();                                         // red may still be read by the previous segment's reduction
 #pragma unroll
-    for (int i = 0; i < NGR; ++i) {
-      const int tt = c0 + g8 + 8 * i;
-      vg[i] = (fok && tt < T) ? Gu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
-    }
-  };
-  fetch(0);
-  for (int c0 = 0; c0 < T; c0 += GL_CH) {
+    for (int j = 0; j < 8; ++j) red[sl][8 * kg + j][b] = make_float2(ac[j].x, ac[j].y);
     __syncthreads();
+    if (sl == 0) {
 #pragma unroll
-    for (int i = 0; i < NXR; ++i) { const int r = g8 + 8 * i; if (r < GL_CH + GL_TAPS - 1) Xs[r * FL_BINS + b] = vx[i]; }
+      for (int j = 0; j < 8; ++j) {
+        float r = red[0][8 * kg + j][b].x, im = red[0][8 * kg + j][b].y;
 #pragma unroll
-    for (int i = 0; i < NGR; ++i) Gs[(g8 + 8 * i) * FL_BINS + b] = vg[i];
-    __syncthreads();
-    if (c0 + GL_CH < T) fetch(c0 + GL_CH);
-    // frame t = c0 + 16 sl + q: X[t + 1 - kk - j] = Xs row (16 sl + q + GL_TAPS - 1 - 8 kg - j)
-    const int base = GL_SLOT * sl + GL_TAPS - 1 - 8 * kg;
-    float2 w[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) w[j] = Xs[(base - j) * FL_BINS + b];
-#pragma unroll
-    for (int q = 0; q < GL_SLOT; ++q) {
-      const float2 gy = Gs[(GL_SLOT * sl + q) * FL_BINS + b];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ac[j] = cmac_conj(ac[j], w[j], gy);
-#pragma unroll
-      for (int j = 7; j > 0; --j) w[j] = w[j - 1];
-      if (q + 1 < GL_SLOT) w[0] = Xs[(base + q + 1) * FL_BINS + b];
+        for (int sg = 1; sg < 4; ++sg) { r += red[sg][8 * kg + j][b].x; im += red[sg][8 * kg + j][b].y; }
+        tot[j] = sg_i == 0 ? make_float2(r, im) : make_float2(r + tot[j].x, im + tot[j].y);
+      }
     }
   }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) red[sl][8 * kg + j][b] = make_float2(ac[j].x, ac[j].y);
-  __syncthreads();
   if (sl == 0 && fok) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = kk + j;
       if (k >= Nf) continue;
-      float r = red[0][8 * kg + j][b].x, im = red[0][8 * kg + j][b].y;
-#pragma unroll
-      for (int sg = 1; sg < 4; ++sg) { r += red[sg][8 * kg + j][b].x; im += red[sg][8 * kg + j][b].y; }
       float2* o = reinterpret_cast<float2*>(GH + ((long long)u * Nf + k) * LDSP) + f0 + b;
+      float r = tot[j].x, im = tot[j].y;
       if (accumulate) { r += o->x; im += o->y; }
       *o = make_float2(r, im);
     }
@@ -311,15 +336,25 @@ __global__ __launch_bounds__(256) void compress_kernel(const float* X, float* Xc
   }
 }
 // loss_u = kappa * sum_{t,f} |Rc - comp(Xh)|^2 ;  G = d loss / d Xh (as dRe + j dIm).  partial sums per block (deterministic).
-__global__ __launch_bounds__(256) void comp_loss_kernel(const float* Rc, const float* Xh, float* G, double* partial, int T, float kappa, float p) {
+// Up to two independent terms per launch (LossJobs: blocks of the second follow those of the first).  Rc == nullptr: the target is the compressed
+// spectrum of what G holds on entry (the regulariser's detached STFT(rir + t n), overwritten in place by its gradient; was compress_kernel).
+struct LossJob { const float* Rc; const float* Xh; float* G; double* partial; int T; float kappa; int blocks; };
+struct LossJobs { LossJob j[2]; };
+__global__ __launch_bounds__(256) void comp_loss_kernel(LossJobs jobs, float p) {
   __shared__ double red[256];
+  const bool second = (int)blockIdx.x >= jobs.j[0].blocks;
+  const LossJob& jb = jobs.j[second ? 1 : 0];
+  const float* Rc = jb.Rc; const float* Xh = jb.Xh; float* G = jb.G;
+  const int T = jb.T, nblk = jb.blocks, bx = (int)blockIdx.x - (second ? jobs.j[0].blocks : 0);
+  const float kappa = jb.kappa;
   const int u = blockIdx.y;
   const long long total = (long long)T * FB;
   double acc = 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)bx * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
     const long long t = i / FB; const int f = (int)(i % FB);
     const long long row = ((long long)u * T + t) * LDSP;
-    const float2 x = reinterpret_cast<const float2*>(Xh + row)[f], rc = reinterpret_cast<const float2*>(Rc + row)[f];
+    const float2 x = reinterpret_cast<const float2*>(Xh + row)[f];
+    const float2 rc = Rc ? reinterpret_cast<const float2*>(Rc + row)[f] : compress(reinterpret_cast<const float2*>(G + row)[f], p);
     const float r = sqrtf(x.x * x.x + x.y * x.y);
     float2 g = make_float2(0.f, 0.f);
     float2 xc;
@@ -344,7 +379,7 @@ __global__ __launch_bounds__(256) void comp_loss_kernel(const float* Rc, const f
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
-  if (threadIdx.x == 0) partial[(long long)u * gridDim.x + blockIdx.x] = red[0];
+  if (threadIdx.x == 0) jb.partial[(long long)u * nblk + bx] = red[0];
 }
 __global__ void loss_finalize_kernel(const double* partial, int nblk, float kappa, float* loss, int accumulate) {
   const int u = blockIdx.x;
@@ -463,23 +498,36 @@ __global__ __launch_bounds__(256) void design_bwd_params_kernel(const float* gdm
 // stage 1: Y1[u][n2][k1] = tw(n2 k1) * sum_{n1} x[256 n1 + n2] W101^(n1 k1).  101 is prime: a naive 101-point DFT per column n2, but a block
 // parks its S1_COLS columns of x (101 x 4 complex) and the twiddles in LDS first, so the inner loop is two LDS reads and a complex FMA.
 constexpr int S1_COLS = 4;
-// Input forms folded into the load (each was a kernel of its own, and every node of the captured loop costs ~5 us): IN 0 = complex array x;
-// IN 1 = x times the Hilbert window (2 on the first half, 0 on the second; mp_window); IN 2 = a REAL signal xr[u][0..Lr) zero-padded to N2
-// (mp_pack); IN 3 = the same with sample 0 forced to zero (mpb_pack: hm[0] is a constant of the projection).
-struct S1In { const float2* x; const float* xr; int Lr; };
-template <int IN>
+// The input is a REAL signal of Lr samples zero-padded to N2, and it is never materialised: it is the overlap-add of the 512-sample frames
+// fr[u][0..Tsrc) at j = n + Q times env[j] (what ola_kernel wrote), or, with fr == nullptr, the array xr[u][0..Lr).  ZERO0: sample 0 forced to zero
+// (hm[0] is a constant of the projection).
+struct S1In { const float* xr; int Lr; const float* fr; int Tsrc, Q; const float* env; };
+template <bool ZERO0>
 __global__ __launch_bounds__(256) void fft_stage1_kernel(S1In in, float2* y1, const float2* w101, const float2* twN, int sign) {
   __shared__ float2 W[F1];
   __shared__ float2 X[F1 * S1_COLS];
   const int u = blockIdx.y, n20 = blockIdx.x * S1_COLS;
-  const float2* xu = in.x + (long long)u * N2;
   for (int i = threadIdx.x; i < F1; i += 256) W[i] = make_float2(w101[i].x, sign * w101[i].y);
   for (int i = threadIdx.x; i < F1 * S1_COLS; i += 256) {
     const int n1 = i / S1_COLS, c = i - n1 * S1_COLS, n = F2 * n1 + n20 + c;
-    float2 v;
-    if (IN >= 2) v = make_float2((n < in.Lr && (IN == 2 || n > 0)) ? in.xr[(long long)u * in.Lr + n] : 0.f, 0.f);
-    else { v = xu[n]; if (IN == 1) { const float w = n < N2 / 2 ? 2.f : 0.f; v.x *= w; v.y *= w; } }
-    X[i] = v;
+    float v = 0.f;
+    if (n < in.Lr && (!ZERO0 || n > 0)) {
+      if (in.fr) {
+        const int j = n + in.Q, tq = j >> 7, m0 = j & (HOP - 1);
+        float fv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                       // ascending frame order, as ola_kernel
+          const int tt = tq - 3 + k;
+          fv[k] = (tt >= 0 && tt < in.Tsrc) ? in.fr[((long long)u * in.Tsrc + tt) * WIN + m0 + HOP * (3 - k)] : 0.f;
+        }
+        const float e = in.env[j];
+        v = (((0.f + fv[0]) + fv[1]) + fv[2]) + fv[3];
+        v *= e;
+      } else {
+        v = in.xr[(long long)u * in.Lr + n];
+      }
+    }
+    X[i] = make_float2(v, 0.f);
   }
   __syncthreads();
   for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
@@ -755,15 +803,24 @@ struct R2cSrc {
   const float* sig; const float* fr; int Ls, P, Tsrc, Q; const float* envA; const float* envB;
   const float* add; float add_scale; const float* add_scale_dev;
 };
+// One launch transforms up to THREE independent frame sets (R2cJobs; same fac / cf): the blocks of job i + 1 follow those of job i.
+struct R2cJob { R2cSrc sc; int Tn; int rows; int blocks; float* out; };
+struct R2cJobs { R2cJob j[3]; };
 template <bool GATHER>
-__global__ __launch_bounds__(256) void fft1024_r2c_kernel(R2cSrc sc, int Tn, long long rows, const float* __restrict__ win,
-                                                          const float2* __restrict__ Wg, float* __restrict__ out, float fac, int cf) {
+__global__ __launch_bounds__(256) void fft1024_r2c_kernel(R2cJobs jobs, const float* __restrict__ win, const float2* __restrict__ Wg, float fac, int cf) {
   __shared__ float2 W[1024];
   __shared__ float2 S[4][16 * FLD];
   for (int i = threadIdx.x; i < 1024; i += 256) W[i] = Wg[i];
   const int w = threadIdx.x >> 6, r = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + w;
-  const bool ok = row < rows;
+  int blk = blockIdx.x;
+  const int ji = blk < jobs.j[0].blocks ? 0 : (blk < jobs.j[0].blocks + jobs.j[1].blocks ? 1 : 2);
+  if (ji >= 1) blk -= jobs.j[0].blocks;
+  if (ji == 2) blk -= jobs.j[1].blocks;
+  const R2cSrc& sc = jobs.j[ji].sc;
+  const int Tn = jobs.j[ji].Tn;
+  float* __restrict__ out = jobs.j[ji].out;
+  const long long row = (long long)blk * 4 + w;
+  const bool ok = row < jobs.j[ji].rows;
   const int u = ok ? (int)(row / Tn) : 0, t = ok ? (int)(row % Tn) : 0;
   const float add_scale = sc.add ? (sc.add_scale_dev ? *sc.add_scale_dev : sc.add_scale) : 0.f;
   float2 v[16];
@@ -816,14 +873,18 @@ __global__ __launch_bounds__(256) void fft1024_r2c_kernel(R2cSrc sc, int Tn, lon
   if (r == 1) o[513] = make_float2(0.f, 0.f);
 }
 // [rows][1028] one-sided spectra -> [rows][512] real frames: frames[n] = fac * win[n] * Re sum_{k <= 512} (cf ? cf(k) : 1) in[k] exp(+2 pi i k n / 1024)
-__global__ __launch_bounds__(256) void fft1024_c2r_kernel(const float* __restrict__ in, long long rows, const float* __restrict__ win,
-                                                          const float2* __restrict__ Wg, float* __restrict__ frames, float fac, int cf) {
+struct C2rJob { const float* in; float* frames; int rows; int blocks; };
+struct C2rJobs { C2rJob j[2]; };
+__global__ __launch_bounds__(256) void fft1024_c2r_kernel(C2rJobs jobs, const float* __restrict__ win, const float2* __restrict__ Wg, float fac, int cf) {
   __shared__ float2 W[1024];
   __shared__ float2 S[4][16 * FLD];
   for (int i = threadIdx.x; i < 1024; i += 256) W[i] = Wg[i];
   const int w = threadIdx.x >> 6, r = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + w;
-  const bool ok = row < rows;
+  const bool second = (int)blockIdx.x >= jobs.j[0].blocks;
+  const float* __restrict__ in = second ? jobs.j[1].in : jobs.j[0].in;
+  float* __restrict__ frames = second ? jobs.j[1].frames : jobs.j[0].frames;
+  const long long row = (long long)((int)blockIdx.x - (second ? jobs.j[0].blocks : 0)) * 4 + w;
+  const bool ok = row < (second ? jobs.j[1].rows : jobs.j[0].rows);
   const float2* f = reinterpret_cast<const float2*>(in + (ok ? row : 0) * LDSP);
   float2 v[16];
 #pragma unroll
@@ -1066,16 +1127,10 @@ struct BlindOp {
   float *H = nullptr, *Yc = nullptr, *Xdelta = nullptr;
   // work buffers
   float *sp = nullptr, *frames = nullptr, *X1 = nullptr, *X2 = nullptr, *X3 = nullptr, *Ybuf = nullptr, *sig1 = nullptr, *sig2 = nullptr;
-  // second scratch set + stream + events: inside the captured graph the RIR-regulariser chain of an iteration (14 nodes) runs as a parallel branch
-  // beside the reconstruction chain (12 nodes); both only read H and meet again at the accumulating tap-gradient
-  float *sp_b = nullptr, *frames_b = nullptr, *X2_b = nullptr, *X3_b = nullptr, *Ybuf_b = nullptr, *sig2_b = nullptr; double* partial_b = nullptr;
+  // second scratch set: the RIR-regulariser chain of an iteration shares every launch with the reconstruction chain (param_grads)
+  float *frames_b = nullptr, *X2_b = nullptr, *X3_b = nullptr, *Ybuf_b = nullptr; double* partial_b = nullptr;
   bool fused_loop = false;           // inside the captured optimisation loop: step counter in design_dm, no loss finalisation, one Adam launch
   bool big_lds = false;              // fir_sb_lds_kernel may take > 64 KB of dynamic LDS (set once at creation, outside any stream capture)
-  hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool fork_ok = false;
-  void swap_scratch() {
-    std::swap(sp, sp_b); std::swap(frames, frames_b); std::swap(X2, X2_b); std::swap(X3, X3_b); std::swap(Ybuf, Ybuf_b); std::swap(sig2, sig2_b);
-    std::swap(partial, partial_b);
-  }
   float *A = nullptr, *Apre = nullptr, *logdm = nullptr, *dmv = nullptr, *gdm = nullptr, *Fin = nullptr, *GFin = nullptr, *GH = nullptr;
   float *gphi = nullptr, *gdecay = nullptr, *gw = nullptr, *h0 = nullptr, *hm = nullptr, *ghm = nullptr, *gh0 = nullptr;
   float2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr, *Hf = nullptr;
@@ -1093,9 +1148,6 @@ struct BlindOp {
   ~BlindOp() {
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
-    if (side_stream) (void)hipStreamDestroy(side_stream);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
     for (void* q : allocs) (void)hipFree(q);
   }
 
@@ -1107,14 +1159,26 @@ struct BlindOp {
     launch_igemm(p, 1, false, tB, batch, st);
   }
   // the four STFT-type transforms: 1024-point FFT kernels (default) or DFT-as-GEMM on the matrix cores (BUDDY_OP_FFT=0)
-  void r2c(const R2cSrc& sc, int Tn, float* out, float fac, int cf) {
-    const long long rows = (long long)U * Tn;
-    if (sc.fr) hipLaunchKernelGGL(fft1024_r2c_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sc, Tn, rows, (const float*)win, (const float2*)w1024, out, fac, cf);
-    else hipLaunchKernelGGL(fft1024_r2c_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, sc, Tn, rows, (const float*)win, (const float2*)w1024, out, fac, cf);
+  // up to three (source, frame count, output) jobs in one launch; all jobs of a launch gather from frames, or none does
+  struct R2cReq { R2cSrc sc; int Tn; float* out; };
+  void r2c_multi(const R2cReq* rq, int n, float fac, int cf) {
+    R2cJobs jobs; std::memset(&jobs, 0, sizeof(jobs));
+    unsigned blocks = 0;
+    for (int i = 0; i < n; ++i) {
+      jobs.j[i].sc = rq[i].sc; jobs.j[i].Tn = rq[i].Tn; jobs.j[i].rows = U * rq[i].Tn; jobs.j[i].blocks = (U * rq[i].Tn + 3) / 4; jobs.j[i].out = rq[i].out;
+      blocks += (unsigned)jobs.j[i].blocks;
+    }
+    if (rq[0].sc.fr) hipLaunchKernelGGL(fft1024_r2c_kernel<true>, dim3(blocks), dim3(256), 0, st, jobs, (const float*)win, (const float2*)w1024, fac, cf);
+    else hipLaunchKernelGGL(fft1024_r2c_kernel<false>, dim3(blocks), dim3(256), 0, st, jobs, (const float*)win, (const float2*)w1024, fac, cf);
   }
-  void c2r(const float* in, long long rows, float* fr, float fac, int cf) {
-    hipLaunchKernelGGL(fft1024_c2r_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, in, rows, (const float*)win, (const float2*)w1024, fr, fac, cf);
+  void r2c(const R2cSrc& sc, int Tn, float* out, float fac, int cf) { const R2cReq rq{sc, Tn, out}; r2c_multi(&rq, 1, fac, cf); }
+  void c2r2(const float* in0, long long rows0, float* fr0, const float* in1, long long rows1, float* fr1, float fac, int cf) {
+    C2rJobs jobs; std::memset(&jobs, 0, sizeof(jobs));
+    jobs.j[0].in = in0; jobs.j[0].frames = fr0; jobs.j[0].rows = (int)rows0; jobs.j[0].blocks = (int)((rows0 + 3) / 4);
+    jobs.j[1].in = in1; jobs.j[1].frames = fr1; jobs.j[1].rows = (int)rows1; jobs.j[1].blocks = (int)((rows1 + 3) / 4);
+    hipLaunchKernelGGL(fft1024_c2r_kernel, dim3((unsigned)(jobs.j[0].blocks + jobs.j[1].blocks)), dim3(256), 0, st, jobs, (const float*)win, (const float2*)w1024, fac, cf);
   }
+  void c2r(const float* in, long long rows, float* fr, float fac, int cf) { c2r2(in, rows, fr, nullptr, 0, nullptr, fac, cf); }
   // X[u][t][:] = scale * STFT frames of s (frame t starts at sample 128 t - P), Tn frames
   void stft(const float* s, int Ls, int P, int Tn, float scale, float* X, const float* add = nullptr, float add_scale = 0.f, const float* add_scale_dev = nullptr) {
     if (use_fft) { r2c(R2cSrc{s, nullptr, Ls, P, 0, 0, nullptr, nullptr, add, add_scale, add_scale_dev}, Tn, X, scale, 0); return; }
@@ -1158,12 +1222,11 @@ struct BlindOp {
     c2r(GX, (long long)U * Tx, frames, sx, 0);
     r2c(R2cSrc{nullptr, frames, Ls, Q, Tx, P, ones, inv_env, nullptr, 0.f, nullptr}, Tn, GY, si / NFFT, 1);
   }
-  // first stage (form I) of a transform of the REAL signal xr[u][0..Lr_) zero-padded to N2 (zero0: sample 0 forced to zero) -> c2
-  void fft_first(const float* xr, int Lr_, bool zero0, int sign) {
-    const S1In in{nullptr, xr, Lr_};
+  // first stage (form I) of a transform of a REAL signal of Lr_ samples zero-padded to N2 (zero0: sample 0 forced to zero) -> c2
+  void fft_first(const S1In& in, bool zero0, int sign) {
     const dim3 g1(F2 / S1_COLS, U);
-    if (zero0) hipLaunchKernelGGL(fft_stage1_kernel<3>, g1, dim3(256), 0, st, in, c2, (const float2*)w101, (const float2*)twN, sign);
-    else hipLaunchKernelGGL(fft_stage1_kernel<2>, g1, dim3(256), 0, st, in, c2, (const float2*)w101, (const float2*)twN, sign);
+    if (zero0) hipLaunchKernelGGL(fft_stage1_kernel<true>, g1, dim3(256), 0, st, in, c2, (const float2*)w101, (const float2*)twN, sign);
+    else hipLaunchKernelGGL(fft_stage1_kernel<false>, g1, dim3(256), 0, st, in, c2, (const float2*)w101, (const float2*)twN, sign);
   }
   template <int SGN, int PW> void fft_mid256(float scale) {           // c2 -> c1
     const MpArrays a{Hf, Mabs, phim, gM};
@@ -1185,10 +1248,10 @@ struct BlindOp {
     design_dm();
     hipLaunchKernelGGL(design_A_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)logdm, tabs(), A, Apre, U, K, Nf);
   }
-  // minimum_phase_version (reference reverb_utils.py:9-23) of hin (U, Lin <= Lm samples, zero-padded to N2): out[u][0..Lo) = its real part
+  // minimum_phase_version (reference reverb_utils.py:9-23) of hin (U, <= Lm samples, zero-padded to N2): out[u][0..Lo) = its real part
   // (sample 0 := first when first_set).  Leaves Hf = FFT([hin, 0]), Mabs = |Hf| and phim for the backward pass.
-  void minphase_core(const float* hin, int Lin, float* out, int Lo, bool first_set = false, float first = 0.f) {
-    fft_first(hin, Lin, false, -1);                  // FFT([hin, zeros]) ...
+  void minphase_core(const S1In& hin, float* out, int Lo, bool first_set = false, float first = 0.f) {
+    fft_first(hin, false, -1);                       // FFT([hin, zeros]) ...
     fft_mid256<-1, 0>(1.f);                          // ... | log |.| | FFT ...
     fft_mid101();                                    // ... | Hilbert window | IFFT ...
     fft_mid256<1, 1>(1.f / N2);                      // ... | M exp(-j Im .) | IFFT ...
@@ -1197,14 +1260,25 @@ struct BlindOp {
   // A = design(logdm) and H = cons(A * exp(j phi))   (reference :333-351); needs design_dm() first
   void cons_forward() {
     hipLaunchKernelGGL(design_A_h0_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)logdm, tabs(), (const float*)phi, A, Apre, Fin, U, K, Nf);
-    istft(Fin, Nf + 2, WIN, env_c, Lh, 1.f, h0);
-    minphase_core(h0, Lh, hm, Lm, true, (float)(WIN / (HOP * 2.0)));
+    // h0 = istft(Fin) is never materialised: the first transform of the projection gathers it from the synthesis frames
+    if (use_fft) {
+      c2r(Fin, (long long)U * (Nf + 2), frames, 1.f / NFFT, 1);
+      minphase_core(S1In{nullptr, Lh, frames, Nf + 2, WIN, env_c}, hm, Lm, true, (float)(WIN / (HOP * 2.0)));
+    } else {
+      istft(Fin, Nf + 2, WIN, env_c, Lh, 1.f, h0);
+      minphase_core(S1In{h0, Lh, nullptr, 0, 0, nullptr}, hm, Lm, true, (float)(WIN / (HOP * 2.0)));
+    }
     stft(hm, Lm, WIN - HOP, Nf, 1.f, H);          // frames 1..Nf of the centred STFT: frame k starts at 128 (k+1) - 512
   }
   // G_Fin from G_H
   void cons_backward(const float* GHin) {
-    stft_adj(GHin, Lm, WIN - HOP, Nf, 1.f, ghm);
-    fft_first(ghm, Lm, true, -1);                    // GZ = FFT([0, ghm[1:], zeros]) / N2 ...
+    if (use_fft) {                                   // ghm = stft_adj(G_H), gathered from the frames by the first transform
+      c2r(GHin, (long long)U * Nf, frames, 1.f, 0);
+      fft_first(S1In{nullptr, Lm, frames, Nf, WIN - HOP, ones}, true, -1);      // GZ = FFT([0, ghm[1:], zeros]) / N2 ...
+    } else {
+      stft_adj(GHin, Lm, WIN - HOP, Nf, 1.f, ghm);
+      fft_first(S1In{ghm, Lm, nullptr, 0, 0, nullptr}, true, -1);
+    }
     fft_mid256<-1, 2>(1.f / N2);                     // ... | gM, g_phi | FFT ...
     fft_mid101();                                    // ... | Hilbert window | IFFT ...
     fft_mid256<1, 3>(1.f / N2);                      // ... | G_H | N2 * IFFT
@@ -1212,28 +1286,52 @@ struct BlindOp {
     istft_adj(gh0, Nf + 2, WIN, env_c, Lh, 1.f, GFin);
   }
   void update_H() { design_dm(); cons_forward(); }
-  void fir(const float* X, long long xs, int Tn, float* Y) {
+  bool fir_lds_ok() const {
     static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
+    return lds && big_lds && (size_t)(FL_TB + 2 * Nf - 1) * FL_BINS * sizeof(float2) <= 96 * 1024 && Nf <= 128;
+  }
+  // Y0 = FIR(X0, H) and, when X1b is given, Y1 = FIR(X1b, H) in the same launch (LDS kernel only)
+  void fir2(const float* X0, long long xs0, int T0, float* Y0, const float* X1b, long long xs1, int T1, float* Y1) {
+    FirSegs sg; std::memset(&sg, 0, sizeof(sg));
+    sg.s[0] = FirSeg{X0, xs0, Y0, T0, (T0 + FL_TB - 1) / FL_TB};
+    if (X1b) sg.s[1] = FirSeg{X1b, xs1, Y1, T1, (T1 + FL_TB - 1) / FL_TB};
     const size_t sm = (size_t)(FL_TB + 2 * Nf - 1) * FL_BINS * sizeof(float2);
-    if (lds && big_lds && sm <= 96 * 1024 && Nf <= 128)
-      hipLaunchKernelGGL(fir_sb_lds_kernel, dim3((Tn + FL_TB - 1) / FL_TB, (FB + FL_BINS - 1) / FL_BINS, U), dim3(256), sm, st, X, xs, (const float*)H, Y, Tn, Nf);
-    else
-      hipLaunchKernelGGL(fir_kernel_sb, dim3(gridf((long long)U * ((Tn + FT - 1) / FT) * FB)), dim3(256), 0, st, X, xs, (const float*)H, Y, U, Tn, Nf);
+    hipLaunchKernelGGL(fir_sb_lds_kernel, dim3(sg.s[0].tiles + sg.s[1].tiles, (FB + FL_BINS - 1) / FL_BINS, U), dim3(256), sm, st, sg, (const float*)H, Nf);
+  }
+  void fir(const float* X, long long xs, int Tn, float* Y) {
+    if (fir_lds_ok()) fir2(X, xs, Tn, Y, nullptr, 0, 0, nullptr);
+    else hipLaunchKernelGGL(fir_kernel_sb, dim3(gridf((long long)U * ((Tn + FT - 1) / FT) * FB)), dim3(256), 0, st, X, xs, (const float*)H, Y, U, Tn, Nf);
+  }
+  // GH (+)= gradient of the taps from (X0, GY0) [+ (X1b, GY1)]
+  void gradh2(const float* X0, long long xs0, const float* GY0, int T0, const float* X1b, long long xs1, const float* GY1, int T1, int accumulate) {
+    GradSegs sg; std::memset(&sg, 0, sizeof(sg));
+    sg.s[0] = GradSeg{X0, xs0, GY0, T0}; sg.n = 1;
+    if (X1b) { sg.s[1] = GradSeg{X1b, xs1, GY1, T1}; sg.n = 2; }
+    hipLaunchKernelGGL(fir_gradh_lds_kernel, dim3((Nf + GL_TAPS - 1) / GL_TAPS, (FB + FL_BINS - 1) / FL_BINS, U), dim3(256), 0, st, sg, GH, Nf, accumulate);
   }
   void gradh(const float* X, long long xs, const float* GY, int Tn, int accumulate) {
     static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
-    if (lds)
-      hipLaunchKernelGGL(fir_gradh_lds_kernel, dim3((Nf + GL_TAPS - 1) / GL_TAPS, (FB + FL_BINS - 1) / FL_BINS, U), dim3(256), 0, st, X, xs, GY, GH, Tn, Nf, accumulate);
+    if (lds) gradh2(X, xs, GY, Tn, nullptr, 0, nullptr, 0, accumulate);
     else
       hipLaunchKernelGGL(fir_gradh_kernel, dim3(U * ((Nf + FT - 1) / FT) * ((FB + GH_F - 1) / GH_F)), dim3(256), 0, st, X, xs, GY, GH, U, Tn, Nf, accumulate);
   }
-  // loss_u (+)= kappa * sum |Rc - comp(Xh)|^2, G optional
+  // loss_u (+)= kappa * sum |Rc - comp(Xh)|^2, G optional; a second term (Rc1 == nullptr: target = compress(G1 on entry)) may share the launch
+  static constexpr int LOSS_BLK = 64, LOSS_BLK_B = 32;
+  void comp_loss2(const float* Rc0, const float* Xh0, float* G0, int T0, float w0, float* out0, const float* Rc1, const float* Xh1, float* G1, int T1, float w1,
+                  float* out1, bool two) {
+    LossJobs jobs; std::memset(&jobs, 0, sizeof(jobs));
+    const float k0 = w0 / (float)T0, k1 = two ? w1 / (float)T1 : 0.f;
+    jobs.j[0] = LossJob{Rc0, Xh0, G0, partial, T0, k0, LOSS_BLK};
+    if (two) jobs.j[1] = LossJob{Rc1, Xh1, G1, partial_b, T1, k1, LOSS_BLK_B};
+    hipLaunchKernelGGL(comp_loss_kernel, dim3(LOSS_BLK + (two ? LOSS_BLK_B : 0), U), dim3(256), 0, st, jobs, c.comp);
+    if (!fused_loop) {       // the loop only needs the gradient; the loss VALUES are read through buddy_blindop_param_grads / rec_loss_grad
+      hipLaunchKernelGGL(loss_finalize_kernel, dim3(U), dim3(32), 0, st, (const double*)partial, LOSS_BLK, k0, out0, 0);
+      if (two) hipLaunchKernelGGL(loss_finalize_kernel, dim3(U), dim3(32), 0, st, (const double*)partial_b, LOSS_BLK_B, k1, out1, 0);
+    }
+  }
   void comp_loss(const float* Rcx, const float* Xh, float* G, int Tn, float weight, float* out, int accumulate) {
-    const float kappa = weight / (float)Tn;
-    const int nblk = 64;
-    hipLaunchKernelGGL(comp_loss_kernel, dim3(nblk, U), dim3(256), 0, st, Rcx, Xh, G, partial, Tn, kappa, c.comp);
-    if (!fused_loop)        // the loop only needs the gradient; the loss VALUES are read through buddy_blindop_param_grads / rec_loss_grad
-      hipLaunchKernelGGL(loss_finalize_kernel, dim3(U), dim3(32), 0, st, (const double*)partial, nblk, kappa, out, accumulate);
+    (void)accumulate;
+    comp_loss2(Rcx, Xh, G, Tn, weight, out, nullptr, nullptr, nullptr, 0, 0.f, nullptr, false);
   }
   // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach()), gradient w.r.t. the subband filter's output left in X2
   void reg_chain(const float* noise, float t_op, const float* t_op_dev, float w_reg) {
@@ -1351,8 +1449,8 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
   o->big_lds = hipFuncSetAttribute((const void*)fir_sb_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
   {
     const size_t specD = (size_t)U_ * Td * LDSP + 8;
-    DA(sp_b, (size_t)U_ * ((size_t)(Td + 4) * HOP + NFFT)); DA(frames_b, (size_t)U_ * (Td + 2) * WIN);
-    DA(X2_b, specD); DA(X3_b, specD); DA(Ybuf_b, specD); DA(sig2_b, (size_t)U_ * (o->Lr + 8)); DA(partial_b, (size_t)U_ * 64);
+    DA(frames_b, (size_t)U_ * (Td + 2) * WIN);
+    DA(X2_b, specD); DA(X3_b, specD); DA(Ybuf_b, specD); DA(partial_b, (size_t)U_ * 64);
   }
   DA(rir, (size_t)U_ * o->Lr); DA(Rc, (size_t)U_ * Td * LDSP + 8);
   DA(dpm, (size_t)Nf * FB);
@@ -1458,7 +1556,7 @@ int blindop_apply_stft(BlindOp* o, const float* x, float* X_ref, hipStream_t st)
 // minimum_phase_version (reverb_utils.py:9-23) of h (U, 128 * (Nf + 1)) -- the size cons() uses; no direct-path override
 int blindop_minphase(BlindOp* o, const float* h, float* out, hipStream_t st) {
   o->st = st;
-  o->minphase_core(h, o->Lm, out, o->Lm);
+  o->minphase_core(S1In{h, o->Lm, nullptr, 0, 0, nullptr}, out, o->Lm);
   HIPCHK(hipGetLastError());
   return BUDDY_OK;
 }
@@ -1526,33 +1624,42 @@ int blindop_fir_loss_grad(BlindOp* o, const float* x_den, const float* rir, long
 static int param_grads(BlindOp* o, const float* x_den, const float* noise, float t_op, float w_rec, float w_reg, bool have_Xd, const float* t_op_dev = nullptr) {
   const int U = o->U, T = o->T, Td = o->Td, L = o->L, Nf = o->Nf;
   hipStream_t st = o->st;
+  const float norm = o->norm;
   o->update_H();
-  if (noise && t_op_dev != nullptr && o->side_stream != nullptr && o->fork_ok) {
-    // fork: the regulariser chain only needs H (and this iteration's noise): run it on the side stream with its own scratch set
-    (void)hipEventRecord(o->ev_fork, st);
-    (void)hipStreamWaitEvent(o->side_stream, o->ev_fork, 0);
-    o->swap_scratch(); o->st = o->side_stream;
-    o->reg_chain(noise, t_op, t_op_dev, w_reg);
-    (void)hipEventRecord(o->ev_join, o->side_stream);
-    o->swap_scratch(); o->st = st;
-  }
-  if (!have_Xd) o->stft(x_den, L, WIN, T, 1.f / o->norm, o->X1);          // X1 = STFT(x_den) stays valid across the iterations
-  // reconstruction term
-  o->fir(o->X1, (long long)T * LDSP, T, o->Ybuf);
-  o->istft_stft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, o->norm, WIN, T, 1.f / o->norm, o->X2, nullptr, 0.f, nullptr, o->sig1);
-  o->comp_loss(o->Yc, o->X2, o->X3, T, w_rec, o->losses, 0);
-  o->stft_adj_istft_adj(o->X3, L, WIN, T, 1.f / o->norm, T, WIN + WIN / 2, o->env_T, o->norm, o->X2, o->sig2);
-  o->gradh(o->X1, (long long)T * LDSP, o->X2, T, 0);
-  // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach())
-  if (noise) {
-    const bool fork = t_op_dev != nullptr && o->side_stream != nullptr && o->fork_ok;     // captured-graph mode: a parallel branch
-    auto chain = [&]() { o->reg_chain(noise, t_op, t_op_dev, w_reg); };
-    if (fork) {
-      // the branch was forked right after update_H (below); it used the second scratch set and left its gradient in X2_b
-      (void)hipStreamWaitEvent(st, o->ev_join, 0);
-      o->gradh(o->Xdelta, 0LL, o->X2_b, Td, 1);
-    } else {
-      chain();
+  if (!have_Xd) o->stft(x_den, L, WIN, T, 1.f / norm, o->X1);          // X1 = STFT(x_den) stays valid across the iterations
+  if (noise && o->use_fft && o->fir_lds_ok()) {
+    // The reconstruction term and the RIR-noise regulariser (reference :94-100: loss(rir, (rir + t n).detach())) are the same chain
+    //   FIR by H -> iSTFT -> STFT -> compressed-spectrum loss -> adjoints -> tap gradient
+    // on two inputs (STFT(x_den), T frames; STFT(delta), Td frames): every kernel of the chain takes both as two jobs of ONE launch (7 launches
+    // instead of 16 -- a launch of the captured loop costs ~5 us before it does anything).  The regulariser's scratch is the *_b set.
+    const int Q = WIN + WIN / 2;
+    o->fir2(o->X1, (long long)T * LDSP, T, o->Ybuf, o->Xdelta, 0LL, Td, o->Ybuf_b);
+    o->c2r2(o->Ybuf, (long long)U * T, o->frames, o->Ybuf_b, (long long)U * Td, o->frames_b, norm / NFFT, 1);
+    {   // STFT(istft(.)) of both, and STFT(rir + t n) from the regulariser's frames (the overlap-add happens in the load)
+      const BlindOp::R2cReq rq[3] = {
+          {R2cSrc{nullptr, o->frames, L, WIN, T, Q, o->env_T, nullptr, nullptr, 0.f, nullptr}, T, o->X2},
+          {R2cSrc{nullptr, o->frames_b, o->Lr, WIN, Td, Q, o->env_d, nullptr, nullptr, 0.f, nullptr}, Td, o->X2_b},
+          {R2cSrc{nullptr, o->frames_b, o->Lr, WIN, Td, Q, o->env_d, nullptr, noise, t_op, t_op_dev}, Td, o->X3_b}};
+      o->r2c_multi(rq, 3, 1.f / norm, 0);
+    }
+    o->comp_loss2(o->Yc, o->X2, o->X3, T, w_rec, o->losses, nullptr, o->X2_b, o->X3_b, Td, w_reg, o->losses + U, true);
+    o->c2r2(o->X3, (long long)U * T, o->frames, o->X3_b, (long long)U * Td, o->frames_b, 1.f / norm, 0);
+    {   // istft_adj(stft_adj(.)) of both
+      const BlindOp::R2cReq rq[2] = {
+          {R2cSrc{nullptr, o->frames, L, Q, T, WIN, o->ones, o->env_T, nullptr, 0.f, nullptr}, T, o->X2},
+          {R2cSrc{nullptr, o->frames_b, o->Lr, Q, Td, WIN, o->ones, o->env_d, nullptr, 0.f, nullptr}, Td, o->X2_b}};
+      o->r2c_multi(rq, 2, norm / NFFT, 1);
+    }
+    o->gradh2(o->X1, (long long)T * LDSP, o->X2, T, o->Xdelta, 0LL, o->X2_b, Td, 0);
+  } else {
+    // reconstruction term
+    o->fir(o->X1, (long long)T * LDSP, T, o->Ybuf);
+    o->istft_stft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, norm, WIN, T, 1.f / norm, o->X2, nullptr, 0.f, nullptr, o->sig1);
+    o->comp_loss(o->Yc, o->X2, o->X3, T, w_rec, o->losses, 0);
+    o->stft_adj_istft_adj(o->X3, L, WIN, T, 1.f / norm, T, WIN + WIN / 2, o->env_T, norm, o->X2, o->sig2);
+    o->gradh(o->X1, (long long)T * LDSP, o->X2, T, 0);
+    if (noise) {
+      o->reg_chain(noise, t_op, t_op_dev, w_reg);
       o->gradh(o->Xdelta, 0LL, o->X2, Td, 1);
     }
   }
@@ -1638,14 +1745,6 @@ int blindop_optimize(BlindOp* o, const float* x_den, const float* noise, float t
   if (!o->gexec || o->g_iters != n_iters || std::memcmp(hp, o->g_hp, sizeof(hp)) != 0) {
     if (o->gexec) { (void)hipGraphExecDestroy(o->gexec); o->gexec = nullptr; }
     if (!o->cap_stream) HIPCHK(hipStreamCreateWithFlags(&o->cap_stream, hipStreamNonBlocking));
-    // OFF by default: a captured graph with a parallel branch gains 0.2 ms per call on its own, but its replay no longer overlaps with the other
-    // sub-batch's stream (two concurrent sub-batches: 77.4 ms/step with the branch, 71.1 without -- profiles/README.md r03b)
-    static const bool want_fork = getenv("BUDDY_OP_FORK") && atoi(getenv("BUDDY_OP_FORK")) == 1;
-    if (want_fork && !o->side_stream) {
-      HIPCHK(hipStreamCreateWithFlags(&o->side_stream, hipStreamNonBlocking));
-      HIPCHK(hipEventCreateWithFlags(&o->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&o->ev_join, hipEventDisableTiming));
-    }
-    o->fork_ok = want_fork;
     const bool prof = igemm_prof_enabled();
     igemm_prof_enable(0);                                // no event records inside the captured region
     const int step0 = o->adam_step;
@@ -1655,7 +1754,7 @@ int blindop_optimize(BlindOp* o, const float* x_den, const float* noise, float t
       optimize_iteration(o, o->xden_buf, noise ? o->noise_buf + (long long)it * U * o->Lr : nullptr, t_op, w_rec, w_reg, lr, b1, b2, wd, it > 0, true);
     hipGraph_t graph = nullptr;
     const hipError_t ce = hipStreamEndCapture(o->cap_stream, &graph);
-    o->st = st; o->adam_step = step0; o->fork_ok = false;
+    o->st = st; o->adam_step = step0;
     igemm_prof_enable(prof ? 1 : 0);
     if (ce != hipSuccess || !graph) { set_error(std::string("optimize_op graph capture failed: ") + hipGetErrorString(ce)); return BUDDY_ERR_HIP; }
     const hipError_t ie = hipGraphInstantiate(&o->gexec, graph, nullptr, nullptr, 0);
