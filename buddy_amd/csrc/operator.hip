@@ -393,10 +393,9 @@ __global__ void loss_finalize_kernel(const double* partial, int nblk, float kapp
 // ---- filter design (reference :212-251) ----
 struct DesignTabs { const int* idx; const float* frac; const float* corr; const float* dpm; const int* fge; };   // per-bin knot index / fraction; OLA corr[Nf]; dpm[Nf][FB]
 // dm[u][n][j], j = 0..K-1 knots (rows 0 and K-1 are zero): sum_e w[e][j-1] * exp(decay[e][j-1])^(-n)
-__global__ void design_dm_kernel(const float* decay, const float* wts, float* logdm, float* dmv, int U, int E, int NB, int Nf, int* step_inc) {
+__global__ void design_dm_kernel(const float* decay, const float* wts, float* logdm, float* dmv, int U, int E, int NB, int Nf) {
   const int K = NB + 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (step_inc && i == 0) *step_inc += 1;                  // captured loop: the Adam step counter advances with the first kernel of an iteration
   if (i >= U * Nf * K) return;
   const int j = i % K, n = (i / K) % Nf, u = i / (K * Nf);
   float v = 0.f;
@@ -417,22 +416,35 @@ __global__ __launch_bounds__(256) void design_A_kernel(const float* logdm, Desig
     A[i] = (e + 1e-6f) / tb.corr[n] + tb.dpm[(long long)n * FB + f];
   }
 }
-// design_A_kernel plus the H0 frames Fin[u][k+1][f] = A[u][k][f] * exp(j phi[u][k][f]) (rows 0 and Nf+1 stay zero) in one pass: same index space,
-// one node less in the captured loop
-__global__ __launch_bounds__(256) void design_A_h0_kernel(const float* logdm, DesignTabs tb, const float* phi, float* A, float* Apre, float* Fin, int U, int K,
-                                                          int Nf) {
-  const long long total = (long long)U * Nf * FB;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int f = (int)(i % FB), n = (int)((i / FB) % Nf), u = (int)(i / ((long long)FB * Nf));
-    const float* l = logdm + ((long long)u * Nf + n) * K;
+// design_dm_kernel, design_A_kernel and the H0 frames Fin[u][k+1][f] = A[u][k][f] * exp(j phi[u][k][f]) (rows 0 and Nf+1 stay zero) in one pass:
+// a block owns one (utterance, frame) row -- its K knot values first (LDS), then the 513 bins.  Two nodes less in the captured loop.
+__global__ __launch_bounds__(256) void design_row_kernel(const float* decay, const float* wts, DesignTabs tb, const float* phi, float* logdm, float* dmv, float* A,
+                                                         float* Apre, float* Fin, int U, int E, int NB, int Nf, int* step_inc) {
+  __shared__ float l[64];
+  const int K = NB + 2;
+  const int n = blockIdx.x % Nf, u = blockIdx.x / Nf;
+  if (step_inc && blockIdx.x == 0 && threadIdx.x == 0) *step_inc += 1;     // captured loop: the Adam step counter advances with the first kernel of an iteration
+  for (int j = threadIdx.x; j < K; j += 256) {
+    float v = 0.f;
+    if (j >= 1 && j <= NB)
+      for (int e = 0; e < E; ++e) v += wts[((long long)u * E + e) * NB + j - 1] * powf(expf(decay[((long long)u * E + e) * NB + j - 1]), -(float)n);
+    const float lg = logf(v + 1e-6f);
+    const long long o = ((long long)u * Nf + n) * K + j;
+    dmv[o] = v; logdm[o] = lg; l[j] = lg;
+  }
+  __syncthreads();
+  const long long row = ((long long)u * Nf + n) * FB;
+  const float cn = tb.corr[n];
+  float2* F = reinterpret_cast<float2*>(Fin + ((long long)u * (Nf + 2) + n + 1) * LDSP);
+  for (int f = threadIdx.x; f < FB; f += 256) {
     const int j = tb.idx[f];
     const float v0 = l[j], v1 = l[j + 1];
     const float e = expf(v0 + tb.frac[f] * (v1 - v0));
-    const float a = (e + 1e-6f) / tb.corr[n] + tb.dpm[(long long)n * FB + f];
-    Apre[i] = e;
-    A[i] = a;
-    float sn, cs; sincosf(phi[i], &sn, &cs);
-    reinterpret_cast<float2*>(Fin + ((long long)u * (Nf + 2) + n + 1) * LDSP)[f] = make_float2(a * cs, a * sn);
+    const float a = (e + 1e-6f) / cn + tb.dpm[(long long)n * FB + f];
+    Apre[row + f] = e;
+    A[row + f] = a;
+    float sn, cs; sincosf(phi[row + f], &sn, &cs);
+    F[f] = make_float2(a * cs, a * sn);
   }
 }
 // backward of the H0 frames and of the knot interpolation in one pass
@@ -1010,8 +1022,8 @@ __global__ void project_kernel(float* decay, float* wts, int U, int E, int NB, f
   }
 }
 // One launch for the whole parameter update of an iteration of the captured loop (was step_inc + 3 x adam + project = 5 nodes): blocks
-// [0, pb) take the phases, the rest one (utterance, band) pair per thread -- Adam on its E decays and E weights, then the projection of exactly
-// those values (project_params reads nothing else).  Same per-element arithmetic as adam_kernel / project_kernel.  The step counter is advanced
+// [0, pb) take the phases, the rest one (utterance, band) pair per wave -- the gradients of its E decays and E weights (was design_bwd_params_kernel),
+// Adam on them, then the projection of exactly those values (project_params reads nothing else).  Same per-element arithmetic as adam_kernel / project_kernel.  The step counter is advanced
 // by the FIRST kernel of the iteration (design_dm_kernel), so every block here reads the same value.
 __device__ __forceinline__ float adam_one(float p, float gi, float* m, float* v, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
   if (wd != 0.f) gi += wd * p;
@@ -1021,9 +1033,9 @@ __device__ __forceinline__ float adam_one(float p, float gi, float* m, float* v,
   const float denom = sqrtf(vi) / bc2_sqrt + eps;
   return p - (lr / bc1) * (mi / denom);
 }
-struct AdamAll { float *decay, *wts, *phi; const float *gdecay, *gw, *gphi; float *m_d, *v_d, *m_w, *v_w, *m_p, *v_p; };
-__global__ __launch_bounds__(256) void adam_all_kernel(AdamAll a, long long np, int pb, int U, int E, int NB, float lr, float b1, float b2, float eps, float wd,
-                                                       const int* step_dev, const float2* bc_tab, float dmin, float dmax, float wlo, float whi,
+struct AdamAll { float *decay, *wts, *phi; const float* gphi; float *m_d, *v_d, *m_w, *v_w, *m_p, *v_p; };
+__global__ __launch_bounds__(256) void adam_all_kernel(AdamAll a, const float* gdm, int Nf, long long np, int pb, int U, int E, int NB, float lr, float b1, float b2,
+                                                       float eps, float wd, const int* step_dev, const float2* bc_tab, float dmin, float dmax, float wlo, float whi,
                                                        int clamp_decay, int long2nd) {
   const float2 bc = bc_tab[*step_dev];
   if ((int)blockIdx.x < pb) {
@@ -1031,14 +1043,29 @@ __global__ __launch_bounds__(256) void adam_all_kernel(AdamAll a, long long np, 
       a.phi[i] = adam_one(a.phi[i], a.gphi[i], a.m_p + i, a.v_p + i, lr, b1, b2, eps, wd, bc.x, bc.y);
     return;
   }
-  const int i = ((int)blockIdx.x - pb) * 256 + threadIdx.x;
+  // one WAVE per (utterance, band): for each of its E exponentials the gradient of (decay, weight) from g_dm exactly as design_bwd_params_kernel
+  // forms it (lanes over the frames, fixed-order butterfly -- every lane ends with the sums), then Adam and the projection
+  const int i = ((int)blockIdx.x - pb) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= U * NB) return;
   const int b = i % NB, u = i / NB;
+  const int K = NB + 2;
   float d0 = 0.f, w0 = 0.f;
   for (int e = 0; e < E; ++e) {
     const long long q = ((long long)u * E + e) * NB + b;
-    float d = adam_one(a.decay[q], a.gdecay[q], a.m_d + q, a.v_d + q, lr, b1, b2, eps, wd, bc.x, bc.y);
-    float w = adam_one(a.wts[q], a.gw[q], a.m_w + q, a.v_w + q, lr, b1, b2, eps, wd, bc.x, bc.y);
+    const float dq = a.decay[q], wq = a.wts[q];
+    const float base = expf(dq);
+    float gd = 0.f, gwv = 0.f;
+    for (int n = lane; n < Nf; n += 64) {
+      const float pw = powf(base, -(float)n);
+      const float g = gdm[((long long)u * Nf + n) * K + b + 1];
+      gwv += g * pw;
+      gd += g * wq * (-(float)n) * pw;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { gd += __shfl_xor(gd, off, 64); gwv += __shfl_xor(gwv, off, 64); }
+    float md = a.m_d[q], vd = a.v_d[q], mw = a.m_w[q], vw = a.v_w[q];
+    float d = adam_one(dq, gd, &md, &vd, lr, b1, b2, eps, wd, bc.x, bc.y);
+    float w = adam_one(wq, gwv, &mw, &vw, lr, b1, b2, eps, wd, bc.x, bc.y);
     if (clamp_decay) {
       float hi = dmax;
       if (e > 0 && long2nd) hi = fminf(d0 / 1.01f, dmax);
@@ -1047,7 +1074,7 @@ __global__ __launch_bounds__(256) void adam_all_kernel(AdamAll a, long long np, 
     }
     if (e == 0) { w = fminf(fmaxf(w, wlo), whi); w0 = w; }
     else w = fminf(fmaxf(w, wlo), w0);
-    a.decay[q] = d; a.wts[q] = w;
+    if (lane == 0) { a.decay[q] = d; a.wts[q] = w; a.m_d[q] = md; a.v_d[q] = vd; a.m_w[q] = mw; a.v_w[q] = vw; }
   }
 }
 // reference layout (U, F, Nf) <-> frame-major (U, Nf, F)
@@ -1240,12 +1267,8 @@ struct BlindOp {
   }
   DesignTabs tabs() const { DesignTabs t; t.idx = idx; t.frac = frac; t.corr = corr; t.dpm = dpm; t.fge = fge; return t; }
 
-  void design_dm() {
-    hipLaunchKernelGGL(design_dm_kernel, dim3(cdiv(U * Nf * K, 256)), dim3(256), 0, st, (const float*)decay, (const float*)wts, logdm, dmv, U, E, NB, Nf,
-                       fused_loop ? d_step : (int*)nullptr);
-  }
   void design() {              // the filter magnitudes alone (buddy_blindop_design_filter)
-    design_dm();
+    hipLaunchKernelGGL(design_dm_kernel, dim3(cdiv(U * Nf * K, 256)), dim3(256), 0, st, (const float*)decay, (const float*)wts, logdm, dmv, U, E, NB, Nf);
     hipLaunchKernelGGL(design_A_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)logdm, tabs(), A, Apre, U, K, Nf);
   }
   // minimum_phase_version (reference reverb_utils.py:9-23) of hin (U, <= Lm samples, zero-padded to N2): out[u][0..Lo) = its real part
@@ -1257,9 +1280,10 @@ struct BlindOp {
     fft_mid256<1, 1>(1.f / N2);                      // ... | M exp(-j Im .) | IFFT ...
     fft_last_real(out, Lo, +1, 1.f / N2, first_set, first);
   }
-  // A = design(logdm) and H = cons(A * exp(j phi))   (reference :333-351); needs design_dm() first
+  // A = design(decay, weights) and H = cons(A * exp(j phi))   (reference :212-251, :333-351)
   void cons_forward() {
-    hipLaunchKernelGGL(design_A_h0_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)logdm, tabs(), (const float*)phi, A, Apre, Fin, U, K, Nf);
+    hipLaunchKernelGGL(design_row_kernel, dim3(U * Nf), dim3(256), 0, st, (const float*)decay, (const float*)wts, tabs(), (const float*)phi, logdm, dmv, A, Apre, Fin, U, E, NB,
+                       Nf, fused_loop ? d_step : (int*)nullptr);
     // h0 = istft(Fin) is never materialised: the first transform of the projection gathers it from the synthesis frames
     if (use_fft) {
       c2r(Fin, (long long)U * (Nf + 2), frames, 1.f / NFFT, 1);
@@ -1285,7 +1309,7 @@ struct BlindOp {
     fft_last_real(gh0, Lh, +1, 1.f, false, 0.f);     // g_h0 = Re(N2 * IFFT(GH))[:Lh]
     istft_adj(gh0, Nf + 2, WIN, env_c, Lh, 1.f, GFin);
   }
-  void update_H() { design_dm(); cons_forward(); }
+  void update_H() { cons_forward(); }
   bool fir_lds_ok() const {
     static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
     return lds && big_lds && (size_t)(FL_TB + 2 * Nf - 1) * FL_BINS * sizeof(float2) <= 96 * 1024 && Nf <= 128;
@@ -1666,7 +1690,8 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
   o->cons_backward(o->GH);
   hipLaunchKernelGGL(h0_bwd_knots_kernel, dim3(U * Nf), dim3(256), 0, st, (const float*)o->GFin, (const float*)o->A, (const float*)o->Apre, (const float*)o->phi, o->tabs(),
                      (const float*)o->dmv, o->gphi, o->gdm, U, o->K, Nf);
-  hipLaunchKernelGGL(design_bwd_params_kernel, dim3(cdiv(U * o->E * o->NB, 4)), dim3(256), 0, st, (const float*)o->gdm, (const float*)o->decay, (const float*)o->wts, o->gdecay, o->gw, U, o->E, o->NB, Nf);
+  if (!o->fused_loop)      // the captured loop forms these two inside its Adam kernel
+    hipLaunchKernelGGL(design_bwd_params_kernel, dim3(cdiv(U * o->E * o->NB, 4)), dim3(256), 0, st, (const float*)o->gdm, (const float*)o->decay, (const float*)o->wts, o->gdecay, o->gw, U, o->E, o->NB, Nf);
   return BUDDY_OK;
 }
 
@@ -1694,9 +1719,9 @@ static void optimize_iteration(BlindOp* o, const float* x_den, const float* nois
   o->fused_loop = false;
   o->adam_step += 1;
   if (dev) {
-    const AdamAll a{o->decay, o->wts, o->phi, o->gdecay, o->gw, o->gphi, o->m_d, o->v_d, o->m_w, o->v_w, o->m_p, o->v_p};
-    const int pb = (int)std::min<long long>((np + 255) / 256, 2048), db = cdiv(U * o->NB, 256);
-    hipLaunchKernelGGL(adam_all_kernel, dim3(pb + db), dim3(256), 0, st, a, np, pb, U, o->E, o->NB, lr, b1, b2, 1e-8f, wd, (const int*)o->d_step,
+    const AdamAll a{o->decay, o->wts, o->phi, o->gphi, o->m_d, o->v_d, o->m_w, o->v_w, o->m_p, o->v_p};
+    const int pb = (int)std::min<long long>((np + 255) / 256, 2048), db = cdiv(U * o->NB, 4);
+    hipLaunchKernelGGL(adam_all_kernel, dim3(pb + db), dim3(256), 0, st, a, (const float*)o->gdm, o->Nf, np, pb, U, o->E, o->NB, lr, b1, b2, 1e-8f, wd, (const int*)o->d_step,
                        (const float2*)o->bc_tab, o->c.min_decay, o->c.max_decay, o->c.w_lo, o->c.w_hi, o->c.clamp_decay, o->c.long2nd);
     return;
   }
