@@ -507,20 +507,44 @@ __global__ __launch_bounds__(256) void design_bwd_params_kernel(const float* gdm
 }
 
 // ---- 25856-point complex FFT, two stages (N2 = 101 * 256): n = 256 n1 + n2, k = k1 + 101 k2 ----
-// stage 1: Y1[u][n2][k1] = tw(n2 k1) * sum_{n1} x[256 n1 + n2] W101^(n1 k1).  101 is prime: a naive 101-point DFT per column n2, but a block
-// parks its S1_COLS columns of x (101 x 4 complex) and the twiddles in LDS first, so the inner loop is two LDS reads and a complex FMA.
-constexpr int S1_COLS = 4;
+// stage 1: Y1[u][n2][k1] = tw(n2 k1) * sum_{n1} x[256 n1 + n2] W101^(n1 k1).  101 is prime: a naive 101-point DFT per column n2.  A block parks
+// its S1_COLS = 4 columns of x and the twiddles in LDS; THREAD k1 forms the outputs of all four columns, so one (bank-conflicted: the index n1 k1
+// mod 101 is scattered over the lanes) twiddle read and one 16/32-byte row read serve four complex MACs.  The one-output-per-thread form (two LDS
+// reads per MAC, 404 outputs on 256 threads) was bound by the LDS pipe: 8 us per pass.
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+constexpr int S1_COLS = 4, S1_THREADS = 128;
+// acc[c] += W[(n1 k1) mod 101] * X[n1][c], n1 = 0 .. 100 ascending
+__device__ __forceinline__ void dft101x4(const float2* X, const float2* W, int k1, v2f (&acc)[4]) {
+  const float4* X4 = reinterpret_cast<const float4*>(X);
+  int idx = 0, n1 = 0;
+  for (; n1 + 4 <= F1; n1 += 4) {
+    float2 w[4]; float4 xa[4], xb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { w[j] = W[idx]; xa[j] = X4[2 * (n1 + j)]; xb[j] = X4[2 * (n1 + j) + 1]; idx += k1; if (idx >= F1) idx -= F1; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0] = cmac(acc[0], w[j], make_float2(xa[j].x, xa[j].y)); acc[1] = cmac(acc[1], w[j], make_float2(xa[j].z, xa[j].w));
+      acc[2] = cmac(acc[2], w[j], make_float2(xb[j].x, xb[j].y)); acc[3] = cmac(acc[3], w[j], make_float2(xb[j].z, xb[j].w));
+    }
+  }
+  for (; n1 < F1; ++n1) {
+    const float2 w = W[idx]; const float4 xa = X4[2 * n1], xb = X4[2 * n1 + 1];
+    acc[0] = cmac(acc[0], w, make_float2(xa.x, xa.y)); acc[1] = cmac(acc[1], w, make_float2(xa.z, xa.w));
+    acc[2] = cmac(acc[2], w, make_float2(xb.x, xb.y)); acc[3] = cmac(acc[3], w, make_float2(xb.z, xb.w));
+    idx += k1; if (idx >= F1) idx -= F1;
+  }
+}
 // The input is a REAL signal of Lr samples zero-padded to N2, and it is never materialised: it is the overlap-add of the 512-sample frames
 // fr[u][0..Tsrc) at j = n + Q times env[j] (what ola_kernel wrote), or, with fr == nullptr, the array xr[u][0..Lr).  ZERO0: sample 0 forced to zero
 // (hm[0] is a constant of the projection).
 struct S1In { const float* xr; int Lr; const float* fr; int Tsrc, Q; const float* env; };
 template <bool ZERO0>
-__global__ __launch_bounds__(256) void fft_stage1_kernel(S1In in, float2* y1, const float2* w101, const float2* twN, int sign) {
+__global__ __launch_bounds__(S1_THREADS) void fft_stage1_kernel(S1In in, float2* y1, const float2* w101, const float2* twN, int sign) {
   __shared__ float2 W[F1];
-  __shared__ float2 X[F1 * S1_COLS];
+  __shared__ __align__(16) float X[F1 * S1_COLS];             // real
   const int u = blockIdx.y, n20 = blockIdx.x * S1_COLS;
-  for (int i = threadIdx.x; i < F1; i += 256) W[i] = make_float2(w101[i].x, sign * w101[i].y);
-  for (int i = threadIdx.x; i < F1 * S1_COLS; i += 256) {
+  for (int i = threadIdx.x; i < F1; i += S1_THREADS) W[i] = make_float2(w101[i].x, sign * w101[i].y);
+  for (int i = threadIdx.x; i < F1 * S1_COLS; i += S1_THREADS) {
     const int n1 = i / S1_COLS, c = i - n1 * S1_COLS, n = F2 * n1 + n20 + c;
     float v = 0.f;
     if (n < in.Lr && (!ZERO0 || n > 0)) {
@@ -539,36 +563,34 @@ __global__ __launch_bounds__(256) void fft_stage1_kernel(S1In in, float2* y1, co
         v = in.xr[(long long)u * in.Lr + n];
       }
     }
-    X[i] = make_float2(v, 0.f);
+    X[i] = v;
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
-    const int c = o / F1, k1 = o - c * F1;                  // consecutive threads: consecutive k1 of one column (coalesced store)
-    const int n2 = n20 + c;
-    const float2 t = twN[(long long)n2 * F1 + k1];           // requested before the 101-term sum, needed after it
-    float ar = 0.f, ai = 0.f;
-    int idx = 0;
-    int n1 = 0;
-    for (; n1 + 8 <= F1; n1 += 8) {                        // eight LDS pairs in flight per trip
-      float2 v[8], w[8];
+  const int k1 = threadIdx.x;
+  if (k1 >= F1) return;
+  float2 t[S1_COLS];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { v[j] = X[(n1 + j) * S1_COLS + c]; w[j] = W[idx]; idx += k1; if (idx >= F1) idx -= F1; }
+  for (int c = 0; c < S1_COLS; ++c) t[c] = twN[(long long)(n20 + c) * F1 + k1];     // requested before the 101-term sum, needed after it
+  v2f acc[S1_COLS];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { ar += v[j].x * w[j].x - v[j].y * w[j].y; ai += v[j].x * w[j].y + v[j].y * w[j].x; }
-    }
-    for (; n1 < F1; ++n1) {
-      const float2 v = X[n1 * S1_COLS + c], w = W[idx];
-      ar += v.x * w.x - v.y * w.y; ai += v.x * w.y + v.y * w.x;
-      idx += k1; if (idx >= F1) idx -= F1;
-    }
-    const float tr = t.x, ti = sign * t.y;
-    y1[(long long)u * N2 + (long long)n2 * F1 + k1] = make_float2(ar * tr - ai * ti, ar * ti + ai * tr);
+  for (int c = 0; c < S1_COLS; ++c) acc[c] = v2f{0.f, 0.f};
+  const float4* X4 = reinterpret_cast<const float4*>(X);
+  int idx = 0;
+#pragma unroll 4
+  for (int n1 = 0; n1 < F1; ++n1) {                          // real input: one packed fma per column and term
+    const float2 w = W[idx]; const float4 x = X4[n1];
+    const v2f wv{w.x, w.y};
+    acc[0] = __builtin_elementwise_fma(v2f{x.x, x.x}, wv, acc[0]); acc[1] = __builtin_elementwise_fma(v2f{x.y, x.y}, wv, acc[1]);
+    acc[2] = __builtin_elementwise_fma(v2f{x.z, x.z}, wv, acc[2]); acc[3] = __builtin_elementwise_fma(v2f{x.w, x.w}, wv, acc[3]);
+    idx += k1; if (idx >= F1) idx -= F1;
   }
+#pragma unroll
+  for (int c = 0; c < S1_COLS; ++c)
+    y1[(long long)u * N2 + (long long)(n20 + c) * F1 + k1] = cmul(make_float2(acc[c].x, acc[c].y), make_float2(t[c].x, sign * t[c].y));
 }
 // stage 2: X[k1 + 101 k2] = scale * sum_{n2} Y1[n2][k1] W256^(n2 k2), a 256-point DFT per (utterance, k1) column done as
 // 16 x 16: n2 = 16 a + r, k2 = b + 16 c  =>  W256^(n2 k2) = W16^(a b) * W256^(r b) * W16^(r c).  A block owns 16 columns; thread (col, r)
 // does the 16-point DFT over a in registers (radix 4 x 4), applies W256^(r b), exchanges through LDS, thread (col, b) does the one over r.
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 // y[b] = sum_a x[a] exp(SGN * 2 pi i a b / 16)
 template <int SGN>
 __device__ __forceinline__ void dft16(float2 (&x)[16]) {
@@ -698,69 +720,84 @@ __global__ __launch_bounds__(S2_THREADS) void fft_mid256_kernel(const float2* y1
     }
   }
 }
-// 101-point DFT of the S1_COLS columns parked in X[n1 * S1_COLS + c] (twiddles W, sign applied), outputs o = tid, tid + 256 -> (c, k1) = (o / 101, o % 101)
-__device__ __forceinline__ float2 dft101(const float2* X, const float2* W, int c, int k1) {
-  float ar = 0.f, ai = 0.f;
-  int idx = 0, n1 = 0;
-  for (; n1 + 8 <= F1; n1 += 8) {                          // eight LDS pairs in flight per trip
-    float2 v[8], w[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { v[j] = X[(n1 + j) * S1_COLS + c]; w[j] = W[idx]; idx += k1; if (idx >= F1) idx -= F1; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { ar += v[j].x * w[j].x - v[j].y * w[j].y; ai += v[j].x * w[j].y + v[j].y * w[j].x; }
-  }
-  for (; n1 < F1; ++n1) {
-    const float2 v = X[n1 * S1_COLS + c], w = W[idx];
-    ar += v.x * w.x - v.y * w.y; ai += v.x * w.y + v.y * w.x;
-    idx += k1; if (idx >= F1) idx -= F1;
-  }
-  return make_float2(ar, ai);
-}
 // [101-point stage of form II, sign -] . Hilbert window . [101-point stage of form I + twiddle, sign +]: z[u][q2][m1] -> y1[u][n2][k1], n2 = q2
-__global__ __launch_bounds__(256) void fft_mid101_kernel(const float2* z, float2* y1, const float2* w101, const float2* twN) {
+__global__ __launch_bounds__(S1_THREADS) void fft_mid101_kernel(const float2* z, float2* y1, const float2* w101, const float2* twN) {
   __shared__ float2 Wm[F1], Wp[F1];
-  __shared__ float2 X[F1 * S1_COLS], X2[F1 * S1_COLS];
+  __shared__ __align__(16) float2 X[F1 * S1_COLS], X2[F1 * S1_COLS];
   const int u = blockIdx.y, n20 = blockIdx.x * S1_COLS;
-  for (int i = threadIdx.x; i < F1; i += 256) { const float2 w = w101[i]; Wm[i] = make_float2(w.x, -w.y); Wp[i] = w; }
+  for (int i = threadIdx.x; i < F1; i += S1_THREADS) { const float2 w = w101[i]; Wm[i] = make_float2(w.x, -w.y); Wp[i] = w; }
   const float2* zu = z + (long long)u * N2 + (long long)n20 * F1;
-  for (int i = threadIdx.x; i < F1 * S1_COLS; i += 256) { const int c = i / F1, m1 = i - c * F1; X[m1 * S1_COLS + c] = zu[i]; }
-  __syncthreads();
-  for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
-    const int c = o / F1, q1 = o - c * F1;
-    const float2 x = dft101(X, Wm, c, q1);                  // element n = 256 q1 + n2 of the inner spectrum
-    const float w = (F2 * q1 + n20 + c) < N2 / 2 ? 2.f : 0.f;
-    X2[q1 * S1_COLS + c] = make_float2(x.x * w, x.y * w);
+  {
+    constexpr int NT = (F1 * S1_COLS + S1_THREADS - 1) / S1_THREADS;
+    float2 v[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) { const int i = threadIdx.x + S1_THREADS * q; v[q] = i < F1 * S1_COLS ? zu[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) { const int i = threadIdx.x + S1_THREADS * q; if (i < F1 * S1_COLS) { const int c = i / F1, m1 = i - c * F1; X[m1 * S1_COLS + c] = v[q]; } }
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
-    const int c = o / F1, k1 = o - c * F1, n2 = n20 + c;
-    const float2 t = twN[(long long)n2 * F1 + k1];
-    const float2 x = dft101(X2, Wp, c, k1);
-    y1[(long long)u * N2 + (long long)n2 * F1 + k1] = cmul(x, t);
+  const int k1 = threadIdx.x;                                // first pass: q1
+  float2 t[S1_COLS];
+  if (k1 < F1) {
+#pragma unroll
+    for (int c = 0; c < S1_COLS; ++c) t[c] = twN[(long long)(n20 + c) * F1 + k1];
+    v2f acc[S1_COLS];
+#pragma unroll
+    for (int c = 0; c < S1_COLS; ++c) acc[c] = v2f{0.f, 0.f};
+    dft101x4(X, Wm, k1, acc);                                // element n = 256 q1 + n2 of the inner spectrum
+#pragma unroll
+    for (int c = 0; c < S1_COLS; ++c) {
+      const float w = (F2 * k1 + n20 + c) < N2 / 2 ? 2.f : 0.f;
+      X2[k1 * S1_COLS + c] = make_float2(acc[c].x * w, acc[c].y * w);
+    }
+  }
+  __syncthreads();
+  if (k1 < F1) {
+    v2f acc[S1_COLS];
+#pragma unroll
+    for (int c = 0; c < S1_COLS; ++c) acc[c] = v2f{0.f, 0.f};
+    dft101x4(X2, Wp, k1, acc);
+#pragma unroll
+    for (int c = 0; c < S1_COLS; ++c) y1[(long long)u * N2 + (long long)(n20 + c) * F1 + k1] = cmul(make_float2(acc[c].x, acc[c].y), t[c]);
   }
 }
 // last stage of a form-II transform with REAL output: xr[u][n] = scale * Re sum_{m1} z[u][q2][m1] W101^(sign m1 q1), n = 256 q1 + q2 < Lo;
 // first_set: sample 0 := first (the minimum-phase filter's leading tap is a constant of the projection)
-__global__ __launch_bounds__(256) void fft_stageB_real_kernel(const float2* z, float* xr, int Lo, const float2* w101, int sign, float scale, int first_set, float first) {
+__global__ __launch_bounds__(S1_THREADS) void fft_stageB_real_kernel(const float2* z, float* xr, int Lo, const float2* w101, int sign, float scale, int first_set, float first) {
   __shared__ float2 W[F1];
-  __shared__ float2 X[F1 * S1_COLS];
+  __shared__ __align__(16) float2 X[F1 * S1_COLS];
   const int u = blockIdx.y, n20 = blockIdx.x * S1_COLS;
-  for (int i = threadIdx.x; i < F1; i += 256) W[i] = make_float2(w101[i].x, sign * w101[i].y);
+  if (n20 >= Lo) return;                                     // (uniform) nothing of this block's columns survives even for q1 = 0
+  for (int i = threadIdx.x; i < F1; i += S1_THREADS) W[i] = make_float2(w101[i].x, -sign * w101[i].y);   // conjugated: Re(v w) = v . conj(w) as a dot product
   const float2* zu = z + (long long)u * N2 + (long long)n20 * F1;
-  for (int i = threadIdx.x; i < F1 * S1_COLS; i += 256) { const int c = i / F1, m1 = i - c * F1; X[m1 * S1_COLS + c] = zu[i]; }
+  {
+    constexpr int NT = (F1 * S1_COLS + S1_THREADS - 1) / S1_THREADS;
+    float2 v[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) { const int i = threadIdx.x + S1_THREADS * q; v[q] = i < F1 * S1_COLS ? zu[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) { const int i = threadIdx.x + S1_THREADS * q; if (i < F1 * S1_COLS) { const int c = i / F1, m1 = i - c * F1; X[m1 * S1_COLS + c] = v[q]; } }
+  }
   __syncthreads();
-  for (int o = threadIdx.x; o < F1 * S1_COLS; o += 256) {
-    const int q1 = o / S1_COLS, c = o - q1 * S1_COLS;     // consecutive threads: the block's S1_COLS consecutive samples of one q1
+  const int q1 = threadIdx.x;
+  if (q1 >= F1 || F2 * q1 + n20 >= Lo) return;
+  v2f acc[S1_COLS];
+#pragma unroll
+  for (int c = 0; c < S1_COLS; ++c) acc[c] = v2f{0.f, 0.f};
+  const float4* X4 = reinterpret_cast<const float4*>(X);
+  int idx = 0;
+#pragma unroll 4
+  for (int m1 = 0; m1 < F1; ++m1) {                          // (re, im) partial products of the real part: one packed fma per column and term
+    const float2 w = W[idx]; const float4 xa = X4[2 * m1], xb = X4[2 * m1 + 1];
+    const v2f wv{w.x, w.y};
+    acc[0] = __builtin_elementwise_fma(v2f{xa.x, xa.y}, wv, acc[0]); acc[1] = __builtin_elementwise_fma(v2f{xa.z, xa.w}, wv, acc[1]);
+    acc[2] = __builtin_elementwise_fma(v2f{xb.x, xb.y}, wv, acc[2]); acc[3] = __builtin_elementwise_fma(v2f{xb.z, xb.w}, wv, acc[3]);
+    idx += q1; if (idx >= F1) idx -= F1;
+  }
+#pragma unroll
+  for (int c = 0; c < S1_COLS; ++c) {
     const int n = F2 * q1 + n20 + c;
-    if (n >= Lo) continue;
-    float ar = 0.f;
-    int idx = 0;
-    for (int m1 = 0; m1 < F1; ++m1) {
-      const float2 v = X[m1 * S1_COLS + c], w = W[idx];
-      ar += v.x * w.x - v.y * w.y;
-      idx += q1; if (idx >= F1) idx -= F1;
-    }
-    xr[(long long)u * Lo + n] = (first_set && n == 0) ? first : ar * scale;
+    if (n < Lo) xr[(long long)u * Lo + n] = (first_set && n == 0) ? first : (acc[c].x + acc[c].y) * scale;
   }
 }
 
@@ -1252,18 +1289,18 @@ struct BlindOp {
   // first stage (form I) of a transform of a REAL signal of Lr_ samples zero-padded to N2 (zero0: sample 0 forced to zero) -> c2
   void fft_first(const S1In& in, bool zero0, int sign) {
     const dim3 g1(F2 / S1_COLS, U);
-    if (zero0) hipLaunchKernelGGL(fft_stage1_kernel<true>, g1, dim3(256), 0, st, in, c2, (const float2*)w101, (const float2*)twN, sign);
-    else hipLaunchKernelGGL(fft_stage1_kernel<false>, g1, dim3(256), 0, st, in, c2, (const float2*)w101, (const float2*)twN, sign);
+    if (zero0) hipLaunchKernelGGL(fft_stage1_kernel<true>, g1, dim3(S1_THREADS), 0, st, in, c2, (const float2*)w101, (const float2*)twN, sign);
+    else hipLaunchKernelGGL(fft_stage1_kernel<false>, g1, dim3(S1_THREADS), 0, st, in, c2, (const float2*)w101, (const float2*)twN, sign);
   }
   template <int SGN, int PW> void fft_mid256(float scale) {           // c2 -> c1
     const MpArrays a{Hf, Mabs, phim, gM};
     hipLaunchKernelGGL((fft_mid256_kernel<SGN, PW>), dim3(cdiv(F1, S2_COLS), U), dim3(S2_THREADS), 0, st, (const float2*)c2, c1, (const float2*)w256, (const float2*)twN, scale, a);
   }
   void fft_mid101() {                                                  // c1 -> c2
-    hipLaunchKernelGGL(fft_mid101_kernel, dim3(F2 / S1_COLS, U), dim3(256), 0, st, (const float2*)c1, c2, (const float2*)w101, (const float2*)twN);
+    hipLaunchKernelGGL(fft_mid101_kernel, dim3(F2 / S1_COLS, U), dim3(S1_THREADS), 0, st, (const float2*)c1, c2, (const float2*)w101, (const float2*)twN);
   }
   void fft_last_real(float* out, int Lo, int sign, float scale, bool first_set, float first) {       // c1 -> out
-    hipLaunchKernelGGL(fft_stageB_real_kernel, dim3(F2 / S1_COLS, U), dim3(256), 0, st, (const float2*)c1, out, Lo, (const float2*)w101, sign, scale, first_set ? 1 : 0, first);
+    hipLaunchKernelGGL(fft_stageB_real_kernel, dim3(F2 / S1_COLS, U), dim3(S1_THREADS), 0, st, (const float2*)c1, out, Lo, (const float2*)w101, sign, scale, first_set ? 1 : 0, first);
   }
   DesignTabs tabs() const { DesignTabs t; t.idx = idx; t.frac = frac; t.corr = corr; t.dpm = dpm; t.fge = fge; return t; }
 

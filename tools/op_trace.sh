@@ -15,7 +15,7 @@ for r in rows:
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:40]:
     print(f"{k[0]:36s} grid {k[1]:>7s} {k[2]:>3s} {k[3]:>2s}  x{len(v):4d}  avg {sum(v) / len(v):6.1f} us  total {sum(v) / 1e3:6.2f} ms")
 # one iteration, in order: from the last design_dm_kernel to the end
-idx = [i for i, r in enumerate(rows) if "design_dm_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "design_row_kernel" in r["Kernel_Name"]]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 print("--- one iteration (start us, duration us, gap to previous end us)")
