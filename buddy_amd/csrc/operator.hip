@@ -27,18 +27,6 @@ constexpr int N2 = 25856, F1 = 101, F2 = 256;     // N2 = F1 * F2
 constexpr double PI = 3.14159265358979323846;
 
 // ------------------------------------------------------------------ small kernels
-__global__ __launch_bounds__(256) void pad_const_kernel(const float* s, float* sp, int U, int Ls, int P, int Lpad, const float* add, float add_scale,
-                                                        const float* add_scale_dev) {
-  if (add_scale_dev) add_scale = *add_scale_dev;          // captured-graph mode: the scalar lives in device memory
-  const long long total = (long long)U * Lpad;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int u = (int)(i / Lpad), j = (int)(i % Lpad) - P;
-    float v = 0.f;
-    if (j >= 0 && j < Ls) { v = s[(long long)u * Ls + j]; if (add) v += add_scale * add[(long long)u * Ls + j]; }
-    sp[i] = v;
-  }
-}
-
 // Y[u][t][f] = sum_k H[u][k][f] * X[u][t + 1 - k][f]   (reference subband_filtering :67-74, one pre-impulse frame)
 // A thread owns FOUR consecutive frames of one (utterance, bin): per tap it loads one H value and one new X frame (the other three
 // slide through registers), i.e. 2 loads per 4 complex MACs instead of 8.  Per-output summation order is k ascending, as before.
@@ -844,7 +832,7 @@ __device__ __forceinline__ void fft1024_core(float2 (&v)[16], float2* S, const f
 //
 // Where the frames come from (R2cSrc): every elementwise / gather neighbour of the transform is folded into its first load, because each node
 // of the captured optimisation loop costs ~5 us whatever it does.  Frame t of utterance u covers the samples s = 128 t + n - P, n < 512, of
-//   GATHER = false: the signal sig[u][0..Ls)                                                        (was: pad_const_kernel -> sp)
+//   GATHER = false: the signal sig[u][0..Ls)                                                        (was: a zero-padded copy)
 //   GATHER = true : the overlap-add of fr[u][0..Tsrc)[512] at j = s + Q, times envA[j]              (was: ola_kernel -> signal -> pad_const)
 // zero outside [0, Ls); then (+ add_scale * add[u][s]) and (* envB[128 t + n]) when given           (was: pad_const's noise term / ola_adj_kernel)
 // Every product is formed in the order the separate kernels formed it, so the results are bit-identical to the unfused chain.
@@ -948,80 +936,6 @@ __global__ __launch_bounds__(256) void fft1024_c2r_kernel(C2rJobs jobs, const fl
   if (!ok) return;
 #pragma unroll
   for (int c1 = 0; c1 < 8; ++c1) { const int n = r + 64 * c1; frames[row * WIN + n] = fac * win[n] * v[c1].x; }
-}
-
-// ---- minimum-phase projection glue (reference reverb_utils.py:9-23) ----
-__global__ __launch_bounds__(256) void mp_pack_kernel(const float* h0, int Lh, float2* hp, int U) {      // hp = [h0, zeros] as complex
-  const long long total = (long long)U * N2;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int u = (int)(i / N2), n = (int)(i % N2);
-    hp[i] = make_float2(n < Lh ? h0[(long long)u * Lh + n] : 0.f, 0.f);
-  }
-}
-__global__ __launch_bounds__(256) void mp_logabs_kernel(const float2* Hf, float* M, float2* Lg, long long total) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const float2 h = Hf[i];
-    const float m = sqrtf(h.x * h.x + h.y * h.y);
-    M[i] = m;
-    Lg[i] = make_float2(logf(m + 1e-8f), 0.f);
-  }
-}
-__global__ __launch_bounds__(256) void mp_window_kernel(float2* F, long long total) {     // hilbert window: 2 on the first half, 0 on the second
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int n = (int)(i % N2);
-    const float w = n < N2 / 2 ? 2.f : 0.f;
-    F[i].x *= w; F[i].y *= w;
-  }
-}
-__global__ __launch_bounds__(256) void mp_phase_kernel(const float2* hil, const float* M, float* phim, float2* Z, long long total) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const float ph = -hil[i].y;
-    phim[i] = ph;
-    float s, c; sincosf(ph, &s, &c);
-    Z[i] = make_float2(M[i] * c, M[i] * s);
-  }
-}
-__global__ __launch_bounds__(256) void mp_out_kernel(const float2* o, float* hm, int Lm, int U, float first) {   // hm = Re(o)[:Lm], hm[0] = first
-  const long long total = (long long)U * Lm;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int u = (int)(i / Lm), n = (int)(i % Lm);
-    hm[i] = n == 0 ? first : o[(long long)u * N2 + n].x;
-  }
-}
-// backward glue
-__global__ __launch_bounds__(256) void mpb_pack_kernel(const float* ghm, int Lm, float2* gp, int U) {     // g padded, g[0] = 0 (hm[0] is a constant)
-  const long long total = (long long)U * N2;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int u = (int)(i / N2), n = (int)(i % N2);
-    gp[i] = make_float2((n > 0 && n < Lm) ? ghm[(long long)u * Lm + n] : 0.f, 0.f);
-  }
-}
-// GZ = FFT(g)/N2 ; gM = Re(conj(GZ) e^{j phi}), gphi = -M Im(conj(GZ) e^{j phi})
-__global__ __launch_bounds__(256) void mpb_z_kernel(const float2* GZ, const float* M, const float* phim, float* gM, float2* gphi_c, long long total) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    float s, c; sincosf(phim[i], &s, &c);
-    const float2 g = GZ[i];
-    const float a = g.x * c + g.y * s;         // Re(conj(G) e^{j phi})
-    const float b = g.x * s - g.y * c;         // Im(conj(G) e^{j phi})
-    gM[i] = a;
-    gphi_c[i] = make_float2(-M[i] * b, 0.f);
-  }
-}
-// gLg = Im(IFFT(win FFT(gphi))) ; gM += gLg / (M + 1e-8) ; GH = gM * Hf / |Hf|
-__global__ __launch_bounds__(256) void mpb_h_kernel(const float2* hil, const float* M, const float* gM, const float2* Hf, float2* GH, long long total) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const float m = M[i];
-    const float g = gM[i] + hil[i].y / (m + 1e-8f);
-    const float2 h = Hf[i];
-    GH[i] = m > 0.f ? make_float2(g * h.x / m, g * h.y / m) : make_float2(0.f, 0.f);
-  }
-}
-__global__ __launch_bounds__(256) void mpb_out_kernel(const float2* o, float* gh0, int Lh, int U) {   // g_h0 = Re(N2 * IFFT(GH))[:Lh] (o already scaled)
-  const long long total = (long long)U * Lh;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int u = (int)(i / Lh), n = (int)(i % Lh);
-    gh0[i] = o[(long long)u * N2 + n].x;
-  }
 }
 
 // ---- Adam (torch.optim.Adam single-tensor arithmetic: lerp, addcmul, addcdiv) + projection ----
@@ -1156,13 +1070,6 @@ __global__ __launch_bounds__(256) void copy_spec_kernel(const float* X, float* o
   }
 }
 // plain minimum-phase output: hm = Re(o)[:Lm] (no direct-path override)
-__global__ __launch_bounds__(256) void mp_out_plain_kernel(const float2* o, float* hm, int Lm, int U) {
-  const long long total = (long long)U * Lm;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int u = (int)(i / Lm), n = (int)(i % Lm);
-    hm[i] = o[(long long)u * N2 + n].x;
-  }
-}
 
 inline int gridf(long long total) { long long g = (total + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1; return (int)g; }
 }  // namespace
@@ -1174,10 +1081,10 @@ struct BlindOp {
   hipStream_t st = nullptr;
   std::vector<void*> allocs;
   // tables
-  float *Bf = nullptr, *Bi = nullptr, *BfT = nullptr, *BiT = nullptr, *ones = nullptr, *env_T = nullptr, *env_d = nullptr, *env_c = nullptr;
+  float *ones = nullptr, *env_T = nullptr, *env_d = nullptr, *env_c = nullptr;
   float norm = 1.f;
   int *idx = nullptr, *fge = nullptr; float *frac = nullptr, *corr = nullptr, *dpm = nullptr;
-  float2 *w101 = nullptr, *w256 = nullptr, *twN = nullptr, *w1024 = nullptr; float* win = nullptr; bool use_fft = true;
+  float2 *w101 = nullptr, *w256 = nullptr, *twN = nullptr, *w1024 = nullptr; float* win = nullptr;
   // parameters + Adam state
   float *decay = nullptr, *wts = nullptr, *phi = nullptr;
   float *m_d = nullptr, *v_d = nullptr, *m_w = nullptr, *v_w = nullptr, *m_p = nullptr, *v_p = nullptr;
@@ -1190,14 +1097,14 @@ struct BlindOp {
   // state
   float *H = nullptr, *Yc = nullptr, *Xdelta = nullptr;
   // work buffers
-  float *sp = nullptr, *frames = nullptr, *X1 = nullptr, *X2 = nullptr, *X3 = nullptr, *Ybuf = nullptr, *sig1 = nullptr, *sig2 = nullptr;
+  float *frames = nullptr, *X1 = nullptr, *X2 = nullptr, *X3 = nullptr, *Ybuf = nullptr, *sig1 = nullptr, *sig2 = nullptr;
   // second scratch set: the RIR-regulariser chain of an iteration shares every launch with the reconstruction chain (param_grads)
   float *frames_b = nullptr, *X2_b = nullptr, *X3_b = nullptr, *Ybuf_b = nullptr; double* partial_b = nullptr;
   bool fused_loop = false;           // inside the captured optimisation loop: step counter in design_dm, no loss finalisation, one Adam launch
   bool big_lds = false;              // fir_sb_lds_kernel may take > 64 KB of dynamic LDS (set once at creation, outside any stream capture)
   float *A = nullptr, *Apre = nullptr, *logdm = nullptr, *dmv = nullptr, *gdm = nullptr, *Fin = nullptr, *GFin = nullptr, *GH = nullptr;
-  float *gphi = nullptr, *gdecay = nullptr, *gw = nullptr, *h0 = nullptr, *hm = nullptr, *ghm = nullptr, *gh0 = nullptr;
-  float2 *c1 = nullptr, *c2 = nullptr, *c3 = nullptr, *Hf = nullptr;
+  float *gphi = nullptr, *gdecay = nullptr, *gw = nullptr, *hm = nullptr, *gh0 = nullptr;
+  float2 *c1 = nullptr, *c2 = nullptr, *Hf = nullptr;
   float *Mabs = nullptr, *phim = nullptr, *gM = nullptr;
   double* partial = nullptr; float* losses = nullptr;
   float *rir = nullptr, *Rc = nullptr;
@@ -1216,13 +1123,7 @@ struct BlindOp {
   }
 
   // ---- primitive routines (all batched over U, on stream st) ----
-  void gemm(const float* Am, int ldA, long long sA, const float* Bt, int ldB, bool tB, float* C, int ldC, long long sC, int M, int N, int Kk, float alpha, int batch) {
-    IgemmParams p; std::memset(&p, 0, sizeof(p));
-    p.A0 = Am; p.ldA0 = ldA; p.sA = sA; p.Bt = Bt; p.ldB = ldB; p.C = C; p.ldC = ldC; p.sC = sC; p.M = M; p.N = N; p.Cin = Kk;
-    p.alpha = alpha; p.out_scale = 1.f; p.H = 1; p.W = 1; p.rows_per_batch = 1;
-    launch_igemm(p, 1, false, tB, batch, st);
-  }
-  // the four STFT-type transforms: 1024-point FFT kernels (default) or DFT-as-GEMM on the matrix cores (BUDDY_OP_FFT=0)
+  // the four STFT-type transforms: 1024-point FFT kernels (round 1 ran them as DFT GEMMs on the matrix cores: 42 us per launch instead of 9)
   // up to three (source, frame count, output) jobs in one launch; all jobs of a launch gather from frames, or none does
   struct R2cReq { R2cSrc sc; int Tn; float* out; };
   void r2c_multi(const R2cReq* rq, int n, float fac, int cf) {
@@ -1245,22 +1146,17 @@ struct BlindOp {
   void c2r(const float* in, long long rows, float* fr, float fac, int cf) { c2r2(in, rows, fr, nullptr, 0, nullptr, fac, cf); }
   // X[u][t][:] = scale * STFT frames of s (frame t starts at sample 128 t - P), Tn frames
   void stft(const float* s, int Ls, int P, int Tn, float scale, float* X, const float* add = nullptr, float add_scale = 0.f, const float* add_scale_dev = nullptr) {
-    if (use_fft) { r2c(R2cSrc{s, nullptr, Ls, P, 0, 0, nullptr, nullptr, add, add_scale, add_scale_dev}, Tn, X, scale, 0); return; }
-    const int Lpad = ((Tn - 1) * HOP + WIN + 3) / 4 * 4;
-    hipLaunchKernelGGL(pad_const_kernel, dim3(gridf((long long)U * Lpad)), dim3(256), 0, st, s, sp, U, Ls, P, Lpad, add, add_scale, add_scale_dev);
-    gemm(sp, HOP, Lpad, Bf, WIN, false, X, LDSP, (long long)Tn * LDSP, Tn, LDSP, WIN, scale, U);
+    r2c(R2cSrc{s, nullptr, Ls, P, 0, 0, nullptr, nullptr, add, add_scale, add_scale_dev}, Tn, X, scale, 0);
   }
   // y[u][s] = sum_t frames_t[s + Q - 128 t] * inv_env[s + Q],  frames = scale * iDFT(Y) * window
   void istft(const float* Y, int Tn, int Q, const float* inv_env, int Ls, float scale, float* y) {
-    if (use_fft) c2r(Y, (long long)U * Tn, frames, scale / NFFT, 1);
-    else gemm(Y, LDSP, 0, Bi, LDSP, false, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
+    c2r(Y, (long long)U * Tn, frames, scale / NFFT, 1);
     launch_ola(frames, WIN, Tn, WIN, HOP, inv_env, y, U, Ls, Q, nullptr, nullptr, nullptr, st);
   }
   // X = sx * STFT(istft(Y) (+ add_scale * add)) without the signal in between: the overlap-add happens in the load of the second transform.
   // The frames buffer stays valid afterwards (stft_of_frames below repeats the second half on it, e.g. with and without the noise term).
   void istft_stft(const float* Y, int Tn, int Q, const float* inv_env, int Ls, float si, int P, int Tx, float sx, float* X, const float* add = nullptr,
-                  float add_scale = 0.f, const float* add_scale_dev = nullptr, float* sig_scratch = nullptr) {
-    if (!use_fft) { istft(Y, Tn, Q, inv_env, Ls, si, sig_scratch); stft(sig_scratch, Ls, P, Tx, sx, X, add, add_scale, add_scale_dev); return; }
+                  float add_scale = 0.f, const float* add_scale_dev = nullptr) {
     c2r(Y, (long long)U * Tn, frames, si / NFFT, 1);
     stft_of_frames(Tn, Q, inv_env, Ls, P, Tx, sx, X, add, add_scale, add_scale_dev);
   }
@@ -1270,19 +1166,15 @@ struct BlindOp {
   }
   // adjoint of stft: g_s from G_X
   void stft_adj(const float* GX, int Ls, int P, int Tn, float scale, float* gs) {
-    if (use_fft) c2r(GX, (long long)U * Tn, frames, scale, 0);
-    else gemm(GX, LDSP, 0, BfT, LDSP, false, frames, WIN, 0, U * Tn, WIN, LDSP, scale, 1);
+    c2r(GX, (long long)U * Tn, frames, scale, 0);
     launch_ola(frames, WIN, Tn, WIN, HOP, ones, gs, U, Ls, P, nullptr, nullptr, nullptr, st);
   }
   // adjoint of istft: G_Y from g_y
   void istft_adj(const float* gy, int Tn, int Q, const float* inv_env, int Ls, float scale, float* GY) {
-    if (use_fft) { r2c(R2cSrc{gy, nullptr, Ls, Q, 0, 0, nullptr, inv_env, nullptr, 0.f, nullptr}, Tn, GY, scale / NFFT, 1); return; }
-    launch_ola_adj(gy, U, Ls, Q, Tn, WIN, HOP, inv_env, nullptr, frames, WIN, st);
-    gemm(frames, WIN, 0, BiT, WIN, false, GY, LDSP, 0, U * Tn, LDSP, WIN, scale, 1);
+    r2c(R2cSrc{gy, nullptr, Ls, Q, 0, 0, nullptr, inv_env, nullptr, 0.f, nullptr}, Tn, GY, scale / NFFT, 1);
   }
   // G_Y = istft_adj(stft_adj(G_X)) without the signal in between (both adjoints act on the same Ls samples)
-  void stft_adj_istft_adj(const float* GX, int Ls, int P, int Tx, float sx, int Tn, int Q, const float* inv_env, float si, float* GY, float* sig_scratch) {
-    if (!use_fft) { stft_adj(GX, Ls, P, Tx, sx, sig_scratch); istft_adj(sig_scratch, Tn, Q, inv_env, Ls, si, GY); return; }
+  void stft_adj_istft_adj(const float* GX, int Ls, int P, int Tx, float sx, int Tn, int Q, const float* inv_env, float si, float* GY) {
     c2r(GX, (long long)U * Tx, frames, sx, 0);
     r2c(R2cSrc{nullptr, frames, Ls, Q, Tx, P, ones, inv_env, nullptr, 0.f, nullptr}, Tn, GY, si / NFFT, 1);
   }
@@ -1322,24 +1214,14 @@ struct BlindOp {
     hipLaunchKernelGGL(design_row_kernel, dim3(U * Nf), dim3(256), 0, st, (const float*)decay, (const float*)wts, tabs(), (const float*)phi, logdm, dmv, A, Apre, Fin, U, E, NB,
                        Nf, fused_loop ? d_step : (int*)nullptr);
     // h0 = istft(Fin) is never materialised: the first transform of the projection gathers it from the synthesis frames
-    if (use_fft) {
-      c2r(Fin, (long long)U * (Nf + 2), frames, 1.f / NFFT, 1);
-      minphase_core(S1In{nullptr, Lh, frames, Nf + 2, WIN, env_c}, hm, Lm, true, (float)(WIN / (HOP * 2.0)));
-    } else {
-      istft(Fin, Nf + 2, WIN, env_c, Lh, 1.f, h0);
-      minphase_core(S1In{h0, Lh, nullptr, 0, 0, nullptr}, hm, Lm, true, (float)(WIN / (HOP * 2.0)));
-    }
+    c2r(Fin, (long long)U * (Nf + 2), frames, 1.f / NFFT, 1);
+    minphase_core(S1In{nullptr, Lh, frames, Nf + 2, WIN, env_c}, hm, Lm, true, (float)(WIN / (HOP * 2.0)));
     stft(hm, Lm, WIN - HOP, Nf, 1.f, H);          // frames 1..Nf of the centred STFT: frame k starts at 128 (k+1) - 512
   }
   // G_Fin from G_H
   void cons_backward(const float* GHin) {
-    if (use_fft) {                                   // ghm = stft_adj(G_H), gathered from the frames by the first transform
-      c2r(GHin, (long long)U * Nf, frames, 1.f, 0);
-      fft_first(S1In{nullptr, Lm, frames, Nf, WIN - HOP, ones}, true, -1);      // GZ = FFT([0, ghm[1:], zeros]) / N2 ...
-    } else {
-      stft_adj(GHin, Lm, WIN - HOP, Nf, 1.f, ghm);
-      fft_first(S1In{ghm, Lm, nullptr, 0, 0, nullptr}, true, -1);
-    }
+    c2r(GHin, (long long)U * Nf, frames, 1.f, 0);                              // ghm = stft_adj(G_H), gathered from the frames by the first transform
+    fft_first(S1In{nullptr, Lm, frames, Nf, WIN - HOP, ones}, true, -1);       // GZ = FFT([0, ghm[1:], zeros]) / N2 ...
     fft_mid256<-1, 2>(1.f / N2);                     // ... | gM, g_phi | FFT ...
     fft_mid101();                                    // ... | Hilbert window | IFFT ...
     fft_mid256<1, 3>(1.f / N2);                      // ... | G_H | N2 * IFFT
@@ -1397,12 +1279,11 @@ struct BlindOp {
   // RIR-noise regulariser (reference :94-100): loss(rir, (rir + t n).detach()), gradient w.r.t. the subband filter's output left in X2
   void reg_chain(const float* noise, float t_op, const float* t_op_dev, float w_reg) {
     fir(Xdelta, 0, Td, Ybuf);                                                                       // rir = istft(FIR(Xdelta, H)), never materialised:
-    istft_stft(Ybuf, Td, WIN + WIN / 2, env_d, Lr, norm, WIN, Td, 1.f / norm, X3, noise, t_op, t_op_dev, rir);   // STFT(rir + t n)
+    istft_stft(Ybuf, Td, WIN + WIN / 2, env_d, Lr, norm, WIN, Td, 1.f / norm, X3, noise, t_op, t_op_dev);   // STFT(rir + t n)
     hipLaunchKernelGGL(compress_kernel, dim3(gridf((long long)U * Td * FB)), dim3(256), 0, st, (const float*)X3, Rc, (long long)U * Td, c.comp);
-    if (use_fft) stft_of_frames(Td, WIN + WIN / 2, env_d, Lr, WIN, Td, 1.f / norm, X2);              // STFT(rir) from the same frames
-    else stft(rir, Lr, WIN, Td, 1.f / norm, X2);
+    stft_of_frames(Td, WIN + WIN / 2, env_d, Lr, WIN, Td, 1.f / norm, X2);                           // STFT(rir) from the same frames
     comp_loss(Rc, X2, X3, Td, w_reg, losses + U, 0);
-    stft_adj_istft_adj(X3, Lr, WIN, Td, 1.f / norm, Td, WIN + WIN / 2, env_d, norm, X2, sig2);
+    stft_adj_istft_adj(X3, Lr, WIN, Td, 1.f / norm, Td, WIN + WIN / 2, env_d, norm, X2);
   }
   void degrade(const float* x, float* y) {
     stft(x, L, WIN, T, 1.f / norm, X1);
@@ -1415,19 +1296,10 @@ struct BlindOp {
   }
 };
 
-static void host_tables(BlindOp* o, std::vector<float>& Bf, std::vector<float>& Bi, std::vector<float>& w, double& norm2) {
-  Bf.assign((size_t)LDSP * WIN, 0.f); Bi.assign((size_t)WIN * LDSP, 0.f); w.resize(WIN);
+static void host_window(std::vector<float>& w, double& norm2) {          // hann(512) (periodic) and sum of squares (the STFT's 1/sqrt(sum w^2) norm)
+  w.resize(WIN);
   norm2 = 0;
   for (int n = 0; n < WIN; ++n) { const double v = 0.5 - 0.5 * std::cos(2.0 * PI * n / WIN); w[n] = (float)v; norm2 += (double)(float)v * (double)(float)v; }
-  for (int f = 0; f < FB; ++f)
-    for (int n = 0; n < WIN; ++n) {
-      const double ang = 2.0 * PI * (double)(((long long)f * n) % NFFT) / NFFT;
-      Bf[((size_t)f * 2 + 0) * WIN + n] = (float)(w[n] * std::cos(ang));
-      Bf[((size_t)f * 2 + 1) * WIN + n] = (float)(-w[n] * std::sin(ang));
-      const double cf = (f == 0 || f == NFFT / 2) ? 1.0 : 2.0;
-      Bi[(size_t)n * LDSP + f * 2 + 0] = (float)(cf / NFFT * std::cos(ang) * w[n]);
-      Bi[(size_t)n * LDSP + f * 2 + 1] = (float)(-cf / NFFT * std::sin(ang) * w[n]);
-    }
 }
 static std::vector<float> inv_env_of(const std::vector<float>& w, int Tn) {
   std::vector<double> e((size_t)(Tn - 1) * HOP + NFFT, 0.0);
@@ -1448,15 +1320,9 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
   o->T = 1 + (L + WIN) / HOP;
   o->Lh = HOP * cfg.Nf; o->Lm = o->Lh + HOP; o->Lr = o->Lh + 1024; o->Td = 1 + (o->Lr + WIN) / HOP;
   if (2 * o->Lm != N2) { set_error("Nf must be 100 (25856-point minimum-phase FFT)"); delete o; return BUDDY_ERR_ARG; }
-  std::vector<float> Bf, Bi, w; double norm2;
-  host_tables(o, Bf, Bi, w, norm2);
+  std::vector<float> w; double norm2;
+  host_window(w, norm2);
   o->norm = (float)std::sqrt((double)(float)norm2);
-  UP(Bf, Bf); UP(Bi, Bi);
-  {  // transposed copies for the adjoint GEMMs: the k-contiguous operand path of the GEMM kernel is ~25 % faster than its k-major path
-    std::vector<float> BfT((size_t)WIN * LDSP), BiT((size_t)LDSP * WIN);
-    for (int n = 0; n < LDSP; ++n) for (int k = 0; k < WIN; ++k) { BfT[(size_t)k * LDSP + n] = Bf[(size_t)n * WIN + k]; BiT[(size_t)n * WIN + k] = Bi[(size_t)k * LDSP + n]; }
-    UP(BfT, BfT); UP(BiT, BiT);
-  }
   std::vector<float> eT = inv_env_of(w, o->T), ed = inv_env_of(w, o->Td), ec = inv_env_of(w, cfg.Nf + 2);
   UP(env_T, eT); UP(env_d, ed); UP(env_c, ec);
   std::vector<float> ones((size_t)((o->T > o->Td ? o->T : o->Td) + 8) * HOP + NFFT, 1.f); UP(ones, ones);
@@ -1488,8 +1354,7 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
   UP(w101, w101); UP(w256, w256); UP(twN, tw);
   { std::vector<float2> w1k(1024);
     for (int i = 0; i < 1024; ++i) w1k[i] = make_float2((float)std::cos(2 * PI * i / 1024), (float)std::sin(2 * PI * i / 1024));
-    UP(w1024, w1k); UP(win, w);
-    o->use_fft = !(getenv("BUDDY_OP_FFT") && atoi(getenv("BUDDY_OP_FFT")) == 0); }
+    UP(w1024, w1k); UP(win, w); }
   const int U_ = U, Nf = cfg.Nf, Td = o->Td;
   const int T = o->T > Td ? o->T : Td;            // work buffers hold either the signal (T frames) or the time-RIR (Td frames)
   const int Lmax = L > o->Lr ? L : o->Lr;
@@ -1498,13 +1363,13 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
   DA(m_d, U_ * o->E * o->NB); DA(v_d, U_ * o->E * o->NB); DA(m_w, U_ * o->E * o->NB); DA(v_w, U_ * o->E * o->NB);
   DA(m_p, (size_t)U_ * Nf * FB); DA(v_p, (size_t)U_ * Nf * FB);
   DA(H, specH); DA(Yc, specT); DA(Xdelta, (size_t)Td * LDSP + 8);
-  DA(sp, (size_t)U_ * ((size_t)(T + 4) * HOP + NFFT)); DA(frames, (size_t)U_ * (T + 2) * WIN);
+  DA(frames, (size_t)U_ * (T + 2) * WIN);
   DA(X1, specT); DA(X2, specT); DA(X3, specT); DA(Ybuf, specT); DA(sig1, (size_t)U_ * (Lmax + 8)); DA(sig2, (size_t)U_ * (Lmax + 8));
   DA(A, (size_t)U_ * Nf * FB); DA(Apre, (size_t)U_ * Nf * FB); DA(logdm, U_ * Nf * o->K); DA(dmv, U_ * Nf * o->K); DA(gdm, U_ * Nf * o->K);
   DA(Fin, specH); DA(GFin, specH); DA(GH, specH); DA(gphi, (size_t)U_ * Nf * FB);
   DA(gdecay, U_ * o->E * o->NB); DA(gw, U_ * o->E * o->NB);
-  DA(h0, (size_t)U_ * o->Lh); DA(hm, (size_t)U_ * o->Lm); DA(ghm, (size_t)U_ * o->Lm); DA(gh0, (size_t)U_ * o->Lh);
-  DA(c1, (size_t)U_ * N2); DA(c2, (size_t)U_ * N2); DA(c3, (size_t)U_ * N2); DA(Hf, (size_t)U_ * N2);
+  DA(hm, (size_t)U_ * o->Lm); DA(gh0, (size_t)U_ * o->Lh);
+  DA(c1, (size_t)U_ * N2); DA(c2, (size_t)U_ * N2); DA(Hf, (size_t)U_ * N2);
   DA(Mabs, (size_t)U_ * N2); DA(phim, (size_t)U_ * N2); DA(gM, (size_t)U_ * N2);
   DA(partial, (size_t)U_ * 64); DA(losses, (size_t)U_ * 4);
   o->big_lds = hipFuncSetAttribute((const void*)fir_sb_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
@@ -1651,10 +1516,10 @@ int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* l
   const int U = o->U, T = o->T, L = o->L;
   o->stft(x_den, L, WIN, T, 1.f / o->norm, o->X1);
   o->fir(o->X1, (long long)T * LDSP, T, o->Ybuf);
-  o->istft_stft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, o->norm, WIN, T, 1.f / o->norm, o->X2, nullptr, 0.f, nullptr, o->sig1);
+  o->istft_stft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, o->norm, WIN, T, 1.f / o->norm, o->X2);
   o->comp_loss(o->Yc, o->X2, g_x ? o->X3 : nullptr, T, weight, loss, 0);
   if (g_x) {
-    o->stft_adj_istft_adj(o->X3, L, WIN, T, 1.f / o->norm, T, WIN + WIN / 2, o->env_T, o->norm, o->X2, o->sig2);
+    o->stft_adj_istft_adj(o->X3, L, WIN, T, 1.f / o->norm, T, WIN + WIN / 2, o->env_T, o->norm, o->X2);
     hipLaunchKernelGGL(fir_adjx_kernel, dim3(gridf((long long)U * T * FB)), dim3(256), 0, st, (const float*)o->X2, (const float*)o->H, o->X3, U, T, o->Nf);
     o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, g_x);
   }
@@ -1688,7 +1553,7 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
   const float norm = o->norm;
   o->update_H();
   if (!have_Xd) o->stft(x_den, L, WIN, T, 1.f / norm, o->X1);          // X1 = STFT(x_den) stays valid across the iterations
-  if (noise && o->use_fft && o->fir_lds_ok()) {
+  if (noise && o->fir_lds_ok()) {
     // The reconstruction term and the RIR-noise regulariser (reference :94-100: loss(rir, (rir + t n).detach())) are the same chain
     //   FIR by H -> iSTFT -> STFT -> compressed-spectrum loss -> adjoints -> tap gradient
     // on two inputs (STFT(x_den), T frames; STFT(delta), Td frames): every kernel of the chain takes both as two jobs of ONE launch (7 launches
@@ -1715,9 +1580,9 @@ static int param_grads(BlindOp* o, const float* x_den, const float* noise, float
   } else {
     // reconstruction term
     o->fir(o->X1, (long long)T * LDSP, T, o->Ybuf);
-    o->istft_stft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, norm, WIN, T, 1.f / norm, o->X2, nullptr, 0.f, nullptr, o->sig1);
+    o->istft_stft(o->Ybuf, T, WIN + WIN / 2, o->env_T, L, norm, WIN, T, 1.f / norm, o->X2);
     o->comp_loss(o->Yc, o->X2, o->X3, T, w_rec, o->losses, 0);
-    o->stft_adj_istft_adj(o->X3, L, WIN, T, 1.f / norm, T, WIN + WIN / 2, o->env_T, norm, o->X2, o->sig2);
+    o->stft_adj_istft_adj(o->X3, L, WIN, T, 1.f / norm, T, WIN + WIN / 2, o->env_T, norm, o->X2);
     o->gradh(o->X1, (long long)T * LDSP, o->X2, T, 0);
     if (noise) {
       o->reg_chain(noise, t_op, t_op_dev, w_reg);
