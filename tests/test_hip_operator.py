@@ -96,6 +96,31 @@ def test_parameter_gradients():
     assert rel(gw, gs[1]) < 5e-3
 
 
+def test_parameter_gradients_without_regulariser():
+    """noise == NULL: the reconstruction term alone (the path that does not share its launches with the regulariser chain)"""
+    from buddy_amd import _lib
+    from buddy_amd.utils.losses import get_loss
+    U, L = 2, 16000
+    args, opt, oph, nt, nh = make_ops(U, L)
+    ps = args.tester.posterior_sampling
+    x, y = signals(U, L)
+    oph.hip_bind(y, ps)
+    lp = get_loss(ps.rec_loss_params, opt)
+    for p in opt.params + opt.params_phases:
+        p.requires_grad = True
+    opt.update_H()
+    l1 = lp(y, opt.degradation(x), per_utt=True)
+    gs = torch.autograd.grad(l1.sum(), opt.params + opt.params_phases)
+    gd = torch.empty_like(gs[0]); gw = torch.empty_like(gs[1]); gp = torch.empty_like(gs[2]); ls = torch.zeros(2 * U, device="cuda")
+    _lib.check(_lib.load().buddy_blindop_param_grads(oph._h, x.contiguous().data_ptr(), None, 0.0, 512.0, 0.0, gd.data_ptr(), gw.data_ptr(), gp.data_ptr(),
+                                                     ls.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rel(ls[:U], l1) < 3e-4
+    assert rel(gp, gs[2]) < 5e-3
+    assert rel(gd, gs[0]) < 5e-3
+    assert rel(gw, gs[1]) < 5e-3
+
+
 def test_optimize_loop_matches_torch_adam():
     U, L = 2, 16000
     args, opt, oph, nt, nh = make_ops(U, L)
