@@ -218,29 +218,31 @@ __global__ __launch_bounds__(256) void fir_sb_lds_kernel(FirSegs segs, const flo
 }
 // GH[u][k][f] (+)= sum_t conj(X[u][t + 1 - k][f]) GY[u][t][f]; grid (ceil(Nf / 16), ceil(FB / 32), U), 256 threads = 32 bins x 2 tap groups of 8 x 4
 // frame slots; frames in chunks of 64 (slot s takes frames 16 s ... 16 s + 15 of each chunk); the four slot sums are added in fixed order
-constexpr int GL_TAPS = 16, GL_CH = 64, GL_SLOT = 16;
+constexpr int GL_TPT = 17, GL_TAPS = 2 * GL_TPT, GL_CH = 64, GL_SLOT = 16;      // taps per thread / per workgroup; frames per chunk / per slot
 struct GradSeg { const float* X; long long xs; const float* GY; int T; };
 struct GradSegs { GradSeg s[2]; int n; };
 // one launch sums the tap gradients of up to two (X, GY) pairs; each pair is accumulated from zero and reduced on its own, the second sum is added to
 // the first (exactly what two launches, the second accumulating into GH, did)
 __global__ __launch_bounds__(256) void fir_gradh_lds_kernel(GradSegs segs, float* __restrict__ GH, int Nf, int accumulate) {
-  __shared__ float2 Xs[(GL_CH + GL_TAPS - 1) * FL_BINS];     // frames c0 + 1 - (k0 + 15) ... c0 + 64 - k0
-  __shared__ float2 Gs[GL_CH * FL_BINS];
-  __shared__ float2 red[4][GL_TAPS][FL_BINS];
-  const int u = blockIdx.z, f0 = blockIdx.y * FL_BINS, k0 = blockIdx.x * GL_TAPS;
+  __shared__ float2 sm[(GL_CH + GL_TAPS - 1 + GL_CH) * FL_BINS];
+  __shared__ float2 tot_s[GL_TAPS][FL_BINS];                 // the sums of the segments done so far (written and read by the same sl == 0 thread)
+  float2* Xs = sm;                                           // [GL_CH + GL_TAPS - 1][32]: frames c0 + 1 - (k0 + GL_TAPS - 1) ... c0 + 64 - k0
+  float2* Gs = sm + (GL_CH + GL_TAPS - 1) * FL_BINS;         // [GL_CH][32]
+  float2 (*red)[GL_TAPS][FL_BINS] = reinterpret_cast<float2 (*)[GL_TAPS][FL_BINS]>(sm);     // [4][GL_TAPS][32], after the chunk loop (same memory)
+  static_assert(4 * GL_TAPS <= GL_CH + GL_TAPS - 1 + GL_CH, "the slot sums reuse the slab memory");
+  // grid (bin tiles, U, tap blocks): the linear workgroup id modulo 8 (= the XCD it lands on: 17 * 8 is a multiple of 8) does not depend on the tap block,
+  // so the blocks that read the same (X, GY) slab share one L2
+  const int u = blockIdx.y, f0 = blockIdx.x * FL_BINS, k0 = blockIdx.z * GL_TAPS;
   const int tid = threadIdx.x, b = tid & 31, kg = (tid >> 5) & 1, sl = tid >> 6;
   const bool fok = f0 + b < FB;
-  const int kk = k0 + 8 * kg;                                // this thread's taps kk ... kk + 7
-  float2 tot[8];                                             // (sl == 0 threads) the sums of the segments done so far
-#pragma unroll
-  for (int j = 0; j < 8; ++j) tot[j] = make_float2(0.f, 0.f);
+  const int kk = k0 + GL_TPT * kg;                           // this thread's taps kk ... kk + GL_TPT - 1
   for (int sg_i = 0; sg_i < segs.n; ++sg_i) {
     const int T = segs.s[sg_i].T;
     const float2* Xu = reinterpret_cast<const float2*>(segs.s[sg_i].X + (long long)u * segs.s[sg_i].xs);
     const float2* Gu = reinterpret_cast<const float2*>(segs.s[sg_i].GY + (long long)u * T * LDSP);
-    v2f ac[8];
+    v2f ac[GL_TPT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ac[j] = v2f{0.f, 0.f};
+    for (int j = 0; j < GL_TPT; ++j) ac[j] = v2f{0.f, 0.f};
     // the next chunk's slab is requested before the arithmetic of the current one (registers), stored to LDS after it
     constexpr int NXR = (GL_CH + GL_TAPS - 1 + 7) / 8, NGR = GL_CH / 8;
     const int g8 = tid >> 5;
@@ -267,42 +269,43 @@ __global__ __launch_bounds__(256) void fir_gradh_lds_kernel(GradSegs segs, float
       for (int i = 0; i < NGR; ++i) Gs[(g8 + 8 * i) * FL_BINS + b] = vg[i];
       __syncthreads();
       if (c0 + GL_CH < T) fetch(c0 + GL_CH);
-      // frame t = c0 + 16 sl + q: X[t + 1 - kk - j] = Xs row (16 sl + q + GL_TAPS - 1 - 8 kg - j)
-      const int base = GL_SLOT * sl + GL_TAPS - 1 - 8 * kg;
-      float2 w[8];
+      // frame t = c0 + 16 sl + q: X[t + 1 - kk - j] = Xs row (16 sl + q + GL_TAPS - 1 - GL_TPT kg - j)
+      const int base = GL_SLOT * sl + GL_TAPS - 1 - GL_TPT * kg;
+      float2 w[GL_TPT];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = Xs[(base - j) * FL_BINS + b];
+      for (int j = 0; j < GL_TPT; ++j) w[j] = Xs[(base - j) * FL_BINS + b];
 #pragma unroll
       for (int q = 0; q < GL_SLOT; ++q) {
         const float2 gy = Gs[(GL_SLOT * sl + q) * FL_BINS + b];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ac[j] = cmac_conj(ac[j], w[j], gy);
+        for (int j = 0; j < GL_TPT; ++j) ac[j] = cmac_conj(ac[j], w[j], gy);
 #pragma unroll
-        for (int j = 7; j > 0; --j) w[j] = w[j - 1];
+        for (int j = GL_TPT - 1; j > 0; --j) w[j] = w[j - 1];
         if (q + 1 < GL_SLOT) w[0] = Xs[(base + q + 1) * FL_BINS + b];
       }
     }
     __syncthreads();                                         // red may still be read by the previous segment's reduction
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[sl][8 * kg + j][b] = make_float2(ac[j].x, ac[j].y);
+    for (int j = 0; j < GL_TPT; ++j) red[sl][GL_TPT * kg + j][b] = make_float2(ac[j].x, ac[j].y);
     __syncthreads();
     if (sl == 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float r = red[0][8 * kg + j][b].x, im = red[0][8 * kg + j][b].y;
+      for (int j = 0; j < GL_TPT; ++j) {
+        float r = red[0][GL_TPT * kg + j][b].x, im = red[0][GL_TPT * kg + j][b].y;
 #pragma unroll
-        for (int sg = 1; sg < 4; ++sg) { r += red[sg][8 * kg + j][b].x; im += red[sg][8 * kg + j][b].y; }
-        tot[j] = sg_i == 0 ? make_float2(r, im) : make_float2(r + tot[j].x, im + tot[j].y);
+        for (int sg = 1; sg < 4; ++sg) { r += red[sg][GL_TPT * kg + j][b].x; im += red[sg][GL_TPT * kg + j][b].y; }
+        const float2 pr = tot_s[GL_TPT * kg + j][b];
+        tot_s[GL_TPT * kg + j][b] = sg_i == 0 ? make_float2(r, im) : make_float2(r + pr.x, im + pr.y);
       }
     }
   }
   if (sl == 0 && fok) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < GL_TPT; ++j) {
       const int k = kk + j;
       if (k >= Nf) continue;
       float2* o = reinterpret_cast<float2*>(GH + ((long long)u * Nf + k) * LDSP) + f0 + b;
-      float r = tot[j].x, im = tot[j].y;
+      float r = tot_s[GL_TPT * kg + j][b].x, im = tot_s[GL_TPT * kg + j][b].y;
       if (accumulate) { r += o->x; im += o->y; }
       *o = make_float2(r, im);
     }
@@ -1250,7 +1253,7 @@ struct BlindOp {
     GradSegs sg; std::memset(&sg, 0, sizeof(sg));
     sg.s[0] = GradSeg{X0, xs0, GY0, T0}; sg.n = 1;
     if (X1b) { sg.s[1] = GradSeg{X1b, xs1, GY1, T1}; sg.n = 2; }
-    hipLaunchKernelGGL(fir_gradh_lds_kernel, dim3((Nf + GL_TAPS - 1) / GL_TAPS, (FB + FL_BINS - 1) / FL_BINS, U), dim3(256), 0, st, sg, GH, Nf, accumulate);
+    hipLaunchKernelGGL(fir_gradh_lds_kernel, dim3((FB + FL_BINS - 1) / FL_BINS, U, (Nf + GL_TAPS - 1) / GL_TAPS), dim3(256), 0, st, sg, GH, Nf, accumulate);
   }
   void gradh(const float* X, long long xs, const float* GY, int Tn, int accumulate) {
     static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
