@@ -23,6 +23,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL across processes); must be set before HIP starts
+
 import numpy as np
 import torch
 
