@@ -798,15 +798,31 @@ __global__ __launch_bounds__(S1_THREADS) void fft_stageB_real_kernel(const float
 // Replaces the four DFT-as-GEMM products (forward, inverse and their two adjoints: 2 x 512 x 1028 MACs per frame on the matrix cores) by
 // 5 N log2 N flops per frame; the window, the 1/sqrt(sum w^2) norm, the one-sided factors {1, 2, ..., 2, 1}/N and the scale are folded in.
 constexpr int FLD = 66;                       // LDS row stride (complex) of the [16][64] exchange image
+// The twiddles a lane needs depend on the lane only: its row W1024^(r b), b < 16, of the [64][16] table (`Wrow`, 128 contiguous bytes per lane)
+// and W64^(r0 c0), c0 = 1..3 (`W64t`, [16][4]).  They are loaded straight into registers while the frame's samples are in flight (Fft1024Tw);
+// the first version parked the 1024-entry table in LDS per workgroup: 8 KB more LDS (3 instead of 4 workgroups per CU) and a load -> store -> barrier
+// prologue before the first butterfly.
+struct Fft1024Tw { float2 row[16]; float2 c[3]; };
+__device__ __forceinline__ void fft1024_load_tw(Fft1024Tw& t, const float2* __restrict__ Wrow, const float2* __restrict__ W64t, int r) {
+  const float4* p = reinterpret_cast<const float4*>(Wrow + r * 16);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const float4 q = p[i]; t.row[2 * i] = make_float2(q.x, q.y); t.row[2 * i + 1] = make_float2(q.z, q.w); }
+  const float4* c = reinterpret_cast<const float4*>(W64t + (r & 15) * 4);
+  const float4 c0 = c[0], c1 = c[1];
+  t.c[0] = make_float2(c0.z, c0.w); t.c[1] = make_float2(c1.x, c1.y); t.c[2] = make_float2(c1.z, c1.w);
+}
+// LDS written by this wave, read by this wave: no workgroup barrier, only the wave's own ordering
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <int SGN>
-__device__ __forceinline__ void fft1024_core(float2 (&v)[16], float2* S, const float2* W, int r) {
+__device__ __forceinline__ void fft1024_core(float2 (&v)[16], float2* S, const Fft1024Tw& tw, int r) {
   dft16<SGN>(v);                                                       // over a: v[b] = sum_a x[64 a + r] W16^(a b)
 #pragma unroll
-  for (int b = 0; b < 16; ++b) {
-    const float2 w = W[(r * b) & 1023];
-    S[b * FLD + r] = cmul(v[b], make_float2(w.x, SGN * w.y));
-  }
-  __syncthreads();
+  for (int b = 0; b < 16; ++b) S[b * FLD + r] = cmul(v[b], make_float2(tw.row[b].x, SGN * tw.row[b].y));
+  wave_lds_sync();                                                     // the exchange image S is private to the wave
   const int r0 = r & 15;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {                                        // 4-point DFTs over r1, in place
@@ -818,13 +834,13 @@ __device__ __forceinline__ void fft1024_core(float2 (&v)[16], float2* S, const f
     const float2 jd = make_float2(-SGN * d13.y, SGN * d13.x);           // (SGN i) (x1 - x3)
     const float2 z0 = make_float2(s02.x + s13.x, s02.y + s13.y), z1 = make_float2(d02.x + jd.x, d02.y + jd.y);
     const float2 z2 = make_float2(s02.x - s13.x, s02.y - s13.y), z3 = make_float2(d02.x - jd.x, d02.y - jd.y);
-    const float2 w1 = W[(16 * r0) & 1023], w2 = W[(32 * r0) & 1023], w3 = W[(48 * r0) & 1023];     // W64^(r0 c0)
+    const float2 w1 = tw.c[0], w2 = tw.c[1], w3 = tw.c[2];                                          // W64^(r0 c0)
     q[0] = z0;
     q[16] = cmul(z1, make_float2(w1.x, SGN * w1.y));
     q[32] = cmul(z2, make_float2(w2.x, SGN * w2.y));
     q[48] = cmul(z3, make_float2(w3.x, SGN * w3.y));
   }
-  __syncthreads();
+  wave_lds_sync();                                                     // the exchange image S is private to the wave
   const float2* q = S + (r & 15) * FLD + 16 * (r >> 4);               // lane = (b = r & 15, c0 = r >> 4)
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = q[i];
@@ -847,11 +863,11 @@ struct R2cSrc {
 struct R2cJob { R2cSrc sc; int Tn; int rows; int blocks; float* out; };
 struct R2cJobs { R2cJob j[3]; };
 template <bool GATHER>
-__global__ __launch_bounds__(256) void fft1024_r2c_kernel(R2cJobs jobs, const float* __restrict__ win, const float2* __restrict__ Wg, float fac, int cf) {
-  __shared__ float2 W[1024];
+__global__ __launch_bounds__(256) void fft1024_r2c_kernel(R2cJobs jobs, const float* __restrict__ win, const float2* __restrict__ Wrow,
+                                                          const float2* __restrict__ W64t, float fac, int cf) {
   __shared__ float2 S[4][16 * FLD];
-  for (int i = threadIdx.x; i < 1024; i += 256) W[i] = Wg[i];
   const int w = threadIdx.x >> 6, r = threadIdx.x & 63;
+  Fft1024Tw tw; fft1024_load_tw(tw, Wrow, W64t, r);
   int blk = blockIdx.x;
   const int ji = blk < jobs.j[0].blocks ? 0 : (blk < jobs.j[0].blocks + jobs.j[1].blocks ? 1 : 2);
   if (ji >= 1) blk -= jobs.j[0].blocks;
@@ -867,10 +883,13 @@ __global__ __launch_bounds__(256) void fft1024_r2c_kernel(R2cJobs jobs, const fl
 #pragma unroll
   for (int a = 0; a < 16; ++a) v[a] = make_float2(0.f, 0.f);
   if (ok) {
-    // all loads of the wave's 8 x 64 samples are issued before the first use (a load -> use loop would pay one L2 round trip per sample);
+    // all loads of the wave's 8 x 64 samples are issued before the first use (a load -> use loop would pay one L2 round trip per sample), and
+    // UNCONDITIONALLY, from an index clamped into the array, the condition applied to the loaded value afterwards: a `cond ? p[i] : 0` load is a
+    // branch with its own exec-mask save / restore and wait (the first version of this kernel spent 765 scalar and 151 wait instructions on them);
     // sample j of the overlap-add has exactly four candidate frames j / 128 - 3 .. j / 128, summed in ascending frame order as ola_kernel does
     float fv[8][GATHER ? 4 : 1], ea[8], eb[8], ad[8];
-    bool in[8];
+    bool in[8], fin[8][GATHER ? 4 : 1];
+    const long long ubase = (long long)u * sc.Ls;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       const int n = 64 * a + r, s = HOP * t + n - sc.P;
@@ -881,26 +900,31 @@ __global__ __launch_bounds__(256) void fft1024_r2c_kernel(R2cJobs jobs, const fl
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int tt = tq - 3 + k;
-          fv[a][k] = (in[a] && tt >= 0 && tt < sc.Tsrc) ? sc.fr[((long long)u * sc.Tsrc + tt) * WIN + m0 + HOP * (3 - k)] : 0.f;
+          fin[a][k] = tt >= 0 && tt < sc.Tsrc;
+          fv[a][k] = sc.fr[((long long)u * sc.Tsrc + (fin[a][k] ? tt : 0)) * WIN + m0 + HOP * (3 - k)];
         }
-        ea[a] = in[a] ? sc.envA[j] : 0.f;
+        ea[a] = sc.envA[j];
       } else {
-        fv[a][0] = in[a] ? sc.sig[(long long)u * sc.Ls + sc_s] : 0.f;
+        fv[a][0] = sc.sig[ubase + sc_s];
       }
-      ad[a] = (in[a] && sc.add) ? sc.add[(long long)u * sc.Ls + sc_s] : 0.f;
-      eb[a] = (in[a] && sc.envB) ? sc.envB[HOP * t + n] : 1.f;
+      if (sc.add) ad[a] = sc.add[ubase + sc_s];
+      if (sc.envB) eb[a] = sc.envB[HOP * t + n];
     }
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       float val = fv[a][0];
-      if (GATHER) { val = 0.f; for (int k = 0; k < 4; ++k) val += fv[a][k]; val *= ea[a]; }
+      if (GATHER) {
+        val = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) val += fin[a][k] ? fv[a][k] : 0.f;
+        val *= ea[a];
+      }
       if (sc.add) val += add_scale * ad[a];
       if (sc.envB) val = val * eb[a];
       v[a].x = (in[a] ? val : 0.f) * win[64 * a + r];
     }
   }
-  __syncthreads();
-  fft1024_core<-1>(v, S[w], W, r);
+  fft1024_core<-1>(v, S[w], tw, r);
   if (!ok) return;
   float2* o = reinterpret_cast<float2*>(out + row * LDSP);
 #pragma unroll
@@ -915,11 +939,11 @@ __global__ __launch_bounds__(256) void fft1024_r2c_kernel(R2cJobs jobs, const fl
 // [rows][1028] one-sided spectra -> [rows][512] real frames: frames[n] = fac * win[n] * Re sum_{k <= 512} (cf ? cf(k) : 1) in[k] exp(+2 pi i k n / 1024)
 struct C2rJob { const float* in; float* frames; int rows; int blocks; };
 struct C2rJobs { C2rJob j[2]; };
-__global__ __launch_bounds__(256) void fft1024_c2r_kernel(C2rJobs jobs, const float* __restrict__ win, const float2* __restrict__ Wg, float fac, int cf) {
-  __shared__ float2 W[1024];
+__global__ __launch_bounds__(256) void fft1024_c2r_kernel(C2rJobs jobs, const float* __restrict__ win, const float2* __restrict__ Wrow,
+                                                          const float2* __restrict__ W64t, float fac, int cf) {
   __shared__ float2 S[4][16 * FLD];
-  for (int i = threadIdx.x; i < 1024; i += 256) W[i] = Wg[i];
   const int w = threadIdx.x >> 6, r = threadIdx.x & 63;
+  Fft1024Tw tw; fft1024_load_tw(tw, Wrow, W64t, r);
   const bool second = (int)blockIdx.x >= jobs.j[0].blocks;
   const float* __restrict__ in = second ? jobs.j[1].in : jobs.j[0].in;
   float* __restrict__ frames = second ? jobs.j[1].frames : jobs.j[0].frames;
@@ -934,8 +958,7 @@ __global__ __launch_bounds__(256) void fft1024_c2r_kernel(C2rJobs jobs, const fl
     if (ok && k <= 512) { x = f[k]; if (cf && k != 0 && k != 512) { x.x *= 2.f; x.y *= 2.f; } }
     v[a] = x;
   }
-  __syncthreads();
-  fft1024_core<1>(v, S[w], W, r);
+  fft1024_core<1>(v, S[w], tw, r);
   if (!ok) return;
 #pragma unroll
   for (int c1 = 0; c1 < 8; ++c1) { const int n = r + 64 * c1; frames[row * WIN + n] = fac * win[n] * v[c1].x; }
@@ -1087,7 +1110,7 @@ struct BlindOp {
   float *ones = nullptr, *env_T = nullptr, *env_d = nullptr, *env_c = nullptr;
   float norm = 1.f;
   int *idx = nullptr, *fge = nullptr; float *frac = nullptr, *corr = nullptr, *dpm = nullptr;
-  float2 *w101 = nullptr, *w256 = nullptr, *twN = nullptr, *w1024 = nullptr; float* win = nullptr;
+  float2 *w101 = nullptr, *w256 = nullptr, *twN = nullptr, *w1024r = nullptr, *w64t = nullptr; float* win = nullptr;
   // parameters + Adam state
   float *decay = nullptr, *wts = nullptr, *phi = nullptr;
   float *m_d = nullptr, *v_d = nullptr, *m_w = nullptr, *v_w = nullptr, *m_p = nullptr, *v_p = nullptr;
@@ -1136,15 +1159,15 @@ struct BlindOp {
       jobs.j[i].sc = rq[i].sc; jobs.j[i].Tn = rq[i].Tn; jobs.j[i].rows = U * rq[i].Tn; jobs.j[i].blocks = (U * rq[i].Tn + 3) / 4; jobs.j[i].out = rq[i].out;
       blocks += (unsigned)jobs.j[i].blocks;
     }
-    if (rq[0].sc.fr) hipLaunchKernelGGL(fft1024_r2c_kernel<true>, dim3(blocks), dim3(256), 0, st, jobs, (const float*)win, (const float2*)w1024, fac, cf);
-    else hipLaunchKernelGGL(fft1024_r2c_kernel<false>, dim3(blocks), dim3(256), 0, st, jobs, (const float*)win, (const float2*)w1024, fac, cf);
+    if (rq[0].sc.fr) hipLaunchKernelGGL(fft1024_r2c_kernel<true>, dim3(blocks), dim3(256), 0, st, jobs, (const float*)win, (const float2*)w1024r, (const float2*)w64t, fac, cf);
+    else hipLaunchKernelGGL(fft1024_r2c_kernel<false>, dim3(blocks), dim3(256), 0, st, jobs, (const float*)win, (const float2*)w1024r, (const float2*)w64t, fac, cf);
   }
   void r2c(const R2cSrc& sc, int Tn, float* out, float fac, int cf) { const R2cReq rq{sc, Tn, out}; r2c_multi(&rq, 1, fac, cf); }
   void c2r2(const float* in0, long long rows0, float* fr0, const float* in1, long long rows1, float* fr1, float fac, int cf) {
     C2rJobs jobs; std::memset(&jobs, 0, sizeof(jobs));
     jobs.j[0].in = in0; jobs.j[0].frames = fr0; jobs.j[0].rows = (int)rows0; jobs.j[0].blocks = (int)((rows0 + 3) / 4);
     jobs.j[1].in = in1; jobs.j[1].frames = fr1; jobs.j[1].rows = (int)rows1; jobs.j[1].blocks = (int)((rows1 + 3) / 4);
-    hipLaunchKernelGGL(fft1024_c2r_kernel, dim3((unsigned)(jobs.j[0].blocks + jobs.j[1].blocks)), dim3(256), 0, st, jobs, (const float*)win, (const float2*)w1024, fac, cf);
+    hipLaunchKernelGGL(fft1024_c2r_kernel, dim3((unsigned)(jobs.j[0].blocks + jobs.j[1].blocks)), dim3(256), 0, st, jobs, (const float*)win, (const float2*)w1024r, (const float2*)w64t, fac, cf);
   }
   void c2r(const float* in, long long rows, float* fr, float fac, int cf) { c2r2(in, rows, fr, nullptr, 0, nullptr, fac, cf); }
   // X[u][t][:] = scale * STFT frames of s (frame t starts at sample 128 t - P), Tn frames
@@ -1355,9 +1378,11 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
     tw[(size_t)n2 * F1 + k1] = make_float2((float)std::cos(a), (float)(std::sin(a)));
   }
   UP(w101, w101); UP(w256, w256); UP(twN, tw);
-  { std::vector<float2> w1k(1024);
-    for (int i = 0; i < 1024; ++i) w1k[i] = make_float2((float)std::cos(2 * PI * i / 1024), (float)std::sin(2 * PI * i / 1024));
-    UP(w1024, w1k); UP(win, w); }
+  { std::vector<float2> wr(64 * 16), w64(16 * 4);     // per-lane twiddle rows of the 1024-point kernels: W1024^(r b) and W64^(r0 c0) = W1024^(16 r0 c0)
+    auto W1k = [](int i) { i &= 1023; return make_float2((float)std::cos(2 * PI * i / 1024), (float)std::sin(2 * PI * i / 1024)); };
+    for (int r = 0; r < 64; ++r) for (int b = 0; b < 16; ++b) wr[r * 16 + b] = W1k(r * b);
+    for (int r0 = 0; r0 < 16; ++r0) for (int c0 = 0; c0 < 4; ++c0) w64[r0 * 4 + c0] = W1k(16 * r0 * c0);
+    UP(w1024r, wr); UP(w64t, w64); UP(win, w); }
   const int U_ = U, Nf = cfg.Nf, Td = o->Td;
   const int T = o->T > Td ? o->T : Td;            // work buffers hold either the signal (T frames) or the time-RIR (Td frames)
   const int Lmax = L > o->Lr ? L : o->Lr;
