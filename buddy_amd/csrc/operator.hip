@@ -160,9 +160,12 @@ constexpr int FL_BINS = 32, FL_FT = 8, FL_TB = 64;           // bins per workgro
 // the x tiles of the second follow those of the first.  Every launch of the captured loop costs ~5 us on top of its work.
 struct FirSeg { const float* X; long long xs; float* Y; int T; int tiles; };
 struct FirSegs { FirSeg s[2]; };
-__global__ __launch_bounds__(256) void fir_sb_lds_kernel(FirSegs segs, const float* __restrict__ H, int Nf) {
+// Nf is a template parameter (the 25 856-point minimum-phase transforms fix it at 100 anyway): slab sizes, the tap loop and every row bound are
+// compile-time, so the staging registers are exactly the rows that exist and the only conditions left are the tile's edges.
+template <int Nf>
+__global__ __launch_bounds__(256) void fir_sb_lds_kernel(FirSegs segs, const float* __restrict__ H) {
   extern __shared__ float2 fl_smem[];
-  const int nx = FL_TB + Nf - 1;                             // frames t0 - Nf + 2 ... t0 + 64
+  constexpr int nx = FL_TB + Nf - 1;                         // frames t0 - Nf + 2 ... t0 + 64
   float2* Xs = fl_smem;                                      // [nx][32]
   float2* Hs = fl_smem + nx * FL_BINS;                       // [Nf][32]
   const bool second = (int)blockIdx.x >= segs.s[0].tiles;
@@ -176,23 +179,29 @@ __global__ __launch_bounds__(256) void fir_sb_lds_kernel(FirSegs segs, const flo
   const float2* Hu = reinterpret_cast<const float2*>(H + (long long)u * Nf * LDSP);
   const bool fok = f0 + b < FB;
   const int xbase = t0 - Nf + 2;
-  {   // all global loads of the slab are issued before the first LDS store (a load -> store loop would pay one L2 round trip per row)
-    constexpr int NXR = (FL_TB + 128 - 1 + 7) / 8, NHR = 128 / 8;        // Nf <= 128
+  {   // all global loads of the slab are issued before the first LDS store (a load -> store loop would pay one L2 round trip per row);
+      // unconditional loads from clamped rows / bins, the condition applied to the value (a predicated load is a branch with its own exec-mask
+      // handling and wait)
+    constexpr int NXR = (nx + 7) / 8, NHR = (Nf + 7) / 8;
     float2 vx[NXR], vh[NHR];
+    const int fb = fok ? f0 + b : FB - 1;
 #pragma unroll
     for (int i = 0; i < NXR; ++i) {
       const int r = g + 8 * i, tt = xbase + r;
-      vx[i] = (r < nx && fok && tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+      const bool okx = fok && tt >= 0 && tt < T;
+      const float2 q = Xu[(long long)min(max(tt, 0), T - 1) * (LDSP / 2) + fb];
+      vx[i] = okx ? q : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < NHR; ++i) {
       const int k = g + 8 * i;
-      vh[i] = (k < Nf && fok) ? Hu[(long long)k * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+      const float2 q = Hu[(long long)min(k, Nf - 1) * (LDSP / 2) + fb];
+      vh[i] = fok ? q : make_float2(0.f, 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < NXR; ++i) { const int r = g + 8 * i; if (r < nx) Xs[r * FL_BINS + b] = vx[i]; }
+    for (int i = 0; i < NXR; ++i) { const int r = g + 8 * i; if (8 * i + 7 < nx || r < nx) Xs[r * FL_BINS + b] = vx[i]; }
 #pragma unroll
-    for (int i = 0; i < NHR; ++i) { const int k = g + 8 * i; if (k < Nf) Hs[k * FL_BINS + b] = vh[i]; }
+    for (int i = 0; i < NHR; ++i) { const int k = g + 8 * i; if (8 * i + 7 < Nf || k < Nf) Hs[k * FL_BINS + b] = vh[i]; }
   }
   __syncthreads();
   const int tg = g * FL_FT;                                  // this thread's outputs: t0 + tg + j
@@ -207,8 +216,8 @@ __global__ __launch_bounds__(256) void fir_sb_lds_kernel(FirSegs segs, const flo
     for (int j = 0; j < FL_FT; ++j) ac[j] = cmac(ac[j], h, w[j]);
 #pragma unroll
     for (int j = FL_FT - 1; j > 0; --j) w[j] = w[j - 1];
-    const int r = tg + Nf - 2 - k;                           // row of X[t0 + tg - k]
-    w[0] = r >= 0 ? Xs[r * FL_BINS + b] : make_float2(0.f, 0.f);
+    const int r = tg + Nf - 2 - k;                           // row of X[t0 + tg - k]; r = -1 only for the value shifted in after the last tap (never used)
+    w[0] = Xs[max(r, 0) * FL_BINS + b];
   }
   if (fok) {
 #pragma unroll
@@ -216,6 +225,7 @@ __global__ __launch_bounds__(256) void fir_sb_lds_kernel(FirSegs segs, const flo
       if (t0 + tg + j < T) reinterpret_cast<float2*>(Y + ((long long)u * T + t0 + tg + j) * LDSP)[f0 + b] = make_float2(ac[j].x, ac[j].y);
   }
 }
+constexpr int FIR_NF = 100;
 // GH[u][k][f] (+)= sum_t conj(X[u][t + 1 - k][f]) GY[u][t][f]; grid (ceil(Nf / 16), ceil(FB / 32), U), 256 threads = 32 bins x 2 tap groups of 8 x 4
 // frame slots; frames in chunks of 64 (slot s takes frames 16 s ... 16 s + 15 of each chunk); the four slot sums are added in fixed order
 constexpr int GL_TPT = 17, GL_TAPS = 2 * GL_TPT, GL_CH = 64, GL_SLOT = 16;      // taps per thread / per workgroup; frames per chunk / per slot
@@ -236,6 +246,7 @@ __global__ __launch_bounds__(256) void fir_gradh_lds_kernel(GradSegs segs, float
   const int tid = threadIdx.x, b = tid & 31, kg = (tid >> 5) & 1, sl = tid >> 6;
   const bool fok = f0 + b < FB;
   const int kk = k0 + GL_TPT * kg;                           // this thread's taps kk ... kk + GL_TPT - 1
+  const int fb = fok ? f0 + b : FB - 1;
   for (int sg_i = 0; sg_i < segs.n; ++sg_i) {
     const int T = segs.s[sg_i].T;
     const float2* Xu = reinterpret_cast<const float2*>(segs.s[sg_i].X + (long long)u * segs.s[sg_i].xs);
@@ -250,14 +261,17 @@ __global__ __launch_bounds__(256) void fir_gradh_lds_kernel(GradSegs segs, float
     auto fetch = [&](int c0) {
       const int xb = c0 + 1 - (k0 + GL_TAPS - 1);
 #pragma unroll
-      for (int i = 0; i < NXR; ++i) {
+      for (int i = 0; i < NXR; ++i) {                        // unconditional loads from clamped rows / bins, the condition applied to the value
         const int r = g8 + 8 * i, tt = xb + r;
-        vx[i] = (r < GL_CH + GL_TAPS - 1 && fok && tt >= 0 && tt < T) ? Xu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+        const bool okx = r < GL_CH + GL_TAPS - 1 && fok && tt >= 0 && tt < T;
+        const float2 q = Xu[(long long)min(max(tt, 0), T - 1) * (LDSP / 2) + fb];
+        vx[i] = okx ? q : make_float2(0.f, 0.f);
       }
 #pragma unroll
       for (int i = 0; i < NGR; ++i) {
         const int tt = c0 + g8 + 8 * i;
-        vg[i] = (fok && tt < T) ? Gu[(long long)tt * (LDSP / 2) + f0 + b] : make_float2(0.f, 0.f);
+        const float2 q = Gu[(long long)min(tt, T - 1) * (LDSP / 2) + fb];
+        vg[i] = (fok && tt < T) ? q : make_float2(0.f, 0.f);
       }
     };
     fetch(0);
@@ -1257,7 +1271,7 @@ struct BlindOp {
   void update_H() { cons_forward(); }
   bool fir_lds_ok() const {
     static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
-    return lds && big_lds && (size_t)(FL_TB + 2 * Nf - 1) * FL_BINS * sizeof(float2) <= 96 * 1024 && Nf <= 128;
+    return lds && big_lds && Nf == FIR_NF;
   }
   // Y0 = FIR(X0, H) and, when X1b is given, Y1 = FIR(X1b, H) in the same launch (LDS kernel only)
   void fir2(const float* X0, long long xs0, int T0, float* Y0, const float* X1b, long long xs1, int T1, float* Y1) {
@@ -1265,7 +1279,7 @@ struct BlindOp {
     sg.s[0] = FirSeg{X0, xs0, Y0, T0, (T0 + FL_TB - 1) / FL_TB};
     if (X1b) sg.s[1] = FirSeg{X1b, xs1, Y1, T1, (T1 + FL_TB - 1) / FL_TB};
     const size_t sm = (size_t)(FL_TB + 2 * Nf - 1) * FL_BINS * sizeof(float2);
-    hipLaunchKernelGGL(fir_sb_lds_kernel, dim3(sg.s[0].tiles + sg.s[1].tiles, (FB + FL_BINS - 1) / FL_BINS, U), dim3(256), sm, st, sg, (const float*)H, Nf);
+    hipLaunchKernelGGL(fir_sb_lds_kernel<FIR_NF>, dim3(sg.s[0].tiles + sg.s[1].tiles, (FB + FL_BINS - 1) / FL_BINS, U), dim3(256), sm, st, sg, (const float*)H);
   }
   void fir(const float* X, long long xs, int Tn, float* Y) {
     if (fir_lds_ok()) fir2(X, xs, Tn, Y, nullptr, 0, 0, nullptr);
@@ -1400,7 +1414,7 @@ int blindop_create(const BlindOpCfg& cfg, int U, int L, BlindOp** out) {
   DA(c1, (size_t)U_ * N2); DA(c2, (size_t)U_ * N2); DA(Hf, (size_t)U_ * N2);
   DA(Mabs, (size_t)U_ * N2); DA(phim, (size_t)U_ * N2); DA(gM, (size_t)U_ * N2);
   DA(partial, (size_t)U_ * 64); DA(losses, (size_t)U_ * 4);
-  o->big_lds = hipFuncSetAttribute((const void*)fir_sb_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+  o->big_lds = hipFuncSetAttribute((const void*)fir_sb_lds_kernel<FIR_NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
   {
     const size_t specD = (size_t)U_ * Td * LDSP + 8;
     DA(frames_b, (size_t)U_ * (Td + 2) * WIN);
