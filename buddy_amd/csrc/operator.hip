@@ -551,24 +551,26 @@ __global__ __launch_bounds__(S1_THREADS) void fft_stage1_kernel(S1In in, float2*
   for (int i = threadIdx.x; i < F1; i += S1_THREADS) W[i] = make_float2(w101[i].x, sign * w101[i].y);
   for (int i = threadIdx.x; i < F1 * S1_COLS; i += S1_THREADS) {
     const int n1 = i / S1_COLS, c = i - n1 * S1_COLS, n = F2 * n1 + n20 + c;
-    float v = 0.f;
-    if (n < in.Lr && (!ZERO0 || n > 0)) {
-      if (in.fr) {
-        const int j = n + in.Q, tq = j >> 7, m0 = j & (HOP - 1);
-        float fv[4];
+    float v;
+    const bool inr = n < in.Lr && (!ZERO0 || n > 0);
+    const int nc = n < in.Lr ? n : 0;                       // loads are unconditional (clamped index), the condition selects the value afterwards
+    if (in.fr) {
+      const int j = nc + in.Q, tq = j >> 7, m0 = j & (HOP - 1);
+      float fv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {                       // ascending frame order, as ola_kernel
-          const int tt = tq - 3 + k;
-          fv[k] = (tt >= 0 && tt < in.Tsrc) ? in.fr[((long long)u * in.Tsrc + tt) * WIN + m0 + HOP * (3 - k)] : 0.f;
-        }
-        const float e = in.env[j];
-        v = (((0.f + fv[0]) + fv[1]) + fv[2]) + fv[3];
-        v *= e;
-      } else {
-        v = in.xr[(long long)u * in.Lr + n];
+      for (int k = 0; k < 4; ++k) {                         // ascending frame order, as ola_kernel
+        const int tt = tq - 3 + k;
+        const bool okf = tt >= 0 && tt < in.Tsrc;
+        const float q = in.fr[((long long)u * in.Tsrc + (okf ? tt : 0)) * WIN + m0 + HOP * (3 - k)];
+        fv[k] = okf ? q : 0.f;
       }
+      const float e = in.env[j];
+      v = (((0.f + fv[0]) + fv[1]) + fv[2]) + fv[3];
+      v *= e;
+    } else {
+      v = in.xr[(long long)u * in.Lr + nc];
     }
-    X[i] = v;
+    X[i] = inr ? v : 0.f;
   }
   __syncthreads();
   const int k1 = threadIdx.x;
@@ -702,9 +704,10 @@ __global__ __launch_bounds__(S2_THREADS) void fft_mid256_kernel(const float2* y1
   const float2* yu = y1 + (long long)u * N2;
   float2 v[16];
   MpIn in[16];
+  const int k1c = ok ? k1 : 0;                              // unconditional loads (clamped column), the out-of-range columns are never stored
 #pragma unroll
-  for (int a = 0; a < 16; ++a) v[a] = ok ? yu[(16 * a + r) * F1 + k1] : make_float2(0.f, 0.f);
-  const long long e0 = (long long)u * N2 + (ok ? k1 : 0) + (long long)F1 * r;       // element c of this thread: e0 + 101 * 16 c
+  for (int a = 0; a < 16; ++a) v[a] = yu[(16 * a + r) * F1 + k1c];
+  const long long e0 = (long long)u * N2 + k1c + (long long)F1 * r;                 // element c of this thread: e0 + 101 * 16 c
 #pragma unroll
   for (int c = 0; c < 16; ++c) in[c] = mp_load<PW>(e0 + (long long)F1 * 16 * c, A);
   __syncthreads();
