@@ -19,6 +19,14 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BR = 64, BC = 32, PLD = BC + 4;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// row `row` of a [T][ld] matrix (4 floats at `col`), zeros for row >= T -- as an UNCONDITIONAL load from the clamped row with the condition applied to
+// the value: `row < T ? ld4(..) : 0` compiles to an exec-mask save / branch / restore with its own wait per load (72 such regions and 208 waits in
+// the first flash_bwd_dkv_kernel<256>), which keeps the loads of a stage from flying together
+__device__ __forceinline__ float4 ld4_row(const float* base, int row, int T, long long ld, int col) {
+  const float4 v = ld4(base + (long long)(row < T ? row : T - 1) * ld + col);
+  return row < T ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float ld1_row(const float* base, int row, int T) { const float v = base[row < T ? row : T - 1]; return row < T ? v : 0.f; }
 __device__ __forceinline__ f32x4 zero_acc() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 // reduce over the 16 lanes that hold one accumulator row (lanes with equal lane >> 4)
 __device__ __forceinline__ float row_max16(float v) {
@@ -38,7 +46,7 @@ __device__ __forceinline__ void stage32(const float* __restrict__ src, int r0, i
   constexpr int LD = C + 4, Q = C / 4;
   for (int i = threadIdx.x; i < 32 * Q; i += NT) {
     const int r = i / Q, c = (i - r * Q) * 4;
-    const float4 v = (r0 + r < T) ? ld4(src + (long long)(r0 + r) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = ld4_row(src, r0 + r, T, C, c);
     *reinterpret_cast<float4*>(dst + r * LD + c) = v;
   }
 }
@@ -50,7 +58,7 @@ __device__ __forceinline__ void fetch32(const float* __restrict__ src, int r0, i
 #pragma unroll
   for (int n = 0; n < 32 * Q / NT; ++n) {
     const int i = threadIdx.x + NT * n, row = i / Q, c = (i - row * Q) * 4;
-    r[n] = (r0 + row < T) ? ld4(src + (long long)(r0 + row) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r[n] = ld4_row(src, r0 + row, T, C, c);
   }
 }
 template <int C, int NT = 256>
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(const float* __restr
   const int row0 = blockIdx.x * 16 * NW + 16 * w + 4 * g;    // first of this lane's four accumulator rows
   float4 qa[C / 16];
 #pragma unroll
-  for (int kk = 0; kk < C / 16; ++kk) qa[kk] = row_a < T ? ld4(q + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int kk = 0; kk < C / 16; ++kk) qa[kk] = ld4_row(q + base, row_a, T, C, 16 * kk + 4 * g);
   f32x4 o[C / 16];
 #pragma unroll
   for (int c = 0; c < C / 16; ++c) o[c] = zero_acc();
@@ -192,15 +200,15 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const float* __restri
   float4 qa[C / 16], da[C / 16];
 #pragma unroll
   for (int kk = 0; kk < C / 16; ++kk) {
-    qa[kk] = row_a < T ? ld4(q + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-    da[kk] = row_a < T ? ld4(dO + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    qa[kk] = ld4_row(q + base, row_a, T, C, 16 * kk + 4 * g);
+    da[kk] = ld4_row(dO + base, row_a, T, C, 16 * kk + 4 * g);
   }
   float lse[4], dl[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const bool ok = row0 + r < T;
-    lse[r] = ok ? Lse[(long long)b * T + row0 + r] : 0.f;
-    dl[r] = ok ? D[(long long)b * T + row0 + r] : 0.f;
+    lse[r] = ld1_row(Lse + (long long)b * T, row0 + r, T);
+    dl[r] = ld1_row(D + (long long)b * T, row0 + r, T);
   }
   f32x4 acc[C / 16];
 #pragma unroll
@@ -253,8 +261,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const float* __restr
   float4 ka[C / 16], va[C / 16];
 #pragma unroll
   for (int kk = 0; kk < C / 16; ++kk) {
-    ka[kk] = row_a < T ? ld4(k + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
-    va[kk] = row_a < T ? ld4(v + base + (long long)row_a * C + 16 * kk + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ka[kk] = ld4_row(k + base, row_a, T, C, 16 * kk + 4 * g);
+    va[kk] = ld4_row(v + base, row_a, T, C, 16 * kk + 4 * g);
   }
   f32x4 gk[C / 16], gv[C / 16];
 #pragma unroll
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const float* __restr
     for (int t = 0; t < 2; ++t) {
       const int qc = i0 + 16 * t + i;          // this lane's query column
       const bool qok = qc < T;
-      const float lse = qok ? Lse[(long long)b * T + qc] : 0.f, dl = qok ? D[(long long)b * T + qc] : 0.f;
+      const float lse = ld1_row(Lse + (long long)b * T, qc, T), dl = ld1_row(D + (long long)b * T, qc, T);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = (qok && row0 + r < T) ? expf(s[t][r] * scale - lse) : 0.f;
@@ -318,7 +326,7 @@ __device__ __forceinline__ void stage_rows16(const float* __restrict__ src, int 
   constexpr int LD = C + 8, Q = C / 4;
   for (int it = threadIdx.x; it < 32 * Q; it += 256) {
     const int r = it / Q, c = (it - r * Q) * 4;
-    const float4 v = (r0 + r < T) ? ld4(src + (long long)(r0 + r) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = ld4_row(src, r0 + r, T, C, c);
     T16* d = dst + r * LD + c;
     d[0] = (T16)v.x; d[1] = (T16)v.y; d[2] = (T16)v.z; d[3] = (T16)v.w;
   }
@@ -328,8 +336,8 @@ __device__ __forceinline__ void stage_trans16(const float* __restrict__ src, int
   constexpr int Q = C / 4;
   for (int it = threadIdx.x; it < 16 * Q; it += 256) {
     const int pr = it & 15, c = (it >> 4) * 4, ra = r0 + 2 * pr;
-    const float4 a = (ra < T) ? ld4(src + (long long)ra * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 b = (ra + 1 < T) ? ld4(src + (long long)(ra + 1) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = ld4_row(src, ra, T, C, c);
+    const float4 b = ld4_row(src, ra + 1, T, C, c);
     const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) { T16* d = dst + (c + j) * TLD + 2 * pr; d[0] = (T16)av[j]; d[1] = (T16)bv[j]; }
@@ -436,8 +444,8 @@ __global__ __launch_bounds__(256) void flash16_bwd_dq_kernel(const float* __rest
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const bool ok = row0 + r < T;
-    lse[r] = ok ? Lse[(long long)b * T + row0 + r] : 0.f;
-    dl[r] = ok ? D[(long long)b * T + row0 + r] : 0.f;
+    lse[r] = ld1_row(Lse + (long long)b * T, row0 + r, T);
+    dl[r] = ld1_row(D + (long long)b * T, row0 + r, T);
   }
   f32x4 acc[C / 16];
 #pragma unroll
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(256) void flash16_bwd_dkv_kernel(const float* __res
     for (int t = 0; t < 2; ++t) {
       const int qc = i0 + 16 * t + i;
       const bool qok = qc < T;
-      const float lse = qok ? Lse[(long long)b * T + qc] : 0.f, dl = qok ? D[(long long)b * T + qc] : 0.f;
+      const float lse = ld1_row(Lse + (long long)b * T, qc, T), dl = ld1_row(D + (long long)b * T, qc, T);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = (qok && row0 + r < T) ? expf(s[t][r] * scale - lse) : 0.f;
