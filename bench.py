@@ -57,7 +57,6 @@ def build_stack(args_ns, device, B, first_utt, net=None):
         net = net.replica()             # same weights, own activation arena / VJP tape: a second sub-batch on another stream
     edm = instantiate(args.diff_params)
     tester = Tester(args, net, edm, test_set=None, device=device, in_training=True)
-    tester.blind_backend = None if args_ns.operator == "hip" else "torch"
     L = args_ns.length
     items = [(synth_clean(first_utt + u, L), synth_rir(first_utt + u, 8000), f"utt{first_utt + u}.wav") for u in range(B)]
     torch.manual_seed(1234 + first_utt)
@@ -70,31 +69,19 @@ class StepRunner:
 
     def __init__(self, tester, y, op, device):
         s = tester.sampler
-        from buddy_amd.utils.losses import get_loss
-        ps = s.args.tester.posterior_sampling
-        s.operator, s.y = op, y
-        s.rec_loss = get_loss(ps.rec_loss, operator=op)
-        s._hip_op = hasattr(op, "hip_optimize")
-        if s._hip_op:
-            op.hip_bind(y, ps)
-        else:
-            s.rec_loss_params = get_loss(ps.rec_loss_params, operator=op)
-            s.optimizer_operator = torch.optim.Adam(op.params + op.params_phases, lr=ps.blind_hp.lr_op, weight_decay=ps.blind_hp.weight_decay,
-                                                    betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
-            s.RIR_noise_regularization_loss = get_loss(ps.RIR_noise_regularization.loss, operator=op)
+        s.bind(y, op, True)            # what predict_conditional does before its loop: operator, observation, losses, fresh Adam state (HIP handle)
         # config 4 of BASELINE.json asks for the operator-update share: bracket optimize_op with events on the launch stream
         self.op_events = None
-        if s._hip_op:
-            inner = op.hip_optimize
+        inner = op.hip_optimize
 
-            def timed_optimize(x_den, t):
-                if self.op_events is None:
-                    return inner(x_den, t)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); r = inner(x_den, t); e1.record()
-                self.op_events.append((e0, e1))
-                return r
-            op.hip_optimize = timed_optimize
+        def timed_optimize(x_den, t):
+            if self.op_events is None:
+                return inner(x_den, t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); r = inner(x_den, t); e1.record()
+            self.op_events.append((e0, e1))
+            return r
+        op.hip_optimize = timed_optimize
         self.s = s
         t = s.create_schedule()                            # host-side schedule, as in predict(): no device sync inside a step
         self.t, self.gamma = t.tolist(), s.get_gamma(t).tolist()
@@ -292,7 +279,6 @@ def main():
                     "three-way bf16 split of the fp32 operands, six bf16 MFMA products, fp32 accumulate; fp32 = v_mfma_f32_32x32x2_f32, the reference run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
-    ap.add_argument("--operator", default="hip", choices=["hip", "torch"], help="blind operator backend (torch = interim torch-op path)")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="THREADS", help="internal: run only the CPU leg and print its JSON")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--cpu-utt", type=int, default=0)

@@ -26,6 +26,10 @@ _SIGS = {
     "buddy_ncsnpp_create": (C.c_int, [_f32p, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]),
     "buddy_ncsnpp_destroy": (C.c_int, [C.c_void_p]),
+    "buddy_ncsnpp_replica": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "buddy_ncsnpp_weight_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                            C.POINTER(C.c_int)]),
+    "buddy_conv3_weight_prep": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_void_p]),
     "buddy_ncsnpp_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
     "buddy_ncsnpp_forward": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_ncsnpp_vjp": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_void_p]),

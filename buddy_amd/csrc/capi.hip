@@ -54,6 +54,26 @@ int buddy_ncsnpp_create(const float* host_params, long long n_params, int nf, co
 
 int buddy_ncsnpp_destroy(void* handle) { net_destroy((Net*)handle); return BUDDY_OK; }
 
+int buddy_ncsnpp_replica(void* handle, void** replica) {
+  if (!handle || !replica) { set_error("null argument"); return BUDDY_ERR_ARG; }
+  Net* N = nullptr;
+  int rc = net_replica((Net*)handle, &N);
+  if (rc) return rc;
+  *replica = N;
+  return BUDDY_OK;
+}
+
+int buddy_ncsnpp_weight_bytes(void* handle, long long* params, long long* packed, long long* lazy, int* lazy_forms) {
+  if (!handle) { set_error("null handle"); return BUDDY_ERR_ARG; }
+  return net_weight_bytes((Net*)handle, params, packed, lazy, lazy_forms);
+}
+
+int buddy_conv3_weight_prep(const float* w_oihw, int O, int I, int dgrad, int kind, float* out, void* stream) {
+  if (!w_oihw || !out || O < 1 || I < 1 || conv3_weight_floats(O, I, kind) == 0) { set_error("bad arguments (kind must be 0, 2, 4 or 6)"); return BUDDY_ERR_ARG; }
+  if (launch_conv3_weight_prep(w_oihw, O, I, dgrad != 0, kind, out, (hipStream_t)stream)) { set_error("F(2x2,3x3) form needs an input-channel count that is a multiple of 8"); return BUDDY_ERR_ARG; }
+  return finish();
+}
+
 int buddy_ncsnpp_reserve(void* handle, int B, int L, int with_vjp, long long* bytes) {
   if (!handle) { set_error("null handle"); return BUDDY_ERR_ARG; }
   return net_reserve((Net*)handle, B, L, with_vjp, bytes);

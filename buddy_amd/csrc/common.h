@@ -73,6 +73,11 @@ double wino6_exec_ratio(const IgemmParams& p);
 void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn = nullptr, double* stat = nullptr,
                   const W4Gn* bwd_gn = nullptr, const void* U6x = nullptr);
 void wino6_transform_weights(const float* wt_host, int Cout, int Cin, float* U6_host);
+// device-side weight preparation (wprep.hip): raw torch OIHW [O][I][3][3] -> the operand form of one kernel variant (kind 0 direct [Co][9][Ci],
+// 2 F(2x2) [Ci/8][16][Co][8], 4 F(4x4) [36][Co][Ci], 6 F(6x6) [64][Co][Ci]) for the forward (Co = O, Ci = I) or the data-gradient direction
+// (Co = I, Ci = O, taps flipped); the wino*_transform_weights host functions above are its restatement for the unit tests
+long long conv3_weight_floats(int O, int I, int kind);
+int launch_conv3_weight_prep(const float* w_oihw, int O, int I, bool dgrad, int kind, float* out, hipStream_t st);
 void igemm_prof_record(const IgemmParams& p, int taps, int batch, hipStream_t st, bool begin, double exec_ratio = 4.0 / 9.0);
 void igemm_prof_enable(int level);   // 0 off, 1 the dominant kernel only (36 batched Winograd-domain GEMMs), 2 every instrumented class
 bool igemm_prof_enabled();           // level 2

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -106,21 +108,24 @@ struct Arena {
   float* f(long long n) { return (float*)alloc((size_t)n * 4); }
 };
 
-struct ConvW { int cin = 0, cout = 0, taps = 0; float* wf = nullptr; float* wb = nullptr; float* bias = nullptr;
-               float* uf = nullptr; float* ub = nullptr;      // uf/ub: Winograd F(2x2,3x3)-domain weights (forward / data-gradient)
-               float* uf4 = nullptr; float* ub4 = nullptr;    // F(4x4,3x3)-domain weights [36][Cout][Cin]
-               float* uf6 = nullptr; float* ub6 = nullptr;    // F(6x6,3x3)-domain weights [64][Cout][Cin]
-               void* uf4x = nullptr; void* ub4x = nullptr; void* uf6x = nullptr; void* ub6x = nullptr; };   // ... in the bf16x3 stage image (wgemm.hip)
+// One prepared operand form of a 3x3 convolution's weights: u = fp32 (direct / Winograd-domain), x = the bf16x3 stage image of u (wgemm.hip)
+struct WVar { float* u = nullptr; void* x = nullptr; };
+// raw: the torch OIHW tensor on the device.  3x3 convolutions of the ResBlocks get their operand forms LAZILY (conv_weights below): one
+// (direction, kernel variant, arithmetic) per layer is ever built for a given workload, on the GPU (wprep.hip).  wf / wb: forms prepared at
+// creation (the small 2-channel convolutions, 1x1 convolutions)
+struct ConvW { int cin = 0, cout = 0, taps = 0; const float* raw = nullptr; float* wf = nullptr; float* wb = nullptr; float* bias = nullptr;
+               mutable WVar var[2][4]; };                      // [forward | data-gradient][direct, F(2x2), F(4x4), F(6x6)]
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResW { GNW gn0, gn1; ConvW c0, c1, c2; bool has_c2 = false; int cin = 0, cout = 0, dense_off = 0; };
 struct AttnW { GNW gn; float* Wt[4]; float* Wn[4]; float* b[4]; int C = 0; };
 
-struct Net {
+struct W3Img { const void* img; int N, K; };
+// Everything derived from the parameters: shared (read-only after preparation) by a handle and its replicas (net_replica)
+struct Weights {
   NetCfg cfg;
-  int Fb = 0, Kp = 0, pad = 0;
   std::vector<PSpec> specs;
   float* dparams = nullptr;    // raw parameters (device)
-  float* dpacked = nullptr;    // packed weights (device)
+  float* dpacked = nullptr;    // small packed weights (device): 2-channel convolutions, transposed 1x1 / NIN, Dense_0 stack, DFT bases
   // modules in execution order
   float* Wf = nullptr; float* lin1_w = nullptr; float* lin1_b = nullptr; float* lin2_w = nullptr; float* lin2_b = nullptr;
   float* dense_w = nullptr; float* dense_b = nullptr; int dense_total = 0;
@@ -131,6 +136,25 @@ struct Net {
   std::vector<GNW> pyr_gn; std::vector<ConvW> pyr_conv;   // C -> 2 heads, top level first
   float* out_w = nullptr; float* out_b = nullptr;
   float* basisF = nullptr; float* basisI = nullptr;      // [2Fb][Kp], [Kp][2Fb]
+  unsigned char* dpacked3 = nullptr;   // bf16x3 stage images of the 1x1 / NIN weights
+  std::unordered_map<const float*, W3Img> w3;   // 1x1 / NIN weights [N][K] (fp32, device) -> their bf16x3 stage image and the shape it was packed for
+  // lazily prepared 3x3 operand forms
+  std::mutex mu;
+  std::vector<void*> lazy_allocs; size_t lazy_bytes = 0; int lazy_count = 0;
+  float* prep_tmp = nullptr; size_t prep_cap = 0;        // fp32 staging of a Winograd-domain weight set on its way to the bf16x3 image
+  ~Weights() {
+    if (dparams) (void)hipFree(dparams);
+    if (dpacked) (void)hipFree(dpacked);
+    if (dpacked3) (void)hipFree(dpacked3);
+    if (prep_tmp) (void)hipFree(prep_tmp);
+    for (void* q : lazy_allocs) (void)hipFree(q);
+  }
+};
+
+struct Net {
+  NetCfg cfg;
+  int Fb = 0, Kp = 0, pad = 0;
+  std::shared_ptr<Weights> W;
   // per-(B,L) state
   int B = 0, L = 0, T = 0, Tp = 0, Lp = 0;
   float* inv_env = nullptr; int env_len = 0; int env_Tp = -1;
@@ -148,8 +172,7 @@ struct Net {
   int rsv_B = 0, rsv_L = 0, rsv_vjp = -1;   // shape the arena was last sized for (the sizing dry run is skipped while it still fits)
   int attn_mode = 0;           // see attn_mode_from_env()
   int gemm_mode = 1;           // Winograd-domain GEMM arithmetic: 1 = bf16x3 (exact three-way split, default), 0 = fp32 MFMA; BUDDY_GEMM=fp32|bf16x3
-  unsigned char* dpacked3 = nullptr;   // bf16x3 stage images of the F(4x4) / F(6x6) weights
-  std::unordered_map<const float*, const void*> w3;   // 1x1 / NIN weights [N][K] (fp32, device) -> their bf16x3 stage image
+  bool prep_failed = false;    // a lazily prepared weight form could not be built (out of memory): the call reports it
   bool fir = false;            // fir=True: FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257)
   float* w4_scratch = nullptr; size_t w4_cap = 0, w4_need = 0;   // V / M buffers of the three-pass F(4x4,3x3) convolutions (floats)
   bool dry() const { return arena.dry; }
@@ -181,20 +204,6 @@ struct Packer {
 // (H = time, W = frequency), so tap (dy, dx) of our layout reads W[o][i][ky = dx][kx = dy].
 inline float w3(const float* w, int O, int I, int o, int i, int dy, int dx) { return w[(((long long)o * I + i) * 3 + dx) * 3 + dy]; }
 
-// forward operand Bt[o][(dy*3+dx)*I + i]
-std::vector<float> pack_conv3_fwd(const float* w, int O, int I) {
-  std::vector<float> r((size_t)O * 9 * I);
-  for (int o = 0; o < O; ++o) for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) for (int i = 0; i < I; ++i)
-    r[((size_t)o * 9 + dy * 3 + dx) * I + i] = w3(w, O, I, o, i, dy, dx);
-  return r;
-}
-// data-gradient operand Bt[i][(dy*3+dx)*O + o] = W[o][i][flipped tap]
-std::vector<float> pack_conv3_bwd(const float* w, int O, int I) {
-  std::vector<float> r((size_t)I * 9 * O);
-  for (int i = 0; i < I; ++i) for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) for (int o = 0; o < O; ++o)
-    r[((size_t)i * 9 + dy * 3 + dx) * O + o] = w3(w, O, I, o, i, 2 - dy, 2 - dx);
-  return r;
-}
 std::vector<float> transpose2(const float* w, int R, int Cc) {   // [R][Cc] -> [Cc][R]
   std::vector<float> r((size_t)R * Cc);
   for (int i = 0; i < R; ++i) for (int j = 0; j < Cc; ++j) r[(size_t)j * R + i] = w[(size_t)i * Cc + j];
@@ -208,46 +217,54 @@ static const PSpec* find_spec(const std::vector<PSpec>& v, const std::string& n)
 }
 
 static int attn_mode_from_env();
-int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
-  Net* N = new Net();
+static int gemm_mode_from_env(int* mode) {
+  *mode = 1;
+  if (const char* g = getenv("BUDDY_GEMM")) {
+    const std::string v = g;
+    if (v == "fp32") *mode = 0;
+    else if (v == "bf16x3" || v.empty()) *mode = 1;
+    else { set_error("BUDDY_GEMM must be 'fp32' or 'bf16x3' (got '" + v + "')"); return BUDDY_ERR_ARG; }
+  }
+  return BUDDY_OK;
+}
+
+// Build the shared weight store: the raw parameters go to the device once (every tensor start aligned to 256 B); the host prepares only the
+// small operands (2-channel convolutions, transposed 1x1 / NIN matrices, the Dense_0 stack, the windowed DFT bases: ~4 M floats).  The 3x3
+// convolutions -- 98 % of the parameters -- are NOT touched here: conv_weights() derives the one operand form a layer needs on first use.
+static int weights_create(const float* hp, long long n, const NetCfg& cfg, std::shared_ptr<Weights>* out) {
+  auto Wp = std::make_shared<Weights>();
+  Weights* N = Wp.get();
   N->cfg = cfg;
-  N->attn_mode = attn_mode_from_env();
-  if (const char* g = getenv("BUDDY_GEMM")) N->gemm_mode = std::string(g) == "fp32" ? 0 : 1;
   N->specs = build_specs(cfg);
-  if (n != param_count(cfg)) { set_error("parameter blob size mismatch"); delete N; return BUDDY_ERR_ARG; }
-  if (cfg.n_fft % 2) { set_error("n_fft must be even"); delete N; return BUDDY_ERR_ARG; }
+  if (n != param_count(cfg)) { set_error("parameter blob size mismatch"); return BUDDY_ERR_ARG; }
+  if (cfg.n_fft % 2) { set_error("n_fft must be even"); return BUDDY_ERR_ARG; }
   {  // the GroupNorm partial-sum scratch is sized for at most 1024 channels; the widest tensor is a skip concatenation (2 x the level width)
     int cmax = 0;
     for (int l = 0; l < cfg.nlev; ++l) cmax = std::max(cmax, cfg.nf * cfg.ch_mult[l]);
-    if (2 * cmax > 1024) { set_error("nf * max(ch_mult) must be <= 512 (concatenated skip tensors of up to 1024 channels)"); delete N; return BUDDY_ERR_ARG; }
+    if (2 * cmax > 1024) { set_error("nf * max(ch_mult) must be <= 512 (concatenated skip tensors of up to 1024 channels)"); return BUDDY_ERR_ARG; }
   }
-  N->Fb = cfg.n_fft / 2 + 1;
-  N->Kp = (cfg.n_fft + 3) / 4 * 4;
-  N->pad = cfg.n_fft / 2;
-  if (N->Fb % (1 << (cfg.nlev - 1))) { set_error("frequency bins not divisible by 2^(levels-1)"); delete N; return BUDDY_ERR_ARG; }
-  // device copy of the raw parameters with every tensor start aligned to 256 B (float4 loads on gamma/beta/1x1 weights)
+  const int Fb = cfg.n_fft / 2 + 1, Kp = (cfg.n_fft + 3) / 4 * 4;
+  if (Fb % (1 << (cfg.nlev - 1))) { set_error("frequency bins not divisible by 2^(levels-1)"); return BUDDY_ERR_ARG; }
   std::vector<long long> doff(N->specs.size());
   {
     long long o = 0;
     for (size_t i = 0; i < N->specs.size(); ++i) { doff[i] = o; o += (N->specs[i].numel + 63) / 64 * 64; }
-    std::vector<float> padded((size_t)o, 0.f);
-    for (size_t i = 0; i < N->specs.size(); ++i) std::memcpy(padded.data() + doff[i], hp + N->specs[i].off, (size_t)N->specs[i].numel * 4);
     HIPCHK(hipMalloc(&N->dparams, (size_t)o * 4));
-    HIPCHK(hipMemcpy(N->dparams, padded.data(), (size_t)o * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(N->dparams, 0, (size_t)o * 4, nullptr));
+    // consecutive tensors whose padded and source offsets advance together go up as one copy
+    size_t i = 0;
+    while (i < N->specs.size()) {
+      size_t j = i; long long len = N->specs[i].numel;
+      while (j + 1 < N->specs.size() && N->specs[j].numel % 64 == 0) { ++j; len += N->specs[j].numel; }
+      HIPCHK(hipMemcpyAsync(N->dparams + doff[i], hp + N->specs[i].off, (size_t)len * 4, hipMemcpyHostToDevice, nullptr));
+      i = j + 1;
+    }
   }
 
   Packer pk;
   struct Fix { float** dst; long long off; };
   std::vector<Fix> fixes;
-  struct Pack3 { float** src; void** dst; int P, cout, cin; size_t off; };   // bf16x3 images, built on the device after the upload
   std::vector<std::pair<float**, std::pair<int, int>>> plain3;               // 1x1 / NIN weights [N][K]: registered in N->w3 by pointer
-  std::vector<Pack3> pack3;
-  size_t pack3_bytes = 0;
-  auto want3 = [&](float** src, void** dst, int P, int cout, int cin) {
-    if (!wgemm_supported(cout, cin)) return;
-    pack3.push_back({src, dst, P, cout, cin, pack3_bytes});
-    pack3_bytes += (wgemm_packed_bytes(P, cout, cin) + 255) / 256 * 256;
-  };
   auto raw = [&](const std::string& name) -> float* {
     for (size_t i = 0; i < N->specs.size(); ++i) if (N->specs[i].name == name) return N->dparams + doff[i];
     return nullptr;
@@ -264,21 +281,7 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   std::vector<float> dense_w_all, dense_b_all;
   auto load_gn = [&](GNW& g, const std::string& p, int C) { g.gamma = raw(p + ".weight"); g.beta = raw(p + ".bias"); g.C = C; };
   auto load_conv3 = [&](ConvW& c, const std::string& p, int cin, int cout) {
-    c.cin = cin; c.cout = cout; c.taps = 9; c.bias = raw(p + ".bias");
-    std::vector<float> wfv = pack_conv3_fwd(host(p + ".weight"), cout, cin), wbv = pack_conv3_bwd(host(p + ".weight"), cout, cin);
-    packed(&c.wf, wfv);
-    packed(&c.wb, wbv);
-    if (cin % 8 == 0 && cout % 8 == 0) {     // Winograd F(2x2,3x3) operands U = G g G^T for both directions (wino.hip)
-      std::vector<float> u((size_t)16 * cin * cout);
-      wino_transform_weights(wfv.data(), cout, cin, u.data()); packed(&c.uf, u);
-      wino_transform_weights(wbv.data(), cin, cout, u.data()); packed(&c.ub, u);
-      std::vector<float> u4((size_t)36 * cin * cout);
-      wino4_transform_weights(wfv.data(), cout, cin, u4.data()); packed(&c.uf4, u4); want3(&c.uf4, &c.uf4x, 36, cout, cin);
-      wino4_transform_weights(wbv.data(), cin, cout, u4.data()); packed(&c.ub4, u4); want3(&c.ub4, &c.ub4x, 36, cin, cout);
-      std::vector<float> u6((size_t)64 * cin * cout);
-      wino6_transform_weights(wfv.data(), cout, cin, u6.data()); packed(&c.uf6, u6); want3(&c.uf6, &c.uf6x, 64, cout, cin);
-      wino6_transform_weights(wbv.data(), cin, cout, u6.data()); packed(&c.ub6, u6); want3(&c.ub6, &c.ub6x, 64, cin, cout);
-    }
+    c.cin = cin; c.cout = cout; c.taps = 9; c.bias = raw(p + ".bias"); c.raw = raw(p + ".weight");
   };
   auto load_res = [&](int cin, int cout, bool resample) {
     ResW r; r.cin = cin; r.cout = cout;
@@ -362,44 +365,89 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
   N->dense_total = (int)dense_b_all.size();
   packed(&N->dense_w, dense_w_all); packed(&N->dense_b, dense_b_all);
 
-  // DFT bases with the periodic Hann window folded in (reference ncsnpp.py:464,473-496 via torch.stft/istft).
+  // DFT bases with the periodic Hann window folded in (reference ncsnpp.py:464,473-496 via the stft / istft of PyTorch).
   {
-    const int nfft = cfg.n_fft, Fb = N->Fb, Kp = N->Kp;
+    const int nfft = cfg.n_fft;
     std::vector<float> bf((size_t)2 * Fb * Kp, 0.f), bi((size_t)Kp * 2 * Fb, 0.f);
     const double PI = 3.14159265358979323846;
+    std::vector<double> ct(nfft), sn(nfft);                   // cos / sin of 2 pi j / nfft: one evaluation per angle instead of Fb per angle
+    for (int j = 0; j < nfft; ++j) { ct[j] = std::cos(2.0 * PI * (double)j / nfft); sn[j] = std::sin(2.0 * PI * (double)j / nfft); }
     for (int k = 0; k < nfft; ++k) {
-      const double w = 0.5 - 0.5 * std::cos(2.0 * PI * k / nfft);
+      const double w = 0.5 - 0.5 * ct[k];
       for (int f = 0; f < Fb; ++f) {
-        const double ang = 2.0 * PI * (double)((long long)f * k % nfft) / nfft;
-        bf[((size_t)f * 2 + 0) * Kp + k] = (float)(w * std::cos(ang));
-        bf[((size_t)f * 2 + 1) * Kp + k] = (float)(-w * std::sin(ang));
+        const int j = (int)((long long)f * k % nfft);
+        bf[((size_t)f * 2 + 0) * Kp + k] = (float)(w * ct[j]);
+        bf[((size_t)f * 2 + 1) * Kp + k] = (float)(-w * sn[j]);
         const double cf = (f == 0 || f == nfft / 2) ? 1.0 : 2.0;
-        bi[(size_t)k * 2 * Fb + f * 2 + 0] = (float)(cf / nfft * std::cos(ang) * w);
-        bi[(size_t)k * 2 * Fb + f * 2 + 1] = (float)(-cf / nfft * std::sin(ang) * w);
+        bi[(size_t)k * 2 * Fb + f * 2 + 0] = (float)(cf / nfft * ct[j] * w);
+        bi[(size_t)k * 2 * Fb + f * 2 + 1] = (float)(-cf / nfft * sn[j] * w);
       }
     }
     packed(&N->basisF, bf); packed(&N->basisI, bi);
   }
   HIPCHK(hipMalloc(&N->dpacked, pk.buf.size() * 4));
-  HIPCHK(hipMemcpy(N->dpacked, pk.buf.data(), pk.buf.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(N->dpacked, pk.buf.data(), pk.buf.size() * 4, hipMemcpyHostToDevice, nullptr));
   for (auto& f : fixes) *f.dst = N->dpacked + f.off;
   std::vector<size_t> plain_off;
+  size_t pack3_bytes = 0;
   for (auto& j : plain3) {
     plain_off.push_back(pack3_bytes);
     if (wgemm_supported(j.second.first, j.second.second)) pack3_bytes += (wgemm_packed_bytes(1, j.second.first, j.second.second) + 255) / 256 * 256;
   }
-  if (pack3_bytes) {     // the Winograd-domain weights once more, split into three bf16 planes in the GEMM's LDS stage order
+  if (pack3_bytes) {     // the 1x1 / NIN matrices once more, split into three bf16 planes in the GEMM's LDS stage order
     HIPCHK(hipMalloc(&N->dpacked3, pack3_bytes));
-    for (auto& j : pack3) { *j.dst = N->dpacked3 + j.off; wgemm_pack_weights(*j.src, *j.dst, j.P, j.cout, j.cin, nullptr); }
     for (size_t i = 0; i < plain3.size(); ++i) {
-      const int n = plain3[i].second.first, k = plain3[i].second.second;
-      if (!wgemm_supported(n, k) || *plain3[i].first == nullptr) continue;
-      wgemm_pack_weights(*plain3[i].first, N->dpacked3 + plain_off[i], 1, n, k, nullptr);
-      N->w3[*plain3[i].first] = N->dpacked3 + plain_off[i];
+      const int n3 = plain3[i].second.first, k3 = plain3[i].second.second;
+      if (!wgemm_supported(n3, k3) || *plain3[i].first == nullptr) continue;
+      wgemm_pack_weights(*plain3[i].first, N->dpacked3 + plain_off[i], 1, n3, k3, nullptr);
+      N->w3[*plain3[i].first] = W3Img{N->dpacked3 + plain_off[i], n3, k3};
     }
-    HIPCHK(hipDeviceSynchronize());
   }
+  HIPCHK(hipDeviceSynchronize());     // the host staging buffers go out of scope here
+  *out = Wp;
+  return BUDDY_OK;
+}
+
+static int net_from_weights(std::shared_ptr<Weights> Wp, Net** out) {
+  Net* N = new Net();
+  N->W = std::move(Wp);
+  N->cfg = N->W->cfg;
+  N->attn_mode = attn_mode_from_env();
+  if (int rc = gemm_mode_from_env(&N->gemm_mode)) { delete N; return rc; }
+  N->Fb = N->cfg.n_fft / 2 + 1;
+  N->Kp = (N->cfg.n_fft + 3) / 4 * 4;
+  N->pad = N->cfg.n_fft / 2;
   *out = N;
+  return BUDDY_OK;
+}
+
+int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
+  std::shared_ptr<Weights> Wp;
+  if (int rc = weights_create(hp, n, cfg, &Wp)) return rc;
+  return net_from_weights(std::move(Wp), out);
+}
+
+// A second handle on the SAME prepared weights (read-only, reference-counted): own activation arena, VJP tape and settings.  Costs nothing but
+// the arena of its first forward -- concurrent sub-batches (buddy_amd/testing/concurrent.py) and per-stream handles share one weight store.
+int net_replica(Net* src, Net** out) {
+  Net* N = nullptr;
+  if (int rc = net_from_weights(src->W, &N)) return rc;
+  N->attn_mode = src->attn_mode; N->gemm_mode = src->gemm_mode; N->fir = src->fir;
+  *out = N;
+  return BUDDY_OK;
+}
+
+int net_weight_bytes(Net* N, long long* params, long long* packed, long long* lazy, int* lazy_forms) {
+  Weights* Wt = N->W.get();
+  std::lock_guard<std::mutex> lk(Wt->mu);
+  long long o = 0;
+  for (auto& s : Wt->specs) o += (s.numel + 63) / 64 * 64;
+  if (params) *params = o * 4;
+  long long pk = 0;
+  for (auto& kv : Wt->w3) pk += (long long)wgemm_packed_bytes(1, kv.second.N, kv.second.K);
+  if (packed) *packed = pk;     // bf16x3 images of the 1x1 / NIN matrices (the small fp32 packs are < 20 MB and not counted separately)
+  if (lazy) *lazy = (long long)Wt->lazy_bytes + (long long)Wt->prep_cap * 4;
+  if (lazy_forms) *lazy_forms = Wt->lazy_count;
   return BUDDY_OK;
 }
 
@@ -408,13 +456,53 @@ int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 1) { set_error("gemm
 int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; return BUDDY_OK; }
 void net_destroy(Net* N) {
   if (!N) return;
-  if (N->dparams) (void)hipFree(N->dparams);
-  if (N->dpacked) (void)hipFree(N->dpacked);
-  if (N->dpacked3) (void)hipFree(N->dpacked3);
   if (N->w4_scratch) (void)hipFree(N->w4_scratch);
   if (N->arena.base) (void)hipFree(N->arena.base);
   if (N->inv_env) (void)hipFree(N->inv_env);
   delete N;
+}
+
+// The operand form `kind` (0 direct, 2 / 4 / 6 = Winograd F(kind x kind, 3x3)) of a 3x3 convolution for one direction, built on first use on
+// the GPU from the raw OIHW tensor (wprep.hip) and cached in the shared store.  want_x: the bf16x3 stage image (the fp32 form is then only a
+// staging buffer, reused for the next layer); otherwise the fp32 form itself is kept.  The preparing stream is drained before the pointer is
+// published, so a replica on another stream may use it at once.
+static const WVar* conv_weights(Net* N, const ConvW& c, bool dgrad, int kind, bool want_x) {
+  Weights* Wt = N->W.get();
+  const int ki = kind == 0 ? 0 : kind == 2 ? 1 : kind == 4 ? 2 : 3;
+  WVar& v = c.var[dgrad ? 1 : 0][ki];
+  std::lock_guard<std::mutex> lk(Wt->mu);
+  if (want_x ? v.x != nullptr : v.u != nullptr) return &v;
+  const int Co = dgrad ? c.cin : c.cout, Ci = dgrad ? c.cout : c.cin;
+  const size_t nfl = (size_t)conv3_weight_floats(c.cout, c.cin, kind);
+  hipStream_t st = N->st;
+  float* u = v.u;
+  if (u == nullptr) {
+    if (want_x) {
+      if (Wt->prep_cap < nfl) {
+        if (Wt->prep_tmp) (void)hipFree(Wt->prep_tmp);
+        Wt->prep_tmp = nullptr; Wt->prep_cap = 0;
+        if (hipMalloc(&Wt->prep_tmp, nfl * 4) != hipSuccess) { N->prep_failed = true; set_error("out of memory preparing convolution weights"); return nullptr; }
+        Wt->prep_cap = nfl;
+      }
+      u = Wt->prep_tmp;
+    } else {
+      if (hipMalloc(&u, nfl * 4) != hipSuccess) { N->prep_failed = true; set_error("out of memory preparing convolution weights"); return nullptr; }
+      Wt->lazy_allocs.push_back(u); Wt->lazy_bytes += nfl * 4;
+    }
+    if (launch_conv3_weight_prep(c.raw, c.cout, c.cin, dgrad, kind, u, st) != BUDDY_OK) { N->prep_failed = true; set_error("bad weight form"); return nullptr; }
+  }
+  void* x = nullptr;
+  if (want_x) {
+    const int P = kind == 4 ? 36 : 64;
+    const size_t bytes = wgemm_packed_bytes(P, Co, Ci);
+    if (hipMalloc(&x, bytes) != hipSuccess) { N->prep_failed = true; set_error("out of memory preparing convolution weights"); return nullptr; }
+    Wt->lazy_allocs.push_back(x); Wt->lazy_bytes += bytes;
+    wgemm_pack_weights(u, x, P, Co, Ci, st);
+  }
+  (void)hipStreamSynchronize(st);
+  if (want_x) v.x = x; else v.u = u;
+  ++Wt->lazy_count;
+  return &v;
 }
 
 // ------------------------------------------------------------------------------------------------ op helpers
@@ -456,23 +544,19 @@ struct Conv3 {
 };
 static int conv3(Net* N, const Conv3& c) {
   const float* a = c.a; const int B = c.B, H = c.H, W = c.W, Cin = c.Cin, Cout = c.Cout;
-  const float* wt = c.w ? (c.dgrad ? c.w->wb : c.w->wf) : nullptr;
-  const float* U = c.w ? (c.dgrad ? c.w->ub : c.w->uf) : nullptr;
-  const float* U4 = c.w ? (c.dgrad ? c.w->ub4 : c.w->uf4) : nullptr;
-  const float* U6 = c.w ? (c.dgrad ? c.w->ub6 : c.w->uf6) : nullptr;
-  const void* U4x = (c.w && N->gemm_mode == 1) ? (c.dgrad ? c.w->ub4x : c.w->uf4x) : nullptr;
-  const void* U6x = (c.w && N->gemm_mode == 1) ? (c.dgrad ? c.w->ub6x : c.w->uf6x) : nullptr;
+  // Winograd forms exist for channel counts that are multiples of 8 (every ResBlock convolution of the supported family)
+  const bool wino_ok = c.w != nullptr && c.w->raw != nullptr && Cin % 8 == 0 && Cout % 8 == 0;
   const W4Gn* gn = c.gn; float* gn_tmp = c.gn_tmp; Tens* stat_out = c.stat_out; const W4Gn* bwd_gn = c.bwd_gn; const bool direct = c.direct;
   // BUDDY_CONV = direct | wino2 | wino4 | (default) three-pass F(6x6,3x3) on the large layers, three-pass F(4x4,3x3) where the shape allows,
   // else fused F(2x2,3x3), else direct
   static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
   static const bool use_wino = mode != "direct", use_wino4 = mode != "direct" && mode != "wino2", use_wino6 = use_wino4 && mode != "wino4";
   if (N->dry()) {
-    if (use_wino4 && U4 != nullptr && H % 4 == 0 && W % 4 == 0) {
+    if (use_wino4 && wino_ok && H % 4 == 0 && W % 4 == 0) {
       const size_t need = (size_t)36 * ((size_t)B * H * W / 16) * (size_t)(Cin + Cout);
       if (need > N->w4_need) N->w4_need = need;
     }
-    if (use_wino6 && U6 != nullptr && H >= 6 && W >= 6) {
+    if (use_wino6 && wino_ok && H >= 6 && W >= 6) {
       const size_t need = (size_t)64 * ((size_t)B * ((H + 5) / 6) * ((W + 5) / 6)) * (size_t)(Cin + Cout);
       if (need > N->w4_need) N->w4_need = need;
     }
@@ -480,12 +564,12 @@ static int conv3(Net* N, const Conv3& c) {
   }
   IgemmParams p = ig_base();
   p.A0 = a; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout;
-  p.Bt = wt; p.ldB = 9 * Cin; p.C = c.out; p.ldC = Cout;
+  p.Bt = nullptr; p.ldB = 9 * Cin; p.C = c.out; p.ldC = Cout;
   p.bias_n = c.bias; p.bias_bn = c.bias_bn; p.ld_bias_bn = c.ld_bn; p.rows_per_batch = H * W;
   p.res = c.res; p.ldRes = c.ldRes; p.res_mode = c.res_mode; p.alpha = c.alpha; p.out_scale = c.out_scale;
   static const bool fuse_gn = !(getenv("BUDDY_GN_FUSE") && atoi(getenv("BUDDY_GN_FUSE")) == 0);
-  const bool w6 = use_wino6 && U6 != nullptr && N->w4_scratch != nullptr && wino6_supported(p) && wino6_pays(p);
-  const bool w4 = !w6 && use_wino4 && U4 != nullptr && N->w4_scratch != nullptr && wino4_supported(p);
+  const bool w6 = use_wino6 && wino_ok && N->w4_scratch != nullptr && wino6_supported(p) && wino6_pays(p);
+  const bool w4 = !w6 && use_wino4 && wino_ok && N->w4_scratch != nullptr && wino4_supported(p);
   static const bool fuse_bwd_in = !(getenv("BUDDY_GN_FUSE_BWDIN") && atoi(getenv("BUDDY_GN_FUSE_BWDIN")) == 0);
   if (gn != nullptr && gn->da != nullptr && !(w6 && fuse_gn && fuse_bwd_in)) {       // GroupNorm backward as the input: only F(6x6,3x3) fuses it
     Dst2 d; d.p0 = gn_tmp; d.p1 = nullptr; d.C0 = Cin; d.ld0 = Cin; d.ld1 = 0; d.acc0 = 0; d.acc1 = 0;
@@ -496,7 +580,11 @@ static int conv3(Net* N, const Conv3& c) {
     launch_gn_apply(gn->x, gn->stats, gn->gamma, gn->beta, B, H, W, Cin, gn->G, 0, gn->silu, gn_tmp, nullptr, N->st);
     p.A0 = gn_tmp; gn = nullptr;
   }
+  const bool x3 = N->gemm_mode == 1 && wgemm_supported(Cout, Cin);     // the batched GEMM pass in bf16x3 arithmetic: only the stage image is needed
   if (w6) {
+    const WVar* wv = conv_weights(N, *c.w, c.dgrad, 6, x3);
+    if (!wv) return -1;
+    const float* U6 = wv->u; const void* U6x = x3 ? wv->x : nullptr;
     long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf);
     static const bool fuse_bwd = !(getenv("BUDDY_GN_FUSE_BWD") && atoi(getenv("BUDDY_GN_FUSE_BWD")) == 0);
     const bool want_bwd = bwd_gn != nullptr && fuse_gn && fuse_bwd;
@@ -509,6 +597,9 @@ static int conv3(Net* N, const Conv3& c) {
     if (stat && (want_bwd || direct)) return sc;
     if (stat && stat_out) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
   } else if (w4) {
+    const WVar* wv = conv_weights(N, *c.w, c.dgrad, 4, x3);
+    if (!wv) return -1;
+    const float* U4 = wv->u; const void* U4x = x3 ? wv->x : nullptr;
     long long vf = 0, mf = 0; wino4_scratch(p, &vf, &mf);
     const int sc = (stat_out != nullptr && fuse_gn) ? wino4_stat_chunks(p) : 0;
     const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;     // N->partial holds 256 x 1024 (chunk, channel) pairs per utterance
@@ -516,11 +607,16 @@ static int conv3(Net* N, const Conv3& c) {
     launch_wino4(p, U4, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, U4x);
     igemm_prof_record(p, 9, 1, N->st, false, 0.25);
     if (stat) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
-  } else if (use_wino && U != nullptr && wino_supported(p)) {
+  } else if (use_wino && wino_ok && wino_supported(p)) {
+    const WVar* wv = conv_weights(N, *c.w, c.dgrad, 2, false);
+    if (!wv) return -1;
     igemm_prof_record(p, 9, 1, N->st, true);
-    launch_wino(p, U, N->st);
+    launch_wino(p, wv->u, N->st);
     igemm_prof_record(p, 9, 1, N->st, false);
   } else {
+    const WVar* wv = conv_weights(N, *c.w, c.dgrad, 0, false);
+    if (!wv) return -1;
+    p.Bt = wv->u;
     launch_igemm(p, 9, false, false, 1, N->st);
   }
   return 0;
@@ -528,11 +624,11 @@ static int conv3(Net* N, const Conv3& c) {
 // a plain row-major GEMM against a registered [N][K] weight (1x1 convolution, NIN) in bf16x3 arithmetic when the handle's mode asks for it
 static bool try_wgemm(Net* N, const IgemmParams& p) {
   if (N->gemm_mode != 1 || p.bias_m || p.bias_bn || p.res_mode || p.out_scale != 1.f || p.sA || p.sC) return false;
-  const auto it = N->w3.find(p.Bt);
-  if (it == N->w3.end() || p.ldB != p.Cin) return false;
+  const auto it = N->W->w3.find(p.Bt);
+  if (it == N->W->w3.end() || p.ldB != p.Cin || it->second.N != p.N || it->second.K != p.Cin) return false;
   if (!wgemm_general_supported(p.N, p.Cin, p.A1 ? p.C0 : 0, p.ldA0, p.A1 ? p.ldA1 : 0, p.ldC, p.A0, p.A1, p.C, p.bias_n)) return false;
   igemm_prof_record(p, 1, 1, N->st, true, 1.0);
-  launch_wgemm_bf16x3_general(p.A0, p.ldA0, p.A1, p.ldA1, p.C0, it->second, p.C, p.ldC, p.M, p.N, p.Cin, p.bias_n, p.alpha, p.accumulate, N->st);
+  launch_wgemm_bf16x3_general(p.A0, p.ldA0, p.A1, p.ldA1, p.C0, it->second.img, p.C, p.ldC, p.M, p.N, p.Cin, p.bias_n, p.alpha, p.accumulate, N->st);
   igemm_prof_record(p, 1, 1, N->st, false, 1.0);
   return true;
 }
@@ -588,7 +684,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
     launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
     // same resolution: act(GroupNorm(.)) is applied by the convolution's input transform (a0 / a1 are only its fallback buffers)
     Conv3 c0; c0.a = a0; c0.B = B; c0.H = Ho; c0.W = Wo; c0.Cin = Cin; c0.Cout = Cout; c0.w = &R.c0; c0.bias = R.c0.bias;
-    c0.bias_bn = temb_all + R.dense_off; c0.ld_bn = N->dense_total; c0.out = h1->p;
+    c0.bias_bn = temb_all + R.dense_off; c0.ld_bn = N->W->dense_total; c0.out = h1->p;
     c0.gn = mode == 0 ? &g0 : nullptr; c0.gn_tmp = a0; c0.stat_out = h1; c0.direct = true;
     const int ch1 = conv3(N, c0);
     if (ch1 > 0) launch_gn_stats_partial(N->partial, ch1, B, Ho * Wo, Cout, G1, 1e-6f, stats1, st);   // h1 has this one reader
@@ -851,28 +947,28 @@ static void run_forward(Net* N, const float* x, const float* cnoise, const float
   if (!N->dry()) {
     launch_reflect_pad(x, xp, B, L, N->pad, Lp, 1.f, cin_b, st);
     (void)hipMemsetAsync(spec->p, 0, (size_t)spec->numel() * 4, st);
-    gemm_b(N, xp, hop, Lp, false, N->basisF, Kp, 0, false, spec->p, 2 * Fb, (long long)Tp * 2 * Fb, T, 2 * Fb, Kp, nullptr, nullptr, 1.f, 0, B);
+    gemm_b(N, xp, hop, Lp, false, N->W->basisF, Kp, 0, false, spec->p, 2 * Fb, (long long)Tp * 2 * Fb, T, 2 * Fb, Kp, nullptr, nullptr, 1.f, 0, B);
   }
   // time embedding (reference ncsnpp.py:299-318) and all Dense_0 projections in one launch (layerspp.py:263)
   float* four = N->tmp((long long)B * 2 * nf);
   float* t1 = N->tmp((long long)B * 4 * nf);
   float* temb = N->tmp((long long)B * 4 * nf);
-  float* temb_all = N->tmp((long long)B * N->dense_total);
+  float* temb_all = N->tmp((long long)B * N->W->dense_total);
   if (!N->dry()) {
-    launch_fourier(cnoise, N->Wf, four, B, nf, st);
-    launch_linear(four, N->lin1_w, N->lin1_b, t1, B, 2 * nf, 4 * nf, 0, st);
-    launch_linear(t1, N->lin2_w, N->lin2_b, temb, B, 4 * nf, 4 * nf, 1, st);
-    launch_linear(temb, N->dense_w, N->dense_b, temb_all, B, 4 * nf, N->dense_total, 1, st);
+    launch_fourier(cnoise, N->W->Wf, four, B, nf, st);
+    launch_linear(four, N->W->lin1_w, N->W->lin1_b, t1, B, 2 * nf, 4 * nf, 0, st);
+    launch_linear(t1, N->W->lin2_w, N->W->lin2_b, temb, B, 4 * nf, 4 * nf, 1, st);
+    launch_linear(temb, N->W->dense_w, N->W->dense_b, temb_all, B, 4 * nf, N->W->dense_total, 1, st);
   }
 
   int mi = 3, ri = 0, ci = 0;
   auto tap = [&](int idx, Tens* t) { N->taps.push_back({idx, t}); };
   // input conv
   Tens* h0 = N->mk(B, Tp, Fb, nf, rec);
-  if (!N->dry()) launch_conv_c2in(spec->p, N->conv_in.wf, N->conv_in.bias, nullptr, 0, h0->p, nf, B, Tp, Fb, nf, 9, 0, st);
+  if (!N->dry()) launch_conv_c2in(spec->p, N->W->conv_in.wf, N->W->conv_in.bias, nullptr, 0, h0->p, nf, B, Tp, Fb, nf, 9, 0, st);
   if (rec) N->tape.push_back([=]() {
     if (N->dry()) { spec->ginit = 1; return; }
-    launch_conv_c2out(h0->g, nf, N->conv_in.wb, nullptr, nullptr, spec->g, B, Tp, Fb, nf, 9, spec->ginit, N->st);
+    launch_conv_c2out(h0->g, nf, N->W->conv_in.wb, nullptr, nullptr, spec->g, B, Tp, Fb, nf, 9, spec->ginit, N->st);
     spec->ginit = 1;
   });
   tap(mi, h0); ++mi;
@@ -881,12 +977,12 @@ static void run_forward(Net* N, const float* x, const float* cnoise, const float
   for (int l = 0; l < c.nlev; ++l) {
     for (int b = 0; b < c.nrb; ++b) {
       View v; v.a = hs.back();
-      Tens* h = resblock(N, N->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi;
+      Tens* h = resblock(N, N->W->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi;
       hs.push_back(h);
     }
     if (l != c.nlev - 1) {
       View v; v.a = hs.back();
-      Tens* h = resblock(N, N->res[ri++], v, 1, temb_all, rec); tap(mi, h); ++mi;
+      Tens* h = resblock(N, N->W->res[ri++], v, 1, temb_all, rec); tap(mi, h); ++mi;
       Tens* pin = N->mk(B, pyr_in->H / 2, pyr_in->W / 2, 2, rec);
       Tens* prev = pyr_in;
       if (!N->dry()) {
@@ -901,7 +997,7 @@ static void run_forward(Net* N, const float* x, const float* cnoise, const float
         prev->ginit = 1;
       });
       pyr_in = pin;
-      const ConvW& cw = N->combine[ci++];
+      const ConvW& cw = N->W->combine[ci++];
       Tens* hc = N->mk(B, h->H, h->W, h->C, rec);
       if (!N->dry()) launch_conv_c2in(pin->p, cw.wf, cw.bias, h->p, h->C, hc->p, h->C, B, h->H, h->W, h->C, 1, 0, st);   // Combine 'sum'
       if (rec) { const ConvW* cwp = &cw; N->tape.push_back([=]() {
@@ -916,17 +1012,17 @@ static void run_forward(Net* N, const float* x, const float* cnoise, const float
     }
   }
   Tens* h = hs.back();
-  { View v; v.a = h; h = resblock(N, N->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi; }
-  h = attnblock(N, N->attn, h, rec); tap(mi, h); ++mi;
-  { View v; v.a = h; h = resblock(N, N->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi; }
+  { View v; v.a = h; h = resblock(N, N->W->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi; }
+  h = attnblock(N, N->W->attn, h, rec); tap(mi, h); ++mi;
+  { View v; v.a = h; h = resblock(N, N->W->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi; }
   Tens* pyr = nullptr;
   for (int l = c.nlev - 1, j = 0; l >= 0; --l, ++j) {
     for (int b = 0; b < c.nrb + 1; ++b) {
       View v; v.a = h; v.b = hs.back(); hs.pop_back();
-      h = resblock(N, N->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi;
+      h = resblock(N, N->W->res[ri++], v, 0, temb_all, rec); tap(mi, h); ++mi;
     }
     {  // pyramid head: GroupNorm -> SiLU -> conv3x3 C->2, plus nearest-upsampled previous pyramid (ncsnpp.py:391-412)
-      const GNW& gw = N->pyr_gn[j]; const ConvW& cw = N->pyr_conv[j];
+      const GNW& gw = N->W->pyr_gn[j]; const ConvW& cw = N->W->pyr_conv[j];
       const int C = h->C, G = gn_groups(C), Hh = h->H, Ww = h->W;
       Tens* np = N->mk(B, Hh, Ww, 2, rec);
       float* stats = N->tmp((long long)B * G * 2);
@@ -959,15 +1055,15 @@ static void run_forward(Net* N, const float* x, const float* cnoise, const float
       }); }
       pyr = np; mi += 2; tap(mi - 1, pyr);
     }
-    if (l != 0) { View v; v.a = h; h = resblock(N, N->res[ri++], v, 2, temb_all, rec); tap(mi, h); ++mi; }
+    if (l != 0) { View v; v.a = h; h = resblock(N, N->W->res[ri++], v, 2, temb_all, rec); tap(mi, h); ++mi; }
   }
   N->pyr0 = pyr;
   // output layer (1x1, 2->2), iSTFT as GEMM + overlap-add with the EDM skip/out scaling folded in
   float* o2 = N->tmp((long long)B * Tp * Fb * 2);
   float* frames = N->tmp((long long)B * Tp * Kp);
   if (!N->dry()) {
-    launch_mix2(pyr->p, N->out_w, N->out_b, o2, (long long)B * Tp * Fb, 0, 0, st);
-    gemm_b(N, o2, 2 * Fb, 0, false, N->basisI, 2 * Fb, 0, false, frames, Kp, 0, B * Tp, Kp, 2 * Fb, nullptr, nullptr, 1.f, 0, 1);
+    launch_mix2(pyr->p, N->W->out_w, N->W->out_b, o2, (long long)B * Tp * Fb, 0, 0, st);
+    gemm_b(N, o2, 2 * Fb, 0, false, N->W->basisI, 2 * Fb, 0, false, frames, Kp, 0, B * Tp, Kp, 2 * Fb, nullptr, nullptr, 1.f, 0, 1);
     launch_ola(frames, Kp, Tp, nfft, hop, N->inv_env, y, B, L, N->pad, cskip_b ? x : nullptr, cskip_b, cout_b, st);
   }
   N->have_tape = rec;
@@ -983,14 +1079,14 @@ static void run_vjp(Net* N, const float* cot, float* gx) {
   float* do2 = N->tmp((long long)B * Tp * Fb * 2);
   if (!N->dry()) {
     launch_ola_adj(cot, B, L, N->pad, Tp, nfft, hop, N->inv_env, N->k_cout, dframes, Kp, st);
-    gemm_b(N, dframes, Kp, 0, false, N->basisI, 2 * Fb, 0, true, do2, 2 * Fb, 0, B * Tp, 2 * Fb, Kp, nullptr, nullptr, 1.f, 0, 1);
-    launch_mix2(do2, N->out_w, nullptr, N->pyr0->g, (long long)B * Tp * Fb, 1, 0, st);
+    gemm_b(N, dframes, Kp, 0, false, N->W->basisI, 2 * Fb, 0, true, do2, 2 * Fb, 0, B * Tp, 2 * Fb, Kp, nullptr, nullptr, 1.f, 0, 1);
+    launch_mix2(do2, N->W->out_w, nullptr, N->pyr0->g, (long long)B * Tp * Fb, 1, 0, st);
   }
   N->pyr0->ginit = 1;
   for (int i = (int)N->tape.size() - 1; i >= 0; --i) N->tape[i]();
   float* dfx = N->tmp((long long)B * T * Kp);
   if (!N->dry()) {
-    gemm_b(N, N->spec->g, 2 * Fb, (long long)Tp * 2 * Fb, false, N->basisF, Kp, 0, true, dfx, Kp, (long long)T * Kp, T, Kp, 2 * Fb, nullptr, nullptr,
+    gemm_b(N, N->spec->g, 2 * Fb, (long long)Tp * 2 * Fb, false, N->W->basisF, Kp, 0, true, dfx, Kp, (long long)T * Kp, T, Kp, 2 * Fb, nullptr, nullptr,
            1.f, 0, B);
     launch_unpad_adj(dfx, Kp, T, nfft, hop, B, L, N->pad, 1.f, N->k_cin, N->k_cskip ? cot : nullptr, N->k_cskip, gx, st);
   }
@@ -1040,6 +1136,7 @@ int net_forward(Net* N, const float* x, const float* cnoise, const float* cin_b,
   N->arena.dry = false; N->arena.overflow = false;
   run_forward(N, x, cnoise, cin_b, cskip_b, cout_b, y, B, L, save != 0);
   if (N->arena.overflow) { set_error("arena overflow"); return BUDDY_ERR_STATE; }
+  if (N->prep_failed) { N->prep_failed = false; return BUDDY_ERR_HIP; }
   HIPCHK(hipGetLastError());
   return BUDDY_OK;
 }
@@ -1049,6 +1146,7 @@ int net_vjp(Net* N, const float* cot, float* gx, hipStream_t st) {
   N->st = st;
   run_vjp(N, cot, gx);
   if (N->arena.overflow) { set_error("arena overflow"); return BUDDY_ERR_STATE; }
+  if (N->prep_failed) { N->prep_failed = false; return BUDDY_ERR_HIP; }
   HIPCHK(hipGetLastError());
   return BUDDY_OK;
 }

@@ -2,7 +2,7 @@
 // backward (no autograd), one C-ABI call per optimize_op (reference testing/EulerHeunSamplerDPS.py:71-113) and one per
 // likelihood evaluation (:61-69).  Restates reference testing/operators/subband_filtering.py (SubbandFiltering :8-136,
 // BlindSubbandFiltering :142-351), utils/reverb_utils.py:3-23 (hilbert / minimum_phase_version), utils/losses.py:59-64
-// (l2_comp_stft_summean) and torch.optim.Adam for the shipped op_hp (fix_EQ_extremes, single exponential per band set
+// (l2_comp_stft_summean) and torch Adam (the optimizer the reference constructs, EulerHeunSamplerDPS.py:193) for the shipped op_hp (fix_EQ_extremes, single exponential per band set
 // E >= 1, minimum_phase, fix_direct_path, clamp_decay, enforce_long_decay_in_second_exponential).
 //
 // Layouts: spectrograms [U][T][LDS_=1028] floats = 513 interleaved complex bins + 2 zero pad floats (16-B aligned rows,
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(256) void fft1024_c2r_kernel(C2rJobs jobs, const fl
   for (int c1 = 0; c1 < 8; ++c1) { const int n = r + 64 * c1; frames[row * WIN + n] = fac * win[n] * v[c1].x; }
 }
 
-// ---- Adam (torch.optim.Adam single-tensor arithmetic: lerp, addcmul, addcdiv) + projection ----
+// ---- Adam (torch Adam (the optimizer the reference constructs, EulerHeunSamplerDPS.py:193) single-tensor arithmetic: lerp, addcmul, addcdiv) + projection ----
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float bc2_sqrt, const int* step_dev, const float2* bc_tab) {
   if (step_dev) { const float2 bc = bc_tab[*step_dev]; bc1 = bc.x; bc2_sqrt = bc.y; }   // captured-graph mode: bias corrections by table
@@ -1539,7 +1539,7 @@ int blindop_project(BlindOp* o, hipStream_t st) {
   HIPCHK(hipGetLastError());
   return BUDDY_OK;
 }
-// Adam moments (torch.optim.Adam exp_avg / exp_avg_sq) in the reference layouts; any pointer may be NULL
+// Adam moments (torch Adam (the optimizer the reference constructs, EulerHeunSamplerDPS.py:193) exp_avg / exp_avg_sq) in the reference layouts; any pointer may be NULL
 int blindop_get_adam(BlindOp* o, float* m_decay, float* v_decay, float* m_wts, float* v_wts, float* m_phases, float* v_phases, int* step, hipStream_t st) {
   o->st = st;
   const size_t nb = (size_t)o->U * o->E * o->NB * 4;

@@ -1,0 +1,101 @@
+// Device-side preparation of the 3x3 convolution weights (reference ddpm_conv3x3, networks/ncsnpp_utils/layers.py:119-126): from the raw
+// torch OIHW tensor in HBM straight to the operand form ONE kernel variant reads -- direct [Co][9][Ci], Winograd F(2x2,3x3) [Ci/8][16][Co][8],
+// F(4x4,3x3) [36][Co][Ci] or F(6x6,3x3) [64][Co][Ci] -- for the forward or the data-gradient direction (taps flipped, roles of the channel
+// axes exchanged).  Round 3 did all of this on one host thread for every variant of every layer at handle creation (2.6 GB computed and
+// uploaded, ~7 s); here a layer's variant is produced on first use by one launch (a thread per (co, ci) pair, G g G^T in fp64 like the host
+// restatement kept in wino*.hip for the unit tests), the whole network in a few milliseconds.
+//
+// Spatial axes: the network runs NHWC with H = time frames and W = frequency bins, torch weights are [O][I][ky = frequency][kx = time], so tap
+// (dy, dx) of this layout reads w[o][i][ky = dx][kx = dy].
+#include "common.h"
+
+namespace buddy {
+namespace {
+
+__device__ __forceinline__ void g_rows(const int kind, double G[8][3]) {
+  if (kind == 2) {
+    const double g[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 3; ++c) G[r][c] = g[r][c];
+  } else if (kind == 4) {
+    const double g[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) G[r][c] = g[r][c];
+  } else {
+    const double g[8][3] = {{1, 0, 0}, {-2.0 / 9, -2.0 / 9, -2.0 / 9}, {-2.0 / 9, 2.0 / 9, -2.0 / 9}, {1.0 / 90, 1.0 / 45, 2.0 / 45},
+                            {1.0 / 90, -1.0 / 45, 2.0 / 45}, {32.0 / 45, 16.0 / 45, 8.0 / 45}, {32.0 / 45, -16.0 / 45, 8.0 / 45}, {0, 0, 1}};
+    for (int r = 0; r < 8; ++r) for (int c = 0; c < 3; ++c) G[r][c] = g[r][c];
+  }
+}
+
+// One thread per (co, ci) of THIS convolution (ci fastest: the stores of every position are coalesced along Ci).  O, I: the raw tensor's dims.
+// fp64 products and sums are kept un-contracted (fp contract off: no fma) so the result is the host restatement's, bit for bit.
+template <int KIND>
+__global__ __launch_bounds__(256) void conv3_weight_prep_kernel(const float* __restrict__ w, int O, int I, int dgrad, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int Co = dgrad ? I : O, Ci = dgrad ? O : I;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)Co * Ci) return;
+  const int co = (int)(idx / Ci), ci = (int)(idx % Ci);
+  const int o = dgrad ? ci : co, i = dgrad ? co : ci;
+  const float* src = w + ((long long)o * I + i) * 9;
+  float raw[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) raw[k] = src[k];
+  double g[3][3];                                             // g[dy][dx] of this convolution
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ey = dgrad ? 2 - dy : dy, ex = dgrad ? 2 - dx : dx;
+      g[dy][dx] = (double)raw[ex * 3 + ey];
+    }
+  if (KIND == 0) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) out[((long long)co * 9 + dy * 3 + dx) * Ci + ci] = (float)g[dy][dx];
+    return;
+  }
+  constexpr int R = KIND == 2 ? 4 : (KIND == 4 ? 6 : 8);
+  double G[8][3];
+  g_rows(KIND, G);
+  double t[R][3];
+#pragma unroll
+  for (int xi = 0; xi < R; ++xi)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      t[xi][b] = G[xi][0] * g[0][b] + G[xi][1] * g[1][b] + G[xi][2] * g[2][b];
+#pragma unroll
+  for (int xi = 0; xi < R; ++xi)
+#pragma unroll
+    for (int nu = 0; nu < R; ++nu) {
+      const double u = t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2];
+      long long dst;
+      if (KIND == 2) dst = (((long long)(ci / 8) * 16 + xi * 4 + nu) * Co + co) * 8 + (ci % 8);
+      else dst = ((long long)(xi * R + nu) * Co + co) * Ci + ci;
+      out[dst] = (float)u;
+    }
+}
+
+}  // namespace
+
+long long conv3_weight_floats(int O, int I, int kind) {
+  const long long n = (long long)O * I;
+  return kind == 0 ? 9 * n : kind == 2 ? 16 * n : kind == 4 ? 36 * n : kind == 6 ? 64 * n : 0;
+}
+
+int launch_conv3_weight_prep(const float* w_oihw, int O, int I, bool dgrad, int kind, float* out, hipStream_t st) {
+  const long long n = (long long)O * I;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(conv3_weight_prep_kernel<0>, grid, block, 0, st, w_oihw, O, I, dgrad ? 1 : 0, out); break;
+    case 2: if ((dgrad ? O : I) % 8) return BUDDY_ERR_ARG;
+            hipLaunchKernelGGL(conv3_weight_prep_kernel<2>, grid, block, 0, st, w_oihw, O, I, dgrad ? 1 : 0, out); break;
+    case 4: hipLaunchKernelGGL(conv3_weight_prep_kernel<4>, grid, block, 0, st, w_oihw, O, I, dgrad ? 1 : 0, out); break;
+    case 6: hipLaunchKernelGGL(conv3_weight_prep_kernel<6>, grid, block, 0, st, w_oihw, O, I, dgrad ? 1 : 0, out); break;
+    default: return BUDDY_ERR_ARG;
+  }
+  return BUDDY_OK;
+}
+
+}  // namespace buddy

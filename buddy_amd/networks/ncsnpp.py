@@ -10,6 +10,7 @@ Only the shipped architecture family is supported (biggan resblocks, input_skip/
 """
 from __future__ import annotations
 
+import copy
 import ctypes as C
 
 import numpy as np
@@ -133,6 +134,7 @@ class NCSNppTime(nn.Module):
                                                             requires_grad=False))
         self._handle = None
         self._fwd_id = 0
+        self._parent = None
 
     @staticmethod
     def _init(name, shape, kind, init_scale, fourier_scale):
@@ -161,6 +163,10 @@ class NCSNppTime(nn.Module):
         self._handle = None
 
     def _get_handle(self):
+        if self._handle is None and getattr(self, "_parent", None) is not None:
+            h = C.c_void_p()
+            _lib.check(_lib.require_gpu().buddy_ncsnpp_replica(self._parent._get_handle(), C.byref(h)))
+            self._handle = h
         if self._handle is None:
             lib = _lib.require_gpu()
             blob = np.ascontiguousarray(self._flat_params())
@@ -178,21 +184,26 @@ class NCSNppTime(nn.Module):
         return self._handle
 
     def replica(self):
-        """A second module with the SAME weights and its own library handle (activation arena + VJP tape): lets another sub-batch run
-        concurrently on another HIP stream (buddy_amd/testing/concurrent.py).  110 MB of parameters are copied once."""
-        dev = next(self.parameters()).device
-        r = NCSNppTime(**self._init_kwargs)
-        r.load_state_dict(self.state_dict())
-        return r.to(dev).eval()
+        """A second module on the SAME parameters and the same prepared device weights (``buddy_ncsnpp_replica``: reference-counted, read-only)
+        with its own library handle -- activation arena + VJP tape -- so another sub-batch can run concurrently on another HIP stream
+        (buddy_amd/testing/concurrent.py).  Costs no weight memory and no preparation time.  A replica follows the weights its parent had
+        when the replica's handle was made; reload the parent -> make new replicas."""
+        r = copy.copy(self)                     # shallow: shares _parameters / _modules (the nn.Parameters themselves)
+        r._handle = None
+        r._fwd_id = 0
+        object.__setattr__(r, "_parent", self)   # not a submodule: nn.Module.__setattr__ would register it in the shared _modules
+        return r
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self._drop_handle()
+        self._parent = None                     # new weights: this module owns its handle again
         return r
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._drop_handle()
+        self._parent = None
         return r
 
     def __del__(self):
@@ -200,6 +211,12 @@ class NCSNppTime(nn.Module):
             self._drop_handle()
         except Exception:
             pass
+
+    def weight_bytes(self):
+        """Device bytes of the (shared) weight store: {'params', 'packed_1x1', 'conv3_forms', 'conv3_form_count'}."""
+        a, b, c, n = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_int()
+        _lib.check(_lib.require_gpu().buddy_ncsnpp_weight_bytes(self._get_handle(), C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return {"params": a.value, "packed_1x1": b.value, "conv3_forms": c.value, "conv3_form_count": n.value}
 
     def arena_bytes(self, B, L, with_vjp=True):
         n = C.c_longlong()

@@ -4,8 +4,9 @@
 Batched: ``y`` may be ``(B, L)``; every reduction the reference takes over "the tensor" (``y.std()``,
 ``torch.norm(rec_grads)``, ``x_den.std()``) is taken per utterance, the operator holds per-utterance parameters, Adam
 is elementwise -- so row b of a batched run equals the reference's B=1 run on utterance b.
-The likelihood gradient flows by autograd through the operator/loss and then through the hand-written HIP network
-VJP (``NCSNppTime`` is an autograd Function)."""
+The likelihood loss and its gradient w.r.t. the Tweedie estimate come from the operator's library handle (one call), autograd then
+continues through the hand-written HIP network VJP (``NCSNppTime`` is an autograd Function).  The operator update (``optimize_op``) is one
+library call.  No torch-op operator / Adam path exists in the product (tests/torchops/sampler.py holds that form for host-logic tests)."""
 from __future__ import annotations
 
 import torch
@@ -22,8 +23,6 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
     def __init__(self, model, diff_params, args):
         super().__init__(model, diff_params, args)
         self.zeta = self.args.tester.posterior_sampling.zeta
-        self._hip_op = False
-        self._hip_loss = False
         self.use_hip_update = True      # fused elementwise tail on the GPU (False: torch expressions, as on the CPU)
 
     def initialize_x(self, shape, device, schedule):
@@ -33,7 +32,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         if wi.mode == "reverb_scaled":
             return wi.scaling_factor * self.y.clone() / _row_std(self.y) + schedule[0] * self._randn(shape, device)
         if wi.mode == "wpe_scaled":
-            from ..utils.wpe import wpe_dereverb    # nara_wpe restated (third-party, parity unpinned)
+            from ..utils.wpe import wpe_dereverb    # nara_wpe restated in HIP (third-party, parity unpinned): buddy_wpe_dereverb
             x_pred = wpe_dereverb(self.y, taps=wi.wpe.taps, delay=wi.wpe.delay, iterations=wi.wpe.iterations)
             if x_pred.shape[-1] < self.y.shape[-1]:
                 x_pred = torch.nn.functional.pad(x_pred, (0, self.y.shape[-1] - x_pred.shape[-1]))
@@ -42,49 +41,16 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         raise NotImplementedError
 
     def get_likelihood_score(self, x_den, x, t):
-        if self._hip_op or self._hip_loss:
-            rec = self.operator.hip_rec_loss(x_den)               # fused HIP loss + analytic d/dx_den; autograd continues into the net VJP
-        else:
-            y_hat = self.operator.degradation(x_den, mode="waveform")
-            rec = self.rec_loss(self.y, y_hat)                    # sum over utterances: gradients decouple per row
+        # fused HIP loss + analytic d/dx_den (buddy_blindop_rec_loss_grad / _fir_loss_grad); autograd continues into the network VJP
+        rec = self.operator.hip_rec_loss(x_den)
         rec_grads = torch.autograd.grad(outputs=rec, inputs=x)[0]
         normguide = torch.linalg.vector_norm(rec_grads, dim=-1, keepdim=True) / (self.args.exp.audio_len ** 0.5)
         return self.zeta / (normguide + 1e-8) * rec_grads, rec
 
     def optimize_op(self, x_den, t):
-        if self._hip_op:
-            return self.operator.hip_optimize(x_den, t)           # the whole loop below as one library call (buddy_blindop_optimize)
-        ps = self.args.tester.posterior_sampling
-        for _ in range(ps.blind_hp.op_updates_per_step):
-            for p in self.operator.params:
-                p.requires_grad = True
-            for p in self.operator.params_phases:
-                p.requires_grad = True
-            self.operator.update_H()
-            y_hat = self.operator.degradation(x_den, mode="waveform")
-            if self.rec_loss_params is not None:
-                loss = self.rec_loss_params(self.y, y_hat)
-                assert not torch.isnan(loss).any(), "rec_loss is Nan"
-            else:
-                loss = 0.
-            if self.RIR_noise_regularization_loss is not None:
-                rir_time = self.operator.get_time_RIR()
-                if rir_time.dim() == 1:
-                    rir_time = rir_time.unsqueeze(0)
-                rir_noise = self.operator._randn(rir_time.shape[1:]) if hasattr(self.operator, "_randn") else torch.randn_like(rir_time)
-                reg = ps.RIR_noise_regularization
-                t_op = max(min(float(t), reg.crop_sigma_max), reg.crop_sigma_min)
-                rir_noisy = rir_time + t_op * rir_noise
-                loss = loss + self.RIR_noise_regularization_loss(rir_time, rir_noisy.detach())
-            assert not torch.isnan(loss).any(), "loss is Nan"
-            self.optimizer_operator.zero_grad()
-            loss.backward()
-            self.optimizer_operator.step()
-            for p in self.operator.params:
-                p.detach_()
-            self.operator.project_params()
-            for p in self.operator.params:
-                p.requires_grad = True
+        """reference :71-113: ``op_updates_per_step`` Adam iterations on the operator parameters (update_H, degradation, the two losses,
+        backward, Adam step, projection) -- ONE library call (``buddy_blindop_optimize``: 24 kernels per iteration in a captured hipGraph)."""
+        return self.operator.hip_optimize(x_den, t)
 
     def _guided_eval(self, x_in, t, blind, rescale=True):
         """one guided evaluation; ``rescale=False`` is the Heun corrector, which the reference leaves un-rescaled (:139-149)"""
@@ -155,22 +121,27 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
     def predict_unconditional(self, *args, **kwargs):
         raise ValueError("DPS not made for unconditional sampling")
 
-    def predict_conditional(self, y, operator, shape=None, blind=False, **kwargs):
+    def bind(self, y, operator, blind):
+        """What the reference's predict_conditional sets up before its loop (:181-204): the operator, the observation, the losses and -- blind --
+        a fresh Adam state.  Here all of it lives in the operator's library handle (``hip_bind``): compressed STFT of y cached, loss weights
+        validated (utils/losses.get_loss), Adam moments zeroed.  An operator without the HIP entry points, an unsupported loss or a tensor
+        that is not on the GPU raises: there is no torch-op path."""
         ps = self.args.tester.posterior_sampling
-        self.operator = operator
-        self.y = y
-        self.rec_loss = get_loss(ps.rec_loss, operator=self.operator)
-        self._hip_op = bool(blind and hasattr(operator, "hip_optimize"))
-        self._hip_loss = False
-        if self._hip_op:
-            operator.hip_bind(y, ps)
-        elif not blind and hasattr(operator, "hip_rec_loss") and y.is_cuda:
-            self._hip_loss = bool(operator.hip_bind(y, ps))       # informed: FIR + STFT loss + adjoints in the HIP library
-        elif blind:
-            self.rec_loss_params = get_loss(ps.rec_loss_params, operator=self.operator)
-            self.optimizer_operator = torch.optim.Adam(self.operator.params + self.operator.params_phases, lr=ps.blind_hp.lr_op,
-                                                       weight_decay=ps.blind_hp.weight_decay, betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
-            self.RIR_noise_regularization_loss = get_loss(ps.RIR_noise_regularization.loss, operator=self.operator)
+        self.operator, self.y = operator, y
+        self.rec_loss = get_loss(ps.rec_loss, operator=operator)           # validated specification (the value comes from the library)
+        if not (hasattr(operator, "hip_bind") and hasattr(operator, "hip_rec_loss")):
+            raise NotImplementedError(f"{type(operator).__name__} has no HIP likelihood path (hip_bind / hip_rec_loss)")
+        if blind and not hasattr(operator, "hip_optimize"):
+            raise NotImplementedError(f"{type(operator).__name__} cannot be optimised blindly (no hip_optimize)")
+        if blind:
+            self.rec_loss_params = get_loss(ps.rec_loss_params, operator=operator)
+            self.RIR_noise_regularization_loss = get_loss(ps.RIR_noise_regularization.loss, operator=operator)
+        if operator.hip_bind(y, ps) is False:
+            raise NotImplementedError("this observation / loss configuration is outside what the HIP likelihood kernels are built for "
+                                      "(2-D GPU tensor of >= 1024 samples, l2_comp_stft_summean @ 0.667, operator STFT 1024/512/128 hann)")
+
+    def predict_conditional(self, y, operator, shape=None, blind=False, **kwargs):
+        self.bind(y, operator, blind)
         if shape is None:
             shape = y.shape
         return self.predict(tuple(shape), y.device, blind)

@@ -9,7 +9,6 @@ from __future__ import annotations
 import torch
 
 from ..instantiate import instantiate
-from ..utils.losses import get_loss
 
 
 class SubBatch:
@@ -19,21 +18,9 @@ class SubBatch:
 
     def begin(self):
         """what predict_conditional does before its loop (testing/EulerHeunSamplerDPS.py predict_conditional + predict)"""
-        s, ps = self.s, self.s.args.tester.posterior_sampling
+        s = self.s
         with torch.cuda.stream(self.stream):
-            s.operator, s.y = self.op, self.y
-            s.rec_loss = get_loss(ps.rec_loss, operator=self.op)
-            s._hip_op = bool(self.blind and hasattr(self.op, "hip_optimize"))
-            s._hip_loss = False
-            if s._hip_op:
-                self.op.hip_bind(self.y, ps)
-            elif not self.blind and hasattr(self.op, "hip_rec_loss") and self.y.is_cuda:
-                s._hip_loss = bool(self.op.hip_bind(self.y, ps))
-            elif self.blind:
-                s.rec_loss_params = get_loss(ps.rec_loss_params, operator=self.op)
-                s.optimizer_operator = torch.optim.Adam(self.op.params + self.op.params_phases, lr=ps.blind_hp.lr_op,
-                                                        weight_decay=ps.blind_hp.weight_decay, betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
-                s.RIR_noise_regularization_loss = get_loss(ps.RIR_noise_regularization.loss, operator=self.op)
+            s.bind(self.y, self.op, self.blind)
             t = s.create_schedule()
             self.t, self.g = t.tolist(), s.get_gamma(t).tolist()
             self.x = s.initialize_x(tuple(self.y.shape), self.y.device, t)

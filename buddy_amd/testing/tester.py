@@ -39,7 +39,6 @@ class Tester:
         self.sampler = instantiate(args.tester.sampler, self.network, self.diff_params, self.args)
         self.paths = {}
         self.results = []
-        self.blind_backend = None      # None: HIP operator on a GPU; "torch" forces the torch-op implementation
         # a batch of >= 2 * sub_batches utterances is sampled as that many concurrent sub-batches on their own HIP streams
         # (testing/concurrent.py; identical results, better occupancy); 1 = one batch, one stream.  Default ("auto", tester.sub_batches
         # absent): 2 whenever a group has >= 4 utterances -- the measured optimum (+5 %; 4 loses), DESIGN.md section 6
@@ -108,7 +107,7 @@ class Tester:
             if blind:
                 assert self.args.tester.blind_dereverberation.operator == "subband_filtering"
                 operator = BlindSubbandFiltering(op_hp, sample_rate=self.args.exp.sample_rate, num_utts=len(items), noise=noise, device=self.device,
-                                                 length=seg.shape[-1], backend=self.blind_backend)
+                                                 length=seg.shape[-1])
                 operator.update_H(use_noise=True)
         return seg, y, operator, rirs
 
@@ -190,8 +189,7 @@ class Tester:
             n, clen = parts.shape
             self.sampler.noise = noise(n) if noise is not None else None
             if blind:
-                op = BlindSubbandFiltering(op_hp, sample_rate=sr, num_utts=n, noise=self.sampler.noise, device=self.device, length=clen,
-                                           backend=self.blind_backend)
+                op = BlindSubbandFiltering(op_hp, sample_rate=sr, num_utts=n, noise=self.sampler.noise, device=self.device, length=clen)
                 op.update_H(use_noise=True)
             else:
                 op = RIROperator(op_hp, time_kernel_size=len(rir), sample_rate=sr, device=self.device)

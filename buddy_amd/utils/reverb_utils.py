@@ -2,12 +2,12 @@
 
 ``fast_apply_RIR`` keeps the reference signature but runs the hand-written time-domain FIR kernel
 (``buddy_fir``): the same linear convolution the reference evaluates through a 2^17-point complex FFT, exact to
-fp32 round-off, with its transpose as the autograd backward.  ``hilbert`` / ``minimum_phase_version`` follow the
-reference formulas on torch's device FFT (used by the blind operator's filter projection only)."""
+fp32 round-off, with its transpose as the autograd backward.  ``hilbert`` / ``minimum_phase_version`` (reference :3-23) run inside the
+blind operator's library handle (25 856-point FFT kernels, ``BlindSubbandFiltering.minimum_phase``); their torch restatement is test
+infrastructure (``tests/torchops/operators.py``)."""
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from .. import _lib
 
@@ -42,23 +42,3 @@ def fast_apply_RIR(y, filter, rm_delay=False, zero_pad=False):
     if rm_delay:
         filter = filter[..., int(torch.argmax(filter)):]
     return _FirFn.apply(y, filter.to(y.device))
-
-
-def hilbert(h):
-    """reference reverb_utils.py:3-7: window [2]*ceil(N/2) ++ [0]*floor(N/2), DC/Nyquist not special-cased."""
-    n = h.size(-1)
-    window = 2 * torch.heaviside(torch.linspace(-1, 1, steps=n), values=torch.ones(1)).to(h.device)
-    window = torch.flip(window, dims=(-1,))
-    return torch.fft.ifft(window * torch.fft.fft(h))
-
-
-def minimum_phase_version(h):
-    """reference reverb_utils.py:9-23 (batched over leading dims)."""
-    T = h.size(-1)
-    h = F.pad(h, (0, T))
-    H = torch.fft.fft(h)
-    log_abs = torch.log(torch.abs(H) + 1e-8)
-    phase = -torch.imag(hilbert(log_abs))
-    e = torch.exp(1j * phase)
-    out = torch.real(torch.fft.ifft(torch.abs(H).type(e.dtype) * e))
-    return out[..., :-T]

@@ -26,11 +26,24 @@ int buddy_version(void);
  * Conv_1.*, [Conv_2.*]) -- buddy_amd/synth.py:module_specs is the Python mirror of that order. */
 int buddy_ncsnpp_param_count(int nf, const int* ch_mult, int n_levels, int num_res_blocks, long long* count);
 
-/* build a network handle from a HOST blob (weights are repacked for the MFMA kernels and uploaded once).
- * n_fft / hop: conf/network/ncsnpp.yaml:2-5 (510 / 128). */
+/* build a network handle from a HOST blob: the parameters are uploaded once; the 3x3 convolutions' operand forms (Winograd-domain weights,
+ * bf16x3 stage images) are derived ON THE DEVICE, per layer, for the one kernel variant the first forward / VJP of a workload selects.
+ * n_fft / hop: conf/network/ncsnpp.yaml:2-5 (510 / 128).  (The reference builds its module with `instantiate(args.network)` and loads a
+ * state dict, test.py:60-75; this is the library side of NCSNppTime.load_state_dict + .to(device).) */
 int buddy_ncsnpp_create(const float* host_params, long long n_params, int nf, const int* ch_mult, int n_levels,
                         int num_res_blocks, int n_fft, int hop, void** handle);
 int buddy_ncsnpp_destroy(void* handle);
+/* a second handle on the SAME prepared weights (reference-counted, read-only): own activation arena, VJP tape and attention / gemm / fir
+ * settings (copied from `handle`).  For concurrent sub-batches on several streams; no reference counterpart (testing/tester.py:132-153 samples
+ * one utterance at a time on one module). */
+int buddy_ncsnpp_replica(void* handle, void** replica);
+/* device bytes held by the (shared) weight store of a handle: raw parameters, bf16x3 images of the 1x1 / NIN matrices, lazily prepared 3x3
+ * operand forms (and their count). */
+int buddy_ncsnpp_weight_bytes(void* handle, long long* params, long long* packed, long long* lazy, int* lazy_forms);
+/* the device-side weight preparation on its own: raw torch OIHW [O][I][3][3] (device) -> operand form `kind` (0 direct [Co][9][Ci], 2 Winograd
+ * F(2x2,3x3) [Ci/8][16][Co][8], 4 F(4x4,3x3) [36][Co][Ci], 6 F(6x6,3x3) [64][Co][Ci]); dgrad != 0: the data-gradient direction (Co = I, Ci = O,
+ * taps flipped).  out: conv weight count x (9 | 16 | 36 | 64) floats.  Weights of ddpm_conv3x3, networks/ncsnpp_utils/layers.py:119-126. */
+int buddy_conv3_weight_prep(const float* w_oihw, int O, int I, int dgrad, int kind, float* out, void* stream);
 
 /* size the activation arena for batch B, length L samples (done implicitly by forward; exposed to report bytes). */
 int buddy_ncsnpp_reserve(void* handle, int B, int L, int with_vjp, long long* bytes);

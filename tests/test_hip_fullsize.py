@@ -111,12 +111,7 @@ def _two_blind_steps_vs_oracle(net, L, B, rir_taps, updates=3, check=(0,), floor
     t.sampler.noise = ns
     seg, y, op, _ = t.prepare_batch(items, blind=True, noise=ns)
     smp = t.sampler
-    smp.operator, smp.y = op, y
-    from buddy_amd.utils.losses import get_loss
-    smp.rec_loss = get_loss(args.tester.posterior_sampling.rec_loss, operator=op)
-    smp._hip_op = hasattr(op, "hip_optimize")
-    assert smp._hip_op
-    op.hip_bind(y, args.tester.posterior_sampling)
+    smp.bind(y, op, True)
     sched = smp.create_schedule().cuda(); gam = smp.get_gamma(sched).cuda()
     x = smp.initialize_x(tuple(y.shape), "cuda", sched)
     for i in range(2):
@@ -216,7 +211,6 @@ def test_fullsize_blind_T10_fp64_arbiter(net):
     from buddy_amd.instantiate import instantiate
     from buddy_amd.synth import synth_clean, synth_rir
     from buddy_amd.testing.tester import Tester
-    from buddy_amd.utils.losses import get_loss
     from oracle.arbiter_runs import run_blind, overrides
     from oracle.sampler_ref import NoiseStream
     T, nf, up, taps, seed = 10, 128, 10, 8000, 3
@@ -226,10 +220,7 @@ def test_fullsize_blind_T10_fp64_arbiter(net):
     t.sampler.noise = ns
     seg, y, op, _ = t.prepare_batch([(synth_clean(seed, L), synth_rir(seed, taps), "u.wav")], blind=True, noise=ns)
     smp = t.sampler
-    smp.operator, smp.y = op, y
-    smp.rec_loss = get_loss(args.tester.posterior_sampling.rec_loss, operator=op)
-    smp._hip_op = True
-    op.hip_bind(y, args.tester.posterior_sampling)
+    smp.bind(y, op, True)
     sched = smp.create_schedule()
     tl, gl = sched.tolist(), smp.get_gamma(sched).tolist()
     x = smp.initialize_x(tuple(y.shape), "cuda", sched)

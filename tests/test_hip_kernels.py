@@ -415,7 +415,8 @@ def test_row_ops(lib):
 
 def test_wpe_kernel_vs_torch_restatement(lib):
     """buddy_wpe (one workgroup per frequency bin, Cholesky in LDS, complex128) vs the torch restatement of the same algorithm."""
-    from buddy_amd.utils import wpe
+    from tests.torchops import wpe
+    from buddy_amd.utils.wpe import wpe_hip
     g = torch.Generator(device="cpu").manual_seed(11)
     L = 16000
     src = torch.randn(L, generator=g, dtype=torch.float64) * (torch.rand(L, generator=g, dtype=torch.float64) > 0.7)
@@ -423,13 +424,13 @@ def test_wpe_kernel_vs_torch_restatement(lib):
     y = torch.nn.functional.conv1d(src.view(1, 1, -1), h.flip(0).view(1, 1, -1), padding=2999)[0, 0, :L]
     Y = wpe.stft(y[None].cuda()).permute(2, 0, 1).contiguous()              # (F, 1, T)
     Zt = wpe.wpe(Y, taps=50, delay=2, iterations=5)
-    Zh = wpe.wpe_hip(Y, taps=50, delay=2, iterations=5)
+    Zh = wpe_hip(Y, taps=50, delay=2, iterations=5)
     err = float((torch.view_as_real(Zh) - torch.view_as_real(Zt)).abs().max() / torch.view_as_real(Zt).abs().max())
     # 50 taps on a reverberant signal: cond(R) ~ 1e9..1e10, so Cholesky (kernel) and LU (torch.linalg.solve) agree to cond * eps_fp64
     assert err < 1e-4, err
     # fewer taps / iterations, odd delay
     Zt = wpe.wpe(Y, taps=7, delay=3, iterations=2)
-    Zh = wpe.wpe_hip(Y, taps=7, delay=3, iterations=2)
+    Zh = wpe_hip(Y, taps=7, delay=3, iterations=2)
     assert float((torch.view_as_real(Zh) - torch.view_as_real(Zt)).abs().max() / torch.view_as_real(Zt).abs().max()) < 1e-9
 
 
@@ -480,3 +481,30 @@ def test_fir_resample2_vs_reference(lib, golden):
     assert rel(gu, nhwc(g["vjp_up"])) < 1e-6
     _lib.check(lib.buddy_fir_resample2(P(cd), P(gu), B, H // 2, W // 2, Cc, 1, 0.25, 1, S()))
     assert rel(gu, nhwc(g["vjp_up"]) + nhwc(g["vjp_down"])) < 1e-6
+
+
+@pytest.mark.parametrize("O,I", [(128, 128), (256, 384), (32, 64)])
+@pytest.mark.parametrize("kind", [0, 2, 4, 6])
+@pytest.mark.parametrize("dgrad", [0, 1])
+def test_conv3_weight_prep_vs_host_restatement(lib, O, I, kind, dgrad):
+    """buddy_conv3_weight_prep (csrc/wprep.hip: raw torch OIHW -> operand form of one kernel variant, on the device) against the host
+    restatement the library exports for the unit tests (buddy_winograd{,4,6}_transform_weights on the tap-major packing): bit for bit --
+    both evaluate G g G^T in un-contracted fp64 and round once."""
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(O * 7 + I + kind + dgrad)
+    w = torch.randn(O, I, 3, 3, generator=g) * torch.logspace(-2, 1, O)[:, None, None, None]
+    # tap-major packing of THIS convolution: forward [o][(dy*3+dx)*I + i] = w[o][i][ky=dx][kx=dy]; dgrad [i][(dy*3+dx)*O + o], taps flipped
+    wt = w.permute(0, 3, 2, 1) if not dgrad else w.flip(2, 3).permute(1, 3, 2, 0)     # [co][dy][dx][ci]
+    Co, Ci = (O, I) if not dgrad else (I, O)
+    wt = wt.contiguous().reshape(Co, 9 * Ci)
+    n = {0: 9, 2: 16, 4: 36, 6: 64}[kind] * O * I
+    out = torch.full((n,), float("nan"), device="cuda")
+    _lib.check(lib.buddy_conv3_weight_prep(P(w.cuda().contiguous()), O, I, dgrad, kind, P(out), S()))
+    torch.cuda.synchronize()
+    if kind == 0:
+        ref = wt.reshape(-1)
+    else:
+        ref = torch.empty(n)
+        fn = {2: lib.buddy_winograd_transform_weights, 4: lib.buddy_winograd4_transform_weights, 6: lib.buddy_winograd6_transform_weights}[kind]
+        _lib.check(fn(wt.numpy().ctypes.data, Co, Ci, ref.numpy().ctypes.data))
+    assert torch.equal(out.cpu(), ref)

@@ -125,3 +125,44 @@ def test_gemm_modes_vs_golden(golden, gemm):
     ey, eg = rel(y.detach().cpu().numpy(), g["y"]), rel(gx.cpu().numpy(), g["vjp"])
     print(f"gemm={gemm}: forward {ey:.2e} vjp {eg:.2e}")
     assert ey < TOL and eg < TOL
+
+
+def test_cold_start_budget_and_shared_replica():
+    """a network handle must be cheap.  Full-width network (111 MB of parameters): buddy_ncsnpp_create + the first forward
+    (which prepares, on the GPU, the ONE operand form each 3x3 convolution uses for this workload) under 1.5 s of wall time here (measured
+    ~0.3 s; the bound leaves room for a cold driver), prepared weights < 1.3 GB for a forward-only handle and < 2.6 GB with the data-gradient
+    forms of the VJP (round 3: 5.7 GB and ~7 s per handle); a replica shares all of it (no new bytes, no new forms) and returns the parent's
+    output bit for bit."""
+    import time
+    net = build(128, 510, 128, 0)
+    B, L = 2, 64000
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy((0.3 * rs.standard_normal((B, L))).astype(np.float32)).cuda()
+    cn = torch.tensor([-0.7, -0.1], device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        y = net(x, cn)
+    torch.cuda.synchronize()
+    cold = time.perf_counter() - t0
+    wb = net.weight_bytes()
+    assert cold < 1.5, f"handle creation + first forward took {cold:.2f} s"
+    assert wb["conv3_forms"] < 1.3e9, wb
+    n_fwd = wb["conv3_form_count"]
+    xg = x.clone().requires_grad_(True)
+    yg = net(xg, cn)
+    g, = torch.autograd.grad(yg, xg, torch.ones_like(yg))
+    torch.cuda.synchronize()
+    wb2 = net.weight_bytes()
+    assert wb2["conv3_forms"] < 2.6e9 and wb2["conv3_form_count"] <= 2 * n_fwd, wb2
+    t0 = time.perf_counter()
+    rep = net.replica()
+    with torch.no_grad():
+        yr = rep(x, cn)
+    torch.cuda.synchronize()
+    warm = time.perf_counter() - t0
+    wb3 = rep.weight_bytes()
+    assert wb3 == wb2, (wb2, wb3)
+    assert torch.equal(yr, y)
+    assert warm < 0.5, f"replica + its first forward took {warm:.2f} s"
+    print(f"cold start {cold * 1e3:.0f} ms, replica first forward {warm * 1e3:.0f} ms, weight store {wb2}")

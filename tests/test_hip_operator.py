@@ -1,6 +1,7 @@
 """GPU parity of the hand-written blind operator (buddy_blindop_*: analytic forward/backward, fused Adam loop) against the
-torch-op implementation of the same reference code on the same device, inputs and noise draws (that torch path is pinned to
-the reference fixtures by tests/test_host_logic.py + tests/test_hip_sampler.py).  Tolerances relative to abs-max."""
+torch-op restatement of the same reference code (tests/torchops: autograd, rocFFT, torch's Adam -- test infrastructure, not product) on the
+same device, inputs and noise draws; that restatement is pinned to the reference fixtures by tests/test_host_logic.py.  Tolerances
+relative to abs-max."""
 import numpy as np
 import pytest
 import torch
@@ -15,15 +16,16 @@ def rel(a, b):
 
 def make_ops(U, L, seed=40):
     from buddy_amd.config import compose
-    from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering, BlindSubbandFilteringHIP
+    from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering
+    from tests.torchops.operators import BlindSubbandFiltering as BlindSubbandFilteringTorch
     from oracle.sampler_ref import NoiseStream
     args = compose(overrides=["tester.posterior_sampling.warm_initialization.mode=reverb_scaled"])
     op_hp = args.tester.informed_dereverberation.op_hp
     nt = [NoiseStream(seed + u) for u in range(U)]
     nh = [NoiseStream(seed + u) for u in range(U)]
-    opt = BlindSubbandFiltering(op_hp, 16000, num_utts=U, noise=nt, device="cuda", backend="torch")
+    opt = BlindSubbandFilteringTorch(op_hp, 16000, num_utts=U, noise=nt, device="cuda")
     oph = BlindSubbandFiltering(op_hp, 16000, num_utts=U, noise=nh, device="cuda", length=L)
-    assert isinstance(oph, BlindSubbandFilteringHIP) and not isinstance(opt, BlindSubbandFilteringHIP)
+    assert hasattr(oph, "hip_optimize") and not hasattr(opt, "hip_optimize")
     return args, opt, oph, nt, nh
 
 
@@ -51,7 +53,7 @@ def test_forward_pieces():
 
 
 def test_likelihood_loss_and_gradient():
-    from buddy_amd.utils.losses import get_loss
+    from tests.torchops.losses import get_loss
     U, L = 2, 16000
     args, opt, oph, nt, nh = make_ops(U, L)
     ps = args.tester.posterior_sampling
@@ -69,7 +71,7 @@ def test_likelihood_loss_and_gradient():
 
 def test_parameter_gradients():
     from buddy_amd import _lib
-    from buddy_amd.utils.losses import get_loss
+    from tests.torchops.losses import get_loss
     U, L = 2, 16000
     args, opt, oph, nt, nh = make_ops(U, L)
     ps = args.tester.posterior_sampling
@@ -99,7 +101,7 @@ def test_parameter_gradients():
 def test_parameter_gradients_without_regulariser():
     """noise == NULL: the reconstruction term alone (the path that does not share its launches with the regulariser chain)"""
     from buddy_amd import _lib
-    from buddy_amd.utils.losses import get_loss
+    from tests.torchops.losses import get_loss
     U, L = 2, 16000
     args, opt, oph, nt, nh = make_ops(U, L)
     ps = args.tester.posterior_sampling
@@ -129,16 +131,12 @@ def test_optimize_loop_matches_torch_adam():
     ps = args.tester.posterior_sampling
     x, y = signals(U, L)
     args.tester.posterior_sampling.blind_hp.op_updates_per_step = 3
-    smp_t = instantiate(args.tester.sampler, torch.nn.Identity(), instantiate(args.diff_params), args)
+    from tests.torchops.sampler import EulerHeunSamplerDPSTorch
+    smp_t = EulerHeunSamplerDPSTorch(torch.nn.Identity(), instantiate(args.diff_params), args)
     smp_h = instantiate(args.tester.sampler, torch.nn.Identity(), instantiate(args.diff_params), args)
-    for smp, op in ((smp_t, opt), (smp_h, oph)):
-        smp.operator, smp.y = op, y
-        smp._hip_op = hasattr(op, "hip_optimize")
-    from buddy_amd.utils.losses import get_loss
-    smp_t.rec_loss_params = get_loss(ps.rec_loss_params, opt)
-    smp_t.RIR_noise_regularization_loss = get_loss(ps.RIR_noise_regularization.loss, opt)
-    smp_t.optimizer_operator = torch.optim.Adam(opt.params + opt.params_phases, lr=ps.blind_hp.lr_op, betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
-    oph.hip_bind(y, ps)
+    assert type(smp_h).__name__ == "EulerHeunSamplerDPS"
+    smp_t.bind(y, opt, True)            # torch losses + torch's Adam on the torch-op operator
+    smp_h.bind(y, oph, True)            # hip_bind: everything inside the library handle
     t = torch.tensor(0.02)
     smp_t.optimize_op(x.clone(), t)
     smp_h.optimize_op(x.clone(), t)
@@ -159,7 +157,7 @@ def test_informed_likelihood_loss_and_gradient():
     from buddy_amd.config import compose
     from buddy_amd.synth import synth_rir
     from buddy_amd.testing.operators.reverb import RIROperator
-    from buddy_amd.utils.losses import get_loss
+    from tests.torchops.losses import get_loss
     U, L = 2, 16000
     args = compose(tester="informed_dereverberation_DPS")
     ps = args.tester.posterior_sampling
@@ -171,8 +169,10 @@ def test_informed_likelihood_loss_and_gradient():
     xh = xd.clone().requires_grad_(True)
     rec_h = op.hip_rec_loss(xh)
     gh, = torch.autograd.grad(rec_h, xh)
+    from tests.torchops.operators import StftOnly
+    st = StftOnly(args.tester.informed_dereverberation.op_hp, 16000, "cuda")     # the loss formula's STFT through torch; the FIR is the HIP kernel (autograd Function)
     xt = xd.clone().requires_grad_(True)
-    rec_t = get_loss(ps.rec_loss, operator=op)(y, op.degradation(xt))
+    rec_t = get_loss(ps.rec_loss, operator=st)(y, op.degradation(xt))
     gt, = torch.autograd.grad(rec_t, xt)
     assert abs(float(rec_h) - float(rec_t)) < 2e-4 * abs(float(rec_t))
     assert rel(gh, gt) < 5e-4
@@ -181,5 +181,5 @@ def test_informed_likelihood_loss_and_gradient():
     xh = xd.clone().requires_grad_(True)
     gh, = torch.autograd.grad(op.hip_rec_loss(xh), xh)
     xt = xd.clone().requires_grad_(True)
-    gt, = torch.autograd.grad(get_loss(ps.rec_loss, operator=op)(y, op.degradation(xt)), xt)
+    gt, = torch.autograd.grad(get_loss(ps.rec_loss, operator=st)(y, op.degradation(xt)), xt)
     assert rel(gh, gt) < 5e-4

@@ -57,27 +57,32 @@ def test_informed_dps_vs_reference_fixture(golden):
 
 
 def _run_blind(g, extra, backend):
-    from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering, BlindSubbandFilteringHIP
     from buddy_amd.instantiate import instantiate
     from oracle.sampler_ref import NoiseStream
     args, net, edm, meta = _setup(g, "blind_dereverberation_BUDDy", extra)
     ns = [NoiseStream(meta[6])]
-    smp = instantiate(args.tester.sampler, net, edm, args)
+    if backend == "hip":                 # the product: sampler from the config's _target_, HIP operator
+        from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering
+        smp = instantiate(args.tester.sampler, net, edm, args)
+        op = BlindSubbandFiltering(args.tester.informed_dereverberation.op_hp, 16000, num_utts=1, noise=ns, device="cuda", length=meta[1])
+        assert hasattr(op, "hip_optimize")
+    else:                                # cross-check: the torch-op restatement (tests/torchops) around the same HIP network
+        from tests.torchops.operators import BlindSubbandFiltering
+        from tests.torchops.sampler import EulerHeunSamplerDPSTorch
+        smp = EulerHeunSamplerDPSTorch(net, edm, args)
+        op = BlindSubbandFiltering(args.tester.informed_dereverberation.op_hp, 16000, num_utts=1, noise=ns, device="cuda")
     smp.noise = ns
-    kw = dict(length=meta[1]) if backend == "hip" else dict(backend="torch")
-    op = BlindSubbandFiltering(args.tester.informed_dereverberation.op_hp, 16000, num_utts=1, noise=ns, device="cuda", **kw)
-    assert isinstance(op, BlindSubbandFilteringHIP) == (backend == "hip")
     op.update_H(use_noise=True)
     y = torch.from_numpy(g["y"]).cuda()
     pred = smp.predict_conditional(y, op, shape=(1, meta[1]), blind=True)
     assert ns[0].k == int(g["n_draws"])
-    assert smp._hip_op == (backend == "hip")
     return pred.cpu().numpy(), op, smp
 
 
 @pytest.mark.parametrize("backend", ["hip", "torch"])
 def test_blind_dps_vs_reference_fixture(golden, backend):
-    """backend "hip": the hand-written operator (csrc/operator.hip -- what the bench and the Tester run); "torch": the torch-op class."""
+    """backend "hip": the hand-written operator (csrc/operator.hip -- what the bench and the Tester run); "torch": the torch-op restatement
+    of tests/torchops (test infrastructure) driving the same HIP network."""
     g = golden("e2e_blind")
     p, op, smp = _run_blind(g, ["tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
                                 "tester.posterior_sampling.blind_hp.op_updates_per_step=3"], backend)
@@ -118,7 +123,6 @@ def test_blind_T10_shipped_updates_fp64_arbiter(golden):
     from buddy_amd.instantiate import instantiate
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
     from buddy_amd.testing.tester import Tester
-    from buddy_amd.utils.losses import get_loss
     from oracle.arbiter_runs import run_blind, overrides
     from oracle.sampler_ref import NoiseStream
     L, T, nf, up, taps, seeds = 8192, 10, 32, 10, 2000, [0, 1]
@@ -131,10 +135,7 @@ def test_blind_T10_shipped_updates_fp64_arbiter(golden):
     t.sampler.noise = ns
     seg, y, op, _ = t.prepare_batch([(synth_clean(s, L), synth_rir(s, taps), f"u{s}.wav") for s in seeds], blind=True, noise=ns)
     smp = t.sampler
-    smp.operator, smp.y = op, y
-    smp.rec_loss = get_loss(args.tester.posterior_sampling.rec_loss, operator=op)
-    smp._hip_op = True
-    op.hip_bind(y, args.tester.posterior_sampling)
+    smp.bind(y, op, True)
     sched = smp.create_schedule()
     tl, gl = sched.tolist(), smp.get_gamma(sched).tolist()
     x = smp.initialize_x(tuple(y.shape), "cuda", sched)

@@ -115,16 +115,12 @@ def test_shipped_blind_config_three_steps_vs_oracle():
     three diffusion steps of the second utterance against the oracle's single-utterance run with the same noise draws.  Ten scale-free Adam
     updates per step amplify fp32 round-off by tens of dB per step, so the agreement is asserted per step with the
     measured decay, the first step (no feedback yet) at round-off level."""
-    from buddy_amd.utils.losses import get_loss
     from buddy_amd.utils.metrics import si_sdr
     L, seeds, steps = 64000, [3, 4], 3
     args, t, ns, items, y, op = _stack(201, 128, L, 2, seeds)
     assert args.tester.posterior_sampling.blind_hp.op_updates_per_step == 10 and args.tester.sampling_params.order == 1
     smp = t.sampler
-    smp.operator, smp.y = op, y
-    smp.rec_loss = get_loss(args.tester.posterior_sampling.rec_loss, operator=op)
-    smp._hip_op = True
-    op.hip_bind(y, args.tester.posterior_sampling)
+    smp.bind(y, op, True)
     sched = smp.create_schedule()
     tl, gl = sched.tolist(), smp.get_gamma(sched).tolist()
     x = smp.initialize_x(tuple(y.shape), "cuda", sched)

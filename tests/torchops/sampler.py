@@ -1,0 +1,64 @@
+"""TEST INFRASTRUCTURE, not product: the DPS sampler with the operator update and the likelihood evaluated through torch ops -- the
+reference's own formulation (``testing/EulerHeunSamplerDPS.py:56-113``: autograd through degradation + loss, ``torch.optim.Adam`` loop),
+batched per utterance.  It subclasses the product sampler, so the CPU host-logic tests still exercise the product's schedule / step /
+noise-stream / batching control flow; only ``bind``, ``optimize_op`` and ``get_likelihood_score`` are replaced (in the product those three are
+library calls into ``libbuddy_hip.so``)."""
+from __future__ import annotations
+
+import torch
+
+from buddy_amd.testing.EulerHeunSamplerDPS import EulerHeunSamplerDPS
+
+from .losses import get_loss
+
+
+class EulerHeunSamplerDPSTorch(EulerHeunSamplerDPS):
+    def bind(self, y, operator, blind):
+        ps = self.args.tester.posterior_sampling
+        self.operator, self.y = operator, y
+        self.rec_loss = get_loss(ps.rec_loss, operator=operator)
+        if blind:
+            self.rec_loss_params = get_loss(ps.rec_loss_params, operator=operator)
+            self.optimizer_operator = torch.optim.Adam(operator.params + operator.params_phases, lr=ps.blind_hp.lr_op,
+                                                       weight_decay=ps.blind_hp.weight_decay, betas=(ps.blind_hp.beta1, ps.blind_hp.beta2))
+            self.RIR_noise_regularization_loss = get_loss(ps.RIR_noise_regularization.loss, operator=operator)
+
+    def get_likelihood_score(self, x_den, x, t):
+        y_hat = self.operator.degradation(x_den, mode="waveform")
+        rec = self.rec_loss(self.y, y_hat)                    # sum over utterances: gradients decouple per row
+        rec_grads = torch.autograd.grad(outputs=rec, inputs=x)[0]
+        normguide = torch.linalg.vector_norm(rec_grads, dim=-1, keepdim=True) / (self.args.exp.audio_len ** 0.5)
+        return self.zeta / (normguide + 1e-8) * rec_grads, rec
+
+    def optimize_op(self, x_den, t):
+        ps = self.args.tester.posterior_sampling
+        for _ in range(ps.blind_hp.op_updates_per_step):
+            for p in self.operator.params:
+                p.requires_grad = True
+            for p in self.operator.params_phases:
+                p.requires_grad = True
+            self.operator.update_H()
+            y_hat = self.operator.degradation(x_den, mode="waveform")
+            if self.rec_loss_params is not None:
+                loss = self.rec_loss_params(self.y, y_hat)
+                assert not torch.isnan(loss).any(), "rec_loss is Nan"
+            else:
+                loss = 0.
+            if self.RIR_noise_regularization_loss is not None:
+                rir_time = self.operator.get_time_RIR()
+                if rir_time.dim() == 1:
+                    rir_time = rir_time.unsqueeze(0)
+                rir_noise = self.operator._randn(rir_time.shape[1:]) if hasattr(self.operator, "_randn") else torch.randn_like(rir_time)
+                reg = ps.RIR_noise_regularization
+                t_op = max(min(float(t), reg.crop_sigma_max), reg.crop_sigma_min)
+                rir_noisy = rir_time + t_op * rir_noise
+                loss = loss + self.RIR_noise_regularization_loss(rir_time, rir_noisy.detach())
+            assert not torch.isnan(loss).any(), "loss is Nan"
+            self.optimizer_operator.zero_grad()
+            loss.backward()
+            self.optimizer_operator.step()
+            for p in self.operator.params:
+                p.detach_()
+            self.operator.project_params()
+            for p in self.operator.params:
+                p.requires_grad = True

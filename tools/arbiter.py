@@ -82,7 +82,6 @@ def phase_build(a):
     from buddy_amd.instantiate import instantiate
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
     from buddy_amd.testing.tester import Tester
-    from buddy_amd.utils.losses import get_loss
     from oracle.sampler_ref import NoiseStream          # deterministic noise stream only
     args = compose(overrides=overrides(a))
     net = instantiate(args.network)
@@ -97,10 +96,7 @@ def phase_build(a):
         t.sampler.noise = ns
         seg, y, op, _ = t.prepare_batch(items, blind=True, noise=ns)
         smp = t.sampler
-        smp.operator, smp.y = op, y
-        smp.rec_loss = get_loss(args.tester.posterior_sampling.rec_loss, operator=op)
-        smp._hip_op = True
-        op.hip_bind(y, args.tester.posterior_sampling)
+        smp.bind(y, op, True)
         sched = smp.create_schedule()
         gam = smp.get_gamma(sched).tolist()
         x = smp.initialize_x(tuple(y.shape), "cuda", sched)

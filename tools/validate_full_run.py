@@ -27,12 +27,7 @@ t.sampler.noise = ns
 seg, y, op, _ = t.prepare_batch([item], blind=BLIND, noise=ns)
 t0 = time.time()
 smp = t.sampler
-from buddy_amd.utils.losses import get_loss
-smp.operator, smp.y = op, y
-smp.rec_loss = get_loss(args.tester.posterior_sampling.rec_loss, operator=op)
-smp._hip_op = bool(BLIND and hasattr(op, "hip_optimize"))
-if BLIND:
-    op.hip_bind(y, args.tester.posterior_sampling)
+smp.bind(y, op, BLIND)
 sched = smp.create_schedule().cuda(); gam = smp.get_gamma(sched).cuda()
 xg = smp.initialize_x(tuple(y.shape), "cuda", sched)
 trace_g = []
