@@ -38,50 +38,69 @@ PEAK_FP32_MFMA = 157.3   # TFLOP/s, MI355X dense fp32 matrix peak (MI355X_MICROA
 PEAK_BF16_MFMA = 2500.0  # TFLOP/s, MI355X dense bf16 matrix peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 
 
-def build_stack(args_ns, device, B, first_utt, net=None):
+SETUP = {}     # wall times of the one-off set-up pieces of the FIRST stack (rank-local): reported as `cold_start`
+
+
+def build_stack(args_ns, device, B, first_utt, net=None, tester_cfg="blind_dereverberation_BUDDy", blind=True, T=None, length=None, extra=()):
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
     from buddy_amd.testing.tester import Tester
-    ov = [f"tester.sampling_params.T={args_ns.T}", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled"]
+    ov = [f"tester.sampling_params.T={T or args_ns.T}"] + list(extra)
+    if tester_cfg != "only_unconditional":
+        ov.append("tester.posterior_sampling.warm_initialization.mode=reverb_scaled")
     if getattr(args_ns, "attention", None):
         ov.append(f"+network.attention={args_ns.attention}")
     if getattr(args_ns, "gemm", None):
         ov.append(f"+network.gemm={args_ns.gemm}")
-    args = compose(tester="blind_dereverberation_BUDDy", overrides=ov)
+    args = compose(tester=tester_cfg, overrides=ov)
+    L = length or args_ns.length
     if net is None:
+        t0 = time.perf_counter()
         net = instantiate(args.network)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(0, args.network.nf).items()})
         net = net.to(device).eval()
+        torch.cuda.synchronize()
+        SETUP["module_build_s"] = time.perf_counter() - t0        # torch side: module construction, synthetic state dict, H2D of 111 MB
+        # cold start of the library handle: buddy_ncsnpp_create (parameter upload, small packs, 1x1 images) + the first forward, which
+        # prepares on the GPU the one operand form each 3x3 convolution uses at this shape
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            net(torch.zeros(B, L, device=device), torch.zeros(B, device=device))
+        torch.cuda.synchronize()
+        SETUP["cold_start_s"] = time.perf_counter() - t0
     else:
-        net = net.replica()             # same weights, own activation arena / VJP tape: a second sub-batch on another stream
+        net = net.replica()             # same prepared weights (shared, read-only), own activation arena / VJP tape
     edm = instantiate(args.diff_params)
     tester = Tester(args, net, edm, test_set=None, device=device, in_training=True)
-    L = args_ns.length
+    if tester_cfg == "only_unconditional":
+        return args, net, edm, tester, None, None, None
     items = [(synth_clean(first_utt + u, L), synth_rir(first_utt + u, 8000), f"utt{first_utt + u}.wav") for u in range(B)]
     torch.manual_seed(1234 + first_utt)
-    seg, y, op, _ = tester.prepare_batch(items, blind=True)
+    seg, y, op, _ = tester.prepare_batch(items, blind=blind)
     return args, net, edm, tester, seg, y, op
 
 
 class StepRunner:
     """Drives the sampler one diffusion step at a time (what predict() does in its loop)."""
 
-    def __init__(self, tester, y, op, device):
+    def __init__(self, tester, y, op, device, blind=True):
         s = tester.sampler
-        s.bind(y, op, True)            # what predict_conditional does before its loop: operator, observation, losses, fresh Adam state (HIP handle)
+        self.blind = blind
+        s.bind(y, op, blind)           # what predict_conditional does before its loop: operator, observation, losses, fresh Adam state (HIP handle)
         # config 4 of BASELINE.json asks for the operator-update share: bracket optimize_op with events on the launch stream
         self.op_events = None
-        inner = op.hip_optimize
+        if blind:
+            inner = op.hip_optimize
 
-        def timed_optimize(x_den, t):
-            if self.op_events is None:
-                return inner(x_den, t)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); r = inner(x_den, t); e1.record()
-            self.op_events.append((e0, e1))
-            return r
-        op.hip_optimize = timed_optimize
+            def timed_optimize(x_den, t):
+                if self.op_events is None:
+                    return inner(x_den, t)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); r = inner(x_den, t); e1.record()
+                self.op_events.append((e0, e1))
+                return r
+            op.hip_optimize = timed_optimize
         self.s = s
         t = s.create_schedule()                            # host-side schedule, as in predict(): no device sync inside a step
         self.t, self.gamma = t.tolist(), s.get_gamma(t).tolist()
@@ -93,19 +112,41 @@ class StepRunner:
         s = self.s
         if self.i >= s.T - 1:           # stay inside the schedule (the last step has t_{i+1} = 0): restart the trajectory
             self.i = 0
-        self.x, self.x_den = s.step(self.x, self.t[self.i], self.t[self.i + 1], self.gamma[self.i], blind=True)
+        self.x, self.x_den = s.step(self.x, self.t[self.i], self.t[self.i + 1], self.gamma[self.i], blind=self.blind)
         self.i += 1
 
 
-def cpu_baseline(length, n_threads, reps, utt=0):
-    """The CPU oracle (oracle/, reference-faithful restatement, torch fp32) on the host cores: blind DPS steps (order 1, 10 operator
-    updates) for ONE utterance -- the same unit of work as the GPU metric.  1 warm-up step, then `reps` timed steps (per-step seconds)."""
+class UncondRunner:
+    """Steps of the unconditional Euler-Heun sampler (reference testing/EulerHeunSampler.py:47-72): score-network FORWARD evaluations only."""
+
+    def __init__(self, tester, B, L, device):
+        s = tester.sampler
+        self.s = s
+        t = s.create_schedule()
+        self.t, self.gamma = t.tolist(), s.get_gamma(t).tolist()
+        self.x = s.initialize_x((B, L), device, t)
+        self.i = 0
+        self.x_den = None
+
+    def step(self):
+        s = self.s
+        if self.i >= s.T - 1:
+            self.i = 0
+        self.x, self.x_den = s.step(self.x, self.t[self.i], self.t[self.i + 1], self.gamma[self.i])
+        self.i += 1
+
+
+def cpu_baseline(length, n_threads, reps, utt=0, mode="blind"):
+    """The CPU oracle (oracle/, reference-faithful restatement, torch fp32) on the host cores for ONE utterance -- the same unit of work as
+    the GPU metric.  mode "blind": blind DPS steps (order 1, 10 operator updates; T=50 schedule); "informed": informed DPS steps (order 2 = two
+    forward+VJP evaluations per step; T=10 schedule, BASELINE configs[0] shape).  1 warm-up step, then `reps` timed steps (per-step seconds)."""
     from buddy_amd.config import compose
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
     from oracle import ncsnpp_ref, operators_ref as O, sampler_ref as S
     torch.set_num_threads(n_threads)
-    args = compose(tester="blind_dereverberation_BUDDy", overrides=["tester.sampling_params.T=50",
-                                                                     "tester.posterior_sampling.warm_initialization.mode=reverb_scaled"])
+    blind = mode == "blind"
+    args = compose(tester="blind_dereverberation_BUDDy" if blind else "informed_dereverberation_DPS",
+                   overrides=[f"tester.sampling_params.T={50 if blind else 10}", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled"])
     P = ncsnpp_ref.to_torch(synth_state_dict(0, 128))
     net = lambda x, cn: ncsnpp_ref.ncsnpp_time(P, x, cn, 510, 128)
     ns = S.NoiseStream(1 + utt)
@@ -115,23 +156,26 @@ def cpu_baseline(length, n_threads, reps, utt=0):
     op_ref = O.RIROperatorRef(op_hp)
     op_ref.update_params(rir)
     y = op_ref.degradation(clean[None])
-    op = O.BlindSubbandFilteringRef(op_hp, 16000, ns)
-    op.update_H(use_noise=True, noise=ns)
-    hp = args.tester.posterior_sampling.blind_hp
+    op = op_ref
+    smp.rec_loss = O.get_loss_ref(args.tester.posterior_sampling.rec_loss, op_ref)
+    if blind:
+        op = O.BlindSubbandFilteringRef(op_hp, 16000, ns)
+        op.update_H(use_noise=True, noise=ns)
+        hp = args.tester.posterior_sampling.blind_hp
+        smp.rec_loss = O.get_loss_ref(args.tester.posterior_sampling.rec_loss, op)
+        smp.rec_loss_params = O.get_loss_ref(args.tester.posterior_sampling.rec_loss_params, op)
+        smp.optim = torch.optim.Adam(op.params + op.params_phases, lr=hp.lr_op, weight_decay=hp.weight_decay, betas=(hp.beta1, hp.beta2))
+        smp.rir_reg_loss = O.get_loss_ref(args.tester.posterior_sampling.RIR_noise_regularization.loss, op)
     smp.operator, smp.y = op, y
-    smp.rec_loss = O.get_loss_ref(args.tester.posterior_sampling.rec_loss, op)
-    smp.rec_loss_params = O.get_loss_ref(args.tester.posterior_sampling.rec_loss_params, op)
-    smp.optim = torch.optim.Adam(op.params + op.params_phases, lr=hp.lr_op, weight_decay=hp.weight_decay, betas=(hp.beta1, hp.beta2))
-    smp.rir_reg_loss = O.get_loss_ref(args.tester.posterior_sampling.RIR_noise_regularization.loss, op)
     t = S.create_schedule(smp.sde_hp, smp.T)
     gamma = S.get_gamma(t, smp.sp)
     x = smp.initialize_x(y.shape, t)
     times = []
     for i in range(1 + reps):
         t0 = time.time()
-        x, _ = smp.step(x, t[i], t[i + 1], gamma[i], True)
+        x, _ = smp.step(x, t[i], t[i + 1], gamma[i], blind)
         times.append(time.time() - t0)
-    return {"step_seconds": times[1:], "warmup_seconds": times[0], "threads": n_threads}
+    return {"step_seconds": times[1:], "warmup_seconds": times[0], "threads": n_threads, "mode": mode}
 
 
 def _effective_cores():
@@ -175,10 +219,11 @@ def run_cpu_baseline(length, reps=3):
     out = {"value": None, "unit": "utterance-steps/s", "cores": None, "kind": "port", "cpu_model": _cpu_model(), "host_logical_cores": os.cpu_count(),
            "usable_cores": cores}
 
-    def spawn(threads, utt):
+    def spawn(threads, utt, mode="blind", nreps=reps):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
         return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(threads), "--length", str(length),
-                                 "--cpu-reps", str(reps), "--cpu-utt", str(utt)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+                                 "--cpu-reps", str(nreps), "--cpu-utt", str(utt), "--cpu-mode", mode], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                text=True, env=env)
 
     def collect(procs, timeout):
         res = []
@@ -206,6 +251,12 @@ def run_cpu_baseline(length, reps=3):
         out["B8"] = {"utterance_steps_per_s": 8.0 / med8, "threads": 8 * t8, "batch_step_seconds": [float(v) for v in per_step]}
         if out["value"] is None or 8.0 / med8 > out["value"]:
             out.update(value=8.0 / med8, cores=8 * t8)
+    # the informed order-2 step: one utterance, two forward+VJP evaluations per step, no operator update
+    ri = collect([spawn(t1, 0, "informed", 2)], 180)[0]
+    if ri:
+        medi = float(np.median(ri["step_seconds"]))
+        out["informed_order2_B1"] = {"utterance_steps_per_s": 1.0 / medi, "score_evals_per_s": 2.0 / medi, "threads": t1, "step_seconds": ri["step_seconds"],
+                                     "warmup_seconds": ri["warmup_seconds"], "what": "informed DPS, order 2, T=10 schedule: 1 warm-up + 2 timed steps, median"}
     out["sample"] = (f"oracle/ (torch fp32 restatement of the reference, parity-pinned): blind DPS steps (order 1, 10 operator updates) of {length / 16000:g} s "
                      f"utterances, 1 warm-up + {reps} timed steps, median; B1 = one utterance on {t1} threads, B8 = eight utterances side by side on "
                      f"{t8} threads each; value = the better of the two")
@@ -278,13 +329,19 @@ def main():
     ap.add_argument("--gemm", default=None, choices=["bf16x3", "fp32"], help="arithmetic of the Winograd-domain GEMMs (default: the library's, bf16x3 = exact "
                     "three-way bf16 split of the fp32 operands, six bf16 MFMA products, fp32 accumulate; fp32 = v_mfma_f32_32x32x2_f32, the reference run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rccl-selftest", action="store_true", help="skip the one-rank RCCL bring-up at the end of an N=1 run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="THREADS", help="internal: run only the CPU leg and print its JSON")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--cpu-utt", type=int, default=0)
+    ap.add_argument("--cpu-mode", default="blind", choices=["blind", "informed"])
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (--backend, default nccl = RCCL) even with one rank and run the "
+                    "end-of-run gather through it: exercises communicator set-up and the collective on a 1-GPU box")
+    ap.add_argument("--legs", default="auto", help="extra untimed-from-`value` legs (BASELINE.md section 3): comma list of informed,informed_b1,blind_b1,"
+                    "forward_only,longform,full_run or 'all' / 'none'; auto = all at N=1 with the default workload, full_run only otherwise")
     a = ap.parse_args()
     if a.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(a.length, a.cpu_baseline_only, a.cpu_reps, a.cpu_utt)))
+        print(json.dumps(cpu_baseline(a.length, a.cpu_baseline_only, a.cpu_reps, a.cpu_utt, a.cpu_mode)))
         return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -313,13 +370,22 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    dist_init_ms = 0.0
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                   # --force-dist on one rank: a private rendezvous
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+        t0 = time.perf_counter()
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")
+        dist_init_ms = (time.perf_counter() - t0) * 1e3
     coll_dev = device if a.backend == "nccl" else torch.device("cpu")
 
     def log(msg):
@@ -353,7 +419,10 @@ def main():
 
     S = a.sub_batches if (a.sub_batches > 1 and B % a.sub_batches == 0) else 1
     log(f"building stack: B={B}/GPU as {S} sub-batch(es), L={a.length}, world={world}")
+    t_sb = time.perf_counter()
     runs, streams = make_runners(S)
+    torch.cuda.synchronize()
+    stack_build_s = time.perf_counter() - t_sb
     run = _All(runs, streams)
 
     def barrier():
@@ -363,8 +432,13 @@ def main():
         torch.cuda.synchronize()
 
     log("stack ready; warmup")
-    for _ in range(a.warmup):
+    first_step_ms = None
+    for k in range(a.warmup):
+        t0 = time.perf_counter()
         run.step()
+        if k == 0:                       # first sampler step of the process: arena sizing dry run, data-gradient weight forms, operator graph capture
+            torch.cuda.synchronize()
+            first_step_ms = (time.perf_counter() - t0) * 1e3
         log("warmup step done")
     barrier()
     # Timed region.  A HIP event pair around a kernel costs a dispatch bubble (~7 us: the next kernel's launch is no longer overlapped with the
@@ -438,6 +512,92 @@ def main():
                         "beside the large kernels of the other; separate timed region, same steps / warm-up"}
         del runs2, run2
 
+    # ---- further legs, each its own untimed-from-`value` region on a replica of the same network -------------------------
+    default_workload = (B == 8 and a.length == 64000)
+    if a.legs == "auto":
+        want = {"informed", "informed_b1", "blind_b1", "forward_only", "longform", "full_run"} if (world == 1 and default_workload) else {"full_run"}
+    elif a.legs == "all":
+        want = {"informed", "informed_b1", "blind_b1", "forward_only", "longform", "full_run"}
+    else:
+        want = {w for w in a.legs.split(",") if w and w != "none"}
+    legs = {}
+
+    def time_leg(name, runner, units_per_step, n_steps, n_warm, extra):
+        for _ in range(n_warm):
+            runner.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            runner.step()
+        barrier()
+        e = torch.tensor([time.perf_counter() - t0], device=coll_dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        e = float(e.item())
+        assert torch.isfinite(runner.x_den).all(), f"leg {name} diverged"
+        legs[name] = dict({"ms_per_step": e / n_steps * 1e3, "value": world * units_per_step * n_steps / e, "unit": "utterance-steps/s", "steps": n_steps,
+                           "warmup": n_warm}, **extra)
+        log(f"leg {name}: {legs[name]['ms_per_step']:.2f} ms/step")
+
+    def stack_runner(tester_cfg, Bl, blind, T, length=None, extra=()):
+        _, _, _, tester, _, y, op = build_stack(a, device, Bl, rank * Bl, net0[0], tester_cfg=tester_cfg, blind=blind, T=T, length=length, extra=extra)
+        return StepRunner(tester, y, op, device, blind=blind)
+
+    if "informed" in want:       # (ii) of BASELINE.md section 3: informed sampler, order 2 (two forward+VJP evaluations per step), T=10 schedule
+        r_ = stack_runner("informed_dereverberation_DPS", B, False, 10)
+        time_leg("informed_order2", r_, B, 6, 2, {"config": f"informed DPS (known RIR, 8000 taps), order 2, T=10 schedule, B={B} x {a.length} samples "
+                                                          "(conf/tester/informed_dereverberation_DPS.yaml; BASELINE configs[0] is its B=1 real-clip case)",
+                                                "score_evals_per_step": 2})
+        legs["informed_order2"]["score_evals_per_s"] = 2 * legs["informed_order2"]["value"]
+        del r_
+    if "informed_b1" in want:    # the reference's own shape: one utterance at a time (testing/tester.py:132-153)
+        r_ = stack_runner("informed_dereverberation_DPS", 1, False, 10)
+        time_leg("informed_order2_B1", r_, 1, 6, 2, {"config": f"as informed_order2 with B=1 (latency of one utterance; BASELINE configs[0] shape)", "score_evals_per_step": 2})
+        del r_
+    if "blind_b1" in want:
+        r_ = stack_runner("blind_dereverberation_BUDDy", 1, True, a.T)
+        time_leg("blind_B1", r_, 1, 6, 2, {"config": f"the headline blind step with B=1 x {a.length} samples: per-utterance latency, the reference's own shape "
+                                                     "(testing/tester.py:132-153 samples one utterance at a time)"})
+        del r_
+    if "forward_only" in want:   # score-network forward evaluations only (unconditional Euler-Heun sampler, order 2: two forwards per step)
+        _, _, _, tester_u, _, _, _ = build_stack(a, device, B, 0, net0[0], tester_cfg="only_unconditional", T=a.T)
+        r_ = UncondRunner(tester_u, B, a.length, device)
+        time_leg("forward_only", r_, B, 6, 2, {"config": f"unconditional Euler-Heun sampler (reference testing/EulerHeunSampler.py:47-72), order 2, B={B} x {a.length}: "
+                                                         "two score-network FORWARD evaluations per utterance-step, no VJP, no operator", "score_evals_per_step": 2})
+        legs["forward_only"]["forward_evals_per_s"] = 2 * legs["forward_only"]["value"]
+        del r_, tester_u
+    if "longform" in want:       # BASELINE configs[4], one-GPU slice: B=4 x 30 s un-chunked, fp32 flash attention unless --attention says otherwise
+        r_ = stack_runner("blind_dereverberation_BUDDy", 4, True, a.T, length=480000)
+        time_leg("longform_480000_B4", r_, 4, 3, 1, {"config": "blind step, B=4 x 480000 samples (30 s@16 kHz), un-chunked (BASELINE configs[4], one-GPU slice of "
+                                                               "batch=32 across 8)", "attention": a.attention or os.environ.get("BUDDY_ATTN", "flash (fp32)"),
+                                                    "value_in_4s_units": None})
+        legs["longform_480000_B4"]["value_in_4s_units"] = legs["longform_480000_B4"]["value"] * 7.5
+        del r_
+        torch.cuda.empty_cache()
+
+    # ---- one REAL run end to end: predict_conditional over the whole T-step schedule, init included; then the end-of-run gather ---------------
+    full_run = None
+    if "full_run" in want:
+        t0 = time.perf_counter()
+        _, _, _, tester_f, _, y_f, op_f = build_stack(a, device, B, rank * B, net0[0])
+        torch.cuda.synchronize()
+        setup_s = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
+        pred_f = tester_f.sampler.predict_conditional(y_f, op_f, shape=(B, a.length), blind=True)
+        torch.cuda.synchronize()
+        run_s = time.perf_counter() - t0
+        fr = torch.tensor([run_s], device=coll_dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(fr, op=dist.ReduceOp.MAX)
+        assert torch.isfinite(pred_f).all(), "full run diverged"
+        full_run = {"T": a.T, "batch_per_gpu": B, "wall_s": float(fr.item()), "operator_and_batch_setup_s": setup_s,
+                    "utterance_steps_per_s": world * B * a.T / float(fr.item()), "ms_per_step": float(fr.item()) / a.T * 1e3,
+                    "what": "Sampler.predict_conditional (bind + initialize_x + all T steps + final sync) of one batch on one stream through the product classes; "
+                            "operator_and_batch_setup_s = Tester.prepare_batch (synthetic y = clean * RIR through the HIP FIR, blind operator handle) before it"}
+        log(f"full run: {full_run['wall_s']:.2f} s for T={a.T}")
+        del tester_f, y_f, op_f, pred_f
+
     # end-of-run gather of the (B_local, L) outputs: the only collective on this path (RCCL over xGMI)
     gather_ms = gather_first_ms = 0.0
     out = torch.cat([r.x_den for r in runs]).contiguous()
@@ -453,6 +613,38 @@ def main():
             gather_first_ms, gather_ms = (g, g) if k == 0 else (gather_first_ms, g)
         assert torch.isfinite(torch.stack(bufs)).all()
         assert torch.equal(bufs[rank].to(out.device), out), "gather returned another rank's rows in this rank's slot"
+        # the harness's own gather (buddy_amd/dist.py: lengths, then zero-padded rows) on the same communicator
+        from buddy_amd import dist as bdist
+        rows = bdist.gather_ragged([out[i] for i in range(out.shape[0])], world * out.shape[0], rank, world, device=device)
+        assert len(rows) == world * out.shape[0] and all(torch.equal(rows[rank + world * i].to(out.device), out[i]) for i in range(out.shape[0]))
+    rccl_selftest = None
+    if dist is None and world == 1 and not a.no_rccl_selftest:
+        # N=1 default run: bring RCCL up once anyway (one rank, this GPU) after everything that is timed, so that communicator set-up, the
+        # IPC-mode setting and the nccl side of buddy_amd/dist.py have run on this box before an 8-GPU node appears.  Failure is reported, not fatal.
+        rccl_selftest = {"ok": False}
+        try:
+            import socket
+            import torch.distributed as tdist
+            from buddy_amd import dist as bdist
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            t0 = time.perf_counter()
+            tdist.init_process_group("nccl", device_id=device)
+            rccl_selftest["init_ms"] = (time.perf_counter() - t0) * 1e3
+            tms = []
+            for k in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                full = bdist.gather_rows(out, out.shape[0], 0, 1)
+                torch.cuda.synchronize(); tms.append((time.perf_counter() - t0) * 1e3)
+            rows = bdist.gather_ragged([out[i, : a.length - 17 * i] for i in range(out.shape[0])], out.shape[0], 0, 1, device=device)
+            rccl_selftest.update(ok=bool(torch.equal(full, out) and all(torch.equal(r, out[i, : a.length - 17 * i]) for i, r in enumerate(rows))),
+                                 gather_first_call_ms=tms[0], gather_ms=tms[1], backend=tdist.get_backend(), world=1,
+                                 what="init_process_group('nccl') on one rank + buddy_amd.dist.gather_rows / gather_ragged on device tensors (all_gather through RCCL)")
+            tdist.destroy_process_group()
+        except Exception as e:       # noqa: BLE001 -- reported in the line
+            rccl_selftest["error"] = f"{type(e).__name__}: {str(e)[:300]}"
     assert torch.isfinite(out).all(), "sampler diverged"
 
     if rank == 0:
@@ -490,10 +682,19 @@ def main():
                                    f"NCSN++ nf=128 STFT 510/128" + (" (BASELINE.json configs[1])" if (B == 8 and a.length == 64000) else ""),
                        "batch_per_gpu": B, "length": a.length, "T": a.T, "order": 1, "op_updates_per_step": 10,
                        "parallelism": f"utterance-sharded x{world}", "sub_batches_per_gpu": S, "attention": a.attention or os.environ.get("BUDDY_ATTN", "flash (fp32)")},
-            "score_evals_per_s": n_utt_steps / elapsed,   # order 1: one forward+VJP evaluation per utterance-step
+            "score_evals_per_s": n_utt_steps / elapsed,   # forward + input-VJP evaluations per second (order 1: one per utterance-step); forward-only: legs.forward_only
+            "value_mode": ("one batch of B utterances on one stream (per-kernel attribution is clean); the harness default (Tester, groups of >= 4 "
+                           "utterances) samples them as two concurrent sub-batches = `concurrent_sub_batches`") if S == 1 else f"{S} concurrent sub-batches",
+            "cold_start": {"cold_start_s": SETUP.get("cold_start_s"), "first_step_ms": first_step_ms, "module_build_s": SETUP.get("module_build_s"),
+                           "stack_build_s": stack_build_s, "weight_store_bytes": net0[0].weight_bytes(),
+                           "what": "cold_start_s = buddy_ncsnpp_create (parameter upload, small packs) + the first forward of the batch, which prepares on the "
+                                   "GPU the one operand form each 3x3 convolution uses (wprep.hip); first_step_ms = the first sampler step (arena dry run, "
+                                   "data-gradient forms, operator hipGraph capture); module_build_s = torch-side module construction + synthetic state dict "
+                                   "+ .to(device); replicas (concurrent sub-batches, legs, full_run) share the weight store"},
+            "legs": legs, "full_run": full_run, "rccl_selftest": rccl_selftest, "dist_init_ms": dist_init_ms,
             "network_algorithmic_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
             "gather_ms": gather_ms, "gather_first_call_ms": gather_first_ms, "gather_bytes_per_rank": int(out.numel() * 4),
-            "gather_backend": (a.backend if world > 1 else None),
+            "gather_backend": (a.backend if dist is not None else None),
             # dominant kernel: the batched Winograd-domain GEMMs of the 3x3 convolutions.  bf16x3 (default): every fp32 multiply-add is SIX bf16 MFMA
             # multiply-adds -> achieved = 6 x the fp32-equivalent rate, against the bf16 matrix peak; the fp32-equivalent rate against the fp32 matrix
             # peak is beside it (the kernel replaces v_mfma_f32_32x32x2_f32 at equal accuracy; --gemm fp32 is the reference run)

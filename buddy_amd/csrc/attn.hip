@@ -206,8 +206,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const float* __restri
   float lse[4], dl[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const bool ok = row0 + r < T;
-    lse[r] = ld1_row(Lse + (long long)b * T, row0 + r, T);
+    lse[r] = ld1_row(Lse + (long long)b * T, row0 + r, T);     // clamped to row T - 1 (launchers guarantee T >= 1)
     dl[r] = ld1_row(D + (long long)b * T, row0 + r, T);
   }
   f32x4 acc[C / 16];
@@ -443,8 +442,7 @@ __global__ __launch_bounds__(256) void flash16_bwd_dq_kernel(const float* __rest
   float lse[4], dl[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const bool ok = row0 + r < T;
-    lse[r] = ld1_row(Lse + (long long)b * T, row0 + r, T);
+    lse[r] = ld1_row(Lse + (long long)b * T, row0 + r, T);     // clamped to row T - 1 (launchers guarantee T >= 1)
     dl[r] = ld1_row(D + (long long)b * T, row0 + r, T);
   }
   f32x4 acc[C / 16];

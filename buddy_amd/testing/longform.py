@@ -62,7 +62,10 @@ def predict_chunked(sample_batch, y, chunk, overlap, level_match=False):
     (``constraint_speech_magnitude``, reference EulerHeunSamplerDPS.py:127-129) -- per CHUNK here, so a chunk that is mostly a pause would come
     back as loud as a chunk of running speech and the cross-fade would mix segments of different gains.  With ``level_match`` each chunk's
     estimate is scaled by std(y_chunk) / std(y_clip) (the observation's own level profile) before the merge, which restores one gain for the clip;
-    what remains chunk-specific is the RIR estimate (one operator per chunk), see DESIGN.md section 5."""
+    what remains chunk-specific is the RIR estimate (one operator per chunk), see DESIGN.md section 5.  Residual bias: the gain profile is the
+    OBSERVATION's, and reverberation fills pauses, so a pause comes back louder than in the clean signal (measured pause / speech level 0.107
+    against 0.052 in the input of tests/test_hip_cli.py's clip).  Chunks are never padded (equal chunks, the last one starts at L - chunk), so
+    every std is over valid samples."""
     parts, starts = split(y, chunk, overlap)
     est = sample_batch(parts)
     if level_match and parts.shape[0] > 1:

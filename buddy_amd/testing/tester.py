@@ -40,8 +40,11 @@ class Tester:
         self.paths = {}
         self.results = []
         # a batch of >= 2 * sub_batches utterances is sampled as that many concurrent sub-batches on their own HIP streams
-        # (testing/concurrent.py; identical results, better occupancy); 1 = one batch, one stream.  Default ("auto", tester.sub_batches
-        # absent): 2 whenever a group has >= 4 utterances -- the measured optimum (+5 %; 4 loses), DESIGN.md section 6
+        # (testing/concurrent.py; better occupancy); 1 = one batch, one stream.  Default ("auto", tester.sub_batches absent): 2 whenever
+        # a group has >= 4 utterances -- the measured optimum (+5 %; 4 loses), DESIGN.md section 6.  Results equal the single-batch run
+        # row for row only with per-utterance noise streams (noise_factory); with the torch RNG the draw ORDER differs between the two
+        # modes, so tester.sub_batches=1 is the way to reproduce a same-seed run of an earlier round.  The second sub-batch's network is a
+        # replica: it shares the prepared weights and costs only its activation arena
         sb = args.tester.get("sub_batches", None) if hasattr(args.tester, "get") else None
         self.sub_batches = None if sb in (None, "auto") else int(sb)
         self._concurrent = None
@@ -197,7 +200,8 @@ class Tester:
             return self.sampler.predict_conditional(parts.contiguous(), op, shape=(n, clen), blind=blind)
 
         csm = ps.get("constraint_speech_magnitude", None) if hasattr(ps, "get") else None
-        level = bool(blind and csm is not None and csm.get("use", False))      # per-chunk magnitude constraint -> restore one gain for the clip
+        # per-chunk magnitude constraint (blind yaml; an informed run that switches it on is treated alike) -> restore one gain for the clip
+        level = bool(csm is not None and csm.get("use", False))
         pred = longform.predict_chunked(sample_batch, y[0], chunk, overlap, level_match=level)
         return seg[0], y[0], pred
 

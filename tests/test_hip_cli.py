@@ -149,3 +149,34 @@ def test_bench_line_contract():
     assert rf["launches"] == 80                      # all 80 launches of the dominant kernel on the one sampled step
     if rf["traffic"] is not None:                    # quoted only when the stamped PMC summary matches the kernel sources
         assert 0.5e9 < rf["traffic"] < 3e9 and rf["traffic_conv_group_over_fused_form"] > 1.0
+    # round 4: cold start, the BASELINE.md section 3 legs, one full run, the one-rank RCCL bring-up
+    cs = j["cold_start"]
+    assert 0.0 < cs["cold_start_s"] < 1.5 and 0.0 < cs["first_step_ms"] < 3000.0, cs
+    ws = cs["weight_store_bytes"]
+    assert ws["conv3_forms"] < 2.6e9 and ws["params"] < 1.2e8, ws          # shared by every replica (round 3: 5.7 GB per handle)
+    assert "one stream" in j["value_mode"]
+    for name in ("informed_order2", "informed_order2_B1", "blind_B1", "forward_only", "longform_480000_B4"):
+        leg = j["legs"][name]
+        assert leg["ms_per_step"] > 0 and leg["value"] > 0 and leg["unit"] == "utterance-steps/s" and leg["config"], name
+    assert j["legs"]["longform_480000_B4"]["attention"]
+    assert j["legs"]["forward_only"]["forward_evals_per_s"] > j["score_evals_per_s"]          # a forward costs less than forward + VJP + operator update
+    fr = j["full_run"]
+    assert fr["T"] == 50 and fr["batch_per_gpu"] == 8 and 1.0 < fr["wall_s"] < 30.0 and abs(fr["utterance_steps_per_s"] - 400 / fr["wall_s"]) < 1e-6 * 400
+    rs = j["rccl_selftest"]
+    assert rs["ok"] is True and rs["backend"] == "nccl" and rs["init_ms"] > 0 and rs["gather_first_call_ms"] > 0, rs
+
+
+def test_bench_force_dist_one_rank_rccl():
+    """`bench.py --gpus 1 --force-dist`: the N>1 code path (process group, barriers, all_reduce of the elapsed time, all_gather of the outputs,
+    buddy_amd.dist.gather_ragged) on ONE rank with backend nccl = RCCL, so the distributed branch has run on RCCL before an 8-GPU node appears."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--also-concurrent", "0", "--no-cpu-baseline", "--legs", "none"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["gather_backend"] == "nccl" and j["gather_first_call_ms"] > 0 and j["gather_ms"] > 0 and j["dist_init_ms"] > 0
+    assert j["rccl_selftest"] is None and j["full_run"] is None and j["legs"] == {}

@@ -100,3 +100,46 @@ def test_concurrent_sub_batches_equal_single_batch():
             err = float((a.double() - b.double()).abs().max() / b.double().abs().max())
             print("blind" if blind else "informed", n1, f"{err:.2e}")
             assert err < tol, (blind, n1, err)
+
+
+def _rccl_one_rank(port, out_path):
+    """child process: RCCL (backend "nccl") with ONE rank on the one GPU -- communicator set-up, the dmabuf IPC mode, and the nccl branch of
+    buddy_amd/dist.py (device tensors through all_gather) -- which no multi-rank test on a 1-GPU box can take (RCCL wants one device per rank)."""
+    import json
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from buddy_amd import dist as bd
+    torch.cuda.set_device(0)
+    t0 = time.time()
+    r, _, w = bd.init(backend="nccl", device=torch.device("cuda", 0), force=True)
+    assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_backend() == "nccl"
+    rows = torch.arange(3 * 1000, dtype=torch.float32, device="cuda").reshape(3, 1000)
+    full = bd.gather_rows(rows, 3, 0, 1)                       # all_gather on device tensors through RCCL
+    rag = bd.gather_ragged([rows[0], rows[1, :777], rows[2, :5]], 3, 0, 1, device=torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(full, rows)) and [int(v.shape[0]) for v in rag] == [1000, 777, 5] and all(v.is_cuda for v in rag) \
+        and bool(torch.equal(rag[1], rows[1, :777]))
+    dist.barrier()
+    dist.destroy_process_group()
+    json.dump({"ok": ok, "seconds": time.time() - t0}, open(out_path, "w"))
+
+
+def test_rccl_one_rank_gathers_on_device(tmp_path):
+    """`init_process_group("nccl")` has run at least once on this code before an 8-GPU node appears."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "rccl.json")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_one_rank, args=(port, out))
+    p.start(); p.join(300)
+    assert p.exitcode == 0, f"RCCL one-rank child failed (exit {p.exitcode})"
+    j = json.load(open(out))
+    assert j["ok"], j
+    print(f"RCCL one-rank init + gathers: {j['seconds']:.2f} s")
