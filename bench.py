@@ -357,6 +357,12 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.call(cmd, env=env))
 
+    # stdout carries exactly ONE line (the JSON).  RCCL prints a version banner to the C-level stdout when a communicator comes up, so file
+    # descriptor 1 points at stderr for the whole run and the line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -767,7 +773,9 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle on host cores)")
             res["cpu_baseline"] = run_cpu_baseline(a.length)
-        print(json.dumps(res))
+        C.CDLL(None).fflush(None)          # anything buffered by C stdio (the RCCL banner) leaves through stderr before the line is written
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
