@@ -134,3 +134,33 @@ def test_shipped_blind_config_three_steps_vs_oracle():
     sd = [float(si_sdr(tr[i][1:2], tro[i][None])) for i in range(steps)]
     print("shipped blind config (wpe_scaled, T=201, 10 updates), full size: per-step SI-SDR(build; oracle) dB:", [round(v, 1) for v in sd])
     assert sd[0] > 80.0 and sd[1] > 35.0 and sd[2] > 15.0, sd
+
+
+def test_shipped_blind_config_to_the_end_sanity():
+    """The shipped configuration run THROUGH: conf/tester/blind_dereverberation_BUDDy.yaml untouched -- wpe_scaled, all
+    T = 201 steps, order 1, 10 operator updates per step -- full-width network, two 4 s utterances through Sampler.predict_conditional.
+    The chain is chaotic (no sample-wise reference exists after a few steps), so this is the sanity gate a harness run
+    needs: finite everywhere, every estimate at the level the speech-magnitude constraint pins (std = speech_scaling), the operator
+    parameters inside their projection box, the estimated RIR finite with its direct path in place, the noise streams fully consumed in
+    step.  The measured comparison against the float64 arbiter and the fp32 oracles is profiles/r04_shipped_T201.json (tools/shipped_run.py)."""
+    import time
+    L, seeds = 64000, [3, 4]
+    args, t, ns, items, y, op = _stack(201, 128, L, 2, seeds)
+    ps = args.tester.posterior_sampling
+    assert args.tester.sampling_params.T == 201 and ps.blind_hp.op_updates_per_step == 10 and ps.constraint_speech_magnitude.use
+    torch.cuda.synchronize()
+    t0 = time.time()
+    pred = t.sampler.predict_conditional(y, op, shape=(2, L), blind=True)
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    assert pred.shape == (2, L) and torch.isfinite(pred).all()
+    lvl = pred.std(dim=1).cpu()
+    assert torch.allclose(lvl, torch.full((2,), float(ps.constraint_speech_magnitude.speech_scaling)), rtol=1e-3), lvl
+    d, w = (p.cpu() for p in op.params)
+    assert torch.isfinite(d).all() and torch.isfinite(w).all()
+    assert float(d.min()) >= op.min_decay * (1 - 1e-6) and float(d.max()) <= op.max_decay * (1 + 1e-6)
+    assert float(w.min()) >= 10 ** (op.Amin / 20) * (1 - 1e-6) and float(w.max()) <= 10 ** (op.Amax / 20) * (1 + 1e-6)
+    rir = op.get_time_RIR().cpu()
+    assert torch.isfinite(rir).all() and float(rir.abs().max()) > 0
+    assert ns[0].k == ns[1].k and ns[0].k > 201 * 11          # one churn draw + ten regulariser draws per step, plus the initial ones
+    print(f"shipped blind config, T=201, B=2: {wall:.2f} s wall incl. WPE warm start ({wall / 201 * 1e3:.1f} ms/step); levels {lvl.tolist()}")

@@ -107,9 +107,17 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
 
   float4 ra[4];
   u32x4 rb[6];
+  // PROBE & 64: the same bytes fetched with a coalesced lane pattern (instruction j = rows 8j..8j+7 of the wave, 8 lanes per 128-byte row piece);
+  // the lanes then hold the wrong elements (timing only)
+  int crow = m0 + wid * 32 + (lane >> 3); if (crow + 24 >= a.Mt) crow = a.Mt - 25;
+  const float* Apc = V + (long long)crow * a.Cin + 4 * (lane & 7);
   auto loadA = [&](int s) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(((GEN && Ap1 && s * WKS >= a.C0) ? Ap1 : Ap) + s * WKS + 4 * j);
+    for (int j = 0; j < 4; ++j) {
+      if (PROBE & 64) ra[j] = *reinterpret_cast<const float4*>(Apc + (long long)(8 * j) * a.Cin + s * WKS);
+      else if (PROBE & 256) { typedef float nf4 __attribute__((ext_vector_type(4))); const nf4 vv = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(Ap + s * WKS + 4 * j)); ra[j] = make_float4(vv[0], vv[1], vv[2], vv[3]); }
+      else ra[j] = *reinterpret_cast<const float4*>(((GEN && Ap1 && s * WKS >= a.C0) ? Ap1 : Ap) + s * WKS + 4 * j);
+    }
   };
   auto loadB = [&](int s) {
 #pragma unroll
@@ -174,7 +182,10 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
       for (int it = 0; it < 8; ++it) {
         const int r = 4 * it + rr;
         const float4 v = *reinterpret_cast<const float4*>(St + r * SP + c4);
-        if (m0 + wid * 32 + r < a.Mt) *reinterpret_cast<float4*>(Mrow + (long long)r * a.Cout + hb * 64 + c4) = v;
+        if (m0 + wid * 32 + r < a.Mt) {
+          if (PROBE & 128) { typedef float nf4 __attribute__((ext_vector_type(4))); nf4 vv = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(vv, reinterpret_cast<nf4*>(Mrow + (long long)r * a.Cout + hb * 64 + c4)); }
+          else *reinterpret_cast<float4*>(Mrow + (long long)r * a.Cout + hb * 64 + c4) = v;
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -197,21 +208,172 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
     }
 }
 
+// ---- persistent variant: a workgroup walks row tiles g, g + G, ... of ONE (position, column block); the K-stage stream runs on across tile
+// boundaries (the next tile's first A / B stage is in flight under the last MFMAs of the current one), the finished tile's accumulators leave
+// by direct stores while the next tile computes.  WAVES x 32 rows per tile.  AD: A prefetch depth in stages.
+template <int WAVES, int AD, int MINB, int BMODE>
+__global__ __launch_bounds__(64 * WAVES, MINB) void wgemm_p_kernel(const WgemmArgs a, const int G) {
+  constexpr int NT = 64 * WAVES, BM = 32 * WAVES, NPC = STAGE_BYTES / 16 / NT;      // 16-byte pieces of a B stage per thread
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int lid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int nb = lid % a.NB, qq = lid / a.NB, g = qq % G, p = qq / G;
+  const int ntile = (a.Mt + BM - 1) / BM;
+  if (g >= ntile) return;
+  const float* __restrict__ V = a.V + (long long)p * a.sV;
+  const unsigned char* __restrict__ U3 = a.U3 + ((long long)p * a.NB + nb) * a.S * STAGE_BYTES;
+  const int S = a.S;
+  const int total = ((ntile - g + G - 1) / G) * S;
+
+  auto aptr = [&](int t) {
+    int row = t * BM + wid * 32 + (lane & 31);
+    if (row >= a.Mt) row = a.Mt - 1;
+    return V + (long long)row * a.Cin + 16 * (lane >> 5);
+  };
+  const u32x4* Bg = reinterpret_cast<const u32x4*>(U3) + tid;
+  u32x4* Bs = reinterpret_cast<u32x4*>(smem) + tid;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  float4 ra[AD][4];
+  u32x4 rb[NPC];
+  // stream position of the A prefetch (AD stages ahead) 
+  int pt = g, ps = 0;
+  const float* pA = aptr(pt);
+  auto loadA = [&](float4* dst) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const float4*>(pA + ps * WKS + 4 * j);
+    if (++ps == S) { ps = 0; pt += G; pA = aptr(pt < ntile ? pt : g); }
+  };
+  auto loadB = [&](int s, int buf) {
+    if (BMODE == 1) {                  // LDS-DMA: global -> LDS without passing through registers (destination = wave-uniform base + lane * 16)
+#pragma unroll
+      for (int j = 0; j < NPC; ++j)
+        __builtin_amdgcn_global_load_lds(Bg + (long long)s * (STAGE_BYTES / 16) + j * NT,
+                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<u32x4*>(smem) + buf * (STAGE_BYTES / 16) + j * NT + wid * 64), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) rb[j] = Bg[(long long)s * (STAGE_BYTES / 16) + j * NT];
+    }
+  };
+  auto storeB = [&](int buf) {
+    if (BMODE == 1) return;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) Bs[buf * (STAGE_BYTES / 16) + j * NT] = rb[j];
+  };
+#pragma unroll
+  for (int d = 0; d < AD; ++d) loadA(ra[d]);
+  loadB(0, 0);
+  storeB(0);
+  __syncthreads();
+  int tile = g, s = 0;
+  for (int gs = 0; gs < total; ++gs) {
+    const float4 ca[4] = {ra[0][0], ra[0][1], ra[0][2], ra[0][3]};
+#pragma unroll
+    for (int d = 0; d + 1 < AD; ++d)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ra[d][j] = ra[d + 1][j];
+    const int sn = (s + 1 == S) ? 0 : s + 1;
+    if (gs + AD < total) loadA(ra[AD - 1]);
+    if (gs + 1 < total) loadB(sn, (gs + 1) & 1);
+    const unsigned char* Bcur = smem + (gs & 1) * STAGE_BYTES + lane * 16;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      const Split3 av = split3(ca[2 * kc], ca[2 * kc + 1]);
+      bf16x8 b[4][3];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[cb][q] = *reinterpret_cast<const bf16x8*>(Bcur + ((kc * 4 + cb) * 3 + q) * FRAG);
+      constexpr int PB[6] = {1, 2, 0, 1, 0, 0}, PA[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][PB[t]], av.p[PA[t]], acc[cb], 0, 0, 0);
+    }
+    if (gs + 1 < total) storeB((gs + 1) & 1);
+    __syncthreads();
+    if (s + 1 == S) {           // tile finished: its accumulators leave while the next tile's first stage is already in flight
+      const int row = tile * BM + wid * 32 + (lane & 31);
+      if (row < a.Mt) {
+        float* dst = a.M + (long long)p * a.sM + (long long)row * a.Cout + nb * WBN + 4 * (lane >> 5);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg)
+            *reinterpret_cast<float4*>(dst + cb * 32 + 8 * gg) = make_float4(acc[cb][4 * gg], acc[cb][4 * gg + 1], acc[cb][4 * gg + 2], acc[cb][4 * gg + 3]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+      tile += G;
+    }
+    s = sn;
+  }
+}
+
 }  // namespace
 }  // namespace buddy
 #include <vector>
+#include <time.h>
 #include <cstdio>
 #include <cstring>
 using namespace buddy;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
-template <int PROBE> static float run(const WgemmArgs& a, dim3 grid, int reps) {
+static int g_gap_us = 300;
+template <typename F> static float gapped(F launch, int reps) {     // each launch alone, after an idle gap: the regime of the real step (GEMMs between memory-bound kernels)
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true, PROBE>), grid, dim3(WNT), 0, 0, a);
-  hipEventRecord(e0, 0);
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true, PROBE>), grid, dim3(WNT), 0, 0, a);
-  hipEventRecord(e1, 0); hipEventSynchronize(e1);
-  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-  return ms / reps;
+  float tot = 0;
+  for (int i = 0; i < reps + 2; ++i) {
+    hipDeviceSynchronize();
+    if (g_gap_us) { timespec ts{0, g_gap_us * 1000}; nanosleep(&ts, nullptr); }
+    hipEventRecord(e0, 0); launch(); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    if (i >= 2) tot += ms;
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return tot / reps;
+}
+template <int PROBE> static float run(const WgemmArgs& a, dim3 grid, int reps) {
+  return gapped([&] { hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true, PROBE>), grid, dim3(WNT), 0, 0, a); }, reps);
+}
+template <int WAVES, int AD, int MINB, int BMODE> static float run_p(const WgemmArgs& a, int P, int wg_target, int reps, int* Gout) {
+  const int BM = 32 * WAVES, ntile = (a.Mt + BM - 1) / BM;
+  int G = wg_target / (P * a.NB); if (G < 1) G = 1; if (G > ntile) G = ntile;
+  *Gout = G;
+  const dim3 grid((unsigned)(P * a.NB * G));
+  return gapped([&] { hipLaunchKernelGGL((wgemm_p_kernel<WAVES, AD, MINB, BMODE>), grid, dim3(64 * WAVES), 0, 0, a, G); }, reps);
+}
+static bool same(const float* dM, const std::vector<float>& ref) {
+  std::vector<float> h(ref.size());
+  hipMemcpy(h.data(), dM, ref.size() * 4, hipMemcpyDeviceToHost);
+  return memcmp(h.data(), ref.data(), ref.size() * 4) == 0;
+}
+// one launch at a time with an idle gap before it (host sleep): does the kernel run faster when the chip had time to cool / bank power?
+template <int PROBE> static void run_gapped(const WgemmArgs& a, dim3 grid, int gap_us, const char* name, double fl) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float tot = 0, mn = 1e9f, mx = 0;
+  const int R = 12;
+  for (int i = 0; i < R + 2; ++i) {
+    hipDeviceSynchronize();
+    if (gap_us) { timespec ts{0, gap_us * 1000}; nanosleep(&ts, nullptr); }
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true, PROBE>), grid, dim3(WNT), 0, 0, a);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    if (i >= 2) { tot += ms; mn = ms < mn ? ms : mn; mx = ms > mx ? ms : mx; }
+  }
+  printf("  %-30s gap %6d us: avg %8.1f us (min %8.1f max %8.1f)  %7.0f bf16-TF\n", name, gap_us, tot / R * 1e3, mn * 1e3, mx * 1e3, 6 * fl / (tot / R * 1e-3) / 1e12);
 }
 int main() {
   const int shapes[][4] = {{29584, 256, 256, 64}, {29584, 128, 128, 64}, {29584, 128, 384, 64}, {7568, 256, 512, 64}};
@@ -232,11 +394,21 @@ int main() {
     const double fl = 2.0 * P * Mt * (double)N * K;
     const int R = 10;
     struct { const char* name; float ms; } r[] = {
-      {"full", run<0>(a, grid, R)}, {"no A loads", run<1>(a, grid, R)}, {"no B copy", run<2>(a, grid, R)}, {"no B copy, no barrier", run<6>(a, grid, R)},
+      {"full", run<0>(a, grid, R)}, {"nt stores of M", run<128>(a, grid, R)}, {"nt loads of V", run<256>(a, grid, R)}, {"nt both", run<384>(a, grid, R)}, {"full again", run<0>(a, grid, R)}, {"coalesced A pattern", run<64>(a, grid, R)}, {"coalesced A, no B copy", run<66>(a, grid, R)}, {"coalesced A, no epilogue", run<96>(a, grid, R)}, {"no A loads", run<1>(a, grid, R)}, {"no B copy", run<2>(a, grid, R)}, {"no B copy, no barrier", run<6>(a, grid, R)},
       {"no A, no B, no barrier", run<7>(a, grid, R)}, {"no split", run<8>(a, grid, R)}, {"no A/B/barrier/split", run<15>(a, grid, R)},
       {"no MFMA", run<16>(a, grid, R)}, {"no epilogue", run<32>(a, grid, R)}, {"no A/B/bar/split/epi (MFMA+LDS reads)", run<47>(a, grid, R)},
       {"no MFMA no epi", run<48>(a, grid, R)} };
     printf("Mt=%d N=%d K=%d P=%d\n", Mt, N, K, P);
+    {
+      run<0>(a, grid, 1);
+      std::vector<float> ref((size_t)P * Mt * N);
+      CK(hipMemcpy(ref.data(), M, ref.size() * 4, hipMemcpyDeviceToHost));
+      int G = 0;
+      struct { const char* name; float ms; bool ok; int G; } pr[12]; int np = 0;
+#define PV(W, AD, MB, BM_, TGT, NAME) { CK(hipMemset(M, 0xff, ref.size() * 4)); float t_ = run_p<W, AD, MB, BM_>(a, P, TGT, R, &G); pr[np++] = {NAME, t_, same(M, ref), G}; }
+      PV(4, 1, 3, 0, 1 << 30, "4 waves/tile 128 rows, reg-staged B")
+      for (int i = 0; i < np; ++i) printf("  %-44s %8.1f us  %7.1f TF-eq  %7.0f bf16-TF  G=%d %s\n", pr[i].name, pr[i].ms * 1e3, fl / (pr[i].ms * 1e-3) / 1e12, 6 * fl / (pr[i].ms * 1e-3) / 1e12, pr[i].G, pr[i].ok ? "bit-exact" : "MISMATCH");
+    }
     for (auto& x : r) printf("  %-44s %8.1f us  %7.1f TF-eq  %7.0f bf16-TF\n", x.name, x.ms * 1e3, fl / (x.ms * 1e-3) / 1e12, 6 * fl / (x.ms * 1e-3) / 1e12);
     hipFree(V); hipFree(U); hipFree(M); hipFree(U3);
   }
