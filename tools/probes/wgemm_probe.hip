@@ -322,6 +322,92 @@ __global__ __launch_bounds__(64 * WAVES, MINB) void wgemm_p_kernel(const WgemmAr
   }
 }
 
+// ---- N = 256 per workgroup: a wave owns 32 rows x 256 columns (8 accumulator tiles), so a V row is loaded and split ONCE for both column
+// blocks (the 128-column kernel does it once per column block).  K advances in 16-k sub-stages (one MFMA k-chunk; 24 KB of B per sub-stage,
+// double-buffered, by LDS-DMA); 48 MFMAs per wave per barrier as in the 128-column kernel.  Cout % 256 == 0.
+__global__ __launch_bounds__(256, 2) void wgemm_n256_kernel(const WgemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int lid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int NB2 = a.NB / 2;
+  const int nb2 = lid % NB2, m0 = (lid / NB2) * WBM;
+  const int p = blockIdx.z;
+  const float* __restrict__ V = a.V + (long long)p * a.sV;
+  const int S = a.S, U = 2 * S;                                 // 16-k sub-stages
+  int row = m0 + wid * 32 + (lane & 31);
+  const bool row_ok = row < a.Mt;
+  if (!row_ok) row = a.Mt - 1;
+  const float* Ap = V + (long long)row * a.Cin + 16 * (lane >> 5);
+  // B sub-stage u = (s, kc): 12 KB from each of the two column blocks' stage images
+  const unsigned char* U3a = a.U3 + ((long long)p * a.NB + 2 * nb2) * S * STAGE_BYTES;
+  const unsigned char* U3b = U3a + (long long)S * STAGE_BYTES;
+  auto copyB = [&](int u, int buf) {
+    const int s = u >> 1, kc = u & 1;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const u32x4* src = reinterpret_cast<const u32x4*>((half ? U3b : U3a) + (long long)s * STAGE_BYTES + kc * (STAGE_BYTES / 2));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int piece = (j * 4 + wid) * 64;                  // wave-uniform first piece of this instruction
+        __builtin_amdgcn_global_load_lds(src + piece + lane,
+            (__attribute__((address_space(3))) void*)(reinterpret_cast<u32x4*>(smem) + buf * (STAGE_BYTES / 16) + half * (STAGE_BYTES / 32) + piece), 16, 0, 0);
+      }
+    }
+  };
+  f32x16 acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  float4 ra[4];
+  auto loadA = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(Ap + s * WKS + 4 * j);
+  };
+  loadA(0);
+  copyB(0, 0);
+  __syncthreads();
+  float4 ca[4];
+  for (int u = 0; u < U; ++u) {
+    const int kc = u & 1;
+    if (kc == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ca[j] = ra[j];
+      if (u + 2 < U) loadA((u >> 1) + 1);
+    }
+    if (u + 1 < U) copyB(u + 1, (u + 1) & 1);
+    const unsigned char* Bcur = smem + (u & 1) * STAGE_BYTES + lane * 16;
+    const Split3 av = split3(ca[2 * kc], ca[2 * kc + 1]);
+    constexpr int PB[6] = {1, 2, 0, 1, 0, 0}, PA[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      bf16x8 b[4][3];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[cb][q] = *reinterpret_cast<const bf16x8*>(Bcur + half * (STAGE_BYTES / 2) + (cb * 3 + q) * FRAG);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          acc[4 * half + cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][PB[t]], av.p[PA[t]], acc[4 * half + cb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (!row_ok) return;
+  float* dst = a.M + (long long)p * a.sM + (long long)row * a.Cout + nb2 * 256 + 4 * (lane >> 5);
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(dst + cb * 32 + 8 * g) = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+}
+
 }  // namespace
 }  // namespace buddy
 #include <vector>
@@ -407,6 +493,16 @@ int main() {
       struct { const char* name; float ms; bool ok; int G; } pr[12]; int np = 0;
 #define PV(W, AD, MB, BM_, TGT, NAME) { CK(hipMemset(M, 0xff, ref.size() * 4)); float t_ = run_p<W, AD, MB, BM_>(a, P, TGT, R, &G); pr[np++] = {NAME, t_, same(M, ref), G}; }
       PV(4, 1, 3, 0, 1 << 30, "4 waves/tile 128 rows, reg-staged B")
+      if (N % 256 == 0) {
+        CK(hipMemset(M, 0xff, ref.size() * 4));
+        const dim3 g2((unsigned)(((Mt + WBM - 1) / WBM) * (a.NB / 2)), 1, (unsigned)P);
+        float t_ = gapped([&] { hipLaunchKernelGGL(wgemm_n256_kernel, g2, dim3(256), 0, 0, a); }, R);
+        pr[np++] = {"N=256 per workgroup (A split shared), 16-k sub-stages", t_, same(M, ref), 0};
+        float t2_ = gapped([&] { hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true, 0>), grid, dim3(WNT), 0, 0, a); }, R);
+        pr[np++] = {"production kernel (same moment)", t2_, true, 0};
+        float t3_ = gapped([&] { hipLaunchKernelGGL(wgemm_n256_kernel, g2, dim3(256), 0, 0, a); }, R);
+        pr[np++] = {"N=256 per workgroup again", t3_, true, 0};
+      }
       for (int i = 0; i < np; ++i) printf("  %-44s %8.1f us  %7.1f TF-eq  %7.0f bf16-TF  G=%d %s\n", pr[i].name, pr[i].ms * 1e3, fl / (pr[i].ms * 1e-3) / 1e12, 6 * fl / (pr[i].ms * 1e-3) / 1e12, pr[i].G, pr[i].ok ? "bit-exact" : "MISMATCH");
     }
     for (auto& x : r) printf("  %-44s %8.1f us  %7.1f TF-eq  %7.0f bf16-TF\n", x.name, x.ms * 1e3, fl / (x.ms * 1e-3) / 1e12, 6 * fl / (x.ms * 1e-3) / 1e12);
