@@ -104,80 +104,8 @@ __device__ __forceinline__ void tile_pb(const float* Ps, const float* Bs, int i,
   }
 }
 
-
-// ---- "bf16x3": the same products at fp32 accuracy on the bf16 matrix pipe (the arithmetic of wgemm.hip).  Every fp32 operand is split EXACTLY
-// into three bf16 terms by truncation (x = hi + mid + lo, 8 + 8 + 8 significant bits) and a product is accumulated in fp32 as
-// mid*mid + hi*lo + lo*hi + hi*mid + mid*hi + hi*hi on v_mfma_f32_16x16x32_bf16 (smallest terms first; the dropped terms are <= 2^-23 of a
-// product).  Six 16-cycle MFMAs per 32 k replace eight 32-cycle fp32 MFMAs per 32 k: 2.67x fewer matrix-pipe cycles.  The LDS tiles stay fp32
-// (no extra LDS): a wave splits the fragments it reads (5.5 VALU per element), so the loop is VALU / matrix balanced instead of matrix bound.
-// The k index a lane holds is free as long as both operands agree: lane (i, g) keeps the fp32 kernels' element order, k slots
-// {16 (j / 4) + 4 g + j % 4, j < 8} of a 32-wide chunk, so every register and LDS access pattern of the fp32 tiles is reused.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-struct S3 { bf16x8_t p[3]; };
-__device__ __forceinline__ S3 split3(const float4 a, const float4 b) {
-  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  unsigned int h[8], m[8], l[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const unsigned int u = __float_as_uint(x[i]);
-    h[i] = u;
-    const float r = x[i] - __uint_as_float(u & 0xFFFF0000u);
-    m[i] = __float_as_uint(r);
-    l[i] = __float_as_uint(r - __uint_as_float(m[i] & 0xFFFF0000u));
-  }
-  u32x4_t ph, pm, pl;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    ph[q] = __builtin_amdgcn_perm(h[2 * q + 1], h[2 * q], 0x07060302u);
-    pm[q] = __builtin_amdgcn_perm(m[2 * q + 1], m[2 * q], 0x07060302u);
-    pl[q] = __builtin_amdgcn_perm(l[2 * q + 1], l[2 * q], 0x07060302u);
-  }
-  S3 s;
-  s.p[0] = (bf16x8_t)ph; s.p[1] = (bf16x8_t)pm; s.p[2] = (bf16x8_t)pl;
-  return s;
-}
-// the six products of one (A, B) fragment pair into two accumulators alternately (no two consecutive MFMAs share an accumulator)
-__device__ __forceinline__ void mma3x2(const S3& a, const S3& b0, const S3& b1, f32x4& c0, f32x4& c1) {
-  constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
-#pragma unroll
-  for (int t = 0; t < 6; ++t) {
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[PA[t]], b0.p[PB[t]], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[PA[t]], b1.p[PB[t]], c1, 0, 0, 0);
-  }
-}
-template <int C>
-__device__ __forceinline__ void tile_abt3(const float4 (&a)[C / 16], const float* Bs, int i, int g, f32x4 (&acc)[2]) {
-  constexpr int LD = C + 4;
-#pragma unroll
-  for (int kk = 0; kk < C / 32; ++kk) {
-    const S3 av = split3(a[2 * kk], a[2 * kk + 1]);
-    const float* b0 = Bs + i * LD + 32 * kk + 4 * g;
-    const float* b1 = b0 + 16 * LD;
-    const S3 bv0 = split3(*reinterpret_cast<const float4*>(b0), *reinterpret_cast<const float4*>(b0 + 16));
-    const S3 bv1 = split3(*reinterpret_cast<const float4*>(b1), *reinterpret_cast<const float4*>(b1 + 16));
-    mma3x2(av, bv0, bv1, acc[0], acc[1]);
-  }
-}
-template <int C>
-__device__ __forceinline__ void tile_pb3(const float* Ps, const float* Bs, int i, int g, f32x4 (&o)[C / 16]) {
-  constexpr int LD = C + 4;
-  const S3 pv = split3(*reinterpret_cast<const float4*>(Ps + i * PLD + 4 * g), *reinterpret_cast<const float4*>(Ps + i * PLD + 16 + 4 * g));
-  const float* brow = Bs + (4 * g) * LD + i;                   // k slot j <-> key row 16 (j / 4) + 4 g + j % 4
-#pragma unroll
-  for (int c = 0; c < C / 16; c += 2) {
-    float4 x0, x1, y0, y1;
-    x0.x = brow[16 * c]; x0.y = brow[LD + 16 * c]; x0.z = brow[2 * LD + 16 * c]; x0.w = brow[3 * LD + 16 * c];
-    x1.x = brow[16 * LD + 16 * c]; x1.y = brow[17 * LD + 16 * c]; x1.z = brow[18 * LD + 16 * c]; x1.w = brow[19 * LD + 16 * c];
-    y0.x = brow[16 * c + 16]; y0.y = brow[LD + 16 * c + 16]; y0.z = brow[2 * LD + 16 * c + 16]; y0.w = brow[3 * LD + 16 * c + 16];
-    y1.x = brow[16 * LD + 16 * c + 16]; y1.y = brow[17 * LD + 16 * c + 16]; y1.z = brow[18 * LD + 16 * c + 16]; y1.w = brow[19 * LD + 16 * c + 16];
-    const S3 b0 = split3(x0, x1), b1 = split3(y0, y1);
-    mma3x2(pv, b0, b1, o[c], o[c + 1]);
-  }
-}
-
 // NW waves per workgroup = 16 NW query rows share every staged key / value block (NW = 8: half the L2 -> LDS traffic per FLOP of NW = 4)
-template <int C, int NW, bool X3>
+template <int C, int NW>
 __global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                             float* __restrict__ O, float* __restrict__ Lse, int T, float scale) {
   constexpr int LD = C + 4;
@@ -209,7 +137,7 @@ __global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(const float* __restr
     __syncthreads();
     if (j0 + BC < T) { fetch32<C, NT>(k + base, j0 + BC, T, pk); fetch32<C, NT>(v + base, j0 + BC, T, pv); }
     f32x4 s[2] = {zero_acc(), zero_acc()};
-    if (X3) tile_abt3<C>(qa, Ks, i, g, s); else tile_abt<C>(qa, Ks, i, g, s);
+    tile_abt<C>(qa, Ks, i, g, s);
     float alpha[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -229,7 +157,7 @@ __global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[c][r] *= alpha[r];
     __syncthreads();
-    if (X3) tile_pb3<C>(Ps[w], Vs, i, g, o); else tile_pb<C>(Ps[w], Vs, i, g, o);
+    tile_pb<C>(Ps[w], Vs, i, g, o);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -258,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
   if (lane == 0) D[row] = acc;
 }
 
-template <int C, bool X3>
+template <int C>
 __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                            const float* __restrict__ dO, const float* __restrict__ Lse, const float* __restrict__ D,
                                                            float* __restrict__ dq, int T, float scale) {
@@ -294,7 +222,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const float* __restri
     __syncthreads();
     if (j0 + BC < T) { fetch32<C>(k + base, j0 + BC, T, pk); fetch32<C>(v + base, j0 + BC, T, pv); }
     f32x4 s[2] = {zero_acc(), zero_acc()}, dp[2] = {zero_acc(), zero_acc()};
-    if (X3) { tile_abt3<C>(qa, Ks, i, g, s); tile_abt3<C>(da, Vs, i, g, dp); } else { tile_abt<C>(qa, Ks, i, g, s); tile_abt<C>(da, Vs, i, g, dp); }
+    tile_abt<C>(qa, Ks, i, g, s);
+    tile_abt<C>(da, Vs, i, g, dp);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -305,7 +234,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const float* __restri
       }
     }
     __syncthreads();
-    if (X3) tile_pb3<C>(Ps[w], Ks, i, g, acc); else tile_pb<C>(Ps[w], Ks, i, g, acc);
+    tile_pb<C>(Ps[w], Ks, i, g, acc);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -316,7 +245,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const float* __restri
   }
 }
 
-template <int C, bool X3>
+template <int C>
 __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                             const float* __restrict__ dO, const float* __restrict__ Lse, const float* __restrict__ D,
                                                             float* __restrict__ dk, float* __restrict__ dv, int T, float scale) {
@@ -347,8 +276,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const float* __restr
     __syncthreads();
     if (i0 + BC < T) { fetch32<C>(q + base, i0 + BC, T, pq); fetch32<C>(dO + base, i0 + BC, T, po); }
     f32x4 s[2] = {zero_acc(), zero_acc()}, dp[2] = {zero_acc(), zero_acc()};
-    if (X3) { tile_abt3<C>(ka, Qs, i, g, s); tile_abt3<C>(va, Os, i, g, dp); }      // S^T[key row][query col], dP^T
-    else { tile_abt<C>(ka, Qs, i, g, s); tile_abt<C>(va, Os, i, g, dp); }
+    tile_abt<C>(ka, Qs, i, g, s);              // S^T[key row][query col]
+    tile_abt<C>(va, Os, i, g, dp);             // dP^T
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int qc = i0 + 16 * t + i;          // this lane's query column
@@ -362,7 +291,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const float* __restr
       }
     }
     __syncthreads();
-    if (X3) { tile_pb3<C>(Ps[w], Os, i, g, gv); tile_pb3<C>(Ss[w], Qs, i, g, gk); } else { tile_pb<C>(Ps[w], Os, i, g, gv); tile_pb<C>(Ss[w], Qs, i, g, gk); }
+    tile_pb<C>(Ps[w], Os, i, g, gv);
+    tile_pb<C>(Ss[w], Qs, i, g, gk);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -607,8 +537,7 @@ __global__ __launch_bounds__(256) void flash16_bwd_dkv_kernel(const float* __res
 
 bool flash_attn_supported(int C) { return C == 64 || C == 128 || C == 256; }
 
-// O [B][T][C], Lse [B][T]; prec: 0 = fp32 accuracy on the bf16 matrix pipe (exact three-way operand split, default), 1 = bf16 operands,
-// 2 = f16 operands (fp32 accumulate), 3 = fp32 operands on v_mfma_f32_16x16x4_f32 (the round-1..3 kernels, kept as the reference run)
+// O [B][T][C], Lse [B][T]; prec: 0 = fp32 operands (exact-fp32 MFMA), 1 = bf16 operands, 2 = f16 operands (fp32 accumulate)
 void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, int prec, hipStream_t st) {
   const dim3 grid(cdiv(T, BR), B), block(256);
   // fp32: 128-row workgroups (8 waves) once there are enough of them to fill the chip, 64-row ones otherwise (BUDDY_ATTN_NW=4|8 forces one)
@@ -618,10 +547,8 @@ void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float
 #define FA_FWD(CC)                                                                                                           \
   if (prec == 1) hipLaunchKernelGGL((flash16_fwd_kernel<CC, __bf16>), grid, block, 0, st, q, k, v, O, Lse, T, scale);            \
   else if (prec == 2) hipLaunchKernelGGL((flash16_fwd_kernel<CC, _Float16>), grid, block, 0, st, q, k, v, O, Lse, T, scale);    \
-  else if (prec == 3 && wide) hipLaunchKernelGGL((flash_fwd_kernel<CC, 8, false>), grid8, block8, 0, st, q, k, v, O, Lse, T, scale); \
-  else if (prec == 3) hipLaunchKernelGGL((flash_fwd_kernel<CC, 4, false>), grid, block, 0, st, q, k, v, O, Lse, T, scale);        \
-  else if (wide) hipLaunchKernelGGL((flash_fwd_kernel<CC, 8, true>), grid8, block8, 0, st, q, k, v, O, Lse, T, scale);            \
-  else hipLaunchKernelGGL((flash_fwd_kernel<CC, 4, true>), grid, block, 0, st, q, k, v, O, Lse, T, scale);
+  else if (wide) hipLaunchKernelGGL((flash_fwd_kernel<CC, 8>), grid8, block8, 0, st, q, k, v, O, Lse, T, scale);                 \
+  else hipLaunchKernelGGL((flash_fwd_kernel<CC, 4>), grid, block, 0, st, q, k, v, O, Lse, T, scale);
   if (C == 64) { FA_FWD(64) } else if (C == 128) { FA_FWD(128) } else { FA_FWD(256) }
 #undef FA_FWD
 }
@@ -639,12 +566,9 @@ void launch_flash_attn_bwd(const float* q, const float* k, const float* v, const
   } else if (prec == 2) {                                                                                                    \
     hipLaunchKernelGGL((flash16_bwd_dq_kernel<CC, _Float16>), grid, block, 0, st, q, k, v, dO, Lse, Dc, dq, T, scale);           \
     hipLaunchKernelGGL((flash16_bwd_dkv_kernel<CC, _Float16>), grid, block, 0, st, q, k, v, dO, Lse, Dc, dk, dv, T, scale);      \
-  } else if (prec == 3) {                                                                                                    \
-    hipLaunchKernelGGL((flash_bwd_dq_kernel<CC, false>), grid, block, 0, st, q, k, v, dO, Lse, Dc, dq, T, scale);                \
-    hipLaunchKernelGGL((flash_bwd_dkv_kernel<CC, false>), grid, block, 0, st, q, k, v, dO, Lse, Dc, dk, dv, T, scale);           \
   } else {                                                                                                                   \
-    hipLaunchKernelGGL((flash_bwd_dq_kernel<CC, true>), grid, block, 0, st, q, k, v, dO, Lse, Dc, dq, T, scale);                 \
-    hipLaunchKernelGGL((flash_bwd_dkv_kernel<CC, true>), grid, block, 0, st, q, k, v, dO, Lse, Dc, dk, dv, T, scale);            \
+    hipLaunchKernelGGL(flash_bwd_dq_kernel<CC>, grid, block, 0, st, q, k, v, dO, Lse, Dc, dq, T, scale);                         \
+    hipLaunchKernelGGL(flash_bwd_dkv_kernel<CC>, grid, block, 0, st, q, k, v, dO, Lse, Dc, dk, dv, T, scale);                    \
   }
   if (C == 64) { FA_BWD(64) } else if (C == 128) { FA_BWD(128) } else { FA_BWD(256) }
 #undef FA_BWD

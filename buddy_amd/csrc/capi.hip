@@ -351,13 +351,13 @@ int buddy_fir_resample2(const float* x, float* y, int B, int H, int W, int C, in
 
 int buddy_flash_attention_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, int prec,
                               void* stream) {
-  if (!q || !k || !v || !O || !lse || B < 1 || T < 1 || !flash_attn_supported(C) || prec < 0 || prec > 3) { set_error("bad attention arguments (C in {64, 128, 256}; prec 0..3)"); return BUDDY_ERR_ARG; }
+  if (!q || !k || !v || !O || !lse || B < 1 || T < 1 || !flash_attn_supported(C) || prec < 0 || prec > 2) { set_error("bad attention arguments (C in {64, 128, 256})"); return BUDDY_ERR_ARG; }
   launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, prec, (hipStream_t)stream);
   return finish();
 }
 int buddy_flash_attention_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta, float* dq,
                               float* dk, float* dv, int B, int T, int C, float scale, int prec, void* stream) {
-  if (prec < 0 || prec > 3 || !q || !k || !v || !O || !dO || !lse || !delta || !dq || !dk || !dv || B < 1 || T < 1 || !flash_attn_supported(C)) {
+  if (prec < 0 || prec > 2 || !q || !k || !v || !O || !dO || !lse || !delta || !dq || !dk || !dv || B < 1 || T < 1 || !flash_attn_supported(C)) {
     set_error("bad attention arguments (C in {64, 128, 256})"); return BUDDY_ERR_ARG;
   }
   launch_flash_attn_bwd(q, k, v, O, dO, lse, delta, dq, dk, dv, B, T, C, scale, prec, (hipStream_t)stream);

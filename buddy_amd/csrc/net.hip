@@ -451,7 +451,7 @@ int net_weight_bytes(Net* N, long long* params, long long* packed, long long* la
   return BUDDY_OK;
 }
 
-int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 4) { set_error("attention mode must be 0..4"); return BUDDY_ERR_ARG; } N->attn_mode = mode; N->rsv_vjp = -1; return BUDDY_OK; }
+int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 3) { set_error("attention mode must be 0..3"); return BUDDY_ERR_ARG; } N->attn_mode = mode; N->rsv_vjp = -1; return BUDDY_OK; }
 int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 1) { set_error("gemm mode must be 0 (fp32 MFMA) or 1 (bf16x3)"); return BUDDY_ERR_ARG; } N->gemm_mode = mode; return BUDDY_OK; }
 int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; return BUDDY_OK; }
 void net_destroy(Net* N) {
@@ -781,17 +781,16 @@ static void gemm_b(Net* N, const float* A, int ldA, long long sA, bool tA, const
   launch_igemm(p, 1, tA, tB, batch, N->st);
 }
 
-// Attention mode of a handle: 0 = flash, fp32 accuracy on the bf16 matrix pipe ("bf16x3": exact three-way operand split, default); 1 / 2 = flash
-// with plain bf16 / f16 MFMA operands (opt-in fast mode); 3 = the materialised T x T form (P in HBM: 16.8 MB / utterance at
-// 4 s, 905 MB at 30 s); 4 = flash on v_mfma_f32_16x16x4_f32 (the round-1..3 kernels: the reference run of mode 0).  Initialised from BUDDY_ATTN
-// (flash | bf16 | f16 | matrix | fp32), changed per handle with buddy_ncsnpp_set_attention.
+// Attention mode of a handle: 0 = flash, fp32 operands (default); 1 / 2 = flash with bf16 / f16 MFMA operands (opt-in fast mode, DESIGN.md
+// section 7); 3 = the materialised T x T form (P in HBM: 16.8 MB / utterance at 4 s, 905 MB at 30 s).  Initialised from BUDDY_ATTN
+// (matrix | flash | bf16 | f16), changed per handle with buddy_ncsnpp_set_attention.
 static int attn_mode_from_env() {
   const char* e = getenv("BUDDY_ATTN");
   const std::string m = e ? e : "";
-  return m == "matrix" ? 3 : m == "bf16" ? 1 : m == "f16" ? 2 : m == "fp32" ? 4 : 0;
+  return m == "matrix" ? 3 : m == "bf16" ? 1 : m == "f16" ? 2 : 0;
 }
 static bool attn_use_flash(const Net* N, int C) { return N->attn_mode != 3 && flash_attn_supported(C); }
-static int attn_prec(const Net* N) { return N->attn_mode == 1 || N->attn_mode == 2 ? N->attn_mode : (N->attn_mode == 4 ? 3 : 0); }
+static int attn_prec(const Net* N) { return N->attn_mode == 1 || N->attn_mode == 2 ? N->attn_mode : 0; }
 
 static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
   const int B = x->B, H = x->H, W = x->W, C = A.C, T = H * W, G = gn_groups(C);

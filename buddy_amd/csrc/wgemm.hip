@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void wgemm_pack_kernel(const float* __restrict
 struct WgemmArgs {
   const float* V; const unsigned char* U3; float* M;
   int Mt, Cin, Cout, S, NB;                                    // rows per position, K, N, K-stages, column blocks
+  int pz, gx;                                                  // pz > 0: positions folded into a 1-D grid (pz positions x gx workgroups each), XCD x owns positions x mod 8
   long long sV, sM;                                            // strides between positions (floats)
   // general form (GEN = true; 1x1 convolutions, NIN): A from up to two sources (channel concatenation, split at C0), row strides, C = alpha * A W^T
   // + bias [+ C]
@@ -93,16 +94,23 @@ template <bool GEN, bool EPI>
 __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  // XCD-aware order (hardware places block b on XCD b % 8): each XCD gets a contiguous range of logical tiles, the column blocks of one row
-  // tile adjacent, so the second column block finds its V rows in the same L2
-  int lid;
-  {
+  // XCD-aware order (hardware places workgroup b of the flattened grid on XCD b % 8, each XCD with its own L2).
+  //  * batched form, positions a multiple of 8 (a.pz > 0: 1-D grid of pz * tiles * NB workgroups): XCD x takes the positions x, x + 8, ... and walks
+  //    all their tiles, so a position's weight panel (K x 128 x 6 B per column block) is fetched into ONE L2 instead of all eight (r03 PMC:
+  //    the GEMM fetched 1.42x its V bytes; 8 x 25 MB of panels per 256 -> 256 convolution were most of the excess);
+  //  * otherwise (blockIdx.z = position): each XCD gets a contiguous range of logical tiles.
+  // In both, the column blocks of one row tile are adjacent, so the second column block finds its V rows in the same L2.
+  int lid, p;
+  if (a.pz > 0) {
+    const int orig = blockIdx.x, xcd = orig & 7, k = orig >> 3;     // k-th workgroup of this XCD: gx * pz / 8 of them
+    lid = k % a.gx; p = xcd + 8 * (k / a.gx);
+  } else {
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    p = blockIdx.z;
   }
   const int nb = lid % a.NB, m0 = (lid / a.NB) * WBM;
-  const int p = blockIdx.z;
   const float* __restrict__ V = a.V + (long long)p * a.sV;
   const unsigned char* __restrict__ U3 = a.U3 + ((long long)p * a.NB + nb) * a.S * STAGE_BYTES;
   const int S = a.S;
@@ -229,6 +237,7 @@ void launch_wgemm_bf16x3_general(const float* A0, int ldA0, const float* A1, int
   a.V = A0; a.U3 = reinterpret_cast<const unsigned char*>(W3); a.M = C;
   a.Mt = (int)M; a.Cin = K; a.Cout = N; a.S = K / WKS; a.NB = N / WBN; a.sV = 0; a.sM = 0;
   a.A1 = A1; a.C0 = A1 ? C0 : K; a.ldA0 = ldA0; a.ldA1 = ldA1; a.ldC = ldC; a.bias_n = bias_n; a.alpha = alpha; a.accumulate = accumulate;
+  a.pz = 0; a.gx = 0;
   const dim3 grid((unsigned)(cdiv((int)M, WBM) * a.NB), 1, 1);
   hipLaunchKernelGGL((wgemm_bf16x3_kernel<true, false>), grid, dim3(WNT), 0, st, a);
 }
@@ -239,7 +248,11 @@ void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt,
   a.V = V; a.U3 = reinterpret_cast<const unsigned char*>(U3); a.M = M;
   a.Mt = (int)Mt; a.Cin = Cin; a.Cout = Cout; a.S = Cin / WKS; a.NB = Cout / WBN;
   a.sV = Mt * Cin; a.sM = Mt * Cout;
-  const dim3 grid((unsigned)(cdiv((int)Mt, WBM) * a.NB), 1, (unsigned)P);
+  static const bool by_pos = !(getenv("BUDDY_WGEMM_XCDPOS") && atoi(getenv("BUDDY_WGEMM_XCDPOS")) == 0);     // A/B switch
+  const int gx = cdiv((int)Mt, WBM) * a.NB;
+  const bool fold = by_pos && P % 8 == 0 && (long long)gx * P < (1LL << 31);
+  a.pz = fold ? P : 0; a.gx = gx;
+  const dim3 grid(fold ? (unsigned)(gx * P) : (unsigned)gx, 1, fold ? 1u : (unsigned)P);
   static const bool direct_store = getenv("BUDDY_WGEMM_EPI") && atoi(getenv("BUDDY_WGEMM_EPI")) == 0;      // A/B switch: 32-byte-piece stores (+0.3 ... 1.9 % slower)
   if (direct_store) hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, false>), grid, dim3(WNT), 0, st, a);
   else hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true>), grid, dim3(WNT), 0, st, a);

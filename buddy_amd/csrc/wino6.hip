@@ -55,7 +55,7 @@ __device__ __forceinline__ void at8(const float4 (&m)[8], float4 (&y)[6]) {
   y[5] = d12 + 32.f * d34 + 0.03125f * d56 + m[7];
 }
 
-struct W6Geo { int B, H, W, TH, TW, QC, TPB; long long Mt; };   // TH x TW tiles per utterance, Mt = B * TH * TW
+struct W6Geo { int B, H, W, TH, TW, QC, TPB; long long Mt; int xcd; };   // TH x TW tiles per utterance, Mt = B * TH * TW
 
 // grid (ceil(Mt / TPB), ceil(q / QC)); V[(pos * Mt + tile) * Cin + c]
 // GN 1: the input is act(GroupNorm(x)) of a (channel-concatenated) view, applied while loading (zero padding applies to the ACTIVATED tensor)
@@ -67,8 +67,18 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
   __shared__ float4 lds[32 * 64];
   const int tid = threadIdx.x, QC = geo.QC;
   const int ql = tid % QC, col = (tid / QC) & 7, tl = tid / (QC * 8);
-  const int quad = blockIdx.y * QC + ql, c = quad * 4;
-  const long long tile = (long long)blockIdx.x * geo.TPB + tl;
+  // XCD-aware tile order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (own L2 each), which puts the two tiles that share
+  // two of their eight patch columns -- and the tile row below, which shares two rows -- on different L2s: the 1.78x patch overlap was fetched
+  // from the fabric almost in full (PMC r03: 2.09x the input instead of ~1.1x).  Each XCD gets a contiguous range of tiles instead.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (geo.xcd) {
+    const int n = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = n >> 3, r8 = n & 7, xcd = lin & 7, k = lin >> 3;
+    const int nl = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    bx = nl % gridDim.x; by = nl / gridDim.x;
+  }
+  const int quad = by * QC + ql, c = quad * 4;
+  const long long tile = (long long)bx * geo.TPB + tl;
   const bool live = tile < geo.Mt && c < Cin;
   const int H = geo.H, W = geo.W;
   int b = 0, ty = 0, tx = 0;
@@ -268,6 +278,8 @@ W6Geo geometry(const IgemmParams& p, int C) {
   const int q = C / 4;
   g.QC = q >= 32 ? 32 : (q > 16 ? 32 : (q > 8 ? 16 : (q > 4 ? 8 : (q > 2 ? 4 : (q > 1 ? 2 : 1)))));
   g.TPB = 32 / g.QC;
+  static const int xcd = !(getenv("BUDDY_W6_XCD") && atoi(getenv("BUDDY_W6_XCD")) == 0);     // A/B switch of the XCD-aware tile order of the input transform
+  g.xcd = xcd;
   return g;
 }
 // iterations of TPB tiles a workgroup of the output transform walks: about 512 workgroups (= statistics partials) per utterance

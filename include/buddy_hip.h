@@ -166,10 +166,8 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
  * The transposes are the other direction times 4 resp. 1/4.  buddy_ncsnpp_set_fir switches a network handle to this resampling (no parameters). */
 int buddy_fir_resample2(const float* x, float* y, int B, int H, int W, int C, int up, float scale, int accumulate, void* stream);
 int buddy_ncsnpp_set_fir(void* handle, int fir);
-/* attention core of a network handle: 0 = online-softmax kernels at fp32 accuracy on the bf16 matrix pipe (every fp32 operand split exactly
- * into three bf16 terms, six products, fp32 accumulate -- default); 1 / 2 = the same kernels with plain bf16 / f16 MFMA operands (opt-in fast mode,
- * fp32 accumulate + fp32 softmax); 3 = materialised T x T matrix (fp32); 4 = the online-softmax kernels on the fp32 matrix pipe.  Initial value
- * from BUDDY_ATTN = flash | bf16 | f16 | matrix | fp32. */
+/* attention core of a network handle: 0 = online-softmax kernels, fp32 operands (default); 1 / 2 = the same with bf16 / f16 MFMA operands (opt-in
+ * fast mode, fp32 accumulate + fp32 softmax); 3 = materialised T x T matrix.  Initial value from BUDDY_ATTN = flash | bf16 | f16 | matrix. */
 int buddy_ncsnpp_set_attention(void* handle, int mode);
 /* Arithmetic of the Winograd-domain GEMMs of the 3x3 convolutions (94 % of the FLOPs): 1 (default) = "bf16x3" -- every fp32 operand split
  * exactly into three bf16 terms, six bf16 MFMA products, fp32 accumulation: the fp32 kernel's accuracy against float64 (unit test) at
@@ -179,8 +177,7 @@ int buddy_ncsnpp_set_gemm(void* handle, int mode);
 /* single-head attention over T tokens without the T x T matrix (online softmax, fp32 MFMA), token-major q, k, v, O [B][T][C], C in {64,128,256}:
  * O = softmax(scale * q k^T) v, lse [B][T] = row log-sum-exp; replaces the einsum / softmax / einsum of AttnBlockpp.forward
  * (networks/ncsnpp_utils/layerspp.py:82-86).  bwd: gradients of the same three steps given dO (delta [B][T] is scratch).
- * prec: 0 = fp32 accuracy via exact three-way bf16 operand splits on v_mfma_f32_16x16x32_bf16 (default), 3 = fp32 operands on v_mfma_f32_16x16x4_f32
- * (same accuracy, the reference run), 1 = bf16, 2 = f16 MFMA operands with fp32 accumulation and fp32 softmax (opt-in fast mode). */
+ * prec: 0 = fp32 operands (the reference arithmetic), 1 = bf16, 2 = f16 MFMA operands with fp32 accumulation and fp32 softmax (opt-in fast mode). */
 int buddy_flash_attention_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, int prec, void* stream);
 int buddy_flash_attention_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta,
                               float* dq, float* dk, float* dv, int B, int T, int C, float scale, int prec, void* stream);

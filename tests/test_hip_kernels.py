@@ -434,14 +434,13 @@ def test_wpe_kernel_vs_torch_restatement(lib):
     assert float((torch.view_as_real(Zh) - torch.view_as_real(Zt)).abs().max() / torch.view_as_real(Zt).abs().max()) < 1e-9
 
 
-@pytest.mark.parametrize("prec", [0, 1, 2, 3])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("B,T,Cc", [(2, 2048, 256), (3, 144, 64), (1, 320, 128), (2, 1000, 256)])
 def test_flash_attention_fwd_bwd(lib, B, T, Cc, prec):
     """online-softmax attention (no T x T matrix) vs the reference formulation in fp64: w = softmax(q k^T C^-1/2), h = w v
     (networks/ncsnpp_utils/layerspp.py:82-86) and its three input gradients; ragged T (not a multiple of the 64-row / 32-column blocks).
-    prec 0 = the product path: fp32 accuracy on the bf16 matrix pipe (every fp32 operand split exactly into three bf16 terms, six products,
-    fp32 accumulate); prec 3 = the same kernels on v_mfma_f32_16x16x4_f32.  BOTH are held to the same fp32 bound: 1e-5 / 2e-5 of the abs-max.
-    prec 1 / 2 = plain bf16 / f16 MFMA operands (opt-in fast mode): operand rounding 2^-9 / 2^-12 -> stated 2e-2 / 3e-3."""
+    prec 0 = fp32 operands (the product path): 1e-5 / 2e-5.  prec 1 / 2 = bf16 / f16 MFMA operands (opt-in fast mode): operand rounding
+    2^-9 / 2^-12 -> stated 2e-2 / 3e-3 of the tensor's abs-max."""
     from buddy_amd import _lib
     g = torch.Generator(device="cpu").manual_seed(B * 1000 + T + Cc)
     q, k, v, dO = (torch.randn(B, T, Cc, generator=g).cuda() for _ in range(4))
@@ -458,7 +457,7 @@ def test_flash_attention_fwd_bwd(lib, B, T, Cc, prec):
     ref = torch.einsum("bij,bjc->bic", w, vd)
     gq, gk, gv = torch.autograd.grad(ref, (qd, kd, vd), dO.double())
     lse_ref = torch.logsumexp(torch.einsum("bic,bjc->bij", qd, kd) * scale, dim=-1)
-    tf, tb, tl = [(1e-5, 2e-5, 1e-4), (2e-2, 2e-2, 5e-2), (3e-3, 3e-3, 1e-2), (1e-5, 2e-5, 1e-4)][prec]
+    tf, tb, tl = [(1e-5, 2e-5, 1e-4), (2e-2, 2e-2, 5e-2), (3e-3, 3e-3, 1e-2)][prec]
     errs = dict(O=rel(O, ref.detach()), lse=float((lse.double() - lse_ref.detach()).abs().max()), dq=rel(dq, gq), dk=rel(dk, gk), dv=rel(dv, gv))
     print(prec, (B, T, Cc), {k_: f"{v_:.1e}" for k_, v_ in errs.items()})
     assert errs["O"] < tf and errs["lse"] < tl
