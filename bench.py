@@ -585,8 +585,9 @@ def main():
     full_run = None
     if "full_run" in want:
         t0 = time.perf_counter()
-        _, _, _, tester_f, _, y_f, op_f = build_stack(a, device, B, rank * B, net0[0])
-        torch.cuda.synchronize()
+        _, net_f, _, tester_f, _, y_f, op_f = build_stack(a, device, B, rank * B, net0[0])
+        arena_b = net_f.arena_bytes(B, a.length, True)     # a harness keeps its network handle across batches: the activation arena (hipMalloc of
+        torch.cuda.synchronize()                           # tens of GB, 0.1 ... 3 s depending on the box's memory state) is set-up, not run
         setup_s = time.perf_counter() - t0
         barrier()
         t0 = time.perf_counter()
@@ -597,10 +598,11 @@ def main():
         if dist is not None:
             dist.all_reduce(fr, op=dist.ReduceOp.MAX)
         assert torch.isfinite(pred_f).all(), "full run diverged"
-        full_run = {"T": a.T, "batch_per_gpu": B, "wall_s": float(fr.item()), "operator_and_batch_setup_s": setup_s,
+        full_run = {"T": a.T, "batch_per_gpu": B, "wall_s": float(fr.item()), "operator_and_batch_setup_s": setup_s, "arena_bytes": int(arena_b),
                     "utterance_steps_per_s": world * B * a.T / float(fr.item()), "ms_per_step": float(fr.item()) / a.T * 1e3,
                     "what": "Sampler.predict_conditional (bind + initialize_x + all T steps + final sync) of one batch on one stream through the product classes; "
-                            "operator_and_batch_setup_s = Tester.prepare_batch (synthetic y = clean * RIR through the HIP FIR, blind operator handle) before it"}
+                            "operator_and_batch_setup_s = Tester.prepare_batch (synthetic y = clean * RIR through the HIP FIR, blind operator handle) and the "
+                            "replica handle's activation arena (hipMalloc) before it"}
         log(f"full run: {full_run['wall_s']:.2f} s for T={a.T}")
         del tester_f, y_f, op_f, pred_f
 

@@ -240,6 +240,54 @@ def test_fullsize_blind_T10_fp64_arbiter(net):
         assert dev["build"][i] > min(100.0, min(dev["fp32t16"][i], dev["fp32t8"][i]) - 10.0), (i, dev)
 
 
+def test_fullsize_blind_T50_two_seeds_fp64_arbiter(net):
+    """BASELINE configs[1] as specified, through the WHOLE schedule, under the driver (the 8-seed T = 50 evidence of
+    profiles/r0*_arbiter_L64000_T50.json was builder-run): L = 64 000, nf = 128, T = 50, order 1, 10 operator updates per step, two utterances /
+    noise seeds sampled as one batch.  Arbiter = the restated algorithm in float64 through torch ops on the GPU; the second fp32 execution is the
+    fp32 oracle through torch's own GPU kernels (rocFFT / MIOpen / ATen: other summation orders than the CPU's; 50 CPU steps would take four
+    minutes per seed).  Asserted at every step: the build's SI-SDR to the float64 trajectory is not more than 10 dB below the fp32 oracle's
+    (capped at 100 dB = the fp32 round-off floor), the first step is at that floor, and the final estimates are statistically the same
+    (|delta SI-SDR to clean| of the build against float64 within 3 dB: two float64 executions of this chaotic chain differ by up to ~1.5 dB)."""
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_clean, synth_rir
+    from buddy_amd.testing.tester import Tester
+    from oracle.arbiter_runs import run_blind, overrides
+    from oracle.sampler_ref import NoiseStream
+    T, nf, up, taps, seeds = 50, 128, 10, 8000, [1, 6]
+    args = compose(overrides=overrides(T, up, nf))
+    t = Tester(args, net, instantiate(args.diff_params), test_set=None, device="cuda", in_training=True)
+    ns = [NoiseStream(9000 + s) for s in seeds]
+    t.sampler.noise = ns
+    seg, y, op, _ = t.prepare_batch([(synth_clean(s, L), synth_rir(s, taps), f"u{s}.wav") for s in seeds], blind=True, noise=ns)
+    smp = t.sampler
+    smp.bind(y, op, True)
+    sched = smp.create_schedule()
+    tl, gl = sched.tolist(), smp.get_gamma(sched).tolist()
+    x = smp.initialize_x(tuple(y.shape), "cuda", sched)
+    tr = []
+    for i in range(T):
+        x, xd = smp.step(x, tl[i], tl[i + 1], gl[i], blind=True)
+        tr.append(xd.cpu())
+    assert torch.isfinite(x).all()
+    for b, seed in enumerate(seeds):
+        x64, clean, k = run_blind(seed, L, T, nf, up, taps, fp64=True, device="cuda")
+        assert k == ns[b].k, "noise streams out of step"
+        x32, _, k32 = run_blind(seed, L, T, nf, up, taps, device="cuda")
+        assert k32 == k
+        bd = [_sd(tr[i][b], x64[i]) for i in range(T)]
+        od = [_sd(x32[i], x64[i]) for i in range(T)]
+        show = [0, 1, 2, 3, 5, 9, 19, 29, 49]
+        print(f"full size T50 seed {seed}: build      vs float64 per step {[round(bd[i], 1) for i in show]}")
+        print(f"full size T50 seed {seed}: fp32 torch vs float64 per step {[round(od[i], 1) for i in show]}")
+        dc_b, dc_o = _sd(tr[-1][b], clean) - _sd(x64[-1], clean), _sd(x32[-1], clean) - _sd(x64[-1], clean)
+        print(f"full size T50 seed {seed}: delta SI-SDR to clean vs float64: build {dc_b:+.2f} dB, fp32 torch oracle {dc_o:+.2f} dB")
+        assert bd[0] > 105.0
+        for i in range(T):
+            assert bd[i] > min(100.0, od[i]) - 10.0, (seed, i, bd[i], od[i])
+        assert abs(dc_b) < 3.0, dc_b
+
+
 def test_precision_budget_one_denoiser_evaluation_vs_fp64(net):
     """Gate on the round-off the kernels may spend: ONE denoiser evaluation D(x; sigma) and its input-VJP at full
     width / full length against the algorithm in float64.  Today: build 114 dB (F(6x6,3x3) + F(4x4,3x3) Winograd convolutions with fused

@@ -134,7 +134,10 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
   __syncthreads();
   for (int s = 0; s < S; ++s) {
     const float4 ca[4] = {ra[0], ra[1], ra[2], ra[3]};
-    if (s + 1 < S) { if (!(PROBE & 1)) loadA(s + 1); if (!(PROBE & 2)) loadB(s + 1); }
+    if (s + 1 < S) {
+      if (PROBE & 512) { loadB(s + 1); loadA(s + 1); }      // B first: the wait before the LDS store of B then leaves the A loads in flight
+      else { if (!(PROBE & 1)) loadA(s + 1); if (!(PROBE & 2)) loadB(s + 1); }
+    }
     const unsigned char* Bcur = smem + (s & 1) * STAGE_BYTES + lane * 16;
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
@@ -158,7 +161,8 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
         }
     }
     if (s + 1 < S && !(PROBE & 2)) storeB((s + 1) & 1);
-    if (!(PROBE & 4)) __syncthreads();
+    if (PROBE & 512) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    else if (!(PROBE & 4)) __syncthreads();
   }
 
   if (PROBE & 32) { if (acc[0][0] == 123.456f && acc[1][3] == 1.f && acc[2][5] == 2.f && acc[3][7] == 3.f) a.M[0] = 1.f; return; }
@@ -283,8 +287,8 @@ __global__ __launch_bounds__(64 * WAVES, MINB) void wgemm_p_kernel(const WgemmAr
 #pragma unroll
       for (int j = 0; j < 4; ++j) ra[d][j] = ra[d + 1][j];
     const int sn = (s + 1 == S) ? 0 : s + 1;
-    if (gs + AD < total) loadA(ra[AD - 1]);
-    if (gs + 1 < total) loadB(sn, (gs + 1) & 1);
+    if (BMODE == 2) { if (gs + 1 < total) loadB(sn, (gs + 1) & 1); if (gs + AD < total) loadA(ra[AD - 1]); }
+    else { if (gs + AD < total) loadA(ra[AD - 1]); if (gs + 1 < total) loadB(sn, (gs + 1) & 1); }
     const unsigned char* Bcur = smem + (gs & 1) * STAGE_BYTES + lane * 16;
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(64 * WAVES, MINB) void wgemm_p_kernel(const WgemmAr
         for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][PB[t]], av.p[PA[t]], acc[cb], 0, 0, 0);
     }
     if (gs + 1 < total) storeB((gs + 1) & 1);
-    __syncthreads();
+    if (BMODE == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    else __syncthreads();
     if (s + 1 == S) {           // tile finished: its accumulators leave while the next tile's first stage is already in flight
       const int row = tile * BM + wid * 32 + (lane & 31);
       if (row < a.Mt) {
@@ -480,7 +485,7 @@ int main() {
     const double fl = 2.0 * P * Mt * (double)N * K;
     const int R = 10;
     struct { const char* name; float ms; } r[] = {
-      {"full", run<0>(a, grid, R)}, {"nt stores of M", run<128>(a, grid, R)}, {"nt loads of V", run<256>(a, grid, R)}, {"nt both", run<384>(a, grid, R)}, {"full again", run<0>(a, grid, R)}, {"coalesced A pattern", run<64>(a, grid, R)}, {"coalesced A, no B copy", run<66>(a, grid, R)}, {"coalesced A, no epilogue", run<96>(a, grid, R)}, {"no A loads", run<1>(a, grid, R)}, {"no B copy", run<2>(a, grid, R)}, {"no B copy, no barrier", run<6>(a, grid, R)},
+      {"full", run<0>(a, grid, R)}, {"B loads first + raw barrier (no vmcnt drain)", run<512>(a, grid, R)}, {"full again", run<0>(a, grid, R)}, {"B first + raw barrier again", run<512>(a, grid, R)}, {"coalesced A pattern", run<64>(a, grid, R)}, {"coalesced A, no B copy", run<66>(a, grid, R)}, {"coalesced A, no epilogue", run<96>(a, grid, R)}, {"no A loads", run<1>(a, grid, R)}, {"no B copy", run<2>(a, grid, R)}, {"no B copy, no barrier", run<6>(a, grid, R)},
       {"no A, no B, no barrier", run<7>(a, grid, R)}, {"no split", run<8>(a, grid, R)}, {"no A/B/barrier/split", run<15>(a, grid, R)},
       {"no MFMA", run<16>(a, grid, R)}, {"no epilogue", run<32>(a, grid, R)}, {"no A/B/bar/split/epi (MFMA+LDS reads)", run<47>(a, grid, R)},
       {"no MFMA no epi", run<48>(a, grid, R)} };
@@ -489,20 +494,19 @@ int main() {
       run<0>(a, grid, 1);
       std::vector<float> ref((size_t)P * Mt * N);
       CK(hipMemcpy(ref.data(), M, ref.size() * 4, hipMemcpyDeviceToHost));
+      { CK(hipMemset(M, 0xff, ref.size() * 4)); hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true, 512>), grid, dim3(WNT), 0, 0, a); hipDeviceSynchronize();
+        printf("  B-first + raw barrier variant: %s\n", same(M, ref) ? "bit-exact" : "MISMATCH"); }
       int G = 0;
       struct { const char* name; float ms; bool ok; int G; } pr[12]; int np = 0;
 #define PV(W, AD, MB, BM_, TGT, NAME) { CK(hipMemset(M, 0xff, ref.size() * 4)); float t_ = run_p<W, AD, MB, BM_>(a, P, TGT, R, &G); pr[np++] = {NAME, t_, same(M, ref), G}; }
-      PV(4, 1, 3, 0, 1 << 30, "4 waves/tile 128 rows, reg-staged B")
-      if (N % 256 == 0) {
-        CK(hipMemset(M, 0xff, ref.size() * 4));
-        const dim3 g2((unsigned)(((Mt + WBM - 1) / WBM) * (a.NB / 2)), 1, (unsigned)P);
-        float t_ = gapped([&] { hipLaunchKernelGGL(wgemm_n256_kernel, g2, dim3(256), 0, 0, a); }, R);
-        pr[np++] = {"N=256 per workgroup (A split shared), 16-k sub-stages", t_, same(M, ref), 0};
-        float t2_ = gapped([&] { hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true, 0>), grid, dim3(WNT), 0, 0, a); }, R);
-        pr[np++] = {"production kernel (same moment)", t2_, true, 0};
-        float t3_ = gapped([&] { hipLaunchKernelGGL(wgemm_n256_kernel, g2, dim3(256), 0, 0, a); }, R);
-        pr[np++] = {"N=256 per workgroup again", t3_, true, 0};
-      }
+      PV(4, 1, 3, 0, 1 << 30, "4 waves, A depth 1, syncthreads")
+      PV(4, 1, 3, 2, 1 << 30, "4 waves, A depth 1, B first + raw barrier")
+      PV(4, 2, 2, 2, 1 << 30, "4 waves, A depth 2, B first + raw barrier (2 wg/CU)")
+      PV(4, 3, 2, 2, 1 << 30, "4 waves, A depth 3, B first + raw barrier (2 wg/CU)")
+      PV(4, 1, 3, 2, 768, "4 waves, A depth 1, raw barrier, persistent")
+      PV(4, 2, 2, 2, 512, "4 waves, A depth 2, raw barrier, persistent")
+      PV(8, 2, 1, 2, 1 << 30, "8 waves, A depth 2, raw barrier")
+      PV(8, 3, 1, 2, 256, "8 waves, A depth 3, raw barrier, persistent")
       for (int i = 0; i < np; ++i) printf("  %-44s %8.1f us  %7.1f TF-eq  %7.0f bf16-TF  G=%d %s\n", pr[i].name, pr[i].ms * 1e3, fl / (pr[i].ms * 1e-3) / 1e12, 6 * fl / (pr[i].ms * 1e-3) / 1e12, pr[i].G, pr[i].ok ? "bit-exact" : "MISMATCH");
     }
     for (auto& x : r) printf("  %-44s %8.1f us  %7.1f TF-eq  %7.0f bf16-TF\n", x.name, x.ms * 1e3, fl / (x.ms * 1e-3) / 1e12, 6 * fl / (x.ms * 1e-3) / 1e12);
