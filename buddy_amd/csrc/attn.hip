@@ -12,6 +12,7 @@
 //   flash_bwd_dkv_kernel per 64 key rows:    the same tiles transposed (S^T = K q^T, dP^T = V dO^T), dv += P^T dO, dk += dS^T q
 // Everything is fp32 (exact-fp32 MFMA, expf/logf); only the summation order differs from the materialised form.
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace buddy {
@@ -28,6 +29,15 @@ __device__ __forceinline__ float4 ld4_row(const float* base, int row, int T, lon
 }
 __device__ __forceinline__ float ld1_row(const float* base, int row, int T) { const float v = base[row < T ? row : T - 1]; return row < T ? v : 0.f; }
 __device__ __forceinline__ f32x4 zero_acc() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+// Split z of gridDim.z walks the 32-row blocks [lo, hi) of the loop dimension (keys in the forward / dq kernels, queries in the dkv kernel).  A 4 s
+// utterance has 2048 tokens: 32 workgroups of 64 rows per utterance, each walking 64 blocks one after the other on ONE wave per SIMD -- at B = 1 the
+// three kernels took as long as at B = 8 (0.47 / 0.60 / 0.74 ms) on an eighth of the chip.  The launchers split the loop when the grid is small; the
+// partial results are combined in fixed order (no atomics: results do not depend on the schedule).
+__device__ __forceinline__ void split_range(int T, int& lo, int& hi) {
+  const int nb = (T + BC - 1) / BC, per = (nb + (int)gridDim.z - 1) / (int)gridDim.z;
+  lo = (int)blockIdx.z * per * BC;
+  hi = min(T, lo + per * BC);
+}
 // reduce over the 16 lanes that hold one accumulator row (lanes with equal lane >> 4)
 __device__ __forceinline__ float row_max16(float v) {
 #pragma unroll
@@ -108,10 +118,13 @@ __device__ __forceinline__ void tile_pb(const float* Ps, const float* Bs, int i,
 template <int C, int NW>
 __global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                             float* __restrict__ O, float* __restrict__ Lse, int T, float scale) {
+  // gridDim.z > 1: O / Lse are the partial buffers [split][B][T][C] / [split][B][T] (each split normalised by its own row sum; flash_combine_kernel)
   constexpr int LD = C + 4;
   __shared__ __attribute__((aligned(16))) float Ks[32 * LD];
   __shared__ __attribute__((aligned(16))) float Vs[32 * LD];
   __shared__ __attribute__((aligned(16))) float Ps[NW][16 * PLD];
+  int jlo, jhi; split_range(T, jlo, jhi);
+  O += (long long)blockIdx.z * gridDim.y * T * C; Lse += (long long)blockIdx.z * gridDim.y * T;
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const long long base = (long long)b * T * C;
   const int row_a = blockIdx.x * 16 * NW + 16 * w + i;       // this lane's A-operand row
@@ -128,14 +141,14 @@ __global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(const float* __restr
   constexpr int NT = 64 * NW;
   static_assert(32 * (C / 4) % NT == 0, "staging assumes whole float4 rounds per thread");
   float4 pk[32 * (C / 4) / NT], pv[32 * (C / 4) / NT];
-  fetch32<C, NT>(k + base, 0, T, pk);
-  fetch32<C, NT>(v + base, 0, T, pv);
-  for (int j0 = 0; j0 < T; j0 += BC) {
+  fetch32<C, NT>(k + base, jlo, T, pk);
+  fetch32<C, NT>(v + base, jlo, T, pv);
+  for (int j0 = jlo; j0 < jhi; j0 += BC) {
     __syncthreads();
     put32<C, NT>(pk, Ks);
     put32<C, NT>(pv, Vs);
     __syncthreads();
-    if (j0 + BC < T) { fetch32<C, NT>(k + base, j0 + BC, T, pk); fetch32<C, NT>(v + base, j0 + BC, T, pv); }
+    if (j0 + BC < jhi) { fetch32<C, NT>(k + base, j0 + BC, T, pk); fetch32<C, NT>(v + base, j0 + BC, T, pv); }
     f32x4 s[2] = {zero_acc(), zero_acc()};
     tile_abt<C>(qa, Ks, i, g, s);
     float alpha[4];
@@ -170,6 +183,38 @@ __global__ __launch_bounds__(64 * NW) void flash_fwd_kernel(const float* __restr
   }
 }
 
+// forward partials -> O, Lse: one wave per (utterance, row); Lse = log sum_z exp(Lse_z), O = sum_z exp(Lse_z - Lse) O_z, splits in fixed order
+template <int C>
+__global__ __launch_bounds__(256) void flash_combine_kernel(const float* __restrict__ Op, const float* __restrict__ Lp, float* __restrict__ O,
+                                                            float* __restrict__ Lse, long long rows, int ns) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float mx = -INFINITY;
+  for (int z = 0; z < ns; ++z) mx = fmaxf(mx, Lp[z * rows + row]);
+  float sum = 0.f;
+  for (int z = 0; z < ns; ++z) sum += expf(Lp[z * rows + row] - mx);
+  const float inv = 1.f / sum;
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < ns; ++z) {
+      const float w = expf(Lp[z * rows + row] - mx) * inv;
+      const float4 o = ld4(Op + (z * rows + row) * C + c);
+      acc.x += w * o.x; acc.y += w * o.y; acc.z += w * o.z; acc.w += w * o.w;
+    }
+    *reinterpret_cast<float4*>(O + row * C + c) = acc;
+  }
+  if (lane == 0) Lse[row] = mx + logf(sum);
+}
+// out = sum_z part[z] (n4 float4 per part), z ascending
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, long long n4, int ns) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 a = ld4(part + i * 4);
+    for (int z = 1; z < ns; ++z) { const float4 b = ld4(part + (z * n4 + i) * 4); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    *reinterpret_cast<float4*>(out + i * 4) = a;
+  }
+}
+
 // D[b][t] = sum_c dO * O
 template <int C>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ D, long long rows) {
@@ -190,10 +235,13 @@ template <int C>
 __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                            const float* __restrict__ dO, const float* __restrict__ Lse, const float* __restrict__ D,
                                                            float* __restrict__ dq, int T, float scale) {
+  // gridDim.z > 1: dq is the partial buffer [split][B][T][C] (summed by sum_parts_kernel)
   constexpr int LD = C + 4;
   __shared__ __attribute__((aligned(16))) float Ks[32 * LD];
   __shared__ __attribute__((aligned(16))) float Vs[32 * LD];
   __shared__ __attribute__((aligned(16))) float Ps[4][16 * PLD];
+  int jlo, jhi; split_range(T, jlo, jhi);
+  dq += (long long)blockIdx.z * gridDim.y * T * C;
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const long long base = (long long)b * T * C;
   const int row_a = blockIdx.x * BR + 16 * w + i, row0 = blockIdx.x * BR + 16 * w + 4 * g;
@@ -213,14 +261,14 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const float* __restri
 #pragma unroll
   for (int c = 0; c < C / 16; ++c) acc[c] = zero_acc();
   float4 pk[32 * (C / 4) / 256], pv[32 * (C / 4) / 256];
-  fetch32<C>(k + base, 0, T, pk);
-  fetch32<C>(v + base, 0, T, pv);
-  for (int j0 = 0; j0 < T; j0 += BC) {
+  fetch32<C>(k + base, jlo, T, pk);
+  fetch32<C>(v + base, jlo, T, pv);
+  for (int j0 = jlo; j0 < jhi; j0 += BC) {
     __syncthreads();
     put32<C>(pk, Ks);
     put32<C>(pv, Vs);
     __syncthreads();
-    if (j0 + BC < T) { fetch32<C>(k + base, j0 + BC, T, pk); fetch32<C>(v + base, j0 + BC, T, pv); }
+    if (j0 + BC < jhi) { fetch32<C>(k + base, j0 + BC, T, pk); fetch32<C>(v + base, j0 + BC, T, pv); }
     f32x4 s[2] = {zero_acc(), zero_acc()}, dp[2] = {zero_acc(), zero_acc()};
     tile_abt<C>(qa, Ks, i, g, s);
     tile_abt<C>(da, Vs, i, g, dp);
@@ -256,6 +304,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const float* __restr
   __shared__ __attribute__((aligned(16))) float Ss[4][16 * PLD];      // dS^T tile
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const long long base = (long long)b * T * C;
+  int ilo, ihi; split_range(T, ilo, ihi);          // gridDim.z > 1: dk / dv are partial buffers [split][B][T][C]
+  dk += (long long)blockIdx.z * gridDim.y * T * C; dv += (long long)blockIdx.z * gridDim.y * T * C;
   const int row_a = blockIdx.x * BR + 16 * w + i, row0 = blockIdx.x * BR + 16 * w + 4 * g;     // key / value rows
   float4 ka[C / 16], va[C / 16];
 #pragma unroll
@@ -267,14 +317,14 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const float* __restr
 #pragma unroll
   for (int c = 0; c < C / 16; ++c) { gk[c] = zero_acc(); gv[c] = zero_acc(); }
   float4 pq[32 * (C / 4) / 256], po[32 * (C / 4) / 256];
-  fetch32<C>(q + base, 0, T, pq);
-  fetch32<C>(dO + base, 0, T, po);
-  for (int i0 = 0; i0 < T; i0 += BC) {
+  fetch32<C>(q + base, ilo, T, pq);
+  fetch32<C>(dO + base, ilo, T, po);
+  for (int i0 = ilo; i0 < ihi; i0 += BC) {
     __syncthreads();
     put32<C>(pq, Qs);
     put32<C>(po, Os);
     __syncthreads();
-    if (i0 + BC < T) { fetch32<C>(q + base, i0 + BC, T, pq); fetch32<C>(dO + base, i0 + BC, T, po); }
+    if (i0 + BC < ihi) { fetch32<C>(q + base, i0 + BC, T, pq); fetch32<C>(dO + base, i0 + BC, T, po); }
     f32x4 s[2] = {zero_acc(), zero_acc()}, dp[2] = {zero_acc(), zero_acc()};
     tile_abt<C>(ka, Qs, i, g, s);              // S^T[key row][query col]
     tile_abt<C>(va, Os, i, g, dp);             // dP^T
@@ -537,9 +587,40 @@ __global__ __launch_bounds__(256) void flash16_bwd_dkv_kernel(const float* __res
 
 bool flash_attn_supported(int C) { return C == 64 || C == 128 || C == 256; }
 
-// O [B][T][C], Lse [B][T]; prec: 0 = fp32 operands (exact-fp32 MFMA), 1 = bf16 operands, 2 = f16 operands (fp32 accumulate)
-void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, int prec, hipStream_t st) {
+// Loop splits for a grid of cdiv(T, 64) * B workgroups (fp32 kernels only): as many as keep the grid within ONE workgroup per CU (measured at T = 2048,
+// tools/attn_split_bench.py: B = 1: 8 splits 0.47 / 1.31 -> 0.08 / 0.20 ms forward / backward, 16 splits 0.085 / 0.22; B = 2: 4 splits 0.13 / 0.36,
+// 8 splits 0.14 / 0.38; B = 4: 2 splits 0.26 / 0.69; B = 8: none 0.48 / 1.32, 2 splits 0.49 / 1.36 -- a second workgroup per CU buys nothing), at
+// least four 32-row blocks each, every split non-empty.  BUDDY_ATTN_SPLIT=n forces n (1 = never split).
+int flash_attn_splits(int B, int T, int prec) {
+  if (prec != 0) return 1;
+  static const int force = getenv("BUDDY_ATTN_SPLIT") ? atoi(getenv("BUDDY_ATTN_SPLIT")) : 0;
+  const int nb = cdiv(T, BC);
+  const long long wgs = (long long)cdiv(T, BR) * B;
+  int ns = force > 0 ? force : (int)(256 / (wgs > 0 ? wgs : 1));
+  if (ns > nb / 4) ns = nb / 4;
+  if (ns < 1) ns = 1;
+  while (ns > 1 && (long long)cdiv(nb, ns) * (ns - 1) >= nb) --ns;
+  return ns;
+}
+// floats of workspace the split forms need (forward: ns x (B T C + B T); backward: 2 ns x B T C)
+long long flash_attn_ws_floats(int B, int T, int C, int splits) { return splits > 1 ? 2LL * splits * B * T * C : 0; }
+
+// O [B][T][C], Lse [B][T]; prec: 0 = fp32 operands (exact-fp32 MFMA), 1 = bf16 operands, 2 = f16 operands (fp32 accumulate).  splits > 1 (fp32 only, ws =
+// flash_attn_ws_floats floats): the key loop is split over blockIdx.z and the partial (O, Lse) pairs are combined by flash_combine_kernel
+void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, int prec, float* ws,
+                           int splits, hipStream_t st) {
   const dim3 grid(cdiv(T, BR), B), block(256);
+  if (prec == 0 && splits > 1 && ws != nullptr) {
+    const long long rows = (long long)B * T;
+    float* Op = ws; float* Lp = ws + (long long)splits * rows * C;
+    const dim3 gs(cdiv(T, BR), B, splits), gc((unsigned)((rows + 3) / 4));
+#define FA_FWDS(CC)                                                                                              \
+    hipLaunchKernelGGL((flash_fwd_kernel<CC, 4>), gs, block, 0, st, q, k, v, Op, Lp, T, scale);                    \
+    hipLaunchKernelGGL(flash_combine_kernel<CC>, gc, block, 0, st, Op, Lp, O, Lse, rows, splits);
+    if (C == 64) { FA_FWDS(64) } else if (C == 128) { FA_FWDS(128) } else { FA_FWDS(256) }
+#undef FA_FWDS
+    return;
+  }
   // fp32: 128-row workgroups (8 waves) once there are enough of them to fill the chip, 64-row ones otherwise (BUDDY_ATTN_NW=4|8 forces one)
   static const int force_nw = getenv("BUDDY_ATTN_NW") ? atoi(getenv("BUDDY_ATTN_NW")) : 0;
   const bool wide = force_nw ? force_nw == 8 : (long long)cdiv(T, 128) * B >= 256;
@@ -554,10 +635,26 @@ void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float
 }
 // dq, dk, dv [B][T][C]; D [B][T] scratch
 void launch_flash_attn_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* Lse, float* D, float* dq,
-                           float* dk, float* dv, int B, int T, int C, float scale, int prec, hipStream_t st) {
+                           float* dk, float* dv, int B, int T, int C, float scale, int prec, float* ws, int splits, hipStream_t st) {
   const long long rows = (long long)B * T;
   const dim3 grid(cdiv(T, BR), B), block(256), gd((unsigned)((rows + 3) / 4));
   const float* Dc = D;
+  if (prec == 0 && splits > 1 && ws != nullptr) {     // split loops (keys for dq, queries for dk / dv), partials summed in split order
+    const dim3 gs(cdiv(T, BR), B, splits);
+    const long long n4 = rows * C / 4;
+    const dim3 gr((unsigned)std::min<long long>((n4 + 255) / 256, 256 * 16));
+    float* P0 = ws; float* P1 = ws + (long long)splits * rows * C;
+#define FA_BWDS(CC)                                                                                              \
+    hipLaunchKernelGGL(attn_delta_kernel<CC>, gd, block, 0, st, dO, O, D, rows);                                   \
+    hipLaunchKernelGGL(flash_bwd_dq_kernel<CC>, gs, block, 0, st, q, k, v, dO, Lse, Dc, P0, T, scale);             \
+    hipLaunchKernelGGL(sum_parts_kernel, gr, block, 0, st, P0, dq, n4, splits);                                    \
+    hipLaunchKernelGGL(flash_bwd_dkv_kernel<CC>, gs, block, 0, st, q, k, v, dO, Lse, Dc, P0, P1, T, scale);        \
+    hipLaunchKernelGGL(sum_parts_kernel, gr, block, 0, st, P0, dk, n4, splits);                                    \
+    hipLaunchKernelGGL(sum_parts_kernel, gr, block, 0, st, P1, dv, n4, splits);
+    if (C == 64) { FA_BWDS(64) } else if (C == 128) { FA_BWDS(128) } else { FA_BWDS(256) }
+#undef FA_BWDS
+    return;
+  }
 #define FA_BWD(CC)                                                                                                           \
   hipLaunchKernelGGL(attn_delta_kernel<CC>, gd, block, 0, st, dO, O, D, rows);                                                 \
   if (prec == 1) {                                                                                                           \

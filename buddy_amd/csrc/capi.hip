@@ -352,7 +352,33 @@ int buddy_fir_resample2(const float* x, float* y, int B, int H, int W, int C, in
 int buddy_flash_attention_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, int prec,
                               void* stream) {
   if (!q || !k || !v || !O || !lse || B < 1 || T < 1 || !flash_attn_supported(C) || prec < 0 || prec > 2) { set_error("bad attention arguments (C in {64, 128, 256})"); return BUDDY_ERR_ARG; }
-  launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, prec, (hipStream_t)stream);
+  launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, prec, nullptr, 1, (hipStream_t)stream);
+  return finish();
+}
+long long buddy_flash_attention_workspace(int B, int T, int C, int splits) {
+  if (B < 1 || T < 1 || !flash_attn_supported(C)) return 0;
+  return flash_attn_ws_floats(B, T, C, splits > 0 ? splits : flash_attn_splits(B, T, 0));
+}
+int buddy_flash_attention_splits(int B, int T) { return (B < 1 || T < 1) ? 1 : flash_attn_splits(B, T, 0); }
+static bool split_args_ok(int T, int splits, const float* ws) {
+  const int nb = (T + 31) / 32;
+  if (splits < 1 || splits > nb || (splits > 1 && !ws)) return false;
+  return splits == 1 || (long long)((nb + splits - 1) / splits) * (splits - 1) < nb;     // every split non-empty
+}
+int buddy_flash_attention_fwd_split(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, int splits,
+                                    float* ws, void* stream) {
+  if (!q || !k || !v || !O || !lse || B < 1 || T < 1 || !flash_attn_supported(C) || !split_args_ok(T, splits, ws)) {
+    set_error("bad split-attention arguments (C in {64, 128, 256}; every split needs at least one 32-row block)"); return BUDDY_ERR_ARG;
+  }
+  launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, 0, ws, splits, (hipStream_t)stream);
+  return finish();
+}
+int buddy_flash_attention_bwd_split(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta,
+                                    float* dq, float* dk, float* dv, int B, int T, int C, float scale, int splits, float* ws, void* stream) {
+  if (!q || !k || !v || !O || !dO || !lse || !delta || !dq || !dk || !dv || B < 1 || T < 1 || !flash_attn_supported(C) || !split_args_ok(T, splits, ws)) {
+    set_error("bad split-attention arguments (C in {64, 128, 256}; every split needs at least one 32-row block)"); return BUDDY_ERR_ARG;
+  }
+  launch_flash_attn_bwd(q, k, v, O, dO, lse, delta, dq, dk, dv, B, T, C, scale, 0, ws, splits, (hipStream_t)stream);
   return finish();
 }
 int buddy_flash_attention_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta, float* dq,
@@ -360,7 +386,7 @@ int buddy_flash_attention_bwd(const float* q, const float* k, const float* v, co
   if (prec < 0 || prec > 2 || !q || !k || !v || !O || !dO || !lse || !delta || !dq || !dk || !dv || B < 1 || T < 1 || !flash_attn_supported(C)) {
     set_error("bad attention arguments (C in {64, 128, 256})"); return BUDDY_ERR_ARG;
   }
-  launch_flash_attn_bwd(q, k, v, O, dO, lse, delta, dq, dk, dv, B, T, C, scale, prec, (hipStream_t)stream);
+  launch_flash_attn_bwd(q, k, v, O, dO, lse, delta, dq, dk, dv, B, T, C, scale, prec, nullptr, 1, (hipStream_t)stream);
   return finish();
 }
 

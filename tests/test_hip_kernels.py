@@ -464,6 +464,45 @@ def test_flash_attention_fwd_bwd(lib, B, T, Cc, prec):
     assert errs["dq"] < tb and errs["dk"] < tb and errs["dv"] < tb
 
 
+@pytest.mark.parametrize("B,T,Cc,splits", [(1, 2048, 256, 8), (2, 2048, 256, 4), (1, 1000, 256, 5), (3, 144, 64, 2), (1, 320, 128, 10), (2, 2048, 256, 0)])
+def test_flash_attention_split_loops(lib, B, T, Cc, splits):
+    """the split form of the fp32 attention kernels (sequential key / query loop spread over `splits` workgroups per row block, partials combined in
+    fixed order) against the reference formulation in fp64 at the bounds of the unsplit kernels, and against the unsplit kernels themselves; ragged T,
+    uneven last split, the count the network picks (splits = 0); invalid counts are refused."""
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + T + Cc + 7)
+    q, k, v, dO = (torch.randn(B, T, Cc, generator=g).cuda() for _ in range(4))
+    q = q * 1.5
+    scale = Cc ** -0.5
+    if splits == 0:
+        splits = lib.buddy_flash_attention_splits(B, T)
+        assert splits == 4
+    assert lib.buddy_flash_attention_splits(1, 2048) == 8 and lib.buddy_flash_attention_splits(8, 2048) == 1 and lib.buddy_flash_attention_splits(4, 15040) == 1
+    ws = torch.empty(lib.buddy_flash_attention_workspace(B, T, Cc, splits), device="cuda")
+    out = {}
+    for name, ns in (("split", splits), ("one", 1)):
+        O = torch.empty_like(q); lse = torch.empty(B, T, device="cuda")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        delta = torch.empty(B, T, device="cuda")
+        _lib.check(lib.buddy_flash_attention_fwd_split(P(q), P(k), P(v), P(O), P(lse), B, T, Cc, scale, ns, P(ws), S()))
+        _lib.check(lib.buddy_flash_attention_bwd_split(P(q), P(k), P(v), P(O), P(dO), P(lse), P(delta), P(dq), P(dk), P(dv), B, T, Cc, scale, ns, P(ws), S()))
+        torch.cuda.synchronize()
+        out[name] = (O, lse, dq, dk, dv)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    sc = torch.einsum("bic,bjc->bij", qd, kd) * scale
+    ref = torch.einsum("bij,bjc->bic", torch.softmax(sc, dim=-1), vd)
+    gq, gk, gv = torch.autograd.grad(ref, (qd, kd, vd), dO.double())
+    O, lse, dq, dk, dv = out["split"]
+    errs = dict(O=rel(O, ref.detach()), lse=float((lse.double() - torch.logsumexp(sc, dim=-1).detach()).abs().max()), dq=rel(dq, gq), dk=rel(dk, gk), dv=rel(dv, gv))
+    print((B, T, Cc, splits), {k_: f"{v_:.1e}" for k_, v_ in errs.items()})
+    assert errs["O"] < 1e-5 and errs["lse"] < 1e-4 and errs["dq"] < 2e-5 and errs["dk"] < 2e-5 and errs["dv"] < 2e-5
+    for a, b in zip(out["split"], out["one"]):
+        assert rel(a, b.double()) < 2e-5
+    # a split that would own no block, or a missing workspace, is an argument error
+    assert lib.buddy_flash_attention_fwd_split(P(q), P(k), P(v), P(O), P(lse), B, T, Cc, scale, (T + 31) // 32 + 1, P(ws), S()) != 0
+    assert lib.buddy_flash_attention_fwd_split(P(q), P(k), P(v), P(O), P(lse), B, T, Cc, scale, 2, None, S()) != 0
+
+
 def test_fir_resample2_vs_reference(lib, golden):
     """upsample_2d / downsample_2d with the (1,3,3,1) kernel (reference up_or_down_sampling.py:195-257 -> upfirdn2d) and their transposes
     against vectors recorded from the reference's pure-PyTorch upfirdn2d; NHWC, C = 6 (scalar path) and via the adjoint identities."""
