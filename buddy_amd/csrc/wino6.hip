@@ -100,34 +100,41 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
     }
     const int gx = 6 * tx - 1 + col, gy0 = 6 * ty - 1;
     float4 d[8], t[8];
+    // All loads of the column first, UNCONDITIONAL, from coordinates clamped into the image; the zero padding is applied to the value afterwards.
+    // With the load inside `if (inside)` next to the GroupNorm arithmetic the compiler kept every row's load -> wait -> SiLU chain to itself (10
+    // loads, 18 vmcnt waits in the GN 1 instantiation against 8 / 1 in the plain one): eight load latencies one after the other per thread.
+    const bool okx = (unsigned)gx < (unsigned)W;
+    const int cx = min(max(gx, 0), W - 1);
+    float4 g4[GN == 2 ? 8 : 1];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int gy = gy0 + r;
-      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-        const long long pix = ((long long)b * H + gy) * W + gx;
-        float4 v = ld4(x + pix * ldX);
-        if (GN == 1) {
-          v = make_float4((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y, (v.z - mean) * rstd * gm.z + bt.z,
-                          (v.w - mean) * rstd * gm.w + bt.w);
-          if (gn.silu) v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
-        }
-        if (GN == 2) {
-          const float4 g4 = ld4(da + pix * gn.ldda);
-          const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {g4.x, g4.y, g4.z, g4.w};
-          const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
-          float o[4];
+      const int cy = min(max(gy0 + r, 0), H - 1);
+      const long long pix = ((long long)b * H + cy) * W + cx;
+      d[r] = ld4(x + pix * ldX);
+      if (GN == 2) g4[r] = ld4(da + pix * gn.ldda);
+    }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float xh = (xv[j] - mean) * rstd;
-            const float dxh = dv[j] * (gn.silu ? dsilu_f(xh * gv[j] + bv[j]) : 1.f) * gv[j];
-            o[j] = rstd * (dxh - m1 - xh * m2);
-          }
-          v = make_float4(o[0], o[1], o[2], o[3]);
-        }
-        d[r] = v;
-      } else {
-        d[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < 8; ++r) {
+      const bool ok = okx && (unsigned)(gy0 + r) < (unsigned)H;
+      float4 v = d[r];
+      if (GN == 1) {
+        v = make_float4((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y, (v.z - mean) * rstd * gm.z + bt.z,
+                        (v.w - mean) * rstd * gm.w + bt.w);
+        if (gn.silu) v = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
       }
+      if (GN == 2) {
+        const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {g4[r].x, g4[r].y, g4[r].z, g4[r].w};
+        const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[j] - mean) * rstd;
+          const float dxh = dv[j] * (gn.silu ? dsilu_f(xh * gv[j] + bv[j]) : 1.f) * gv[j];
+          o[j] = rstd * (dxh - m1 - xh * m2);
+        }
+        v = make_float4(o[0], o[1], o[2], o[3]);
+      }
+      d[r] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     bt8(d, t);                                               // column: t[:, col] = B^T d[:, col]
 #pragma unroll
@@ -191,11 +198,11 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
     // STAT 2: this thread's row of x is requested now, together with the M loads of phase 1, not after the LDS exchange
     float4 xpre[6];
     if (STAT == 2 && live && col < 6) {
-      const int ty = lt / geo.TW, tx = lt - ty * geo.TW, hh = 6 * ty + col;
+      const int ty = lt / geo.TW, tx = lt - ty * geo.TW, hh = min(6 * ty + col, H - 1);
 #pragma unroll
-      for (int cc = 0; cc < 6; ++cc) {
-        const int ww = 6 * tx + cc;
-        xpre[cc] = (hh < H && ww < W) ? ld4(xsrc + (((long long)b * H + hh) * W + ww) * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int cc = 0; cc < 6; ++cc) {                        // unconditional (clamped pixel): only read where the output pixel exists
+        const int ww = min(6 * tx + cc, W - 1);
+        xpre[cc] = ld4(xsrc + (((long long)b * H + hh) * W + ww) * ldx);
       }
     }
     if (live) {
