@@ -191,6 +191,9 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
       ldx = second ? bg.x.ld1 : bg.x.ld0;
     }
   }
+  // Every load above (bias, statistics, gamma / beta) is complete before the loop: otherwise the first use of `add` inside the loop carries a
+  // vmcnt(0) on every pixel (the compiler cannot count memory operations across the back edge), which also waits for the previous pixel's store.
+  __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0), expcnt / lgkmcnt untouched
   for (int it = 0; it < TL; ++it) {
     const int lt = (chunk * TL + it) * geo.TPB + tl;          // tile within the utterance
     const bool live = chan && lt < tpb;
