@@ -310,7 +310,11 @@ __global__ __launch_bounds__(256) void gn_apply_m0_kernel(Src2 x, const float* s
   for (; p < p1; p += a.pl) st4(dst + (long long)p * a.C, act(ld4(src + (long long)p * ld)));
 }
 
-// extra_mode 0 / 1 (same-resolution extra gradient), da at the same resolution
+// extra_mode 0 / 1 (same-resolution extra gradient), da at the same resolution.  EX: an extra gradient exists; ACC: some destination accumulates.
+// Both are template parameters so that every load of a pixel pair is unconditional and in flight together: as runtime `ptr ? ld4(..) : 0` they
+// were branches with a vmcnt(0) between the streams (x, da, extra -> wait -> previous value).  A destination that does not accumulate still reads
+// its (arena) memory under ACC and discards the value by a select.
+template <bool EX, bool ACC>
 __global__ __launch_bounds__(256) void gn_bwd_apply_m0_kernel(Src2 x, const float* stats, const float* gamma, const float* beta, const float* da,
                                                               GnFast a, int silu, const float* extra, float extra_scale, const float* red, Dst2 dx) {
   const int tid = threadIdx.x, quad = tid % a.q, lp = tid / a.q, b = blockIdx.y;
@@ -324,15 +328,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_m0_kernel(Src2 x, const floa
   const long long ld = second ? x.ld1 : x.ld0;
   src += (long long)b * a.HW * ld;
   const float* dap = da + (long long)b * a.HW * a.C + c;
-  const float* ex = extra ? extra + (long long)b * a.HW * a.C + c : nullptr;
+  const float* ex = EX ? extra + (long long)b * a.HW * a.C + c : nullptr;
   const bool dsecond = dx.p1 != nullptr && c >= dx.C0;
   float* o = dsecond ? dx.p1 + (c - dx.C0) : dx.p0 + c;
   const long long ldo = dsecond ? dx.ld1 : dx.ld0;
-  const int acc = dsecond ? dx.acc1 : dx.acc0;
+  const bool acc = ACC && (dsecond ? dx.acc1 : dx.acc0) != 0;
   o += (long long)b * a.HW * ldo;
   const int p0 = blockIdx.x * a.ppc, p1 = min(a.HW, p0 + a.ppc);
   auto one = [&](float4 v, float4 d, float4 e, float4 prev) {
-    const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w}, ev[4] = {e.x, e.y, e.z, e.w};
+    const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w}, ev[4] = {e.x, e.y, e.z, e.w}, pv[4] = {prev.x, prev.y, prev.z, prev.w};
     float r[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -340,26 +344,26 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_m0_kernel(Src2 x, const floa
       const float z = xh * gv[j] + bv[j];
       const float dxh = dv[j] * (silu ? dsilu_f(z) : 1.f) * gv[j];
       r[j] = rstd * (dxh - m1 - xh * m2);
-      if (ex) r[j] += extra_scale * ev[j];
+      if (EX) r[j] += extra_scale * ev[j];
+      if (ACC) r[j] = acc ? r[j] + pv[j] : r[j];
     }
-    float4 res = make_float4(r[0], r[1], r[2], r[3]);
-    if (acc) res = add4(res, prev);
-    return res;
+    return make_float4(r[0], r[1], r[2], r[3]);
   };
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int p = p0 + lp;
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the parameter loads are complete, no wait inside the loop refers back to them (and to the stores)
   for (; p + a.pl < p1; p += 2 * a.pl) {
     float4 v[2], d[2], e[2], pr[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const long long pp = p + j * a.pl;
-      v[j] = ld4(src + pp * ld); d[j] = ld4(dap + pp * a.C); e[j] = ex ? ld4(ex + pp * a.C) : z4; pr[j] = acc ? ld4(o + pp * ldo) : z4;
+      v[j] = ld4(src + pp * ld); d[j] = ld4(dap + pp * a.C); e[j] = EX ? ld4(ex + pp * a.C) : z4; pr[j] = ACC ? ld4(o + pp * ldo) : z4;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) st4(o + (long long)(p + j * a.pl) * ldo, one(v[j], d[j], e[j], pr[j]));
   }
   for (; p < p1; p += a.pl)
-    st4(o + (long long)p * ldo, one(ld4(src + (long long)p * ld), ld4(dap + (long long)p * a.C), ex ? ld4(ex + (long long)p * a.C) : z4, acc ? ld4(o + (long long)p * ldo) : z4));
+    st4(o + (long long)p * ldo, one(ld4(src + (long long)p * ld), ld4(dap + (long long)p * a.C), EX ? ld4(ex + (long long)p * a.C) : z4, ACC ? ld4(o + (long long)p * ldo) : z4));
 }
 
 // ------------------------------------------------------------------ elementwise helpers
@@ -956,8 +960,11 @@ void launch_gn_bwd_apply(Src2 x, const float* stats, const float* gamma, const f
   static const bool fast = !(getenv("BUDDY_GN_FAST") && atoi(getenv("BUDDY_GN_FAST")) == 0);
   if (fast && mode == 0 && extra_mode != 2 && C % 4 == 0 && C / 4 <= 256) {
     GnFast g = gn_fast(H * W, C, G);
-    hipLaunchKernelGGL(gn_bwd_apply_m0_kernel, dim3((H * W + g.ppc - 1) / g.ppc, B), dim3(g.q * g.pl), 0, st, x, stats, gamma, beta, da, g, silu,
-                       extra_mode == 1 ? extra : nullptr, extra_scale, red, dx);
+    const bool ex = extra_mode == 1 && extra != nullptr, acc = dx.acc0 != 0 || (dx.p1 != nullptr && dx.acc1 != 0);
+    const dim3 grid((H * W + g.ppc - 1) / g.ppc, B), block(g.q * g.pl);
+#define GN_M0(E, A) hipLaunchKernelGGL((gn_bwd_apply_m0_kernel<E, A>), grid, block, 0, st, x, stats, gamma, beta, da, g, silu, ex ? extra : nullptr, extra_scale, red, dx)
+    if (ex && acc) GN_M0(true, true); else if (ex) GN_M0(true, false); else if (acc) GN_M0(false, true); else GN_M0(false, false);
+#undef GN_M0
   } else
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, stats, gamma, beta, da, B, H, W, C, G, mode, silu, extra,
                      extra_mode, extra_scale, red, dx);

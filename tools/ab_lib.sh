@@ -8,7 +8,7 @@ for v in A B A B; do
 import json,sys
 j=json.loads(sys.stdin.readline())
 tp=j['conv3x3']['transform_passes']
-print('$v', 'ms/step %.2f' % j['ms_per_step'], 'gemm us %.1f' % (j['roofline']['avg_launch_ms']*1e3), 'in GB/s %.0f out GB/s %.0f' % (tp['input_GBps'], tp['output_GBps']), 'mfma box %.0f' % j['peaks']['measured_on_this_box']['bf16_mfma_tflops'])
+print('$v', 'ms/step %.2f' % j['ms_per_step'], 'gemm us %.1f' % (j['roofline']['avg_launch_ms']*1e3), 'in GB/s %.0f out GB/s %.0f' % (tp['input_GBps'], tp['output_GBps']), 'gn GB/s %.0f share %.3f' % (j['roofline_hbm']['achieved'], j['roofline_hbm']['kernel_time_share_of_step']), 'op ms %.2f' % j['operator_update']['ms_per_step'], 'mfma box %.0f' % j['peaks']['measured_on_this_box']['bf16_mfma_tflops'])
 "
 done
 cp buddy_amd/libbuddy_hip_B.so buddy_amd/libbuddy_hip.so
