@@ -69,7 +69,7 @@ int buddy_ncsnpp_weight_bytes(void* handle, long long* params, long long* packed
 }
 
 int buddy_conv3_weight_prep(const float* w_oihw, int O, int I, int dgrad, int kind, float* out, void* stream) {
-  if (!w_oihw || !out || O < 1 || I < 1 || conv3_weight_floats(O, I, kind) == 0) { set_error("bad arguments (kind must be 0, 2, 4 or 6)"); return BUDDY_ERR_ARG; }
+  if (!w_oihw || !out || O < 1 || I < 1 || conv3_weight_floats(O, I, kind) == 0) { set_error("bad arguments (kind must be 0, 2, 4, 6 or 61)"); return BUDDY_ERR_ARG; }
   if (launch_conv3_weight_prep(w_oihw, O, I, dgrad != 0, kind, out, (hipStream_t)stream)) { set_error("F(2x2,3x3) form needs an input-channel count that is a multiple of 8"); return BUDDY_ERR_ARG; }
   return finish();
 }
@@ -318,6 +318,47 @@ int buddy_gnbwd_conv3x3_winograd6(const float* x, const float* gamma, const floa
   launch_gn_bwd_sums(gn.x, stats, gamma, beta, da, B, H, W, C, G, 0, silu, stat_scratch, red, st);
   long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf);
   launch_wino6(p, U6, scratch, scratch + vf, st, &gn);
+  return finish();
+}
+
+int buddy_gn_upconv3x3_winograd6(const float* x, const float* gamma, const float* beta, int G, int silu, const float* U6up, const float* bias, float* y,
+                                 float* scratch, float* stats, double* stat_scratch, double* csum, int B, int H, int W, int Cin, int Cout, void* stream) {
+  if (!x || !gamma || !beta || !U6up || !y || !scratch || !stats || !stat_scratch || G < 1 || Cin % 4 || (Cin / G) % 4 || Cin > 1024 || Cout % 4) {
+    set_error("bad arguments"); return BUDDY_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = y; p.ldC = Cout;
+  p.bias_n = bias; p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
+  if (!wino6_supported(p)) { set_error("shape not supported by the F(6x6,3x3) path (H, W >= 6; Cin, Cout multiples of 4)"); return BUDDY_ERR_ARG; }
+  const int sc = csum ? wino6_stat_chunks(p, 1) : 0;
+  if (csum && (sc == 0 || (long long)sc * Cout > 256LL * 1024)) { set_error("shape not supported by the statistics epilogue"); return BUDDY_ERR_ARG; }
+  W4Gn gn;
+  gn.x.p0 = x; gn.x.p1 = nullptr; gn.x.C0 = Cin; gn.x.ld0 = Cin; gn.x.ld1 = 0;
+  gn.stats = stats; gn.gamma = gamma; gn.beta = beta; gn.G = G; gn.silu = silu;
+  launch_gn_stats(gn.x, B, H * W, Cin, G, 1e-6f, stat_scratch, stats, st);
+  long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf, 1);
+  launch_wino6(p, U6up, scratch, scratch + vf, st, &gn, csum ? stat_scratch : nullptr, nullptr, nullptr, 1);
+  if (csum) launch_csum_collapse(stat_scratch, sc, B, Cout, csum, st);
+  return finish();
+}
+
+int buddy_gnbwd_upconv3x3_winograd6(const float* h, const float* gamma, const float* beta, const float* stats, const float* da, int G, int silu,
+                                    const float* U6upT, float* y, float* scratch, double* stat_scratch, float* red, int B, int H, int W, int C,
+                                    int Cout, void* stream) {
+  if (!h || !gamma || !beta || !stats || !da || !U6upT || !y || !scratch || !stat_scratch || !red || G < 1 || C % 4 || (C / G) % 4 || C > 1024 ||
+      Cout % 4) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  IgemmParams p; std::memset(&p, 0, sizeof(p));
+  p.ldA0 = C; p.Cin = C; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = y; p.ldC = Cout;
+  p.alpha = 1.f; p.out_scale = 1.f; p.rows_per_batch = H * W;
+  if (!wino6_supported(p)) { set_error("shape not supported by the F(6x6,3x3) path (H, W >= 6; channels multiples of 4)"); return BUDDY_ERR_ARG; }
+  W4Gn gn;
+  gn.x.p0 = h; gn.x.p1 = nullptr; gn.x.C0 = C; gn.x.ld0 = C; gn.x.ld1 = 0;
+  gn.stats = stats; gn.gamma = gamma; gn.beta = beta; gn.G = G; gn.silu = silu; gn.da = da; gn.ldda = C; gn.red = red;
+  launch_gn_bwd_sums(gn.x, stats, gamma, beta, da, B, 2 * H, 2 * W, C, G, 0, silu, stat_scratch, red, st);
+  long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf, 2);
+  launch_wino6(p, U6upT, scratch, scratch + vf, st, &gn, nullptr, nullptr, nullptr, 2);
   return finish();
 }
 

@@ -65,13 +65,14 @@ void wino4_transform_weights(const float* wt_host, int Cout, int Cin, float* U4_
 // overhang); same fusions.  wino6_pays: executed work incl. the overhang is at least 10 % below F(4x4,3x3)'s (the large layers).
 bool wino6_supported(const IgemmParams& p);
 bool wino6_pays(const IgemmParams& p);
-void wino6_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats);
-int wino6_stat_chunks(const IgemmParams& p);
+void wino6_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats, int up = 0);
+int wino6_stat_chunks(const IgemmParams& p, int up = 0);
 double wino6_exec_ratio(const IgemmParams& p);
 //   bwd_gn (with stat) -- data-gradient convolutions: the output is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); the partials are the two sums
 //           of that GroupNorm's backward, (dxhat, dxhat * xhat), instead of (sum, sum of squares)
+//   up -- sub-pixel forms of conv3x3(nearest-upsample x2) (1) and of its data-gradient (2); p describes the LOW resolution (wino6.hip)
 void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn = nullptr, double* stat = nullptr,
-                  const W4Gn* bwd_gn = nullptr, const void* U6x = nullptr);
+                  const W4Gn* bwd_gn = nullptr, const void* U6x = nullptr, int up = 0);
 void wino6_transform_weights(const float* wt_host, int Cout, int Cin, float* U6_host);
 // device-side weight preparation (wprep.hip): raw torch OIHW [O][I][3][3] -> the operand form of one kernel variant (kind 0 direct [Co][9][Ci],
 // 2 F(2x2) [Ci/8][16][Co][8], 4 F(4x4) [36][Co][Ci], 6 F(6x6) [64][Co][Ci]) for the forward (Co = O, Ci = I) or the data-gradient direction

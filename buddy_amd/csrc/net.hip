@@ -114,7 +114,7 @@ struct WVar { float* u = nullptr; void* x = nullptr; };
 // (direction, kernel variant, arithmetic) per layer is ever built for a given workload, on the GPU (wprep.hip).  wf / wb: forms prepared at
 // creation (the small 2-channel convolutions, 1x1 convolutions)
 struct ConvW { int cin = 0, cout = 0, taps = 0; const float* raw = nullptr; float* wf = nullptr; float* wb = nullptr; float* bias = nullptr;
-               mutable WVar var[2][4]; };                      // [forward | data-gradient][direct, F(2x2), F(4x4), F(6x6)]
+               mutable WVar var[2][5]; };                      // [forward | data-gradient][direct, F(2x2), F(4x4), F(6x6), F(6x6) sub-pixel up form]
 struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResW { GNW gn0, gn1; ConvW c0, c1, c2; bool has_c2 = false; int cin = 0, cout = 0, dense_off = 0; };
 struct AttnW { GNW gn; float* Wt[4]; float* Wn[4]; float* b[4]; int C = 0; };
@@ -462,17 +462,18 @@ void net_destroy(Net* N) {
   delete N;
 }
 
-// The operand form `kind` (0 direct, 2 / 4 / 6 = Winograd F(kind x kind, 3x3)) of a 3x3 convolution for one direction, built on first use on
+// The operand form `kind` (0 direct, 2 / 4 / 6 = Winograd F(kind x kind, 3x3), 61 = F(6x6,3x3) of the sub-pixel up form) of a 3x3 convolution for one direction, built on first use on
 // the GPU from the raw OIHW tensor (wprep.hip) and cached in the shared store.  want_x: the bf16x3 stage image (the fp32 form is then only a
 // staging buffer, reused for the next layer); otherwise the fp32 form itself is kept.  The preparing stream is drained before the pointer is
 // published, so a replica on another stream may use it at once.
 static const WVar* conv_weights(Net* N, const ConvW& c, bool dgrad, int kind, bool want_x) {
   Weights* Wt = N->W.get();
-  const int ki = kind == 0 ? 0 : kind == 2 ? 1 : kind == 4 ? 2 : 3;
+  const int ki = kind == 0 ? 0 : kind == 2 ? 1 : kind == 4 ? 2 : kind == 6 ? 3 : 4;
   WVar& v = c.var[dgrad ? 1 : 0][ki];
   std::lock_guard<std::mutex> lk(Wt->mu);
   if (want_x ? v.x != nullptr : v.u != nullptr) return &v;
-  const int Co = dgrad ? c.cin : c.cout, Ci = dgrad ? c.cout : c.cin;
+  const int ph = kind == 61 ? 4 : 1;                          // sub-pixel up form: four phase kernels per output channel (wprep.hip)
+  const int Co = dgrad ? c.cin : ph * c.cout, Ci = dgrad ? ph * c.cout : c.cin;
   const size_t nfl = (size_t)conv3_weight_floats(c.cout, c.cin, kind);
   hipStream_t st = N->st;
   float* u = v.u;
@@ -541,7 +542,26 @@ struct Conv3 {
   // bwd_gn (data-gradient convolutions): `out` is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); on the F(6x6,3x3) path the output transform
   // leaves that GroupNorm's backward-sum partials in N->partial and the call returns their chunk count (0: run the reduction pass)
   const W4Gn* bwd_gn = nullptr;
+  // up (sub-pixel forms, launch_wino6): 1 = out (2H, 2W, Cout) = conv3x3(nearest-upsample x2 of the (H, W, Cin) input); 2 = its data-gradient: the
+  // input is the (2H, 2W, Cin) gradient, out is (H, W, Cout).  H, W are the LOW resolution in both.  The caller checks conv3_up_ok first.
+  int up = 0;
 };
+// The BigGAN up block's Conv_0 (layerspp.py:246-257: h = upsample(act(GroupNorm_0(x))), Conv_0(h)) as one three-pass convolution on the low-resolution
+// grid: no upsampled activation in HBM, V 4x smaller, the data-gradient's M and da 4x smaller.  Needs the F(6x6,3x3) path with the GroupNorm
+// fusions on the low-resolution geometry.
+static bool conv3_up_ok(Net* N, int B, int H, int W, int Cin, int Cout) {
+  static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
+  static const bool on = mode.empty() && !(getenv("BUDDY_GN_FUSE") && atoi(getenv("BUDDY_GN_FUSE")) == 0) &&
+                         !(getenv("BUDDY_GN_FUSE_BWDIN") && atoi(getenv("BUDDY_GN_FUSE_BWDIN")) == 0) &&
+                         !(getenv("BUDDY_GN_FUSE_BWD") && atoi(getenv("BUDDY_GN_FUSE_BWD")) == 0) &&
+                         !(getenv("BUDDY_UPCONV") && atoi(getenv("BUDDY_UPCONV")) == 0);     // A/B switch
+  if (!on || Cin % 8 || Cout % 8 || H < 6 || W < 6) return false;
+  IgemmParams p = ig_base();
+  p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.ldC = Cout; p.ld_bias_bn = 4;
+  if (!wino6_supported(p) || !wino6_pays(p)) return false;
+  const int sc = wino6_stat_chunks(p, 1);
+  return sc > 0 && (long long)sc * Cout <= 256LL * 1024 && (long long)wino6_stat_chunks(p, 0) * Cin <= 256LL * 1024;
+}
 static int conv3(Net* N, const Conv3& c) {
   const float* a = c.a; const int B = c.B, H = c.H, W = c.W, Cin = c.Cin, Cout = c.Cout;
   // Winograd forms exist for channel counts that are multiples of 8 (every ResBlock convolution of the supported family)
@@ -557,9 +577,30 @@ static int conv3(Net* N, const Conv3& c) {
       if (need > N->w4_need) N->w4_need = need;
     }
     if (use_wino6 && wino_ok && H >= 6 && W >= 6) {
-      const size_t need = (size_t)64 * ((size_t)B * ((H + 5) / 6) * ((W + 5) / 6)) * (size_t)(Cin + Cout);
+      const size_t need = (size_t)64 * ((size_t)B * ((H + 5) / 6) * ((W + 5) / 6)) * (size_t)((c.up == 2 ? 4 : 1) * Cin + (c.up == 1 ? 4 : 1) * Cout);
       if (need > N->w4_need) N->w4_need = need;
     }
+    return 0;
+  }
+  if (c.up) {
+    IgemmParams p = ig_base();
+    p.A0 = a; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = c.out; p.ldC = Cout;
+    p.bias_n = c.bias; p.bias_bn = c.bias_bn; p.ld_bias_bn = c.ld_bn; p.rows_per_batch = H * W; p.alpha = c.alpha; p.out_scale = c.out_scale;
+    const bool x3 = N->gemm_mode == 1 && wgemm_supported((c.up == 1 ? 4 : 1) * Cout, (c.up == 2 ? 4 : 1) * Cin);
+    const WVar* wv = conv_weights(N, *c.w, c.dgrad, 61, x3);
+    if (!wv || N->w4_scratch == nullptr) return -1;
+    long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf, c.up);
+    const bool want_bwd = c.up == 2 && bwd_gn != nullptr;
+    const int sc = (c.up == 1 ? stat_out != nullptr : want_bwd) ? wino6_stat_chunks(p, c.up) : 0;
+    const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;
+    IgemmParams pr = p; pr.M = 4 * p.M;                       // the direct-convolution work is that of the (2H, 2W) grid
+    const double xr = wino6_exec_ratio(p);
+    igemm_prof_record(pr, 9, 1, N->st, true, xr);
+    launch_wino6(p, wv->u, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, (stat && want_bwd) ? bwd_gn : nullptr,
+                 x3 ? wv->x : nullptr, c.up);
+    igemm_prof_record(pr, 9, 1, N->st, false, xr);
+    if (stat && (want_bwd || direct)) return sc;
+    if (stat && stat_out) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
     return 0;
   }
   IgemmParams p = ig_base();
@@ -669,9 +710,13 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
   float* xs = R.has_c2 ? N->tmp((long long)B * ((mode == 2 && !firm) ? H * W : Ho * Wo) * Cout) : nullptr;
   float* a1 = N->tmp((long long)B * Ho * Wo * Cout);
   float* a0f = firm ? N->tmp((long long)B * H * W * Cin) : nullptr;
+  // up block without FIR: Conv_0 in its sub-pixel form on the (H, W) grid (GroupNorm_0 + SiLU inside its input transform, no upsampled activation)
+  const bool up6 = mode == 2 && !firm && conv3_up_ok(N, B, H, W, Cin, Cout);
   if (N->dry()) {                                         // sizing pass: let the convolutions note their F(4x4,3x3) scratch need
-    Conv3 c; c.B = B; c.H = Ho; c.W = Wo; c.Cin = Cin; c.Cout = Cout; c.w = &R.c0; conv3(N, c);
-    c.Cin = Cout; c.w = &R.c1; conv3(N, c);
+    Conv3 c; c.B = B; c.H = Ho; c.W = Wo; c.Cin = Cin; c.Cout = Cout; c.w = &R.c0;
+    if (up6) { c.H = H; c.W = W; c.up = 1; }
+    conv3(N, c);
+    c.H = Ho; c.W = Wo; c.up = 0; c.Cin = Cout; c.w = &R.c1; conv3(N, c);
   }
   if (!N->dry()) {
     view_stats(N, x, H * W, G0, stats0);
@@ -680,12 +725,13 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, 0, 1, a0f, nullptr, st);
       if (mode == 2) { launch_fir_up2(a0f, a0, B, H, W, Cin, 1.f, 0, st); launch_fir_up2(x.a->p, xr, B, H, W, Cin, 1.f, 0, st); }
       else { launch_fir_down2(a0f, a0, B, H, W, Cin, 1.f, 0, st); launch_fir_down2(x.a->p, xr, B, H, W, Cin, 1.f, 0, st); }
-    } else if (mode != 0)
+    } else if (mode != 0 && !up6)
     launch_gn_apply(src_of(x), stats0, R.gn0.gamma, R.gn0.beta, B, H, W, Cin, G0, mode, 1, a0, xr, st);
     // same resolution: act(GroupNorm(.)) is applied by the convolution's input transform (a0 / a1 are only its fallback buffers)
     Conv3 c0; c0.a = a0; c0.B = B; c0.H = Ho; c0.W = Wo; c0.Cin = Cin; c0.Cout = Cout; c0.w = &R.c0; c0.bias = R.c0.bias;
     c0.bias_bn = temb_all + R.dense_off; c0.ld_bn = N->W->dense_total; c0.out = h1->p;
-    c0.gn = mode == 0 ? &g0 : nullptr; c0.gn_tmp = a0; c0.stat_out = h1; c0.direct = true;
+    c0.gn = (mode == 0 || up6) ? &g0 : nullptr; c0.gn_tmp = a0; c0.stat_out = h1; c0.direct = true;
+    if (up6) { c0.H = H; c0.W = W; c0.up = 1; }
     const int ch1 = conv3(N, c0);
     if (ch1 > 0) launch_gn_stats_partial(N->partial, ch1, B, Ho * Wo, Cout, G1, 1e-6f, stats1, st);   // h1 has this one reader
     else { View vh1; vh1.a = h1; view_stats(N, vh1, Ho * Wo, G1, stats1); }
@@ -751,7 +797,8 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       W4Gn gb1{single(h1->p, Cout), stats1, Rp->gn1.gamma, Rp->gn1.beta, G1, 1};
       gb1.da = da1; gb1.ldda = Cout; gb1.red = n->red;
       Conv3 d0c; d0c.a = dh1; d0c.B = B; d0c.H = Ho; d0c.W = Wo; d0c.Cin = Cout; d0c.Cout = Cin; d0c.w = &Rp->c0; d0c.dgrad = true;
-      d0c.out = da0; d0c.gn = &gb1; d0c.gn_tmp = dh1; d0c.bwd_gn = mode == 0 ? &b0 : nullptr;
+      d0c.out = da0; d0c.gn = &gb1; d0c.gn_tmp = dh1; d0c.bwd_gn = (mode == 0 || up6) ? &b0 : nullptr;
+      if (up6) { d0c.H = H; d0c.W = W; d0c.up = 2; }      // da0 comes out at (H, W): the nearest-upsample's adjoint is inside the convolution
       const int s0 = conv3(n, d0c);
       Dst2 d0 = gdst_of(x);
       if (firm) {
@@ -763,7 +810,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
         }
       } else
       if (!n->dry())
-        launch_gn_bwd(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0, B, H, W, Cin, G0, mode, 1, extra, extra_mode, extra_scale,
+        launch_gn_bwd(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0, B, H, W, Cin, G0, up6 ? 0 : mode, 1, extra, extra_mode, extra_scale,
                       n->partial, n->red, d0, s, s0);
       n->arena.off = mk;
     });

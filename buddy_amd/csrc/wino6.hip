@@ -55,13 +55,15 @@ __device__ __forceinline__ void at8(const float4 (&m)[8], float4 (&y)[6]) {
   y[5] = d12 + 32.f * d34 + 0.03125f * d56 + m[7];
 }
 
-struct W6Geo { int B, H, W, TH, TW, QC, TPB; long long Mt; int xcd; };   // TH x TW tiles per utterance, Mt = B * TH * TW
+struct W6Geo { int B, H, W, TH, TW, QC, TPB; long long Mt; int xcd; int Cl; };   // TH x TW tiles per utterance, Mt = B * TH * TW; Cl: see S2D / UP
 
 // grid (ceil(Mt / TPB), ceil(q / QC)); V[(pos * Mt + tile) * Cin + c]
 // GN 1: the input is act(GroupNorm(x)) of a (channel-concatenated) view, applied while loading (zero padding applies to the ACTIVATED tensor)
 // GN 2: the input is the GroupNorm backward of the gradient gn.da: rstd * (dxhat - m1 - xhat * m2), dxhat = da * act'(z) * gamma (the tensor the
 //       separate apply pass would write and this transform read back)
-template <int GN>
+// S2D (sub-pixel form of the data-gradient of conv3x3(nearest-upsample x2), launch_wino6 up = 2): the input is a (2H, 2W, Cl) tensor read as its
+//       space-to-depth image (H, W, 4 Cl): channel c' = ph * Cl + c, ph = 2 py + px, is pixel (2 y + py, 2 x + px) of channel c.  Single source.
+template <int GN, bool S2D = false>
 __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__ x, int ldX, const W4Gn gn, float* __restrict__ V, int Cin,
                                                        const W6Geo geo) {
   __shared__ float4 lds[32 * 64];
@@ -87,16 +89,17 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
     float mean = 0.f, rstd = 0.f, m1 = 0.f, m2 = 0.f;
     float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), bt = gm;
     const float* da = nullptr;
+    const int ph = S2D ? c / geo.Cl : 0, cl = S2D ? c - ph * geo.Cl : c, py = ph >> 1, px = ph & 1;   // cl: channel of the source tensor
     if (GN) {
-      const int g = c / (Cin / gn.G);
+      const int g = cl / ((S2D ? geo.Cl : Cin) / gn.G);
       mean = gn.stats[((long long)b * gn.G + g) * 2]; rstd = gn.stats[((long long)b * gn.G + g) * 2 + 1];
-      if (GN == 2) { m1 = gn.red[((long long)b * gn.G + g) * 2]; m2 = gn.red[((long long)b * gn.G + g) * 2 + 1]; da = gn.da + c; }
-      gm = ld4(gn.gamma + c); bt = ld4(gn.beta + c);
-      const bool second = gn.x.p1 != nullptr && c >= gn.x.C0;
-      x = second ? gn.x.p1 + (c - gn.x.C0) : gn.x.p0 + c;
+      if (GN == 2) { m1 = gn.red[((long long)b * gn.G + g) * 2]; m2 = gn.red[((long long)b * gn.G + g) * 2 + 1]; da = gn.da + cl; }
+      gm = ld4(gn.gamma + cl); bt = ld4(gn.beta + cl);
+      const bool second = !S2D && gn.x.p1 != nullptr && c >= gn.x.C0;
+      x = second ? gn.x.p1 + (c - gn.x.C0) : gn.x.p0 + cl;
       ldX = second ? gn.x.ld1 : gn.x.ld0;
     } else {
-      x += c;
+      x += cl;
     }
     const int gx = 6 * tx - 1 + col, gy0 = 6 * ty - 1;
     float4 d[8], t[8];
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int cy = min(max(gy0 + r, 0), H - 1);
-      const long long pix = ((long long)b * H + cy) * W + cx;
+      const long long pix = S2D ? ((long long)b * (2 * H) + 2 * cy + py) * (2 * W) + 2 * cx + px : ((long long)b * H + cy) * W + cx;
       d[r] = ld4(x + pix * ldX);
       if (GN == 2) g4[r] = ld4(da + pix * gn.ldda);
     }
@@ -160,7 +163,10 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
 // STAT 2 (data-gradient convolutions): the value written is da, the gradient w.r.t. act(GroupNorm(x)) of the view bg.x; the partials are the two
 // sums that GroupNorm's backward needs, (sum dxhat, sum dxhat * xhat) with dxhat = da * act'(z) * gamma -- x is read here at the output pixels and
 // the reduction pass over (x, da) disappears.  fp32 over the (at most 36 x walk) pixels a thread sees, fp64 beyond.
-template <int STAT>
+// UP (sub-pixel form of conv3x3(nearest-upsample x2), launch_wino6 up = 1): M holds 4 N columns, column n' = ph * N + n = output channel n of phase
+// ph = 2 py + px; tile pixel (y, x) of phase ph is pixel (2 y + py, 2 x + px) of the (2H, 2W, N) output (depth-to-space).  The statistics partials
+// of phase ph are chunks [ph * chunks, (ph + 1) * chunks) of 4 * chunks per utterance.  No residual.
+template <int STAT, bool UP = false>
 __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict__ Mb, const IgemmParams p, const W6Geo geo, int chunks, int TL,
                                                         double* __restrict__ stat, const W4Gn bg) {
   __shared__ float4 lds[32 * 48];
@@ -168,11 +174,13 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
   const int tid = threadIdx.x, QC = geo.QC;
   const int ql = tid % QC, col = (tid / QC) & 7, tl = tid / (QC * 8);
   const int N = p.N, H = geo.H, W = geo.W;
-  const int quad = blockIdx.y * QC + ql, n = quad * 4;
+  const int quad = blockIdx.y * QC + ql, nq = quad * 4;       // nq: column of M
+  const int ph = UP ? nq / N : 0, n = UP ? nq - ph * N : nq, py = ph >> 1, px = ph & 1;
+  const int NM = UP ? 4 * N : N;
   const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
   const int tpb = geo.TH * geo.TW;                            // tiles per utterance
-  const bool chan = n < N;
-  const long long ps = geo.Mt * N;
+  const bool chan = nq < NM;
+  const long long ps = geo.Mt * NM;
   double ssum[4] = {0, 0, 0, 0}, ssq[4] = {0, 0, 0, 0};
   float fs[4] = {0.f, 0.f, 0.f, 0.f}, ft[4] = {0.f, 0.f, 0.f, 0.f};
   float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
       }
     }
     if (live) {
-      const float* src = Mb + tile * N + n;
+      const float* src = Mb + tile * NM + nq;
       float4 m[8], s[6];
 #pragma unroll
       for (int i = 0; i < 8; ++i) m[i] = ld4(src + (long long)(i * 8 + col) * ps);
@@ -230,9 +238,10 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
         for (int cc = 0; cc < 6; ++cc) {
           const int ww = 6 * tx + cc;
           if (ww < W) {
-            const long long pix = ((long long)b * H + hh) * W + ww;
+            const long long pix = UP ? ((long long)b * (2 * H) + 2 * hh + py) * (2 * W) + 2 * ww + px : ((long long)b * H + hh) * W + ww;
             float4 v = p.alpha * y[cc] + add;
-            if (p.res_mode == 1) v = v + ld4(p.res + pix * p.ldRes + n);
+            if (UP) {}
+            else if (p.res_mode == 1) v = v + ld4(p.res + pix * p.ldRes + n);
             else if (p.res_mode == 2) v = v + ld4(p.res + (((long long)b * (H >> 1) + (hh >> 1)) * (W >> 1) + (ww >> 1)) * p.ldRes + n);
             v = p.out_scale * v;
             float* dst = p.C + pix * p.ldC + n;
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
       for (int l = 0; l < 256 / QC; ++l)
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] += red[(l * QC + tid) * 8 + j];
-      double* o = stat + (((long long)b * chunks + chunk) * N + n) * 2;
+      double* o = stat + ((UP ? ((long long)b * 4 + ph) * chunks + chunk : (long long)b * chunks + chunk) * N + n) * 2;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { o[j * 2] = r[j]; o[j * 2 + 1] = r[4 + j]; }
     }
@@ -290,10 +299,12 @@ W6Geo geometry(const IgemmParams& p, int C) {
   g.TPB = 32 / g.QC;
   static const int xcd = !(getenv("BUDDY_W6_XCD") && atoi(getenv("BUDDY_W6_XCD")) == 0);     // A/B switch of the XCD-aware tile order of the input transform
   g.xcd = xcd;
+  g.Cl = C;
   return g;
 }
-// iterations of TPB tiles a workgroup of the output transform walks: about 512 workgroups (= statistics partials) per utterance
-int out_walk(const W6Geo& g) { const int t = g.TH * g.TW, per = g.TPB * 512; return std::max(1, (t + per - 1) / per); }
+// iterations of TPB tiles a workgroup of the output transform walks: about 512 workgroups (= statistics partials) per utterance (the sub-pixel
+// up form has four partials per workgroup row: 128)
+int out_walk(const W6Geo& g, int up = 0) { const int t = g.TH * g.TW, per = g.TPB * (up == 1 ? 128 : 512); return std::max(1, (t + per - 1) / per); }
 }  // namespace
 
 bool wino6_supported(const IgemmParams& p) {
@@ -309,52 +320,77 @@ bool wino6_pays(const IgemmParams& p) {
   const double tiles6 = (double)((p.H + 5) / 6) * ((p.W + 5) / 6), tiles4 = (double)p.H * p.W / 16.0;
   return tiles6 * 64.0 <= 0.90 * tiles4 * 36.0 && tiles6 >= 128;
 }
-void wino6_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats) {
+void wino6_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats, int up) {
   const long long Mt = (long long)(p.M / (p.H * p.W)) * ((p.H + 5) / 6) * ((p.W + 5) / 6);
-  *v_floats = 64 * Mt * p.Cin; *m_floats = 64 * Mt * p.N;
+  *v_floats = 64 * Mt * p.Cin * (up == 2 ? 4 : 1); *m_floats = 64 * Mt * p.N * (up == 1 ? 4 : 1);
 }
-int wino6_stat_chunks(const IgemmParams& p) {
+int wino6_stat_chunks(const IgemmParams& p, int up) {
   if (p.N % 4) return 0;
-  const W6Geo g = geometry(p, p.N);
-  const int per = g.TPB * out_walk(g);
-  return (g.TH * g.TW + per - 1) / per;
+  const W6Geo g = geometry(p, up == 1 ? 4 * p.N : p.N);
+  const int per = g.TPB * out_walk(g, up);
+  return (up == 1 ? 4 : 1) * ((g.TH * g.TW + per - 1) / per);
 }
 double wino6_exec_ratio(const IgemmParams& p) {               // executed / direct-convolution multiply-adds
   const W6Geo g = geometry(p, p.N);
   return 64.0 * (double)g.Mt / (9.0 * (double)p.M);
 }
 
+// up = 1: y (2H, 2W, N) = conv3x3(nearest-upsample x2 of the (H, W, Cin) input): ONE input transform at the low resolution, a GEMM with 4 N columns
+//         (the four sub-pixel phases' 3x3 kernels, conv3_weight_prep kind 61: every output phase sees a 2x2 subset of the upsampled taps, summed
+//         into a zero-padded 3x3 kernel on the low-resolution grid) and a depth-to-space output transform.  U6: [64][4 N][Cin].
+// up = 2: its data-gradient: p.Cin = channels of the (2H, 2W) gradient, read space-to-depth as 4 Cin channels; output (H, W, N).  U6: [64][N][4 Cin].
+// p.H, p.W, p.M describe the LOW resolution in both.
 void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat, const W4Gn* bwd_gn,
-                  const void* U6x) {
-  const W6Geo gi = geometry(p, p.Cin), go = geometry(p, p.N);
+                  const void* U6x, int up) {
+  const int CinG = up == 2 ? 4 * p.Cin : p.Cin, NG = up == 1 ? 4 * p.N : p.N;       // K and N of the batched GEMM
+  W6Geo gi = geometry(p, CinG), go = geometry(p, NG);
+  gi.Cl = p.Cin; go.Cl = p.N;
   const long long Mt = gi.Mt;
   const int plevel = igemm_prof_level();
   const bool prof = plevel >= 2, prof_gemm = plevel == 1;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   if (prof) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], st); }
   if (prof_gemm) { (void)hipEventCreate(&ev[1]); (void)hipEventCreate(&ev[2]); }
-  const dim3 grid_in((unsigned)((Mt + gi.TPB - 1) / gi.TPB), (unsigned)((p.Cin / 4 + gi.QC - 1) / gi.QC));
-  if (gn && gn->da) hipLaunchKernelGGL(w6_input_kernel<2>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
+  const dim3 grid_in((unsigned)((Mt + gi.TPB - 1) / gi.TPB), (unsigned)((CinG / 4 + gi.QC - 1) / gi.QC));
+  if (up == 2) {
+    if (gn && gn->da) hipLaunchKernelGGL((w6_input_kernel<2, true>), grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, CinG, gi);
+    else hipLaunchKernelGGL((w6_input_kernel<0, true>), grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, CinG, gi);
+  }
+  else if (gn && gn->da) hipLaunchKernelGGL(w6_input_kernel<2>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
   else if (gn) hipLaunchKernelGGL(w6_input_kernel<1>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
   else hipLaunchKernelGGL(w6_input_kernel<0>, grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, p.Cin, gi);
   if (prof || prof_gemm) (void)hipEventRecord(ev[1], st);
   IgemmParams g; std::memset(&g, 0, sizeof(g));
-  g.A0 = V; g.ldA0 = p.Cin; g.sA = Mt * p.Cin; g.Cin = p.Cin;
-  g.Bt = U6; g.ldB = p.Cin; g.sB = (long long)p.N * p.Cin;
-  g.C = Mb; g.ldC = p.N; g.sC = Mt * p.N;
-  g.M = (int)Mt; g.N = p.N; g.H = 1; g.W = 1; g.rows_per_batch = 1; g.alpha = 1.f; g.out_scale = 1.f;
+  g.A0 = V; g.ldA0 = CinG; g.sA = Mt * CinG; g.Cin = CinG;
+  g.Bt = U6; g.ldB = CinG; g.sB = (long long)NG * CinG;
+  g.C = Mb; g.ldC = NG; g.sC = Mt * NG;
+  g.M = (int)Mt; g.N = NG; g.H = 1; g.W = 1; g.rows_per_batch = 1; g.alpha = 1.f; g.out_scale = 1.f;
   g.tag = 36;                                                 // the Winograd-domain batched GEMM instantiation (36 or 64 positions)
   igemm_prof_enable(0);
-  if (U6x != nullptr && wgemm_supported(p.N, p.Cin)) launch_wgemm_bf16x3(V, U6x, Mb, Mt, p.N, p.Cin, 64, st);
+  if (U6x != nullptr && wgemm_supported(NG, CinG)) launch_wgemm_bf16x3(V, U6x, Mb, Mt, NG, CinG, 64, st);
   else launch_igemm(g, 1, false, false, 64, st);
   igemm_prof_enable(plevel);
   if (prof || prof_gemm) (void)hipEventRecord(ev[2], st);
-  const int TL = out_walk(go), per = go.TPB * TL, chunks = (go.TH * go.TW + per - 1) / per;
-  const dim3 grid_out((unsigned)(go.B * chunks), (unsigned)((p.N / 4 + go.QC - 1) / go.QC));
-  if (stat && bwd_gn) hipLaunchKernelGGL(w6_output_kernel<2>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, *bwd_gn);
+  const int TL = out_walk(go, up), per = go.TPB * TL, chunks = (go.TH * go.TW + per - 1) / per;
+  const dim3 grid_out((unsigned)(go.B * chunks), (unsigned)((NG / 4 + go.QC - 1) / go.QC));
+  if (up == 1) {
+    if (stat) hipLaunchKernelGGL((w6_output_kernel<1, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, W4Gn{});
+    else hipLaunchKernelGGL((w6_output_kernel<0, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
+  }
+  else if (stat && bwd_gn) hipLaunchKernelGGL(w6_output_kernel<2>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, *bwd_gn);
   else if (stat) hipLaunchKernelGGL(w6_output_kernel<1>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, W4Gn{});
   else hipLaunchKernelGGL(w6_output_kernel<0>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
   const double mt = (double)Mt, m = (double)p.M;
+  if (up) {                                                   // sub-pixel forms: the GEMM's own K / N; the (2H, 2W) side has 4 m pixels
+    const double kg = CinG, ng = NG, gf = 2.0 * 64.0 * mt * kg * ng, gb = 4.0 * 64.0 * (mt * kg + mt * ng + ng * kg);
+    if (prof_gemm) prof_w4_push(nullptr, ev[1], ev[2], nullptr, gf, 0.0, 0.0, gb);
+    if (prof) {
+      (void)hipEventRecord(ev[3], st);
+      const double in_reads = (gn && gn->da) ? 2.0 : 1.0, out_extra = (stat && bwd_gn) ? 1.0 : 0.0;
+      prof_w4_push(ev[0], ev[1], ev[2], ev[3], gf, 4.0 * (in_reads * m * kg + 64.0 * mt * kg), 4.0 * (64.0 * mt * ng + m * ng * (1.0 + out_extra)), gb);
+    }
+    return;
+  }
   if (prof_gemm) prof_w4_push(nullptr, ev[1], ev[2], nullptr, 2.0 * 64.0 * mt * p.Cin * p.N, 0.0, 0.0, 4.0 * 64.0 * (mt * p.Cin + mt * p.N + (double)p.N * p.Cin));
   if (prof) {
     (void)hipEventRecord(ev[3], st);

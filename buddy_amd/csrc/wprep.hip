@@ -77,11 +77,61 @@ __global__ __launch_bounds__(256) void conv3_weight_prep_kernel(const float* __r
     }
 }
 
+// Sub-pixel form of conv3x3(nearest-upsample x2 of x) (the BigGAN up block's Conv_0, reference layerspp.py:246-257 with up_or_down_sampling.py
+// naive_upsample_2d) in the F(6x6,3x3) domain.  Output pixel (2 i + py, 2 j + px) only ever reads low-resolution pixels (i - 1 + py .. i + py) x
+// (j - 1 + px .. j + px): per axis the three taps fold into a zero-padded 3-tap kernel on the low-resolution grid,
+//   py = 0: [g0, g1 + g2, 0],   py = 1: [0, g0 + g1, g2]     (offsets -1, 0, +1)
+// so the convolution is an ordinary 3x3 convolution with 4 O output channels (phase-major: column ph * O + o, ph = 2 py + px) followed by a
+// depth-to-space; its data-gradient is an ordinary 3x3 convolution from the 4 O space-to-depth channels of the gradient to I channels with the
+// flipped kernels.  One thread per (co', ci') of the Winograd-domain GEMM: forward [64][4 O][I], data-gradient [64][I][4 O].  fp64, un-contracted.
+__global__ __launch_bounds__(256) void conv3_up_weight_prep_kernel(const float* __restrict__ w, int O, int I, int dgrad, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int Co = dgrad ? I : 4 * O, Ci = dgrad ? 4 * O : I;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)Co * Ci) return;
+  const int co = (int)(idx / Ci), ci = (int)(idx % Ci);
+  const int po = dgrad ? ci : co, ph = po / O, o = po - ph * O, i = dgrad ? co : ci, py = ph >> 1, px = ph & 1;
+  const float* src = w + ((long long)o * I + i) * 9;
+  double g[3][3];                                             // g[dy][dx] in this layout (dy: time, dx: frequency) = w[o][i][ky = dx][kx = dy]
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) g[dy][dx] = (double)src[dx * 3 + dy];
+  double k[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ey = py == 0 ? (dy == 0 ? 0 : 1) : (dy == 2 ? 2 : 1), ex = px == 0 ? (dx == 0 ? 0 : 1) : (dx == 2 ? 2 : 1);
+      k[ey][ex] = k[ey][ex] + g[dy][dx];
+    }
+  if (dgrad) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const double t0 = k[a][0]; k[a][0] = k[a][2]; k[a][2] = t0; }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { const double t0 = k[0][b]; k[0][b] = k[2][b]; k[2][b] = t0; }
+  }
+  double G[8][3];
+  g_rows(6, G);
+  double t[8][3];
+#pragma unroll
+  for (int xi = 0; xi < 8; ++xi)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) t[xi][b] = G[xi][0] * k[0][b] + G[xi][1] * k[1][b] + G[xi][2] * k[2][b];
+#pragma unroll
+  for (int xi = 0; xi < 8; ++xi)
+#pragma unroll
+    for (int nu = 0; nu < 8; ++nu) {
+      const double u = t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2];
+      out[((long long)(xi * 8 + nu) * Co + co) * Ci + ci] = (float)u;
+    }
+}
+
 }  // namespace
 
 long long conv3_weight_floats(int O, int I, int kind) {
   const long long n = (long long)O * I;
-  return kind == 0 ? 9 * n : kind == 2 ? 16 * n : kind == 4 ? 36 * n : kind == 6 ? 64 * n : 0;
+  return kind == 0 ? 9 * n : kind == 2 ? 16 * n : kind == 4 ? 36 * n : kind == 6 ? 64 * n : kind == 61 ? 256 * n : 0;
 }
 
 int launch_conv3_weight_prep(const float* w_oihw, int O, int I, bool dgrad, int kind, float* out, hipStream_t st) {
@@ -93,6 +143,7 @@ int launch_conv3_weight_prep(const float* w_oihw, int O, int I, bool dgrad, int 
             hipLaunchKernelGGL(conv3_weight_prep_kernel<2>, grid, block, 0, st, w_oihw, O, I, dgrad ? 1 : 0, out); break;
     case 4: hipLaunchKernelGGL(conv3_weight_prep_kernel<4>, grid, block, 0, st, w_oihw, O, I, dgrad ? 1 : 0, out); break;
     case 6: hipLaunchKernelGGL(conv3_weight_prep_kernel<6>, grid, block, 0, st, w_oihw, O, I, dgrad ? 1 : 0, out); break;
+    case 61: hipLaunchKernelGGL(conv3_up_weight_prep_kernel, dim3((unsigned)((4 * n + 255) / 256)), block, 0, st, w_oihw, O, I, dgrad ? 1 : 0, out); break;
     default: return BUDDY_ERR_ARG;
   }
   return BUDDY_OK;

@@ -40,7 +40,7 @@ int buddy_ncsnpp_replica(void* handle, void** replica);
 /* device bytes held by the (shared) weight store of a handle: raw parameters, bf16x3 images of the 1x1 / NIN matrices, lazily prepared 3x3
  * operand forms (and their count). */
 int buddy_ncsnpp_weight_bytes(void* handle, long long* params, long long* packed, long long* lazy, int* lazy_forms);
-/* the device-side weight preparation on its own: raw torch OIHW [O][I][3][3] (device) -> operand form `kind` (0 direct [Co][9][Ci], 2 Winograd
+/* the device-side weight preparation on its own: raw torch OIHW [O][I][3][3] (device) -> operand form `kind` (61: the sub-pixel up form, see buddy_gn_upconv3x3_winograd6; 0 direct [Co][9][Ci], 2 Winograd
  * F(2x2,3x3) [Ci/8][16][Co][8], 4 F(4x4,3x3) [36][Co][Ci], 6 F(6x6,3x3) [64][Co][Ci]); dgrad != 0: the data-gradient direction (Co = I, Ci = O,
  * taps flipped).  out: conv weight count x (9 | 16 | 36 | 64) floats.  Weights of ddpm_conv3x3, networks/ncsnpp_utils/layers.py:119-126. */
 int buddy_conv3_weight_prep(const float* w_oihw, int O, int I, int dgrad, int kind, float* out, void* stream);
@@ -153,6 +153,22 @@ int buddy_conv3x3_winograd6_gn_bwd_sums(const float* g, const float* U6, float* 
 int buddy_gnbwd_conv3x3_winograd6(const float* x, const float* gamma, const float* beta, const float* stats, const float* da, int G, int silu,
                                   const float* U6, float* y, float* scratch, double* stat_scratch, float* red, int B, int H, int W, int C, int Cout,
                                   void* stream);
+/* The up ResBlock's first convolution, Conv_0(naive_upsample_2d(act(GroupNorm_0(x)))) (layerspp.py:243-257, up_or_down_sampling.py:172-176), as ONE
+ * three-pass F(6x6,3x3) convolution on the LOW-resolution grid ("sub-pixel" form): x (B, H, W, Cin) -> y (B, 2H, 2W, Cout).  Output pixel
+ * (2i + py, 2j + px) reads a 2x2 subset of the upsampled taps, so each of the four phases is a 3x3 convolution of x with summed taps; U6up
+ * [64][4 Cout][Cin] = buddy_conv3_weight_prep(kind 61, dgrad 0).  Neither the activated nor the upsampled tensor reaches HBM.  csum (optional):
+ * per-(utterance, channel) (sum, sum of squares) of y, float64.  scratch: 64 * B * ceil(H/6) * ceil(W/6) * (Cin + 4 Cout) floats; stats [B][G][2]
+ * out; stat_scratch >= B*256*1024*16 bytes. */
+int buddy_gn_upconv3x3_winograd6(const float* x, const float* gamma, const float* beta, int G, int silu, const float* U6up, const float* bias, float* y,
+                                 float* scratch, float* stats, double* stat_scratch, double* csum, int B, int H, int W, int Cin, int Cout, void* stream);
+/* Its data-gradient with the GroupNorm_1 backward in front (the up block's backward between Conv_1 and Conv_0): y (B, H, W, Cout) = the gradient
+ * w.r.t. the LOW-resolution input of conv3x3(upsample(.)) for the high-resolution gradient dx, dx = input-gradient of act(GroupNorm(h)) for the
+ * incoming da; h, da: (B, 2H, 2W, C), read space-to-depth inside the input transform.  U6upT [64][Cout][4 C] = buddy_conv3_weight_prep(kind 61,
+ * dgrad 1) of the OIHW tensor [C][Cout][3][3].  stats: forward (mean, rstd) of h [B][G][2]; red [B][G][2] out; scratch: 64 * tiles * (4 C + Cout)
+ * floats; stat_scratch >= B*256*C*16 bytes. */
+int buddy_gnbwd_upconv3x3_winograd6(const float* h, const float* gamma, const float* beta, const float* stats, const float* da, int G, int silu,
+                                    const float* U6upT, float* y, float* scratch, double* stat_scratch, float* red, int B, int H, int W, int C,
+                                    int Cout, void* stream);
 /* GroupNorm(G, C, eps=1e-6) [+SiLU] [+2x down(mode 1)/up(mode 2)] forward; replaces nn.GroupNorm + nn.SiLU +
  * naive_{up,down}sample_2d (layerspp.py:243-258). stats: [B][G][2] out; scratch: >= B*256*C*16 bytes. */
 int buddy_groupnorm_act(const float* x, const float* gamma, const float* beta, float* y, float* stats, void* scratch, int B,

@@ -342,6 +342,83 @@ def test_gnbwd_conv3x3_winograd6(lib, B, H, W, C, Cout, silu):
     assert e < 2e-4
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,silu,stat", [(2, 16, 16, 32, 32, 1, 1), (1, 32, 20, 128, 256, 1, 1), (2, 13, 18, 64, 128, 0, 0),
+                                                        (1, 24, 36, 256, 256, 1, 1)])
+def test_gn_upconv3x3_winograd6(lib, B, H, W, Cin, Cout, silu, stat):
+    """The up block's Conv_0(naive_upsample_2d(act(GroupNorm_0(x)))) (layerspp.py:243-257) in its sub-pixel form: one F(6x6,3x3) convolution on the
+    low-resolution grid with four phase kernels (summed taps, buddy_conv3_weight_prep kind 61) and a depth-to-space output transform, against
+    fp64 torch on the materialised upsampled tensor.  Network axis convention: H = time (kx), W = frequency (ky).  Same 1e-4 as the plain form."""
+    from buddy_amd import _lib
+    G = min(Cin // 4, 32)
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin + Cout + 61)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 1.5 + 0.3).cuda()          # NHWC, H = time, W = frequency
+    gamma = (1 + 0.2 * torch.randn(Cin, generator=g)).cuda()
+    beta = (0.2 * torch.randn(Cin, generator=g)).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin)).cuda()   # torch OIHW: [o][i][ky = frequency][kx = time]
+    b = torch.randn(Cout, generator=g).cuda()
+    X = x.permute(0, 3, 2, 1).double()                                        # (B, C, F, T)
+    z = F.group_norm(X, G, gamma.double(), beta.double(), eps=1e-6)
+    if silu:
+        z = F.silu(z)
+    ref = F.conv2d(F.interpolate(z, scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1).permute(0, 3, 2, 1)   # (B, 2H, 2W, Cout)
+    U = torch.full((256 * Cin * Cout,), float("nan"), device="cuda")
+    _lib.check(lib.buddy_conv3_weight_prep(P(w.contiguous()), Cout, Cin, 0, 61, P(U), S()))
+    y = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), device="cuda")
+    scratch = torch.empty(64 * B * ((H + 5) // 6) * ((W + 5) // 6) * (Cin + 4 * Cout), device="cuda")
+    stats = torch.empty(B, G, 2, device="cuda")
+    stat_scratch = torch.empty(B * 256 * 1024 * 2, dtype=torch.float64, device="cuda")
+    csum = torch.zeros(B, Cout, 2, dtype=torch.float64, device="cuda")
+    _lib.check(lib.buddy_gn_upconv3x3_winograd6(P(x), P(gamma), P(beta), G, silu, P(U), P(b), P(y), P(scratch), P(stats), stat_scratch.data_ptr(),
+                                                csum.data_ptr() if stat else None, B, H, W, Cin, Cout, S()))
+    torch.cuda.synchronize()
+    e = rel(y, ref.float())
+    print(f"sub-pixel up conv {B}x{H}x{W} {Cin}->{Cout}: {e:.2e}")
+    assert e < 1e-4
+    if stat:
+        yd = y.double()
+        s_ref, q_ref = yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))
+        assert float((csum[..., 0] - s_ref).abs().max() / yd.abs().sum(dim=(1, 2)).max()) < 1e-6
+        assert float((csum[..., 1] - q_ref).abs().max() / q_ref.max()) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,C,Cout,silu", [(2, 16, 16, 32, 32, 1), (1, 32, 20, 256, 128, 1), (2, 13, 18, 64, 64, 0), (1, 24, 36, 256, 256, 1)])
+def test_gnbwd_upconv3x3_winograd6(lib, B, H, W, C, Cout, silu):
+    """Backward of the same piece of the up block: gradient w.r.t. the LOW-resolution input u of Conv_0(upsample(u)) for dx = the input-gradient of
+    act(GroupNorm_1(h)) under the incoming da (h, da at (2H, 2W)): GroupNorm backward apply + space-to-depth inside the input transform, flipped
+    phase kernels (kind 61, dgrad), output at (H, W) -- against fp64 autograd through upsample + conv + GroupNorm.  2e-4 like the plain form."""
+    from buddy_amd import _lib
+    G = min(C // 4, 32)
+    gen = torch.Generator(device="cpu").manual_seed(B * 1000 + C + Cout + 62)
+    h = (torch.randn(B, 2 * H, 2 * W, C, generator=gen) * 1.5 + 0.3).cuda()   # Conv_0's output (+ bias), NHWC
+    da = torch.randn(B, 2 * H, 2 * W, C, generator=gen).cuda()
+    gamma = (1 + 0.2 * torch.randn(C, generator=gen)).cuda()
+    beta = (0.2 * torch.randn(C, generator=gen)).cuda()
+    w = (torch.randn(C, Cout, 3, 3, generator=gen) / np.sqrt(9 * Cout)).cuda()   # Conv_0: Cout (low-res channels) -> C
+    hd = h.permute(0, 3, 2, 1).double().requires_grad_(True)
+    z = F.group_norm(hd, G, gamma.double(), beta.double(), eps=1e-6)
+    a = F.silu(z) if silu else z
+    dx, = torch.autograd.grad(a, hd, da.permute(0, 3, 2, 1).double())
+    u = torch.zeros(B, Cout, W, H, dtype=torch.float64, device="cuda", requires_grad=True)
+    hh = F.conv2d(F.interpolate(u, scale_factor=2, mode="nearest"), w.double(), None, padding=1)
+    ref, = torch.autograd.grad(hh, u, dx)
+    ref = ref.permute(0, 3, 2, 1)                                               # (B, H, W, Cout)
+    hg = h.permute(0, 3, 1, 2).double().reshape(B, G, C // G, 4 * H * W)
+    mean = hg.mean(dim=(2, 3)); rstd = 1.0 / torch.sqrt(hg.var(dim=(2, 3), unbiased=False) + 1e-6)
+    stats = torch.stack([mean, rstd], dim=-1).float().contiguous()
+    U = torch.full((256 * C * Cout,), float("nan"), device="cuda")
+    _lib.check(lib.buddy_conv3_weight_prep(P(w.contiguous()), C, Cout, 1, 61, P(U), S()))
+    y = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    scratch = torch.empty(64 * B * ((H + 5) // 6) * ((W + 5) // 6) * (4 * C + Cout), device="cuda")
+    stat_scratch = torch.empty(B * 256 * C * 2, dtype=torch.float64, device="cuda")
+    red = torch.empty(B, G, 2, device="cuda")
+    _lib.check(lib.buddy_gnbwd_upconv3x3_winograd6(P(h), P(gamma), P(beta), P(stats), P(da), G, silu, P(U), P(y), P(scratch), stat_scratch.data_ptr(), P(red),
+                                                   B, H, W, C, Cout, S()))
+    torch.cuda.synchronize()
+    e = rel(y, ref.float())
+    print(f"gn-bwd + sub-pixel up data-gradient {B}x{H}x{W} {C}->{Cout}: {e:.2e}")
+    assert e < 2e-4
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("C,silu", [(32, 1), (96, 1), (128, 0), (384, 1), (512, 1)])
 def test_groupnorm_act_fwd_bwd(lib, mode, C, silu):
