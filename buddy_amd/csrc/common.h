@@ -67,7 +67,7 @@ bool wino6_supported(const IgemmParams& p);
 bool wino6_pays(const IgemmParams& p);
 void wino6_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats, int up = 0);
 int wino6_stat_chunks(const IgemmParams& p, int up = 0);
-double wino6_exec_ratio(const IgemmParams& p);
+double wino6_exec_ratio(const IgemmParams& p, int up = 0);
 //   bwd_gn (with stat) -- data-gradient convolutions: the output is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); the partials are the two sums
 //           of that GroupNorm's backward, (dxhat, dxhat * xhat), instead of (sum, sum of squares)
 //   up -- sub-pixel forms of conv3x3(nearest-upsample x2) (1) and of its data-gradient (2); p describes the LOW resolution (wino6.hip)

@@ -550,6 +550,7 @@ struct Conv3 {
 // grid: no upsampled activation in HBM, V 4x smaller, the data-gradient's M and da 4x smaller.  Needs the F(6x6,3x3) path with the GroupNorm
 // fusions on the low-resolution geometry.
 static bool conv3_up_ok(Net* N, int B, int H, int W, int Cin, int Cout) {
+  if (H < 7 || W < 7) return false;
   static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
   static const bool on = mode.empty() && !(getenv("BUDDY_GN_FUSE") && atoi(getenv("BUDDY_GN_FUSE")) == 0) &&
                          !(getenv("BUDDY_GN_FUSE_BWDIN") && atoi(getenv("BUDDY_GN_FUSE_BWDIN")) == 0) &&
@@ -577,7 +578,8 @@ static int conv3(Net* N, const Conv3& c) {
       if (need > N->w4_need) N->w4_need = need;
     }
     if (use_wino6 && wino_ok && H >= 6 && W >= 6) {
-      const size_t need = (size_t)64 * ((size_t)B * ((H + 5) / 6) * ((W + 5) / 6)) * (size_t)((c.up == 2 ? 4 : 1) * Cin + (c.up == 1 ? 4 : 1) * Cout);
+      const size_t th = c.up == 1 ? H / 7 + 1 : c.up == 2 ? (H + 6) / 7 : (H + 5) / 6, tw = c.up == 1 ? W / 7 + 1 : c.up == 2 ? (W + 6) / 7 : (W + 5) / 6;
+      const size_t need = (size_t)64 * ((size_t)B * th * tw) * (size_t)((c.up == 2 ? 4 : 1) * Cin + (c.up == 1 ? 4 : 1) * Cout);
       if (need > N->w4_need) N->w4_need = need;
     }
     return 0;
@@ -594,7 +596,7 @@ static int conv3(Net* N, const Conv3& c) {
     const int sc = (c.up == 1 ? stat_out != nullptr : want_bwd) ? wino6_stat_chunks(p, c.up) : 0;
     const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;
     IgemmParams pr = p; pr.M = 4 * p.M;                       // the direct-convolution work is that of the (2H, 2W) grid
-    const double xr = wino6_exec_ratio(p);
+    const double xr = wino6_exec_ratio(p, c.up);
     igemm_prof_record(pr, 9, 1, N->st, true, xr);
     launch_wino6(p, wv->u, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, (stat && want_bwd) ? bwd_gn : nullptr,
                  x3 ? wv->x : nullptr, c.up);

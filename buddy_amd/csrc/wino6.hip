@@ -55,15 +55,30 @@ __device__ __forceinline__ void at8(const float4 (&m)[8], float4 (&y)[6]) {
   y[5] = d12 + 32.f * d34 + 0.03125f * d56 + m[7];
 }
 
+// y = A^T m (8 -> 7): F(7x7,2x2) on the same points / the same B^T (the sub-pixel up forms: every phase of conv3x3(upsample x2) is a 2x2-tap
+// correlation on the low-resolution grid)
+__device__ __forceinline__ void at8(const float4 (&m)[8], float4 (&y)[7]) {
+  const float4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
+  y[0] = m[0] + s12 + s34 + s56;
+  y[1] = d12 + 2.f * d34 + 0.5f * d56;
+  y[2] = s12 + 4.f * s34 + 0.25f * s56;
+  y[3] = d12 + 8.f * d34 + 0.125f * d56;
+  y[4] = s12 + 16.f * s34 + 0.0625f * s56;
+  y[5] = d12 + 32.f * d34 + 0.03125f * d56;
+  y[6] = s12 + 64.f * s34 + 0.015625f * s56 + m[7];
+}
+
 struct W6Geo { int B, H, W, TH, TW, QC, TPB; long long Mt; int xcd; int Cl; };   // TH x TW tiles per utterance, Mt = B * TH * TW; Cl: see S2D / UP
 
 // grid (ceil(Mt / TPB), ceil(q / QC)); V[(pos * Mt + tile) * Cin + c]
 // GN 1: the input is act(GroupNorm(x)) of a (channel-concatenated) view, applied while loading (zero padding applies to the ACTIVATED tensor)
 // GN 2: the input is the GroupNorm backward of the gradient gn.da: rstd * (dxhat - m1 - xhat * m2), dxhat = da * act'(z) * gamma (the tensor the
 //       separate apply pass would write and this transform read back)
-// S2D (sub-pixel form of the data-gradient of conv3x3(nearest-upsample x2), launch_wino6 up = 2): the input is a (2H, 2W, Cl) tensor read as its
-//       space-to-depth image (H, W, 4 Cl): channel c' = ph * Cl + c, ph = 2 py + px, is pixel (2 y + py, 2 x + px) of channel c.  Single source.
-template <int GN, bool S2D = false>
+// TS: tile stride = outputs per tile and axis: 6 = F(6x6,3x3); 7 = F(7x7,2x2) of the sub-pixel up forms (same 8x8 patch, same B^T).
+// S2D (sub-pixel form of the data-gradient of conv3x3(nearest-upsample x2), launch_wino6 up = 2; TS = 7): the input is a (2H, 2W, Cl) tensor read as
+//       its space-to-depth image (H, W, 4 Cl): channel c' = ph * Cl + c, ph = 2 py + px, is pixel (2 y + py, 2 x + px) of channel c; the patch of phase
+//       (py, px) starts at (7 ty - py, 7 tx - px) (the even phase reads rows i, i + 1 of its image, the odd one i - 1, i).  Single source.
+template <int GN, bool S2D = false, int TS = 6>
 __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__ x, int ldX, const W4Gn gn, float* __restrict__ V, int Cin,
                                                        const W6Geo geo) {
   __shared__ float4 lds[32 * 64];
@@ -101,7 +116,7 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
     } else {
       x += cl;
     }
-    const int gx = 6 * tx - 1 + col, gy0 = 6 * ty - 1;
+    const int gx = TS * tx - (S2D ? px : 1) + col, gy0 = TS * ty - (S2D ? py : 1);
     float4 d[8], t[8];
     // All loads of the column first, UNCONDITIONAL, from coordinates clamped into the image; the zero padding is applied to the value afterwards.
     // With the load inside `if (inside)` next to the GroupNorm arithmetic the compiler kept every row's load -> wait -> SiLU chain to itself (10
@@ -165,11 +180,12 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
 // the reduction pass over (x, da) disappears.  fp32 over the (at most 36 x walk) pixels a thread sees, fp64 beyond.
 // UP (sub-pixel form of conv3x3(nearest-upsample x2), launch_wino6 up = 1): M holds 4 N columns, column n' = ph * N + n = output channel n of phase
 // ph = 2 py + px; tile pixel (y, x) of phase ph is pixel (2 y + py, 2 x + px) of the (2H, 2W, N) output (depth-to-space).  The statistics partials
-// of phase ph are chunks [ph * chunks, (ph + 1) * chunks) of 4 * chunks per utterance.  No residual.
-template <int STAT, bool UP = false>
+// of phase ph are chunks [ph * chunks, (ph + 1) * chunks) of 4 * chunks per utterance.  No residual.  TS = 7: tile row r of phase py is row
+// 7 ty + r - py of the phase image (the patch starts at low-resolution row 7 ty - 1 for both phases).
+template <int STAT, bool UP = false, int TS = 6>
 __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict__ Mb, const IgemmParams p, const W6Geo geo, int chunks, int TL,
                                                         double* __restrict__ stat, const W4Gn bg) {
-  __shared__ float4 lds[32 * 48];
+  __shared__ float4 lds[32 * TS * 8];
   __shared__ double red[STAT ? 256 * 8 : 1];
   const int tid = threadIdx.x, QC = geo.QC;
   const int ql = tid % QC, col = (tid / QC) & 7, tl = tid / (QC * 8);
@@ -207,37 +223,37 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
     const bool live = chan && lt < tpb;
     const long long tile = (long long)b * tpb + lt;
     // STAT 2: this thread's row of x is requested now, together with the M loads of phase 1, not after the LDS exchange
-    float4 xpre[6];
-    if (STAT == 2 && live && col < 6) {
-      const int ty = lt / geo.TW, tx = lt - ty * geo.TW, hh = min(6 * ty + col, H - 1);
+    float4 xpre[TS];
+    if (STAT == 2 && live && col < TS) {
+      const int ty = lt / geo.TW, tx = lt - ty * geo.TW, hh = min(TS * ty + col, H - 1);
 #pragma unroll
-      for (int cc = 0; cc < 6; ++cc) {                        // unconditional (clamped pixel): only read where the output pixel exists
-        const int ww = min(6 * tx + cc, W - 1);
+      for (int cc = 0; cc < TS; ++cc) {                       // unconditional (clamped pixel): only read where the output pixel exists
+        const int ww = min(TS * tx + cc, W - 1);
         xpre[cc] = ld4(xsrc + (((long long)b * H + hh) * W + ww) * ldx);
       }
     }
     if (live) {
       const float* src = Mb + tile * NM + nq;
-      float4 m[8], s[6];
+      float4 m[8], s[TS];
 #pragma unroll
       for (int i = 0; i < 8; ++i) m[i] = ld4(src + (long long)(i * 8 + col) * ps);
       at8(m, s);                                             // column: s[:, col] = A^T m[:, col]
 #pragma unroll
-      for (int r = 0; r < 6; ++r) lds[(tl * 48 + r * 8 + col) * QC + ql] = s[r];
+      for (int r = 0; r < TS; ++r) lds[(tl * (TS * 8) + r * 8 + col) * QC + ql] = s[r];
     }
     __syncthreads();
-    if (live && col < 6) {
+    if (live && col < TS) {
       const int r = col, ty = lt / geo.TW, tx = lt - ty * geo.TW;
-      const int hh = 6 * ty + r;
-      float4 m[8], y[6];
+      const int hh = TS * ty + r - (UP ? py : 0);
+      float4 m[8], y[TS];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m[j] = lds[(tl * 48 + r * 8 + j) * QC + ql];
+      for (int j = 0; j < 8; ++j) m[j] = lds[(tl * (TS * 8) + r * 8 + j) * QC + ql];
       at8(m, y);                                             // row: y[r, :] = s[r, :] A
-      if (hh < H) {
+      if ((unsigned)hh < (unsigned)H) {
 #pragma unroll
-        for (int cc = 0; cc < 6; ++cc) {
-          const int ww = 6 * tx + cc;
-          if (ww < W) {
+        for (int cc = 0; cc < TS; ++cc) {
+          const int ww = TS * tx + cc - (UP ? px : 0);
+          if ((unsigned)ww < (unsigned)W) {
             const long long pix = UP ? ((long long)b * (2 * H) + 2 * hh + py) * (2 * W) + 2 * ww + px : ((long long)b * H + hh) * W + ww;
             float4 v = p.alpha * y[cc] + add;
             if (UP) {}
@@ -289,10 +305,13 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
   }
 }
 
-W6Geo geometry(const IgemmParams& p, int C) {
+// tiles per axis: F(6x6,3x3) ceil(n / 6); sub-pixel up form (F(7x7,2x2) tiles on the low-resolution grid, patch origin 7 t - 1): forward
+// floor(n / 7) + 1 (the odd phase's last output row n - 1 is row n - 1 + 1 of the tiling), data-gradient ceil(n / 7)
+int tiles_axis(int n, int up) { return up == 1 ? n / 7 + 1 : up == 2 ? (n + 6) / 7 : (n + 5) / 6; }
+W6Geo geometry(const IgemmParams& p, int C, int up = 0) {
   W6Geo g;
   g.H = p.H; g.W = p.W; g.B = p.M / (p.H * p.W);
-  g.TH = (p.H + 5) / 6; g.TW = (p.W + 5) / 6;
+  g.TH = tiles_axis(p.H, up); g.TW = tiles_axis(p.W, up);
   g.Mt = (long long)g.B * g.TH * g.TW;
   const int q = C / 4;
   g.QC = q >= 32 ? 32 : (q > 16 ? 32 : (q > 8 ? 16 : (q > 4 ? 8 : (q > 2 ? 4 : (q > 1 ? 2 : 1)))));
@@ -321,17 +340,17 @@ bool wino6_pays(const IgemmParams& p) {
   return tiles6 * 64.0 <= 0.90 * tiles4 * 36.0 && tiles6 >= 128;
 }
 void wino6_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats, int up) {
-  const long long Mt = (long long)(p.M / (p.H * p.W)) * ((p.H + 5) / 6) * ((p.W + 5) / 6);
+  const long long Mt = (long long)(p.M / (p.H * p.W)) * tiles_axis(p.H, up) * tiles_axis(p.W, up);
   *v_floats = 64 * Mt * p.Cin * (up == 2 ? 4 : 1); *m_floats = 64 * Mt * p.N * (up == 1 ? 4 : 1);
 }
 int wino6_stat_chunks(const IgemmParams& p, int up) {
   if (p.N % 4) return 0;
-  const W6Geo g = geometry(p, up == 1 ? 4 * p.N : p.N);
+  const W6Geo g = geometry(p, up == 1 ? 4 * p.N : p.N, up);
   const int per = g.TPB * out_walk(g, up);
   return (up == 1 ? 4 : 1) * ((g.TH * g.TW + per - 1) / per);
 }
-double wino6_exec_ratio(const IgemmParams& p) {               // executed / direct-convolution multiply-adds
-  const W6Geo g = geometry(p, p.N);
+double wino6_exec_ratio(const IgemmParams& p, int up) {       // executed / direct-convolution multiply-adds (sub-pixel forms: 4 x 64 per tile, 4 M pixels)
+  const W6Geo g = geometry(p, p.N, up);
   return 64.0 * (double)g.Mt / (9.0 * (double)p.M);
 }
 
@@ -343,7 +362,7 @@ double wino6_exec_ratio(const IgemmParams& p) {               // executed / dire
 void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat, const W4Gn* bwd_gn,
                   const void* U6x, int up) {
   const int CinG = up == 2 ? 4 * p.Cin : p.Cin, NG = up == 1 ? 4 * p.N : p.N;       // K and N of the batched GEMM
-  W6Geo gi = geometry(p, CinG), go = geometry(p, NG);
+  W6Geo gi = geometry(p, CinG, up), go = geometry(p, NG, up);
   gi.Cl = p.Cin; go.Cl = p.N;
   const long long Mt = gi.Mt;
   const int plevel = igemm_prof_level();
@@ -353,8 +372,11 @@ void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hi
   if (prof_gemm) { (void)hipEventCreate(&ev[1]); (void)hipEventCreate(&ev[2]); }
   const dim3 grid_in((unsigned)((Mt + gi.TPB - 1) / gi.TPB), (unsigned)((CinG / 4 + gi.QC - 1) / gi.QC));
   if (up == 2) {
-    if (gn && gn->da) hipLaunchKernelGGL((w6_input_kernel<2, true>), grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, CinG, gi);
-    else hipLaunchKernelGGL((w6_input_kernel<0, true>), grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, CinG, gi);
+    if (gn && gn->da) hipLaunchKernelGGL((w6_input_kernel<2, true, 7>), grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, CinG, gi);
+    else hipLaunchKernelGGL((w6_input_kernel<0, true, 7>), grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, CinG, gi);
+  } else if (up == 1) {
+    if (gn) hipLaunchKernelGGL((w6_input_kernel<1, false, 7>), grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
+    else hipLaunchKernelGGL((w6_input_kernel<0, false, 7>), grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, p.Cin, gi);
   }
   else if (gn && gn->da) hipLaunchKernelGGL(w6_input_kernel<2>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
   else if (gn) hipLaunchKernelGGL(w6_input_kernel<1>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
@@ -374,8 +396,11 @@ void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hi
   const int TL = out_walk(go, up), per = go.TPB * TL, chunks = (go.TH * go.TW + per - 1) / per;
   const dim3 grid_out((unsigned)(go.B * chunks), (unsigned)((NG / 4 + go.QC - 1) / go.QC));
   if (up == 1) {
-    if (stat) hipLaunchKernelGGL((w6_output_kernel<1, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, W4Gn{});
-    else hipLaunchKernelGGL((w6_output_kernel<0, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
+    if (stat) hipLaunchKernelGGL((w6_output_kernel<1, true, 7>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, W4Gn{});
+    else hipLaunchKernelGGL((w6_output_kernel<0, true, 7>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
+  } else if (up == 2) {
+    if (stat && bwd_gn) hipLaunchKernelGGL((w6_output_kernel<2, false, 7>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, *bwd_gn);
+    else hipLaunchKernelGGL((w6_output_kernel<0, false, 7>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
   }
   else if (stat && bwd_gn) hipLaunchKernelGGL(w6_output_kernel<2>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, *bwd_gn);
   else if (stat) hipLaunchKernelGGL(w6_output_kernel<1>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, W4Gn{});

@@ -78,12 +78,13 @@ __global__ __launch_bounds__(256) void conv3_weight_prep_kernel(const float* __r
 }
 
 // Sub-pixel form of conv3x3(nearest-upsample x2 of x) (the BigGAN up block's Conv_0, reference layerspp.py:246-257 with up_or_down_sampling.py
-// naive_upsample_2d) in the F(6x6,3x3) domain.  Output pixel (2 i + py, 2 j + px) only ever reads low-resolution pixels (i - 1 + py .. i + py) x
-// (j - 1 + px .. j + px): per axis the three taps fold into a zero-padded 3-tap kernel on the low-resolution grid,
-//   py = 0: [g0, g1 + g2, 0],   py = 1: [0, g0 + g1, g2]     (offsets -1, 0, +1)
-// so the convolution is an ordinary 3x3 convolution with 4 O output channels (phase-major: column ph * O + o, ph = 2 py + px) followed by a
-// depth-to-space; its data-gradient is an ordinary 3x3 convolution from the 4 O space-to-depth channels of the gradient to I channels with the
-// flipped kernels.  One thread per (co', ci') of the Winograd-domain GEMM: forward [64][4 O][I], data-gradient [64][I][4 O].  fp64, un-contracted.
+// naive_upsample_2d) in the Winograd domain.  Output pixel (2 i + py, 2 j + px) only ever reads the low-resolution pixels (i - 1 + py, i + py) x
+// (j - 1 + px, j + px): per axis the three taps fold into TWO taps on the low-resolution grid,
+//   py = 0: [g0, g1 + g2] on rows (i - 1, i),   py = 1: [g0 + g1, g2] on rows (i, i + 1)
+// so each phase is a 2x2-tap correlation, evaluated as F(7x7,2x2) on the F(6x6,3x3) points (same 8x8 patch and B^T; G rows c [1, p]; wino6.hip):
+// the convolution is one input transform at the low resolution, a GEMM with 4 O columns (phase-major: column ph * O + o, ph = 2 py + px) and a
+// depth-to-space output transform; its data-gradient is a GEMM from the 4 O space-to-depth channels of the gradient to I channels with each
+// phase's taps flipped.  One thread per (co', ci') of the Winograd-domain GEMM: forward [64][4 O][I], data-gradient [64][I][4 O].  fp64, un-contracted.
 __global__ __launch_bounds__(256) void conv3_up_weight_prep_kernel(const float* __restrict__ w, int O, int I, int dgrad, float* __restrict__ out) {
 #pragma clang fp contract(off)
   const int Co = dgrad ? I : 4 * O, Ci = dgrad ? 4 * O : I;
@@ -97,32 +98,31 @@ __global__ __launch_bounds__(256) void conv3_up_weight_prep_kernel(const float* 
   for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) g[dy][dx] = (double)src[dx * 3 + dy];
-  double k[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  double k[2][2] = {{0, 0}, {0, 0}};
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-      const int ey = py == 0 ? (dy == 0 ? 0 : 1) : (dy == 2 ? 2 : 1), ex = px == 0 ? (dx == 0 ? 0 : 1) : (dx == 2 ? 2 : 1);
+      const int ey = py == 0 ? (dy == 0 ? 0 : 1) : (dy == 2 ? 1 : 0), ex = px == 0 ? (dx == 0 ? 0 : 1) : (dx == 2 ? 1 : 0);
       k[ey][ex] = k[ey][ex] + g[dy][dx];
     }
-  if (dgrad) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { const double t0 = k[a][0]; k[a][0] = k[a][2]; k[a][2] = t0; }
-#pragma unroll
-    for (int b = 0; b < 3; ++b) { const double t0 = k[0][b]; k[0][b] = k[2][b]; k[2][b] = t0; }
+  if (dgrad) {                                                // the adjoint of a correlation: both axes flipped
+    const double t0 = k[0][0]; k[0][0] = k[1][1]; k[1][1] = t0;
+    const double t1 = k[0][1]; k[0][1] = k[1][0]; k[1][0] = t1;
   }
   double G[8][3];
-  g_rows(6, G);
-  double t[8][3];
+  g_rows(6, G);                                               // F(7x7,2x2) on the same points: the first two columns (c, c p); the point at infinity takes the last tap
+  G[7][1] = 1.0;
+  double t[8][2];
 #pragma unroll
   for (int xi = 0; xi < 8; ++xi)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) t[xi][b] = G[xi][0] * k[0][b] + G[xi][1] * k[1][b] + G[xi][2] * k[2][b];
+    for (int b = 0; b < 2; ++b) t[xi][b] = G[xi][0] * k[0][b] + G[xi][1] * k[1][b];
 #pragma unroll
   for (int xi = 0; xi < 8; ++xi)
 #pragma unroll
     for (int nu = 0; nu < 8; ++nu) {
-      const double u = t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2];
+      const double u = t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1];
       out[((long long)(xi * 8 + nu) * Co + co) * Ci + ci] = (float)u;
     }
 }

@@ -153,7 +153,7 @@ def test_bench_line_contract():
     cs = j["cold_start"]
     assert 0.0 < cs["cold_start_s"] < 1.5 and 0.0 < cs["first_step_ms"] < 3000.0, cs
     ws = cs["weight_store_bytes"]
-    assert ws["conv3_forms"] < 2.6e9 and ws["params"] < 1.2e8, ws          # shared by every replica (round 3: 5.7 GB per handle)
+    assert ws["conv3_forms"] < 3.2e9 and ws["params"] < 1.2e8, ws          # shared by every replica (round 3: 5.7 GB per handle); the sub-pixel up forms carry 4 phase kernels each
     assert "one stream" in j["value_mode"]
     for name in ("informed_order2", "informed_order2_B1", "blind_B1", "forward_only", "longform_480000_B4"):
         leg = j["legs"][name]
