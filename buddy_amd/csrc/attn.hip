@@ -587,15 +587,19 @@ __global__ __launch_bounds__(256) void flash16_bwd_dkv_kernel(const float* __res
 
 bool flash_attn_supported(int C) { return C == 64 || C == 128 || C == 256; }
 
-// Loop splits for a grid of cdiv(T, 64) * B workgroups (fp32 kernels only): as many as keep the grid within ONE workgroup per CU (measured at T = 2048,
-// tools/attn_split_bench.py: B = 1: 8 splits 0.47 / 1.31 -> 0.08 / 0.20 ms forward / backward, 16 splits 0.085 / 0.22; B = 2: 4 splits 0.13 / 0.36,
-// 8 splits 0.14 / 0.38; B = 4: 2 splits 0.26 / 0.69; B = 8: none 0.48 / 1.32, 2 splits 0.49 / 1.36 -- a second workgroup per CU buys nothing), at
-// least four 32-row blocks each, every split non-empty.  BUDDY_ATTN_SPLIT=n forces n (1 = never split).
+// Loop splits of the fp32 kernels: a function of T ALONE -- what fills the chip for ONE utterance (cdiv(T, 64) workgroups per split, up to 256 in
+// all; at least four 32-row blocks per split, every split non-empty).  The count fixes the summation order of every row, so it must not depend on
+// the batch: row b of a batched call equals the B = 1 call bit for bit (tests/test_hip_fullsize.py, tests/test_hip_multirank.py: a sharded run
+// equals the single-process run).  Measured at T = 2048 (tools/attn_split_bench.py, forward / backward ms): B = 1: none 0.47 / 1.31, 8 splits
+// 0.076 / 0.203; B = 2: 0.47 / 1.31 -> 0.141 / 0.379; B = 4: 0.47 / 1.31 -> 0.270 / 0.746; B = 8: 0.477 / 1.317 -> 0.535 / 1.530 (the price of
+// the rule: +0.27 ms on a 68 ms step; a batch-dependent count would save it and lose the reproducibility).  Long form (T = 15008): no split.
+// BUDDY_ATTN_SPLIT=n forces n (1 = never split).
 int flash_attn_splits(int B, int T, int prec) {
+  (void)B;
   if (prec != 0) return 1;
   static const int force = getenv("BUDDY_ATTN_SPLIT") ? atoi(getenv("BUDDY_ATTN_SPLIT")) : 0;
   const int nb = cdiv(T, BC);
-  const long long wgs = (long long)cdiv(T, BR) * B;
+  const long long wgs = (long long)cdiv(T, BR);
   int ns = force > 0 ? force : (int)(256 / (wgs > 0 ? wgs : 1));
   if (ns > nb / 4) ns = nb / 4;
   if (ns < 1) ns = 1;

@@ -198,8 +198,9 @@ int buddy_flash_attention_fwd(const float* q, const float* k, const float* v, fl
 int buddy_flash_attention_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta,
                               float* dq, float* dk, float* dv, int B, int T, int C, float scale, int prec, void* stream);
 /* The same fp32 kernels with their sequential loop (keys in fwd / dq, queries in dk / dv) split over `splits` workgroups per row block and the partial
- * results combined in fixed split order (no atomics): what the network uses when B * T / 64 workgroups would leave most of the 256 CUs idle -- ONE
- * utterance at a time is the reference's own shape (testing/tester.py:132-153).  buddy_flash_attention_splits = the count the network would pick,
+ * results combined in fixed split order (no atomics): what the network uses when T / 64 workgroups per utterance would leave most of the 256 CUs idle
+ * -- ONE utterance at a time is the reference's own shape (testing/tester.py:132-153).  buddy_flash_attention_splits = the count the network picks: a
+ * function of T alone (B is ignored), so that a row's result does not depend on the batch it is computed in,
  * buddy_flash_attention_workspace = floats of `ws` for a count (splits <= 0: for the picked one); every split must own at least one 32-row block. */
 int buddy_flash_attention_splits(int B, int T);
 long long buddy_flash_attention_workspace(int B, int T, int C, int splits);
