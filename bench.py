@@ -41,7 +41,7 @@ PEAK_BF16_MFMA = 2500.0  # TFLOP/s, MI355X dense bf16 matrix peak (MI355X_MICROA
 SETUP = {}     # wall times of the one-off set-up pieces of the FIRST stack (rank-local): reported as `cold_start`
 
 
-def build_stack(args_ns, device, B, first_utt, net=None, tester_cfg="blind_dereverberation_BUDDy", blind=True, T=None, length=None, extra=()):
+def build_stack(args_ns, device, B, first_utt, net=None, tester_cfg="blind_dereverberation_BUDDy", blind=True, T=None, length=None, extra=(), attention=None):
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
@@ -70,7 +70,7 @@ def build_stack(args_ns, device, B, first_utt, net=None, tester_cfg="blind_derev
         torch.cuda.synchronize()
         SETUP["cold_start_s"] = time.perf_counter() - t0
     else:
-        net = net.replica()             # same prepared weights (shared, read-only), own activation arena / VJP tape
+        net = net.replica(attention=attention)   # same prepared weights (shared, read-only), own activation arena / VJP tape
     edm = instantiate(args.diff_params)
     tester = Tester(args, net, edm, test_set=None, device=device, in_training=True)
     if tester_cfg == "only_unconditional":
@@ -545,8 +545,9 @@ def main():
                            "warmup": n_warm}, **extra)
         log(f"leg {name}: {legs[name]['ms_per_step']:.2f} ms/step")
 
-    def stack_runner(tester_cfg, Bl, blind, T, length=None, extra=()):
-        _, _, _, tester, _, y, op = build_stack(a, device, Bl, rank * Bl, net0[0], tester_cfg=tester_cfg, blind=blind, T=T, length=length, extra=extra)
+    def stack_runner(tester_cfg, Bl, blind, T, length=None, extra=(), attention=None):
+        _, _, _, tester, _, y, op = build_stack(a, device, Bl, rank * Bl, net0[0], tester_cfg=tester_cfg, blind=blind, T=T, length=length, extra=extra,
+                                                attention=attention)
         return StepRunner(tester, y, op, device, blind=blind)
 
     if "informed" in want:       # (ii) of BASELINE.md section 3: informed sampler, order 2 (two forward+VJP evaluations per step), T=10 schedule
@@ -580,6 +581,13 @@ def main():
         legs["longform_480000_B4"]["value_in_4s_units"] = legs["longform_480000_B4"]["value"] * 7.5
         del r_
         torch.cuda.empty_cache()
+        if not a.attention:      # ... and as configs[4] words it: "fp16 MFMA attention path" (opt-in fast mode, DESIGN.md section 7: inside the 0.1 dB gate)
+            r_ = stack_runner("blind_dereverberation_BUDDy", 4, True, a.T, length=480000, attention="f16")
+            time_leg("longform_480000_B4_f16", r_, 4, 3, 1, {"config": "as longform_480000_B4 with the attention kernels on f16 MFMA operands (fp32 accumulation and softmax "
+                                                                       "statistics) -- the 'fp16 MFMA attention path' BASELINE configs[4] names; everything else fp32", "attention": "f16"})
+            legs["longform_480000_B4_f16"]["value_in_4s_units"] = legs["longform_480000_B4_f16"]["value"] * 7.5
+            del r_
+            torch.cuda.empty_cache()
 
     # ---- one REAL run end to end: predict_conditional over the whole T-step schedule, init included; then the end-of-run gather ---------------
     full_run = None

@@ -165,7 +165,10 @@ class NCSNppTime(nn.Module):
     def _get_handle(self):
         if self._handle is None and getattr(self, "_parent", None) is not None:
             h = C.c_void_p()
-            _lib.check(_lib.require_gpu().buddy_ncsnpp_replica(self._parent._get_handle(), C.byref(h)))
+            lib = _lib.require_gpu()
+            _lib.check(lib.buddy_ncsnpp_replica(self._parent._get_handle(), C.byref(h)))
+            if self.attention is not None:      # per-handle setting: a replica may run another attention core on the shared weights
+                _lib.check(lib.buddy_ncsnpp_set_attention(h, self.ATTENTION_MODES[self.attention]))
             self._handle = h
         if self._handle is None:
             lib = _lib.require_gpu()
@@ -183,12 +186,16 @@ class NCSNppTime(nn.Module):
             self._handle = h
         return self._handle
 
-    def replica(self):
+    def replica(self, attention=None):
         """A second module on the SAME parameters and the same prepared device weights (``buddy_ncsnpp_replica``: reference-counted, read-only)
         with its own library handle -- activation arena + VJP tape -- so another sub-batch can run concurrently on another HIP stream
-        (buddy_amd/testing/concurrent.py).  Costs no weight memory and no preparation time.  A replica follows the weights its parent had
+        (buddy_amd/testing/concurrent.py).  Costs no weight memory and no preparation time.  ``attention``: the replica's attention core (per-handle).  A replica follows the weights its parent had
         when the replica's handle was made; reload the parent -> make new replicas."""
         r = copy.copy(self)                     # shallow: shares _parameters / _modules (the nn.Parameters themselves)
+        if attention is not None:
+            if attention not in self.ATTENTION_MODES:
+                raise NotImplementedError(f"attention must be one of {sorted(self.ATTENTION_MODES)}")
+            r.attention = attention
         r._handle = None
         r._fwd_id = 0
         object.__setattr__(r, "_parent", self)   # not a submodule: nn.Module.__setattr__ would register it in the shared _modules
