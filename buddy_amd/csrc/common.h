@@ -47,6 +47,11 @@ void launch_wino(const IgemmParams& p, const float* Uw, hipStream_t st);
 void wino_transform_weights(const float* wt_host, int Cout, int Cin, float* U_host);
 struct Src2 { const float* p0; const float* p1; int C0; int ld0; int ld1; };   // channel-concatenated input view
 struct Dst2 { float* p0; float* p1; int C0; int ld0; int ld1; int acc0; int acc1; };
+// the skip path's 1x1 data-gradient GEMM with the GroupNorm_0 backward's apply pass as its epilogue (wgemm.hip, GNB): d (two-destination channel view,
+// accumulating where its acc flag says) = alpha * A (M x K) W^T (N x K, bf16x3 image) + rstd * (dxhat - m1 - xhat * m2) of (x, da); stats / red [B][G][2]
+bool wgemm_gnbwd_supported(int N, int K, int ldA, const Src2& x, const Dst2& d, const void* A, const void* da);
+void launch_wgemm_bf16x3_gnbwd(const float* A, int ldA, const void* W3, long long M, int N, int K, float alpha, Src2 x, const float* da, const float* stats,
+                               const float* red, const float* gamma, const float* beta, int G, int silu, int HW, Dst2 d, hipStream_t st);
 // Winograd F(4x4,3x3) in three passes (wino4.hip): weights U4[36][Cout][Cin], scratch V (36*M/16*Cin floats) and Mb (36*M/16*N floats)
 // Fusions with the GroupNorms either side of the convolution (both optional):
 //   gn   -- the input is act(GroupNorm(gn->x)) of a same-resolution (concatenated) view, applied inside the input transform (p.A0 unused)

@@ -758,6 +758,25 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       const size_t mk = n->arena.off;
       const float* dout = out->g;
       const float* extra; int extra_mode = 1; float extra_scale = 1.f;
+      Dst2 d0 = gdst_of(x);
+      // skip path through Conv_2 at the block's input resolution: its 1x1 data-gradient GEMM takes the GroupNorm_0 backward's apply pass as its epilogue
+      // (wgemm.hip GNB): the block's input gradient in one launch, neither the 1x1 result nor a separate apply pass in HBM
+      const W3Img* c2i = nullptr;
+      const float* c2a = dout;                               // A operand of that GEMM (the pooled gradient for the sub-pixel up block)
+      static const bool fuse_c2_on = !(getenv("BUDDY_C2_FUSE") && atoi(getenv("BUDDY_C2_FUSE")) == 0);     // A/B switch
+      if (fuse_c2_on && Rp->has_c2 && !firm && (mode == 0 || (mode == 2 && up6)) && n->gemm_mode == 1 && Cin % 4 == 0 && (Cin / G0) % 4 == 0) {
+        const auto it = n->W->w3.find(Rp->c2.wb);
+        if (it != n->W->w3.end() && it->second.N == Cin && it->second.K == Cout && wgemm_gnbwd_supported(Cin, Cout, Cout, src_of(x), d0, dout, dout))
+          c2i = &it->second;
+      }
+      if (c2i) {
+        if (mode == 2) {
+          float* pooled = n->tmp((long long)B * H * W * Cout);
+          if (!n->dry()) launch_pool2(dout, pooled, B, Ho, Wo, Cout, 1.f, 0, s);
+          c2a = pooled;
+        }
+        extra = nullptr;
+      } else
       if (Rp->has_c2) {
         float* tx;
         if (firm) {                                        // d x_resampled at (Ho, Wo), then the FIR adjoint back to (H, W)
@@ -802,7 +821,16 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       d0c.out = da0; d0c.gn = &gb1; d0c.gn_tmp = dh1; d0c.bwd_gn = (mode == 0 || up6) ? &b0 : nullptr;
       if (up6) { d0c.H = H; d0c.W = W; d0c.up = 2; }      // da0 comes out at (H, W): the nearest-upsample's adjoint is inside the convolution
       const int s0 = conv3(n, d0c);
-      Dst2 d0 = gdst_of(x);
+      if (c2i) {
+        if (!n->dry()) {
+          launch_gn_bwd_sums(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0, B, H, W, Cin, G0, 0, 1, n->partial, n->red, s, s0);
+          IgemmParams pr = ig_base(); pr.M = B * H * W; pr.N = Cin; pr.Cin = Cout;
+          igemm_prof_record(pr, 1, 1, s, true, 1.0);
+          launch_wgemm_bf16x3_gnbwd(c2a, Cout, c2i->img, (long long)B * H * W, Cin, Cout, INV_SQRT2, src_of(x), da0, stats0, n->red, Rp->gn0.gamma,
+                                    Rp->gn0.beta, G0, 1, H * W, d0, s);
+          igemm_prof_record(pr, 1, 1, s, false, 1.0);
+        }
+      } else
       if (firm) {
         float* da0f = n->tmp((long long)B * H * W * Cin);
         if (!n->dry()) {

@@ -84,13 +84,24 @@ struct WgemmArgs {
   // general form (GEN = true; 1x1 convolutions, NIN): A from up to two sources (channel concatenation, split at C0), row strides, C = alpha * A W^T
   // + bias [+ C]
   const float* A1; int C0, ldA0, ldA1, ldC; const float* bias_n; float alpha; int accumulate;
+  // GNB epilogue (general form): C = alpha * A W^T + the GroupNorm backward's apply pass, written to a two-destination view
+  Src2 gxv; Dst2 gd; const float* gda; const float* gstats; const float* gred; const float* ggamma; const float* gbeta; int gG, gsilu, gHW;
 };
+
+__device__ __forceinline__ float dsilu_g(float z) {
+  const float s = __builtin_amdgcn_rcpf(1.f + __expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
 
 // GEN: the general form (two-source A, row strides, alpha / bias / accumulate epilogue).  EPI: the accumulator tile goes through a wave-private LDS
 // slab (the weight buffers are free after the last stage) and leaves as 256-byte row pieces instead of 32-byte pieces per lane pair.
 // Measured and rejected (profiles/README.md r03a): a second stage of A in flight (190 VGPRs: -3 %), 64 rows per wave (256+ VGPRs: -25 %), two
 // instead of three workgroups per CU (-2...4 %).
-template <bool GEN, bool EPI>
+// GNB (with GEN): the skip path's 1x1 data-gradient of a ResBlock (Conv_2^T, layerspp.py:262-264) and the GroupNorm_0 backward's apply pass in ONE launch:
+// out[row][c] = alpha * (A W^T)[row][c] + rstd * (dxhat - m1 - xhat * m2), dxhat = da * act'(z) * gamma -- the block's whole input gradient.  The separate
+// apply kernel read x, da and the materialised 1x1 result and wrote dx (5 C-channel streams with the GEMM's store); here the epilogue reads x and da and
+// writes dx (3).  x / out are two-source / two-destination channel views split at a multiple of 128 (a column block never straddles).
+template <bool GEN, bool EPI, bool GNB = false>
 __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -175,11 +186,12 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
   }
 
   // epilogue: accumulator = C^T tile, lane (row = lane & 31, h = lane >> 5) holds channels 8 g + 4 h + 0..3 of each 32-channel block
-  if (EPI && !GEN) {
+  if (EPI && !GNB) {
     constexpr int SP = 68;                                   // floats per staged row (64 columns + 4: conflict-free 16-byte writes down a column)
     float* St = reinterpret_cast<float*>(smem) + wid * (32 * SP);
     const int rr = lane >> 4, c4 = (lane & 15) * 4;
-    float* Mrow = a.M + (long long)p * a.sM + (long long)(m0 + wid * 32) * a.Cout + nb * WBN;
+    const long long ldc = GEN ? a.ldC : a.Cout;
+    float* Mrow = a.M + (long long)p * a.sM + (long long)(m0 + wid * 32) * ldc + nb * WBN;
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
@@ -190,11 +202,96 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
               make_float4(acc[2 * hb + cl][4 * g], acc[2 * hb + cl][4 * g + 1], acc[2 * hb + cl][4 * g + 2], acc[2 * hb + cl][4 * g + 3]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      if (GEN) {                                              // general form: alpha * acc, + bias, + C (same operation order as the direct-store epilogue)
+        float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias_n) bs = *reinterpret_cast<const float4*>(a.bias_n + nb * WBN + hb * 64 + c4);
+        float4 pv[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {                       // previous values (accumulate) in flight together, rows clamped
+          const int r = min(4 * it + rr, a.Mt - 1 - (m0 + wid * 32));
+          pv[it] = a.accumulate ? *reinterpret_cast<const float4*>(Mrow + (long long)r * ldc + hb * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int r = 4 * it + rr;
+          float4 v = *reinterpret_cast<const float4*>(St + r * SP + c4);
+          v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+          if (a.bias_n) { v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w; }
+          if (a.accumulate) { v.x += pv[it].x; v.y += pv[it].y; v.z += pv[it].z; v.w += pv[it].w; }
+          if (m0 + wid * 32 + r < a.Mt) *reinterpret_cast<float4*>(Mrow + (long long)r * ldc + hb * 64 + c4) = v;
+        }
+      } else {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int r = 4 * it + rr;
         const float4 v = *reinterpret_cast<const float4*>(St + r * SP + c4);
         if (m0 + wid * 32 + r < a.Mt) *reinterpret_cast<float4*>(Mrow + (long long)r * a.Cout + hb * 64 + c4) = v;
+      }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  if constexpr (GNB) {
+    // The accumulator tile goes through the wave-private LDS slab of the EPI epilogue so that a lane owns 16-byte pieces of 256-byte ROW pieces
+    // (16 lanes per row): the x / da loads and the dx stores are whole cache lines (in MFMA order a lane pair covers 32 bytes of 32 rows).
+    constexpr int SP = 68;
+    float* St = reinterpret_cast<float*>(smem) + wid * (32 * SP);
+    const int rr = lane >> 4, c4 = (lane & 15) * 4;
+    const int rbase = m0 + wid * 32;
+    const int cpg = a.Cout / a.gG;
+    const bool second = a.gxv.p1 != nullptr && nb * WBN >= a.gxv.C0, dsecond = a.gd.p1 != nullptr && nb * WBN >= a.gd.C0;
+    const long long ldx = second ? a.gxv.ld1 : a.gxv.ld0, ldo = dsecond ? a.gd.ld1 : a.gd.ld0;
+    const bool accd = (dsecond ? a.gd.acc1 : a.gd.acc0) != 0;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int col = nb * WBN + hb * 64 + c4, grp = col / cpg;
+      const float* xs = (second ? a.gxv.p1 + (col - a.gxv.C0) : a.gxv.p0 + col);
+      float* o = (dsecond ? a.gd.p1 + (col - a.gd.C0) : a.gd.p0 + col);
+      const float* das = a.gda + col;
+      const float4 gm = *reinterpret_cast<const float4*>(a.ggamma + col), bt = *reinterpret_cast<const float4*>(a.gbeta + col);
+      const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(St + (lane & 31) * SP + cl * 32 + 8 * g + 4 * (lane >> 5)) =
+              make_float4(acc[2 * hb + cl][4 * g], acc[2 * hb + cl][4 * g + 1], acc[2 * hb + cl][4 * g + 2], acc[2 * hb + cl][4 * g + 3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // 16 rows at a time: the loads of the batch first (rows clamped: never stored past Mt), then the arithmetic (registers: 12 float4 + 16 scalars)
+#pragma unroll
+      for (int bt4 = 0; bt4 < 2; ++bt4) {
+        float4 xv[4], dv[4], pv[4];
+        float mean[4], rstd[4], m1[4], m2[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int r = min(rbase + 16 * bt4 + 4 * it + rr, a.Mt - 1), bb = r / a.gHW;
+          xv[it] = *reinterpret_cast<const float4*>(xs + (long long)r * ldx);
+          dv[it] = *reinterpret_cast<const float4*>(das + (long long)r * a.Cout);
+          pv[it] = accd ? *reinterpret_cast<const float4*>(o + (long long)r * ldo) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float2 sm = *reinterpret_cast<const float2*>(a.gstats + ((long long)bb * a.gG + grp) * 2), rm = *reinterpret_cast<const float2*>(a.gred + ((long long)bb * a.gG + grp) * 2);
+          mean[it] = sm.x; rstd[it] = sm.y; m1[it] = rm.x; m2[it] = rm.y;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int rl = 16 * bt4 + 4 * it + rr;
+          const float4 cv = *reinterpret_cast<const float4*>(St + rl * SP + c4);
+          const float x4[4] = {xv[it].x, xv[it].y, xv[it].z, xv[it].w}, d4[4] = {dv[it].x, dv[it].y, dv[it].z, dv[it].w};
+          const float p4[4] = {pv[it].x, pv[it].y, pv[it].z, pv[it].w}, c4v[4] = {cv.x, cv.y, cv.z, cv.w};
+          float r[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {                         // same operation order as gn_bwd_apply_m0_kernel: GroupNorm term, + extra_scale * extra, + previous
+            const float xh = (x4[j] - mean[it]) * rstd[it];
+            const float z = xh * g4[j] + b4[j];
+            const float dxh = d4[j] * (a.gsilu ? dsilu_g(z) : 1.f) * g4[j];
+            r[j] = rstd[it] * (dxh - m1[it] - xh * m2[it]);
+            r[j] += a.alpha * c4v[j];
+            r[j] += p4[j];
+          }
+          if (rbase + rl < a.Mt) *reinterpret_cast<float4*>(o + (long long)(rbase + rl) * ldo) = make_float4(r[0], r[1], r[2], r[3]);
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -233,17 +330,38 @@ bool wgemm_general_supported(int N, int K, int C0, int ldA0, int ldA1, int ldC, 
 }
 void launch_wgemm_bf16x3_general(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W3, float* C, int ldC, long long M, int N, int K,
                                  const float* bias_n, float alpha, int accumulate, hipStream_t st) {
-  WgemmArgs a;
+  WgemmArgs a{};
   a.V = A0; a.U3 = reinterpret_cast<const unsigned char*>(W3); a.M = C;
   a.Mt = (int)M; a.Cin = K; a.Cout = N; a.S = K / WKS; a.NB = N / WBN; a.sV = 0; a.sM = 0;
   a.A1 = A1; a.C0 = A1 ? C0 : K; a.ldA0 = ldA0; a.ldA1 = ldA1; a.ldC = ldC; a.bias_n = bias_n; a.alpha = alpha; a.accumulate = accumulate;
   a.pz = 0; a.gx = 0;
   const dim3 grid((unsigned)(cdiv((int)M, WBM) * a.NB), 1, 1);
-  hipLaunchKernelGGL((wgemm_bf16x3_kernel<true, false>), grid, dim3(WNT), 0, st, a);
+  static const bool direct_store = getenv("BUDDY_WGEMM_GEN_EPI") && atoi(getenv("BUDDY_WGEMM_GEN_EPI")) == 0;      // A/B switch: 32-byte-piece stores
+  if (direct_store) hipLaunchKernelGGL((wgemm_bf16x3_kernel<true, false>), grid, dim3(WNT), 0, st, a);
+  else hipLaunchKernelGGL((wgemm_bf16x3_kernel<true, true>), grid, dim3(WNT), 0, st, a);
+}
+
+// out (two-destination view) = alpha * A (M x K) . W^T (N x K, pre-split) + GroupNorm backward apply of (x, da): see the GNB epilogue
+bool wgemm_gnbwd_supported(int N, int K, int ldA, const Src2& x, const Dst2& d, const void* A, const void* da) {
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool split_ok = (x.p1 == nullptr || x.C0 % WBN == 0) && (d.p1 == nullptr || d.C0 % WBN == 0);
+  return wgemm_supported(N, K) && ldA % 4 == 0 && split_ok && x.ld0 % 4 == 0 && x.ld1 % 4 == 0 && d.ld0 % 4 == 0 && d.ld1 % 4 == 0 && al16(A) && al16(da) &&
+         al16(x.p0) && al16(x.p1) && al16(d.p0) && al16(d.p1);
+}
+void launch_wgemm_bf16x3_gnbwd(const float* A, int ldA, const void* W3, long long M, int N, int K, float alpha, Src2 x, const float* da, const float* stats,
+                               const float* red, const float* gamma, const float* beta, int G, int silu, int HW, Dst2 d, hipStream_t st) {
+  WgemmArgs a{};
+  a.V = A; a.U3 = reinterpret_cast<const unsigned char*>(W3); a.M = nullptr;
+  a.Mt = (int)M; a.Cin = K; a.Cout = N; a.S = K / WKS; a.NB = N / WBN; a.sV = 0; a.sM = 0;
+  a.A1 = nullptr; a.C0 = K; a.ldA0 = ldA; a.ldA1 = 0; a.ldC = N; a.bias_n = nullptr; a.alpha = alpha; a.accumulate = 0;
+  a.pz = 0; a.gx = 0;
+  a.gxv = x; a.gd = d; a.gda = da; a.gstats = stats; a.gred = red; a.ggamma = gamma; a.gbeta = beta; a.gG = G; a.gsilu = silu; a.gHW = HW;
+  const dim3 grid((unsigned)(cdiv((int)M, WBM) * a.NB), 1, 1);
+  hipLaunchKernelGGL((wgemm_bf16x3_kernel<true, false, true>), grid, dim3(WNT), 0, st, a);
 }
 
 void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st) {
-  WgemmArgs a;
+  WgemmArgs a{};
   a.A1 = nullptr; a.C0 = Cin; a.ldA0 = Cin; a.ldA1 = 0; a.ldC = Cout; a.bias_n = nullptr; a.alpha = 1.f; a.accumulate = 0;
   a.V = V; a.U3 = reinterpret_cast<const unsigned char*>(U3); a.M = M;
   a.Mt = (int)Mt; a.Cin = Cin; a.Cout = Cout; a.S = Cin / WKS; a.NB = Cout / WBN;
