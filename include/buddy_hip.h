@@ -110,6 +110,14 @@ int buddy_gemm_winograd_domain_bf16x3(const float* V, const void* U3, float* M, 
  * channel concatenation is never materialised.  W3 = buddy_wgemm_pack_weights(W [N][K], ., 1, N, K).  N % 128, K % 32, C0 % 32 == 0. */
 int buddy_gemm_bf16x3(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W3, float* C, int ldC, long long M, int N, int K,
                       const float* bias_n, float alpha, int accumulate, void* stream);
+/* A ResBlock's input gradient in one GEMM launch (layerspp.py:242-274 backward): dx = alpha * A W^T + the input-gradient of act(GroupNorm(cat[x0, x1]))
+ * for the incoming da -- the skip path's 1x1 data-gradient (Conv_2^T; A = the block's output gradient, M = B * HW rows, K channels; W3 =
+ * buddy_wgemm_pack_weights(W [N][K], ., 1, N, K)) with the GroupNorm backward's apply pass as the GEMM's epilogue: neither the 1x1 result nor a separate
+ * apply pass reaches HBM.  x / dx: channel-concatenated views split at C0 (x1 = dx1 = NULL: one tensor); accK != 0: that destination accumulates.
+ * stats: forward (mean, rstd) [B][G][2]; red [B][G][2] out; stat_scratch >= B*256*N*16 bytes.  N % 128, K % 32, C0 % 128 == 0. */
+int buddy_gemm_bf16x3_gn_bwd(const float* A, int ldA, const void* W3, const float* x0, const float* x1, int C0, const float* da, const float* stats,
+                             const float* gamma, const float* beta, int G, int silu, float alpha, float* dx0, float* dx1, int acc0, int acc1,
+                             double* stat_scratch, float* red, int B, int HW, int N, int K, void* stream);
 /* NHWC 3x3 stride-1 pad-1 conv, packed weights wt[Cout][9*Cin] (tap-major, channel-minor); replaces ddpm_conv3x3
  * (networks/ncsnpp_utils/layers.py:119-126). */
 int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,

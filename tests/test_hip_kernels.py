@@ -102,6 +102,51 @@ def test_gemm_bf16x3_general_form(lib, M, N, K, C0):
     assert rel(Cc, 2 * ref - bias) < 2e-5
 
 
+@pytest.mark.parametrize("B,HW,N,K,C0,silu,acc", [(2, 300, 128, 128, 0, 1, 0), (1, 1000, 384, 128, 256, 1, 1), (3, 77, 256, 64, 128, 0, 1), (1, 4096, 512, 256, 256, 1, 0)])
+def test_gemm_bf16x3_gn_bwd(lib, B, HW, N, K, C0, silu, acc):
+    """buddy_gemm_bf16x3_gn_bwd: the skip path's 1x1 data-gradient GEMM with the GroupNorm_0 backward's apply pass as its epilogue (a ResBlock's input
+    gradient, reference layerspp.py:242-274 backward) against fp64 autograd: dx = alpha * A W^T + d/dx [act(GroupNorm(x))] . da, two-source x,
+    two-destination dx (the second accumulating), ragged M.  2e-5 for the GEMM term like the general form, 2e-4 of the abs-max overall (the
+    normalisation backward's cancellation, as test_gnbwd_conv3x3_winograd6)."""
+    from buddy_amd import _lib
+    G = min(N // 4, 32)
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + HW + N + K)
+    A = torch.randn(B * HW, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / np.sqrt(K)).cuda()
+    x = (torch.randn(B, HW, N, generator=g) * 1.5 + 0.3).cuda()
+    da = torch.randn(B, HW, N, generator=g).cuda()
+    gamma = (1 + 0.2 * torch.randn(N, generator=g)).cuda()
+    beta = (0.2 * torch.randn(N, generator=g)).cuda()
+    prev = torch.randn(B, HW, N, generator=g).cuda()
+    xd = x.double().permute(0, 2, 1).requires_grad_(True)                      # (B, C, HW) for F.group_norm
+    z = F.group_norm(xd, G, gamma.double(), beta.double(), eps=1e-6)
+    a = F.silu(z) if silu else z
+    gx, = torch.autograd.grad(a, xd, da.double().permute(0, 2, 1))
+    ref = 0.70710678 * (A.double() @ W.double().t()).reshape(B, HW, N) + gx.permute(0, 2, 1)
+    xg = x.double().permute(0, 2, 1).reshape(B, G, N // G, HW)
+    mean = xg.mean(dim=(2, 3)); rstd = 1.0 / torch.sqrt(xg.var(dim=(2, 3), unbiased=False) + 1e-6)
+    stats = torch.stack([mean, rstd], dim=-1).float().contiguous()
+    W3 = torch.empty(N * K * 6 // 4, dtype=torch.int32, device="cuda")
+    _lib.check(lib.buddy_wgemm_pack_weights(P(W), W3.data_ptr(), 1, N, K, S()))
+    x0 = x[..., :C0].contiguous() if C0 else x
+    x1 = x[..., C0:].contiguous() if C0 else None
+    d0 = torch.full_like(x0, float("nan"))
+    d1 = prev[..., C0:].contiguous() if C0 else None
+    if C0 and not acc:
+        d1.fill_(float("nan"))
+    stat_scratch = torch.empty(B * 256 * N * 2, dtype=torch.float64, device="cuda")
+    red = torch.empty(B, G, 2, device="cuda")
+    _lib.check(lib.buddy_gemm_bf16x3_gn_bwd(P(A), K, W3.data_ptr(), P(x0), P(x1) if C0 else None, C0, P(da), P(stats), P(gamma), P(beta), G, silu, 0.70710678,
+                                            P(d0), P(d1) if C0 else None, 0, acc if C0 else 0, stat_scratch.data_ptr(), P(red), B, HW, N, K, S()))
+    torch.cuda.synchronize()
+    out = torch.cat([d0, d1], dim=-1) if C0 else d0
+    if C0 and acc:
+        ref[..., C0:] += prev[..., C0:].double()
+    e = rel(out, ref.float())
+    print(f"1x1 data-gradient + GroupNorm backward apply {B}x{HW} K={K} -> {N}: {e:.2e}")
+    assert e < 2e-4
+
+
 def test_winograd_domain_gemm_bf16x3_layout(lib):
     """V = I-like selector against asymmetric weights: every (row, channel, k) lands where it should (exactly representable values)."""
     from buddy_amd import _lib
