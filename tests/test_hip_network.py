@@ -166,3 +166,40 @@ def test_cold_start_budget_and_shared_replica():
     assert torch.equal(yr, y)
     assert warm < 0.5, f"replica + its first forward took {warm:.2f} s"
     print(f"cold start {cold * 1e3:.0f} ms, replica first forward {warm * 1e3:.0f} ms, weight store {wb2}")
+
+
+_AB_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from tests.test_hip_network import build
+net = build(128, 510, 128, 0)
+rs = np.random.RandomState(11)
+L, B = 32768, 2
+x = torch.from_numpy((0.3 * rs.standard_normal((B, L))).astype(np.float32)).cuda().requires_grad_(True)
+cn = torch.tensor([-0.3, -1.2]).cuda()
+cot = torch.from_numpy(rs.standard_normal((B, L)).astype(np.float32)).cuda()
+y = net(x, cn)
+g, = torch.autograd.grad(y, x, cot)
+np.savez(sys.argv[2], y=y.detach().cpu().numpy(), g=g.cpu().numpy())
+"""
+
+
+def test_fused_round4_paths_equal_plain_paths(tmp_path):
+    """The two structural fusions of round 4 -- the up blocks' Conv_0 in sub-pixel form (BUDDY_UPCONV) and the skip path's 1x1 data-gradient GEMM with
+    the GroupNorm_0 backward apply as its epilogue (BUDDY_C2_FUSE) -- against the same build with both switched off (the plain three-pass convolution
+    on the materialised upsampled tensor; separate GEMM and apply launches), full-width network, forward and input-VJP.  Both sides are fp32
+    evaluations of the same function in a different summation order: 2e-5 of the abs-max (each holds 5e-4 against the reference fixtures)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ab.py"
+    script.write_text(_AB_SCRIPT)
+    outs = {}
+    for tag, env_over in (("fused", {}), ("plain", {"BUDDY_UPCONV": "0", "BUDDY_C2_FUSE": "0"})):
+        env = dict(os.environ, **env_over)
+        out = tmp_path / f"{tag}.npz"
+        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=env, timeout=600)
+        outs[tag] = np.load(out)
+    ey, eg = rel(outs["fused"]["y"], outs["plain"]["y"]), rel(outs["fused"]["g"], outs["plain"]["g"])
+    print(f"fused vs plain round-4 paths: forward {ey:.2e}, vjp {eg:.2e}")
+    assert not np.array_equal(outs["fused"]["g"], outs["plain"]["g"]), "the switches did not change the path"
+    assert ey < 2e-5 and eg < 2e-5
