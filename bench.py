@@ -324,8 +324,8 @@ def main():
                     "times and the rocprofv3 summary attribute cleanly (co-running kernels stretch each other's durations)")
     ap.add_argument("--also-concurrent", type=int, default=2, help="after the main region, time the same workload as this many concurrent sub-batches "
                     "in a second region and report it as `concurrent_sub_batches` (0 = skip)")
-    ap.add_argument("--attention", default=None, choices=["flash", "matrix", "bf16", "f16"], help="attention core of the network (default: the library's, "
-                    "fp32 online softmax; bf16 / f16 = the opt-in fast mode that passed the 0.1 dB gate, profiles/r02_attention_modes.json)")
+    ap.add_argument("--attention", default=None, choices=["auto", "flash", "matrix", "bf16", "f16"], help="attention core of the network (default: the library's, "
+                    "auto: fp32, materialised for T <= 4096, online softmax beyond; bf16 / f16 = the opt-in fast mode that passed the 0.1 dB gate, profiles/r02_attention_modes.json)")
     ap.add_argument("--gemm", default=None, choices=["bf16x3", "fp32"], help="arithmetic of the Winograd-domain GEMMs (default: the library's, bf16x3 = exact "
                     "three-way bf16 split of the fp32 operands, six bf16 MFMA products, fp32 accumulate; fp32 = v_mfma_f32_32x32x2_f32, the reference run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -576,7 +576,7 @@ def main():
     if "longform" in want:       # BASELINE configs[4], one-GPU slice: B=4 x 30 s un-chunked, fp32 flash attention unless --attention says otherwise
         r_ = stack_runner("blind_dereverberation_BUDDy", 4, True, a.T, length=480000)
         time_leg("longform_480000_B4", r_, 4, 3, 1, {"config": "blind step, B=4 x 480000 samples (30 s@16 kHz), un-chunked (BASELINE configs[4], one-GPU slice of "
-                                                               "batch=32 across 8)", "attention": a.attention or os.environ.get("BUDDY_ATTN", "flash (fp32)"),
+                                                               "batch=32 across 8)", "attention": a.attention or os.environ.get("BUDDY_ATTN", "auto (fp32; T = 15 008 > 4096: online-softmax kernels)"),
                                                     "value_in_4s_units": None})
         legs["longform_480000_B4"]["value_in_4s_units"] = legs["longform_480000_B4"]["value"] * 7.5
         del r_
@@ -697,7 +697,7 @@ def main():
             "config": {"workload": f"blind DPS sampler step, B={B} utterances/GPU x {a.length} samples ({a.length / 16000:g} s@16 kHz), T={a.T}-step schedule, "
                                    f"NCSN++ nf=128 STFT 510/128" + (" (BASELINE.json configs[1])" if (B == 8 and a.length == 64000) else ""),
                        "batch_per_gpu": B, "length": a.length, "T": a.T, "order": 1, "op_updates_per_step": 10,
-                       "parallelism": f"utterance-sharded x{world}", "sub_batches_per_gpu": S, "attention": a.attention or os.environ.get("BUDDY_ATTN", "flash (fp32)")},
+                       "parallelism": f"utterance-sharded x{world}", "sub_batches_per_gpu": S, "attention": a.attention or os.environ.get("BUDDY_ATTN", "auto (fp32: materialised T x T form for T <= 4096, online-softmax kernels beyond)")},
             "score_evals_per_s": n_utt_steps / elapsed,   # forward + input-VJP evaluations per second (order 1: one per utterance-step); forward-only: legs.forward_only
             "value_mode": ("one batch of B utterances on one stream (per-kernel attribution is clean); the harness default (Tester, groups of >= 4 "
                            "utterances) samples them as two concurrent sub-batches = `concurrent_sub_batches`") if S == 1 else f"{S} concurrent sub-batches",

@@ -170,7 +170,7 @@ struct Net {
   const float* k_cin = nullptr; const float* k_cskip = nullptr; const float* k_cout = nullptr;
 
   int rsv_B = 0, rsv_L = 0, rsv_vjp = -1;   // shape the arena was last sized for (the sizing dry run is skipped while it still fits)
-  int attn_mode = 0;           // see attn_mode_from_env()
+  int attn_mode = 4;           // see attn_mode_from_env()
   int gemm_mode = 1;           // Winograd-domain GEMM arithmetic: 1 = bf16x3 (exact three-way split, default), 0 = fp32 MFMA; BUDDY_GEMM=fp32|bf16x3
   bool prep_failed = false;    // a lazily prepared weight form could not be built (out of memory): the call reports it
   bool fir = false;            // fir=True: FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257)
@@ -451,7 +451,7 @@ int net_weight_bytes(Net* N, long long* params, long long* packed, long long* la
   return BUDDY_OK;
 }
 
-int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 3) { set_error("attention mode must be 0..3"); return BUDDY_ERR_ARG; } N->attn_mode = mode; N->rsv_vjp = -1; return BUDDY_OK; }
+int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 4) { set_error("attention mode must be 0..4"); return BUDDY_ERR_ARG; } N->attn_mode = mode; N->rsv_vjp = -1; return BUDDY_OK; }
 int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 1) { set_error("gemm mode must be 0 (fp32 MFMA) or 1 (bf16x3)"); return BUDDY_ERR_ARG; } N->gemm_mode = mode; return BUDDY_OK; }
 int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; return BUDDY_OK; }
 void net_destroy(Net* N) {
@@ -858,15 +858,22 @@ static void gemm_b(Net* N, const float* A, int ldA, long long sA, bool tA, const
   launch_igemm(p, 1, tA, tB, batch, N->st);
 }
 
-// Attention mode of a handle: 0 = flash, fp32 operands (default); 1 / 2 = flash with bf16 / f16 MFMA operands (opt-in fast mode, DESIGN.md
-// section 7); 3 = the materialised T x T form (P in HBM: 16.8 MB / utterance at 4 s, 905 MB at 30 s).  Initialised from BUDDY_ATTN
-// (matrix | flash | bf16 | f16), changed per handle with buddy_ncsnpp_set_attention.
+// Attention mode of a handle: 4 = auto (default): fp32 throughout, the materialised T x T form (the reference's own formulation, layerspp.py:82-86) while
+// the matrix is small -- T <= ATTN_MATRIX_MAX_T: 16.8 MB / utterance at 4 s -- and the online-softmax (flash) kernels beyond (905 MB / utterance at 30 s
+// never exists).  Measured at B = 8, T = 2048 (tools/ab_env.sh BUDDY_ATTN flash matrix): 65.4 -> 64.6 ms/step: six plain batched GEMMs at 100+ TFLOP/s
+// beat kernels that run one wave per SIMD.  The choice depends on T alone: a row's arithmetic does not depend on the batch it is in.
+// 0 = flash, fp32 operands; 1 / 2 = flash with bf16 / f16 MFMA operands (opt-in fast mode); 3 = always the materialised form.
+// Initialised from BUDDY_ATTN (auto | matrix | flash | bf16 | f16), changed per handle with buddy_ncsnpp_set_attention.
+constexpr int ATTN_MATRIX_MAX_T = 4096;
 static int attn_mode_from_env() {
   const char* e = getenv("BUDDY_ATTN");
   const std::string m = e ? e : "";
-  return m == "matrix" ? 3 : m == "bf16" ? 1 : m == "f16" ? 2 : 0;
+  return m == "matrix" ? 3 : m == "bf16" ? 1 : m == "f16" ? 2 : m == "flash" ? 0 : 4;
 }
-static bool attn_use_flash(const Net* N, int C) { return N->attn_mode != 3 && flash_attn_supported(C); }
+static bool attn_use_flash(const Net* N, int C, int T) {
+  if (!flash_attn_supported(C) || N->attn_mode == 3) return false;
+  return N->attn_mode != 4 || T > ATTN_MATRIX_MAX_T;
+}
 static int attn_prec(const Net* N) { return N->attn_mode == 1 || N->attn_mode == 2 ? N->attn_mode : 0; }
 
 static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
@@ -922,7 +929,7 @@ static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
 }
 
 static Tens* attnblock(Net* N, const AttnW& A, Tens* x, bool rec) {
-  if (attn_use_flash(N, A.C)) return attnblock_flash(N, A, x, rec);
+  if (attn_use_flash(N, A.C, x->H * x->W)) return attnblock_flash(N, A, x, rec);
   const int B = x->B, H = x->H, W = x->W, C = A.C, T = H * W, G = gn_groups(C);
   hipStream_t st = N->st;
   const float scale = 1.f / std::sqrt((float)C);

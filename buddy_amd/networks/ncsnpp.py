@@ -64,7 +64,7 @@ class _NetFn(torch.autograd.Function):
 
 
 class NCSNppTime(nn.Module):
-    ATTENTION_MODES = {"flash": 0, "bf16": 1, "f16": 2, "matrix": 3}
+    ATTENTION_MODES = {"flash": 0, "bf16": 1, "f16": 2, "matrix": 3, "auto": 4}
     GEMM_MODES = {"fp32": 0, "bf16x3": 1}
 
     def __init__(self, stft=None, nonlinearity="swish", nf=128, ch_mult=(1, 2, 2, 2), num_res_blocks=1,
@@ -104,7 +104,7 @@ class NCSNppTime(nn.Module):
         self.n_fft, self.hop_length = int(get("n_fft")), int(get("hop_length"))
         assert bool(get("center")), "center=False not supported"
         self.nf, self.ch_mult, self.num_res_blocks = int(nf), tuple(int(c) for c in ch_mult), int(num_res_blocks)
-        # attention core: None = library default (BUDDY_ATTN, else "flash"); "flash" | "bf16" | "f16" | "matrix" (build extension, not a reference key:
+        # attention core: None = library default (BUDDY_ATTN, else "auto": fp32, materialised while T <= 4096, flash beyond); "auto" | "flash" | "bf16" | "f16" | "matrix" (build extension, not a reference key:
         # bf16 / f16 are the opt-in fast mode of DESIGN.md section 7)
         if attention is not None and attention not in self.ATTENTION_MODES:
             raise NotImplementedError(f"attention must be one of {sorted(self.ATTENTION_MODES)}")

@@ -190,8 +190,9 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
  * The transposes are the other direction times 4 resp. 1/4.  buddy_ncsnpp_set_fir switches a network handle to this resampling (no parameters). */
 int buddy_fir_resample2(const float* x, float* y, int B, int H, int W, int C, int up, float scale, int accumulate, void* stream);
 int buddy_ncsnpp_set_fir(void* handle, int fir);
-/* attention core of a network handle: 0 = online-softmax kernels, fp32 operands (default); 1 / 2 = the same with bf16 / f16 MFMA operands (opt-in
- * fast mode, fp32 accumulate + fp32 softmax); 3 = materialised T x T matrix.  Initial value from BUDDY_ATTN = flash | bf16 | f16 | matrix. */
+/* attention core of a network handle: 4 = auto (default; fp32: the materialised T x T form while T <= 4096, the online-softmax kernels beyond -- a
+ * function of T alone); 0 = online-softmax kernels, fp32 operands; 1 / 2 = the same with bf16 / f16 MFMA operands (opt-in fast mode, fp32 accumulate
+ * + fp32 softmax); 3 = always the materialised T x T matrix.  Initial value from BUDDY_ATTN = auto | flash | bf16 | f16 | matrix. */
 int buddy_ncsnpp_set_attention(void* handle, int mode);
 /* Arithmetic of the Winograd-domain GEMMs of the 3x3 convolutions (94 % of the FLOPs): 1 (default) = "bf16x3" -- every fp32 operand split
  * exactly into three bf16 terms, six bf16 MFMA products, fp32 accumulation: the fp32 kernel's accuracy against float64 (unit test) at
