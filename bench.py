@@ -564,8 +564,16 @@ def main():
     if "blind_b1" in want:
         r_ = stack_runner("blind_dereverberation_BUDDy", 1, True, a.T)
         time_leg("blind_B1", r_, 1, 6, 2, {"config": f"the headline blind step with B=1 x {a.length} samples: per-utterance latency, the reference's own shape "
-                                                     "(testing/tester.py:132-153 samples one utterance at a time)"})
+                                                     "(testing/tester.py:132-153 samples one utterance at a time)",
+                                           "attention": a.attention or os.environ.get("BUDDY_ATTN", "auto (materialised form at this length)")})
         del r_
+        if not a.attention and not os.environ.get("BUDDY_ATTN"):
+            # the attention default is a function of T alone (rows must not depend on their batch): the materialised form it picks at 4 s wins at B = 8 and
+            # loses at B = 1 (four of its six products have 32 output tiles per utterance); +network.attention=flash is the single-utterance setting
+            r_ = stack_runner("blind_dereverberation_BUDDy", 1, True, a.T, attention="flash")
+            time_leg("blind_B1_flash", r_, 1, 6, 2, {"config": "as blind_B1 with attention=flash (online-softmax kernels, 8-way loop split): the single-utterance latency setting",
+                                                     "attention": "flash"})
+            del r_
     if "forward_only" in want:   # score-network forward evaluations only (unconditional Euler-Heun sampler, order 2: two forwards per step)
         _, _, _, tester_u, _, _, _ = build_stack(a, device, B, 0, net0[0], tester_cfg="only_unconditional", T=a.T)
         r_ = UncondRunner(tester_u, B, a.length, device)

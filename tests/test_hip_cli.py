@@ -155,7 +155,7 @@ def test_bench_line_contract():
     ws = cs["weight_store_bytes"]
     assert ws["conv3_forms"] < 3.2e9 and ws["params"] < 1.2e8, ws          # shared by every replica (round 3: 5.7 GB per handle); the sub-pixel up forms carry 4 phase kernels each
     assert "one stream" in j["value_mode"]
-    for name in ("informed_order2", "informed_order2_B1", "blind_B1", "forward_only", "longform_480000_B4", "longform_480000_B4_f16"):
+    for name in ("informed_order2", "informed_order2_B1", "blind_B1", "blind_B1_flash", "forward_only", "longform_480000_B4", "longform_480000_B4_f16"):
         leg = j["legs"][name]
         assert leg["ms_per_step"] > 0 and leg["value"] > 0 and leg["unit"] == "utterance-steps/s" and leg["config"], name
     assert j["legs"]["longform_480000_B4"]["attention"]
