@@ -966,14 +966,29 @@ static Tens* attnblock(Net* N, const AttnW& A, Tens* x, bool rec) {
       const long long TC = (long long)T * C, TT = (long long)T * T;
       float* dO = n->tmp(B * TC); float* dP = n->tmp(B * TT); float* dvT = n->tmp(B * TC);
       float* dq = n->tmp(B * TC); float* dk = n->tmp(B * TC); float* dhn = n->tmp(B * TC);
+      // P^T and dS^T by a tiled transpose (T % 32 == 0): the two products that need them then take the row-major-A kernel (and its half-height tiles when
+      // the grid is small) instead of the doubly transposed one (272 us per launch at B = 8 against 41 + ~150)
+      static const bool use_tr = !(getenv("BUDDY_ATTN_TR") && atoi(getenv("BUDDY_ATTN_TR")) == 0);     // A/B switch
+      const bool tr = use_tr && T % 32 == 0;
+      float* Tr = tr ? n->tmp(B * TT) : nullptr;
       gemm_b(n, dout, C, 0, false, Ap->Wn[3], C, 0, false, dO, C, 0, B * T, C, C, nullptr, nullptr, INV_SQRT2, 0, 1);
       gemm_b(n, dO, C, TC, false, vT, T, TC, true, dP, T, TT, T, T, C, nullptr, nullptr, 1.f, 0, B);        // dP = dO V^T
+      if (tr) {
+        if (!n->dry()) launch_transpose_sq(P, Tr, B, T, s);
+        gemm_b(n, Tr, T, TT, false, dO, C, TC, true, dvT, C, TC, T, C, T, nullptr, nullptr, 1.f, 0, B);     // dV = P^T dO  (dvT holds dV [T][C] here)
+      } else
       gemm_b(n, dO, C, TC, true, P, T, TT, true, dvT, T, TC, C, T, T, nullptr, nullptr, 1.f, 0, B);         // dV^T = dO^T P
       if (!n->dry()) launch_softmax_bwd_rows(P, dP, B * T, T, s);                                           // dP <- dS
       gemm_b(n, dP, T, TT, false, k, C, TC, true, dq, C, TC, T, C, T, nullptr, nullptr, scale, 0, B);        // dq = scale dS k
+      if (tr) {
+        if (!n->dry()) launch_transpose_sq(dP, Tr, B, T, s);
+        gemm_b(n, Tr, T, TT, false, q, C, TC, true, dk, C, TC, T, C, T, nullptr, nullptr, scale, 0, B);      // dk = scale dS^T q
+      } else
       gemm_b(n, dP, T, TT, true, q, C, TC, true, dk, C, TC, T, C, T, nullptr, nullptr, scale, 0, B);         // dk = scale dS^T q
       gemm_b(n, dq, C, 0, false, Ap->Wn[0], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 0, 1);
       gemm_b(n, dk, C, 0, false, Ap->Wn[1], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);
+      if (tr) gemm_b(n, dvT, C, 0, false, Ap->Wn[2], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);
+      else
       gemm_b(n, dvT, T, TC, true, Ap->Wn[2], C, 0, false, dhn, C, TC, T, C, C, nullptr, nullptr, 1.f, 1, B);
       View xv; xv.a = x;
       Dst2 d = gdst_of(xv);

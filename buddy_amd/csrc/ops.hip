@@ -449,6 +449,19 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* P, f
   for (int j = lane; j < cols; j += 64) d[j] = p[j] * (d[j] - s);
 }
 
+// dst[b][j][i] = src[b][i][j], n x n per batch entry, 32 x 32 tiles through LDS (both sides coalesced); n % 32 == 0
+__global__ __launch_bounds__(256) void transpose_sq_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  __shared__ float tile[32][33];
+  const long long base = (long long)blockIdx.z * n * n;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[ty + 8 * r][tx] = src[base + (long long)(i0 + ty + 8 * r) * n + j0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dst[base + (long long)(j0 + ty + 8 * r) * n + i0 + tx] = tile[tx][ty + 8 * r];
+}
+
 // y[b][n] = sum_k act(x[b][k]) W[n][k] + bias[n]; one wave per output
 __global__ __launch_bounds__(256) void linear_kernel(const float* x, const float* Wt, const float* bias, float* y, int B, int K, int N, int silu_in) {
   const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1000,6 +1013,9 @@ void launch_up2_acc(const float* src, float* dst, int B, int Hs, int Ws, int C, 
   hipLaunchKernelGGL(up2_acc_kernel, dim3(grid_for((long long)B * Hs * Ws * 4 * (C / 2))), dim3(256), 0, st, src, dst, B, Hs, Ws, C, scale, accumulate);
 }
 
+void launch_transpose_sq(const float* src, float* dst, int batch, int n, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_sq_kernel, dim3(n / 32, n / 32, batch), dim3(256), 0, st, src, dst, n);
+}
 void launch_softmax_rows(float* S, int rows, int cols, hipStream_t st) {
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, S, rows, cols);
 }
