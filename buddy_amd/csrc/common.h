@@ -149,7 +149,6 @@ void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float
                            int splits, hipStream_t st);
 void launch_flash_attn_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* Lse, float* D, float* dq,
                            float* dk, float* dv, int B, int T, int C, float scale, int prec, float* ws, int splits, hipStream_t st);
-void launch_transpose_sq(const float* src, float* dst, int batch, int n, hipStream_t st);   // dst[b] = src[b]^T, n x n, n % 32 == 0
 void launch_softmax_rows(float* S, int rows, int cols, hipStream_t st);
 void launch_softmax_bwd_rows(const float* P, float* dP /*in: dP, out: dS*/, int rows, int cols, hipStream_t st);
 void launch_linear(const float* x, const float* W, const float* b, float* y, int B, int K, int N, int silu_in, hipStream_t st);

@@ -928,6 +928,7 @@ static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
   return out;
 }
 
+void launch_transpose_sq(const float* src, float* dst, int batch, int n, hipStream_t st);   // ops.hip: dst[b] = src[b]^T, n x n, n % 32 == 0
 static Tens* attnblock(Net* N, const AttnW& A, Tens* x, bool rec) {
   if (attn_use_flash(N, A.C, x->H * x->W)) return attnblock_flash(N, A, x, rec);
   const int B = x->B, H = x->H, W = x->W, C = A.C, T = H * W, G = gn_groups(C);
