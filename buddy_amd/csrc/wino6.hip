@@ -333,11 +333,13 @@ bool wino6_supported(const IgemmParams& p) {
          (p.bias_bn == nullptr || p.ld_bias_bn % 4 == 0) && al16(p.A0) && al16(p.C) && al16(p.res) && al16(p.bias_n) && al16(p.bias_bn) &&
          (long long)((p.H + 5) / 6) * ((p.W + 5) / 6) * (p.M / (p.H * p.W)) * 64 < (1LL << 31);
 }
-// worth it against F(4x4,3x3): executed multiply-adds 64 per 6x6 tile (overhang included) against 36 per 4x4 tile, with a margin for the
-// second LDS phase of the transforms; small layers stay with F(4x4,3x3)
+// worth it against F(4x4,3x3): executed multiply-adds 64 per 6x6 tile (overhang included) against 36 per 4x4 tile (at least 5 % fewer), and at least 64
+// tiles per utterance.  Round 4: the thresholds were 10 % / 128 tiles, which left the bottleneck level of the shipped network (32 x 64 per 4 s utterance: 66
+// tiles, 8 % fewer multiply-adds) on F(4x4,3x3); that path has no GroupNorm-backward fusions (sums in the output transform, apply in the input
+// transform), so moving it here saves those passes too: 65.46 -> 64.98 ms/step A/B, one denoiser evaluation 117.0 / 112.7 -> 115.3 / 110.4 dB to float64.
 bool wino6_pays(const IgemmParams& p) {
   const double tiles6 = (double)((p.H + 5) / 6) * ((p.W + 5) / 6), tiles4 = (double)p.H * p.W / 16.0;
-  return tiles6 * 64.0 <= 0.90 * tiles4 * 36.0 && tiles6 >= 128;
+  return tiles6 * 64.0 <= 0.95 * tiles4 * 36.0 && tiles6 >= 64;
 }
 void wino6_scratch(const IgemmParams& p, long long* v_floats, long long* m_floats, int up) {
   const long long Mt = (long long)(p.M / (p.H * p.W)) * tiles_axis(p.H, up) * tiles_axis(p.W, up);
