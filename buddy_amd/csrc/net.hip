@@ -452,7 +452,7 @@ int net_weight_bytes(Net* N, long long* params, long long* packed, long long* la
 }
 
 int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 4) { set_error("attention mode must be 0..4"); return BUDDY_ERR_ARG; } N->attn_mode = mode; N->rsv_vjp = -1; return BUDDY_OK; }
-int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 1) { set_error("gemm mode must be 0 (fp32 MFMA) or 1 (bf16x3)"); return BUDDY_ERR_ARG; } N->gemm_mode = mode; return BUDDY_OK; }
+int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 1) { set_error("gemm mode must be 0 (fp32 MFMA) or 1 (bf16x3)"); return BUDDY_ERR_ARG; } N->gemm_mode = mode; N->rsv_vjp = -1; return BUDDY_OK; }
 int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; return BUDDY_OK; }
 void net_destroy(Net* N) {
   if (!N) return;
@@ -565,6 +565,7 @@ static bool conv3_up_ok(Net* N, int B, int H, int W, int Cin, int Cout) {
 }
 static int conv3(Net* N, const Conv3& c) {
   const float* a = c.a; const int B = c.B, H = c.H, W = c.W, Cin = c.Cin, Cout = c.Cout;
+  if (N->prep_failed) return -1;      // an earlier convolution of this call could not be prepared: launch nothing more on its unwritten output, the call reports the error
   // Winograd forms exist for channel counts that are multiples of 8 (every ResBlock convolution of the supported family)
   const bool wino_ok = c.w != nullptr && c.w->raw != nullptr && Cin % 8 == 0 && Cout % 8 == 0;
   const W4Gn* gn = c.gn; float* gn_tmp = c.gn_tmp; Tens* stat_out = c.stat_out; const W4Gn* bwd_gn = c.bwd_gn; const bool direct = c.direct;
@@ -590,7 +591,7 @@ static int conv3(Net* N, const Conv3& c) {
     p.bias_n = c.bias; p.bias_bn = c.bias_bn; p.ld_bias_bn = c.ld_bn; p.rows_per_batch = H * W; p.alpha = c.alpha; p.out_scale = c.out_scale;
     const bool x3 = N->gemm_mode == 1 && wgemm_supported((c.up == 1 ? 4 : 1) * Cout, (c.up == 2 ? 4 : 1) * Cin);
     const WVar* wv = conv_weights(N, *c.w, c.dgrad, 61, x3);
-    if (!wv || N->w4_scratch == nullptr) return -1;
+    if (!wv || N->w4_scratch == nullptr) { if (wv) { N->prep_failed = true; set_error("convolution scratch buffer missing"); } return -1; }
     long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf, c.up);
     const bool want_bwd = c.up == 2 && bwd_gn != nullptr;
     const int sc = (c.up == 1 ? stat_out != nullptr : want_bwd) ? wino6_stat_chunks(p, c.up) : 0;

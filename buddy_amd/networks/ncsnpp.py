@@ -191,12 +191,12 @@ class NCSNppTime(nn.Module):
         with its own library handle -- activation arena + VJP tape -- so another sub-batch can run concurrently on another HIP stream
         (buddy_amd/testing/concurrent.py).  Costs no weight memory and no preparation time.  ``attention``: the replica's attention core (per-handle).  A replica follows the weights its parent had
         when the replica's handle was made; reload the parent -> make new replicas."""
+        if attention is not None and attention not in self.ATTENTION_MODES:   # validate BEFORE copying: a half-built copy still holds the parent's handle
+            raise NotImplementedError(f"attention must be one of {sorted(self.ATTENTION_MODES)}")
         r = copy.copy(self)                     # shallow: shares _parameters / _modules (the nn.Parameters themselves)
+        r.__dict__["_handle"] = None            # first thing: the copy must never own (and on collection destroy) the parent's library handle
         if attention is not None:
-            if attention not in self.ATTENTION_MODES:
-                raise NotImplementedError(f"attention must be one of {sorted(self.ATTENTION_MODES)}")
             r.attention = attention
-        r._handle = None
         r._fwd_id = 0
         object.__setattr__(r, "_parent", self)   # not a submodule: nn.Module.__setattr__ would register it in the shared _modules
         return r

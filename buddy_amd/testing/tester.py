@@ -60,10 +60,12 @@ class Tester:
         except Exception:
             self.it = 0
         print("loading checkpoint")
+        self._concurrent = None      # cached sub-batch replicas pin the OLD weight store: rebuild them on the reloaded parent
         return load_state_dict(state_dict, ema=self.network)
 
     def load_latest_checkpoint(self):
         """reference :34-58: newest ``<model_dir>/<exp_name>-<it>.pt``; strict 'ema', else 'model' with strict=False."""
+        self._concurrent = None      # see load_checkpoint
         try:
             name = f"{self.args.model_dir}/{self.args.exp.exp_name}-*.pt"
             rx = re.compile(f"{self.args.exp.exp_name}-(\\d*)\\.pt")

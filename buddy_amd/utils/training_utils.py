@@ -26,6 +26,10 @@ Deliberate differences to the reference, each stricter or equal in effect:
   ``{'model', 'ema_weights'}`` file ends up in its strategy 6 -- and there, because tensors saved through ``state_dict()`` carry
   ``requires_grad=False``, it loads the raw ``'model'`` weights.  Loading the EMA list is the evident intent of both strategies and is what
   happens here; a truncated or surplus list can never be accepted by 5 (length check) and goes to 6.
+* strategy 7 copies the prefixed tensors whose stripped name and shape match a parameter and SKIPS the others (a surplus
+  ``diffusion_ema.foo`` entry, a tensor of another shape).  The reference indexes the target by the stripped name, raises ``KeyError`` on
+  the first unknown one and falls through to its strict bare load, which then raises on the prefixed file: a checkpoint with one extra
+  prefixed entry is unusable there and loads here (pinned by tests/test_host_logic.py case 7b).
 A failed strict attempt may have copied some tensors before raising (torch copies matching tensors first); every later success overwrites
 all of them."""
 from __future__ import annotations

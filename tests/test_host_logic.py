@@ -349,6 +349,15 @@ def test_load_checkpoint_reference_fallback_chain(tmp_path):
     fresh()
     assert t.load_checkpoint(str(p)) is True
     assert all(torch.equal(net.state_dict()[k], ema[k]) for k in ema)
+    # 7b. deliberate difference (utils/training_utils.py docstring): a surplus prefixed entry and one of another shape are skipped, the rest loads
+    extra = {"diffusion_ema." + k: v for k, v in ema.items()}
+    extra["diffusion_ema.not_a_parameter"] = torch.zeros(2)
+    extra["diffusion_ema." + key] = torch.ones(3, 3)
+    torch.save({"state_dict": extra}, p)
+    fresh()
+    assert t.load_checkpoint(str(p)) is True
+    sd = net.state_dict()
+    assert torch.equal(sd["all_modules.3.weight"], ema["all_modules.3.weight"]) and float(sd[key].abs().max()) == 0.0
     # 8. a bare state dict (:174-178)
     torch.save(ema, p)
     fresh()
