@@ -85,6 +85,10 @@ _SIGS = {
     "buddy_flash_attention_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "buddy_flash_attention_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,
                                             C.c_int, C.c_void_p]),
+    "buddy_flash_attention16_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "buddy_flash_attention16_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _f32p, C.c_void_p]),
+    "buddy_flash_attention16_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                              C.c_int, _f32p, C.c_void_p]),
     "buddy_flash_attention_splits": (C.c_int, [C.c_int, C.c_int]),
     "buddy_flash_attention_workspace": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "buddy_flash_attention_fwd_split": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _f32p, C.c_void_p]),

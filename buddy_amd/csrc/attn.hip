@@ -10,7 +10,8 @@
 // Backward (two kernels, no atomics, deterministic): with D = rowsum(dO o O),
 //   flash_bwd_dq_kernel  per 64 query rows:  P = exp(S - L), dP = dO V^T, dS = P o (dP - D) * scale, dq += dS K
 //   flash_bwd_dkv_kernel per 64 key rows:    the same tiles transposed (S^T = K q^T, dP^T = V dO^T), dv += P^T dO, dk += dS^T q
-// Everything is fp32 (exact-fp32 MFMA, expf/logf); only the summation order differs from the materialised form.
+// Everything is fp32 (exact-fp32 MFMA, expf/logf); only the summation order differs from the materialised form.  The 16-bit-operand kernels
+// (attention mode bf16 | f16) are in attn16.hip.
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
@@ -356,233 +357,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const float* __restr
   }
 }
 
-// ------------------------------------------------------------------ reduced-precision variant (BASELINE config 5: "fp16 MFMA attention path")
-// Same three kernels with 16-bit MFMA OPERANDS (bf16 or f16, v_mfma_f32_16x16x32_*: 16x the fp32 matrix rate) and fp32 accumulation; the softmax
-// statistics (row max / sum, exp, log-sum-exp, D) stay fp32.  A staged 32-row block lives in LDS as 16-bit values, row-major [32][C + 8] for the
-// X Y^T products (S = q K^T, dP = dO V^T) and transposed [C][32 + 8] for the P Y products (O = P V, dq = dS K, dv = P^T dO, dk = dS^T q), so every
-// B fragment (8 consecutive k per lane) is one 16-byte LDS read.  Opt-in (BUDDY_ATTN=bf16|f16): not the arithmetic of the reference.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <typename T16> struct V8;
-template <> struct V8<__bf16> { typedef bf16x8 t; };
-template <> struct V8<_Float16> { typedef f16x8 t; };
-__device__ __forceinline__ f32x4 mma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x4 mma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-constexpr int TLD = BC + 8;        // row stride (elements) of transposed tiles and of the P tiles
-
-template <int C, typename T16>
-__device__ __forceinline__ void stage_rows16(const float* __restrict__ src, int r0, int T, T16* dst) {
-  constexpr int LD = C + 8, Q = C / 4;
-  for (int it = threadIdx.x; it < 32 * Q; it += 256) {
-    const int r = it / Q, c = (it - r * Q) * 4;
-    const float4 v = ld4_row(src, r0 + r, T, C, c);
-    T16* d = dst + r * LD + c;
-    d[0] = (T16)v.x; d[1] = (T16)v.y; d[2] = (T16)v.z; d[3] = (T16)v.w;
-  }
-}
-template <int C, typename T16>
-__device__ __forceinline__ void stage_trans16(const float* __restrict__ src, int r0, int T, T16* dst) {
-  constexpr int Q = C / 4;
-  for (int it = threadIdx.x; it < 16 * Q; it += 256) {
-    const int pr = it & 15, c = (it >> 4) * 4, ra = r0 + 2 * pr;
-    const float4 a = ld4_row(src, ra, T, C, c);
-    const float4 b = ld4_row(src, ra + 1, T, C, c);
-    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { T16* d = dst + (c + j) * TLD + 2 * pr; d[0] = (T16)av[j]; d[1] = (T16)bv[j]; }
-  }
-}
-template <int C, typename T16>
-__device__ __forceinline__ void load_rowfrag16(const float* __restrict__ src, long long base, int row, int T, int g, typename V8<T16>::t (&a)[C / 32]) {
-#pragma unroll
-  for (int kk = 0; kk < C / 32; ++kk) {
-    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-    if (row < T) { lo = ld4(src + base + (long long)row * C + 32 * kk + 8 * g); hi = ld4(src + base + (long long)row * C + 32 * kk + 8 * g + 4); }
-    a[kk][0] = (T16)lo.x; a[kk][1] = (T16)lo.y; a[kk][2] = (T16)lo.z; a[kk][3] = (T16)lo.w;
-    a[kk][4] = (T16)hi.x; a[kk][5] = (T16)hi.y; a[kk][6] = (T16)hi.z; a[kk][7] = (T16)hi.w;
-  }
-}
-// acc[t] = A (regs) x Br[16 t + col][:]^T
-template <int C, typename T16>
-__device__ __forceinline__ void tile16_abt(const typename V8<T16>::t (&a)[C / 32], const T16* Br, int i, int g, f32x4 (&acc)[2]) {
-  typedef typename V8<T16>::t v8;
-#pragma unroll
-  for (int kk = 0; kk < C / 32; ++kk)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) acc[t] = mma16(a[kk], *reinterpret_cast<const v8*>(Br + (16 * t + i) * (C + 8) + 32 * kk + 8 * g), acc[t]);
-}
-// o[c] += P (wave tile [16][TLD]) x Bt[16 c + col][k]
-template <int C, typename T16>
-__device__ __forceinline__ void tile16_pb(const T16* Ps, const T16* Bt, int i, int g, f32x4 (&o)[C / 16]) {
-  typedef typename V8<T16>::t v8;
-  const v8 p = *reinterpret_cast<const v8*>(Ps + i * TLD + 8 * g);
-#pragma unroll
-  for (int c = 0; c < C / 16; ++c) o[c] = mma16(p, *reinterpret_cast<const v8*>(Bt + (16 * c + i) * TLD + 8 * g), o[c]);
-}
-
-template <int C, typename T16>
-__global__ __launch_bounds__(256) void flash16_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                          float* __restrict__ O, float* __restrict__ Lse, int T, float scale) {
-  __shared__ __attribute__((aligned(16))) T16 Kr[32 * (C + 8)];
-  __shared__ __attribute__((aligned(16))) T16 Vt[C * TLD];
-  __shared__ __attribute__((aligned(16))) T16 Ps[4][16 * TLD];
-  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-  const long long base = (long long)b * T * C;
-  const int row_a = blockIdx.x * BR + 16 * w + i, row0 = blockIdx.x * BR + 16 * w + 4 * g;
-  typename V8<T16>::t qa[C / 32];
-  load_rowfrag16<C, T16>(q, base, row_a, T, g, qa);
-  f32x4 o[C / 16];
-#pragma unroll
-  for (int c = 0; c < C / 16; ++c) o[c] = zero_acc();
-  float m[4], l[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
-  for (int j0 = 0; j0 < T; j0 += BC) {
-    __syncthreads();
-    stage_rows16<C, T16>(k + base, j0, T, Kr);
-    stage_trans16<C, T16>(v + base, j0, T, Vt);
-    __syncthreads();
-    f32x4 s[2] = {zero_acc(), zero_acc()};
-    tile16_abt<C, T16>(qa, Kr, i, g, s);
-    float alpha[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s0 = (j0 + i < T) ? s[0][r] * scale : -INFINITY;
-      float s1 = (j0 + 16 + i < T) ? s[1][r] * scale : -INFINITY;
-      const float mn = fmaxf(m[r], row_max16(fmaxf(s0, s1)));
-      alpha[r] = expf(m[r] - mn);
-      s0 = expf(s0 - mn); s1 = expf(s1 - mn);
-      l[r] = l[r] * alpha[r] + row_sum16(s0 + s1);
-      m[r] = mn;
-      Ps[w][(4 * g + r) * TLD + i] = (T16)s0;
-      Ps[w][(4 * g + r) * TLD + 16 + i] = (T16)s1;
-    }
-#pragma unroll
-    for (int c = 0; c < C / 16; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[c][r] *= alpha[r];
-    __syncthreads();
-    tile16_pb<C, T16>(Ps[w], Vt, i, g, o);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = row0 + r;
-    if (row >= T) continue;
-    const float inv = 1.f / l[r];
-#pragma unroll
-    for (int c = 0; c < C / 16; ++c) O[base + (long long)row * C + 16 * c + i] = o[c][r] * inv;
-    if (i == 0) Lse[(long long)b * T + row] = m[r] + logf(l[r]);
-  }
-}
-
-template <int C, typename T16>
-__global__ __launch_bounds__(256) void flash16_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                             const float* __restrict__ dO, const float* __restrict__ Lse, const float* __restrict__ D,
-                                                             float* __restrict__ dq, int T, float scale) {
-  __shared__ __attribute__((aligned(16))) T16 Kr[32 * (C + 8)];
-  __shared__ __attribute__((aligned(16))) T16 Vr[32 * (C + 8)];
-  __shared__ __attribute__((aligned(16))) T16 Kt[C * TLD];
-  __shared__ __attribute__((aligned(16))) T16 Ps[4][16 * TLD];
-  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-  const long long base = (long long)b * T * C;
-  const int row_a = blockIdx.x * BR + 16 * w + i, row0 = blockIdx.x * BR + 16 * w + 4 * g;
-  typename V8<T16>::t qa[C / 32], da[C / 32];
-  load_rowfrag16<C, T16>(q, base, row_a, T, g, qa);
-  load_rowfrag16<C, T16>(dO, base, row_a, T, g, da);
-  float lse[4], dl[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    lse[r] = ld1_row(Lse + (long long)b * T, row0 + r, T);     // clamped to row T - 1 (launchers guarantee T >= 1)
-    dl[r] = ld1_row(D + (long long)b * T, row0 + r, T);
-  }
-  f32x4 acc[C / 16];
-#pragma unroll
-  for (int c = 0; c < C / 16; ++c) acc[c] = zero_acc();
-  for (int j0 = 0; j0 < T; j0 += BC) {
-    __syncthreads();
-    stage_rows16<C, T16>(k + base, j0, T, Kr);
-    stage_rows16<C, T16>(v + base, j0, T, Vr);
-    stage_trans16<C, T16>(k + base, j0, T, Kt);
-    __syncthreads();
-    f32x4 s[2] = {zero_acc(), zero_acc()}, dp[2] = {zero_acc(), zero_acc()};
-    tile16_abt<C, T16>(qa, Kr, i, g, s);
-    tile16_abt<C, T16>(da, Vr, i, g, dp);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const bool ok = (j0 + 16 * t + i < T) && (row0 + r < T);
-        const float p = ok ? expf(s[t][r] * scale - lse[r]) : 0.f;
-        Ps[w][(4 * g + r) * TLD + 16 * t + i] = (T16)(p * (dp[t][r] - dl[r]) * scale);
-      }
-    __syncthreads();
-    tile16_pb<C, T16>(Ps[w], Kt, i, g, acc);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = row0 + r;
-    if (row >= T) continue;
-#pragma unroll
-    for (int c = 0; c < C / 16; ++c) dq[base + (long long)row * C + 16 * c + i] = acc[c][r];
-  }
-}
-
-template <int C, typename T16>
-__global__ __launch_bounds__(256) void flash16_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                              const float* __restrict__ dO, const float* __restrict__ Lse, const float* __restrict__ D,
-                                                              float* __restrict__ dk, float* __restrict__ dv, int T, float scale) {
-  __shared__ __attribute__((aligned(16))) T16 Qr[32 * (C + 8)];
-  __shared__ __attribute__((aligned(16))) T16 Or[32 * (C + 8)];
-  __shared__ __attribute__((aligned(16))) T16 Qt[C * TLD];
-  __shared__ __attribute__((aligned(16))) T16 Ot[C * TLD];
-  __shared__ __attribute__((aligned(16))) T16 Ps[4][16 * TLD];
-  __shared__ __attribute__((aligned(16))) T16 Ss[4][16 * TLD];
-  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-  const long long base = (long long)b * T * C;
-  const int row_a = blockIdx.x * BR + 16 * w + i, row0 = blockIdx.x * BR + 16 * w + 4 * g;
-  typename V8<T16>::t ka[C / 32], va[C / 32];
-  load_rowfrag16<C, T16>(k, base, row_a, T, g, ka);
-  load_rowfrag16<C, T16>(v, base, row_a, T, g, va);
-  f32x4 gk[C / 16], gv[C / 16];
-#pragma unroll
-  for (int c = 0; c < C / 16; ++c) { gk[c] = zero_acc(); gv[c] = zero_acc(); }
-  for (int i0 = 0; i0 < T; i0 += BC) {
-    __syncthreads();
-    stage_rows16<C, T16>(q + base, i0, T, Qr);
-    stage_rows16<C, T16>(dO + base, i0, T, Or);
-    stage_trans16<C, T16>(q + base, i0, T, Qt);
-    stage_trans16<C, T16>(dO + base, i0, T, Ot);
-    __syncthreads();
-    f32x4 s[2] = {zero_acc(), zero_acc()}, dp[2] = {zero_acc(), zero_acc()};
-    tile16_abt<C, T16>(ka, Qr, i, g, s);
-    tile16_abt<C, T16>(va, Or, i, g, dp);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int qc = i0 + 16 * t + i;
-      const bool qok = qc < T;
-      const float lse = ld1_row(Lse + (long long)b * T, qc, T), dl = ld1_row(D + (long long)b * T, qc, T);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = (qok && row0 + r < T) ? expf(s[t][r] * scale - lse) : 0.f;
-        Ps[w][(4 * g + r) * TLD + 16 * t + i] = (T16)p;
-        Ss[w][(4 * g + r) * TLD + 16 * t + i] = (T16)(p * (dp[t][r] - dl) * scale);
-      }
-    }
-    __syncthreads();
-    tile16_pb<C, T16>(Ps[w], Ot, i, g, gv);
-    tile16_pb<C, T16>(Ss[w], Qt, i, g, gk);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = row0 + r;
-    if (row >= T) continue;
-#pragma unroll
-    for (int c = 0; c < C / 16; ++c) {
-      dk[base + (long long)row * C + 16 * c + i] = gk[c][r];
-      dv[base + (long long)row * C + 16 * c + i] = gv[c][r];
-    }
-  }
-}
 }  // namespace
 
 bool flash_attn_supported(int C) { return C == 64 || C == 128 || C == 256; }
@@ -594,9 +368,8 @@ bool flash_attn_supported(int C) { return C == 64 || C == 128 || C == 256; }
 // 0.076 / 0.203; B = 2: 0.47 / 1.31 -> 0.141 / 0.379; B = 4: 0.47 / 1.31 -> 0.270 / 0.746; B = 8: 0.477 / 1.317 -> 0.535 / 1.530 (the price of
 // the rule: +0.27 ms on a 68 ms step; a batch-dependent count would save it and lose the reproducibility).  Long form (T = 15008): no split.
 // BUDDY_ATTN_SPLIT=n forces n (1 = never split).
-int flash_attn_splits(int B, int T, int prec) {
+int flash_attn_splits(int B, int T) {
   (void)B;
-  if (prec != 0) return 1;
   static const int force = getenv("BUDDY_ATTN_SPLIT") ? atoi(getenv("BUDDY_ATTN_SPLIT")) : 0;
   const int nb = cdiv(T, BC);
   const long long wgs = (long long)cdiv(T, BR);
@@ -609,12 +382,12 @@ int flash_attn_splits(int B, int T, int prec) {
 // floats of workspace the split forms need (forward: ns x (B T C + B T); backward: 2 ns x B T C)
 long long flash_attn_ws_floats(int B, int T, int C, int splits) { return splits > 1 ? 2LL * splits * B * T * C : 0; }
 
-// O [B][T][C], Lse [B][T]; prec: 0 = fp32 operands (exact-fp32 MFMA), 1 = bf16 operands, 2 = f16 operands (fp32 accumulate).  splits > 1 (fp32 only, ws =
-// flash_attn_ws_floats floats): the key loop is split over blockIdx.z and the partial (O, Lse) pairs are combined by flash_combine_kernel
-void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, int prec, float* ws,
-                           int splits, hipStream_t st) {
+// O [B][T][C], Lse [B][T]; fp32 operands (exact-fp32 MFMA); the 16-bit-operand kernels are in attn16.hip.  splits > 1 (ws = flash_attn_ws_floats
+// floats): the key loop is split over blockIdx.z and the partial (O, Lse) pairs are combined by flash_combine_kernel
+void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, float* ws, int splits,
+                           hipStream_t st) {
   const dim3 grid(cdiv(T, BR), B), block(256);
-  if (prec == 0 && splits > 1 && ws != nullptr) {
+  if (splits > 1 && ws != nullptr) {
     const long long rows = (long long)B * T;
     float* Op = ws; float* Lp = ws + (long long)splits * rows * C;
     const dim3 gs(cdiv(T, BR), B, splits), gc((unsigned)((rows + 3) / 4));
@@ -630,20 +403,18 @@ void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float
   const bool wide = force_nw ? force_nw == 8 : (long long)cdiv(T, 128) * B >= 256;
   const dim3 grid8(cdiv(T, 128), B), block8(512);
 #define FA_FWD(CC)                                                                                                           \
-  if (prec == 1) hipLaunchKernelGGL((flash16_fwd_kernel<CC, __bf16>), grid, block, 0, st, q, k, v, O, Lse, T, scale);            \
-  else if (prec == 2) hipLaunchKernelGGL((flash16_fwd_kernel<CC, _Float16>), grid, block, 0, st, q, k, v, O, Lse, T, scale);    \
-  else if (wide) hipLaunchKernelGGL((flash_fwd_kernel<CC, 8>), grid8, block8, 0, st, q, k, v, O, Lse, T, scale);                 \
+  if (wide) hipLaunchKernelGGL((flash_fwd_kernel<CC, 8>), grid8, block8, 0, st, q, k, v, O, Lse, T, scale);                      \
   else hipLaunchKernelGGL((flash_fwd_kernel<CC, 4>), grid, block, 0, st, q, k, v, O, Lse, T, scale);
   if (C == 64) { FA_FWD(64) } else if (C == 128) { FA_FWD(128) } else { FA_FWD(256) }
 #undef FA_FWD
 }
 // dq, dk, dv [B][T][C]; D [B][T] scratch
 void launch_flash_attn_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* Lse, float* D, float* dq,
-                           float* dk, float* dv, int B, int T, int C, float scale, int prec, float* ws, int splits, hipStream_t st) {
+                           float* dk, float* dv, int B, int T, int C, float scale, float* ws, int splits, hipStream_t st) {
   const long long rows = (long long)B * T;
   const dim3 grid(cdiv(T, BR), B), block(256), gd((unsigned)((rows + 3) / 4));
   const float* Dc = D;
-  if (prec == 0 && splits > 1 && ws != nullptr) {     // split loops (keys for dq, queries for dk / dv), partials summed in split order
+  if (splits > 1 && ws != nullptr) {     // split loops (keys for dq, queries for dk / dv), partials summed in split order
     const dim3 gs(cdiv(T, BR), B, splits);
     const long long n4 = rows * C / 4;
     const dim3 gr((unsigned)std::min<long long>((n4 + 255) / 256, 256 * 16));
@@ -661,16 +432,8 @@ void launch_flash_attn_bwd(const float* q, const float* k, const float* v, const
   }
 #define FA_BWD(CC)                                                                                                           \
   hipLaunchKernelGGL(attn_delta_kernel<CC>, gd, block, 0, st, dO, O, D, rows);                                                 \
-  if (prec == 1) {                                                                                                           \
-    hipLaunchKernelGGL((flash16_bwd_dq_kernel<CC, __bf16>), grid, block, 0, st, q, k, v, dO, Lse, Dc, dq, T, scale);             \
-    hipLaunchKernelGGL((flash16_bwd_dkv_kernel<CC, __bf16>), grid, block, 0, st, q, k, v, dO, Lse, Dc, dk, dv, T, scale);        \
-  } else if (prec == 2) {                                                                                                    \
-    hipLaunchKernelGGL((flash16_bwd_dq_kernel<CC, _Float16>), grid, block, 0, st, q, k, v, dO, Lse, Dc, dq, T, scale);           \
-    hipLaunchKernelGGL((flash16_bwd_dkv_kernel<CC, _Float16>), grid, block, 0, st, q, k, v, dO, Lse, Dc, dk, dv, T, scale);      \
-  } else {                                                                                                                   \
-    hipLaunchKernelGGL(flash_bwd_dq_kernel<CC>, grid, block, 0, st, q, k, v, dO, Lse, Dc, dq, T, scale);                         \
-    hipLaunchKernelGGL(flash_bwd_dkv_kernel<CC>, grid, block, 0, st, q, k, v, dO, Lse, Dc, dk, dv, T, scale);                    \
-  }
+  hipLaunchKernelGGL(flash_bwd_dq_kernel<CC>, grid, block, 0, st, q, k, v, dO, Lse, Dc, dq, T, scale);                         \
+  hipLaunchKernelGGL(flash_bwd_dkv_kernel<CC>, grid, block, 0, st, q, k, v, dO, Lse, Dc, dk, dv, T, scale);
   if (C == 64) { FA_BWD(64) } else if (C == 128) { FA_BWD(128) } else { FA_BWD(256) }
 #undef FA_BWD
 }

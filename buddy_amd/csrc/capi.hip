@@ -406,15 +406,34 @@ int buddy_fir_resample2(const float* x, float* y, int B, int H, int W, int C, in
 
 int buddy_flash_attention_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, int prec,
                               void* stream) {
-  if (!q || !k || !v || !O || !lse || B < 1 || T < 1 || !flash_attn_supported(C) || prec < 0 || prec > 2) { set_error("bad attention arguments (C in {64, 128, 256})"); return BUDDY_ERR_ARG; }
-  launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, prec, nullptr, 1, (hipStream_t)stream);
+  if (!q || !k || !v || !O || !lse || B < 1 || T < 1 || !flash_attn_supported(C) || prec != 0) {
+    set_error("bad attention arguments (C in {64, 128, 256}; prec 0 -- the 16-bit-operand kernels are buddy_flash_attention16_*)"); return BUDDY_ERR_ARG;
+  }
+  launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, nullptr, 1, (hipStream_t)stream);
+  return finish();
+}
+long long buddy_flash_attention16_workspace(int B, int T, int C) { return (B < 1 || T < 1 || !flash_attn_supported(C)) ? 0 : flash_attn16_ws_floats(B, T, C); }
+int buddy_flash_attention16_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, int prec, float* ws,
+                                void* stream) {
+  if (!q || !k || !v || !O || !lse || !ws || B < 1 || T < 1 || !flash_attn_supported(C) || prec < 1 || prec > 2) {
+    set_error("bad attention arguments (C in {64, 128, 256}; prec 1 = bf16, 2 = f16; ws = buddy_flash_attention16_workspace floats)"); return BUDDY_ERR_ARG;
+  }
+  launch_flash_attn16_fwd(q, k, v, O, lse, B, T, C, scale, prec, ws, (hipStream_t)stream);
+  return finish();
+}
+int buddy_flash_attention16_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta, float* dq,
+                                float* dk, float* dv, int B, int T, int C, float scale, int prec, float* ws, void* stream) {
+  if (!q || !k || !v || !O || !dO || !lse || !delta || !dq || !dk || !dv || !ws || B < 1 || T < 1 || !flash_attn_supported(C) || prec < 1 || prec > 2) {
+    set_error("bad attention arguments (C in {64, 128, 256}; prec 1 = bf16, 2 = f16; ws = buddy_flash_attention16_workspace floats)"); return BUDDY_ERR_ARG;
+  }
+  launch_flash_attn16_bwd(q, k, v, O, dO, lse, delta, dq, dk, dv, B, T, C, scale, prec, ws, (hipStream_t)stream);
   return finish();
 }
 long long buddy_flash_attention_workspace(int B, int T, int C, int splits) {
   if (B < 1 || T < 1 || !flash_attn_supported(C)) return 0;
-  return flash_attn_ws_floats(B, T, C, splits > 0 ? splits : flash_attn_splits(B, T, 0));
+  return flash_attn_ws_floats(B, T, C, splits > 0 ? splits : flash_attn_splits(B, T));
 }
-int buddy_flash_attention_splits(int B, int T) { return (B < 1 || T < 1) ? 1 : flash_attn_splits(B, T, 0); }
+int buddy_flash_attention_splits(int B, int T) { return (B < 1 || T < 1) ? 1 : flash_attn_splits(B, T); }
 static bool split_args_ok(int T, int splits, const float* ws) {
   const int nb = (T + 31) / 32;
   if (splits < 1 || splits > nb || (splits > 1 && !ws)) return false;
@@ -425,7 +444,7 @@ int buddy_flash_attention_fwd_split(const float* q, const float* k, const float*
   if (!q || !k || !v || !O || !lse || B < 1 || T < 1 || !flash_attn_supported(C) || !split_args_ok(T, splits, ws)) {
     set_error("bad split-attention arguments (C in {64, 128, 256}; every split needs at least one 32-row block)"); return BUDDY_ERR_ARG;
   }
-  launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, 0, ws, splits, (hipStream_t)stream);
+  launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, ws, splits, (hipStream_t)stream);
   return finish();
 }
 int buddy_flash_attention_bwd_split(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta,
@@ -433,15 +452,15 @@ int buddy_flash_attention_bwd_split(const float* q, const float* k, const float*
   if (!q || !k || !v || !O || !dO || !lse || !delta || !dq || !dk || !dv || B < 1 || T < 1 || !flash_attn_supported(C) || !split_args_ok(T, splits, ws)) {
     set_error("bad split-attention arguments (C in {64, 128, 256}; every split needs at least one 32-row block)"); return BUDDY_ERR_ARG;
   }
-  launch_flash_attn_bwd(q, k, v, O, dO, lse, delta, dq, dk, dv, B, T, C, scale, 0, ws, splits, (hipStream_t)stream);
+  launch_flash_attn_bwd(q, k, v, O, dO, lse, delta, dq, dk, dv, B, T, C, scale, ws, splits, (hipStream_t)stream);
   return finish();
 }
 int buddy_flash_attention_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta, float* dq,
                               float* dk, float* dv, int B, int T, int C, float scale, int prec, void* stream) {
-  if (prec < 0 || prec > 2 || !q || !k || !v || !O || !dO || !lse || !delta || !dq || !dk || !dv || B < 1 || T < 1 || !flash_attn_supported(C)) {
-    set_error("bad attention arguments (C in {64, 128, 256})"); return BUDDY_ERR_ARG;
+  if (prec != 0 || !q || !k || !v || !O || !dO || !lse || !delta || !dq || !dk || !dv || B < 1 || T < 1 || !flash_attn_supported(C)) {
+    set_error("bad attention arguments (C in {64, 128, 256}; prec 0 -- the 16-bit-operand kernels are buddy_flash_attention16_*)"); return BUDDY_ERR_ARG;
   }
-  launch_flash_attn_bwd(q, k, v, O, dO, lse, delta, dq, dk, dv, B, T, C, scale, prec, nullptr, 1, (hipStream_t)stream);
+  launch_flash_attn_bwd(q, k, v, O, dO, lse, delta, dq, dk, dv, B, T, C, scale, nullptr, 1, (hipStream_t)stream);
   return finish();
 }
 

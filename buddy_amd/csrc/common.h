@@ -143,12 +143,18 @@ void launch_fir_down2(const float* x, float* y, int B, int H, int W, int C, floa
 void launch_pool2(const float* src, float* dst, int B, int H, int W, int C, float scale, int accumulate, hipStream_t st); // (H,W)->(H/2,W/2), sum*scale
 void launch_up2_acc(const float* src, float* dst, int B, int Hs, int Ws, int C, float scale, int accumulate, hipStream_t st); // (Hs,Ws)->(2Hs,2Ws)
 bool flash_attn_supported(int C);
-int flash_attn_splits(int B, int T, int prec);                       // loop splits the launchers want for this grid (1 = none)
+int flash_attn_splits(int B, int T);                                 // loop splits the launchers want for this grid (1 = none)
 long long flash_attn_ws_floats(int B, int T, int C, int splits);     // workspace floats of the split forms (0 for splits <= 1)
-void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, int prec, float* ws,
-                           int splits, hipStream_t st);
+void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, float* ws, int splits,
+                           hipStream_t st);
 void launch_flash_attn_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* Lse, float* D, float* dq,
-                           float* dk, float* dv, int B, int T, int C, float scale, int prec, float* ws, int splits, hipStream_t st);
+                           float* dk, float* dv, int B, int T, int C, float scale, float* ws, int splits, hipStream_t st);
+// 16-bit-operand attention (attn16.hip; prec 1 = bf16, 2 = f16): ws = flash_attn16_ws_floats floats (operand arrays of the pre-pass)
+long long flash_attn16_ws_floats(int B, int T, int C);
+void launch_flash_attn16_fwd(const float* q, const float* k, const float* v, float* O, float* Lse, int B, int T, int C, float scale, int prec, float* ws,
+                             hipStream_t st);
+void launch_flash_attn16_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* Lse, float* D, float* dq,
+                             float* dk, float* dv, int B, int T, int C, float scale, int prec, float* ws, hipStream_t st);
 void launch_softmax_rows(float* S, int rows, int cols, hipStream_t st);
 void launch_softmax_bwd_rows(const float* P, float* dP /*in: dP, out: dS*/, int rows, int cols, hipStream_t st);
 void launch_linear(const float* x, const float* W, const float* b, float* y, int B, int K, int N, int silu_in, hipStream_t st);

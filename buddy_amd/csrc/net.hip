@@ -889,15 +889,18 @@ static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
   const size_t mark = N->arena.off;
   float* hn = N->tmp(BTC);
   // few utterances: the kernels' sequential loops are split over more workgroups (attn.hip: split_range); workspace from the arena
-  const int splits = flash_attn_splits(B, T, attn_prec(N));
-  float* aws = splits > 1 ? N->tmp(flash_attn_ws_floats(B, T, C, splits)) : nullptr;
+  // 16-bit modes: the operand arrays of the pre-pass (attn16.hip) live in the same scratch
+  const int prec = attn_prec(N);
+  const int splits = prec ? 1 : flash_attn_splits(B, T);
+  float* aws = prec ? N->tmp(flash_attn16_ws_floats(B, T, C)) : splits > 1 ? N->tmp(flash_attn_ws_floats(B, T, C, splits)) : nullptr;
   if (!N->dry()) {
     { View vx; vx.a = x; view_stats(N, vx, T, G, stats); }
     launch_gn_apply(single(x->p, C), stats, A.gn.gamma, A.gn.beta, B, H, W, C, G, 0, 0, hn, nullptr, st);
     gemm_b(N, hn, C, 0, false, A.Wt[0], C, 0, false, q, C, 0, B * T, C, C, A.b[0], nullptr, 1.f, 0, 1);
     gemm_b(N, hn, C, 0, false, A.Wt[1], C, 0, false, k, C, 0, B * T, C, C, A.b[1], nullptr, 1.f, 0, 1);
     gemm_b(N, hn, C, 0, false, A.Wt[2], C, 0, false, v, C, 0, B * T, C, C, A.b[2], nullptr, 1.f, 0, 1);
-    launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, attn_prec(N), aws, splits, st);
+    if (prec) launch_flash_attn16_fwd(q, k, v, O, lse, B, T, C, scale, prec, aws, st);
+    else launch_flash_attn_fwd(q, k, v, O, lse, B, T, C, scale, aws, splits, st);
     IgemmParams p = ig_base();
     p.A0 = O; p.ldA0 = C; p.Cin = C; p.M = B * T; p.N = C; p.Bt = A.Wt[3]; p.ldB = C; p.C = out->p; p.ldC = C; p.bias_n = A.b[3];
     p.res = x->p; p.ldRes = C; p.res_mode = 1; p.out_scale = INV_SQRT2;
@@ -912,10 +915,14 @@ static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
       const float* dout = out->g;
       float* dO = n->tmp(BTC); float* dq = n->tmp(BTC); float* dk = n->tmp(BTC); float* dv = n->tmp(BTC); float* dhn = n->tmp(BTC);
       float* dl = n->tmp((long long)B * T);
-      const int bsplits = flash_attn_splits(B, T, attn_prec(n));
-      float* bws = bsplits > 1 ? n->tmp(flash_attn_ws_floats(B, T, C, bsplits)) : nullptr;
+      const int bprec = attn_prec(n);
+      const int bsplits = bprec ? 1 : flash_attn_splits(B, T);
+      float* bws = bprec ? n->tmp(flash_attn16_ws_floats(B, T, C)) : bsplits > 1 ? n->tmp(flash_attn_ws_floats(B, T, C, bsplits)) : nullptr;
       gemm_b(n, dout, C, 0, false, Ap->Wn[3], C, 0, false, dO, C, 0, B * T, C, C, nullptr, nullptr, INV_SQRT2, 0, 1);
-      if (!n->dry()) launch_flash_attn_bwd(q, k, v, O, dO, lse, dl, dq, dk, dv, B, T, C, scale, attn_prec(n), bws, bsplits, s);
+      if (!n->dry()) {
+        if (bprec) launch_flash_attn16_bwd(q, k, v, O, dO, lse, dl, dq, dk, dv, B, T, C, scale, bprec, bws, s);
+        else launch_flash_attn_bwd(q, k, v, O, dO, lse, dl, dq, dk, dv, B, T, C, scale, bws, bsplits, s);
+      }
       gemm_b(n, dq, C, 0, false, Ap->Wn[0], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 0, 1);
       gemm_b(n, dk, C, 0, false, Ap->Wn[1], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);
       gemm_b(n, dv, C, 0, false, Ap->Wn[2], C, 0, false, dhn, C, 0, B * T, C, C, nullptr, nullptr, 1.f, 1, 1);

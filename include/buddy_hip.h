@@ -202,10 +202,19 @@ int buddy_ncsnpp_set_gemm(void* handle, int mode);
 /* single-head attention over T tokens without the T x T matrix (online softmax, fp32 MFMA), token-major q, k, v, O [B][T][C], C in {64,128,256}:
  * O = softmax(scale * q k^T) v, lse [B][T] = row log-sum-exp; replaces the einsum / softmax / einsum of AttnBlockpp.forward
  * (networks/ncsnpp_utils/layerspp.py:82-86).  bwd: gradients of the same three steps given dO (delta [B][T] is scratch).
- * prec: 0 = fp32 operands (the reference arithmetic), 1 = bf16, 2 = f16 MFMA operands with fp32 accumulation and fp32 softmax (opt-in fast mode). */
+ * prec must be 0 (fp32 operands, the reference arithmetic); the 16-bit-operand kernels take a workspace and are the next three entries. */
 int buddy_flash_attention_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, int prec, void* stream);
 int buddy_flash_attention_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta,
                               float* dq, float* dk, float* dv, int B, int T, int C, float scale, int prec, void* stream);
+/* The same three steps with 16-bit MFMA operands (prec 1 = bf16, 2 = f16; v_mfma_f32_32x32x16_*), fp32 accumulation and fp32 softmax statistics --
+ * the opt-in fast mode of buddy_ncsnpp_set_attention(handle, 1 | 2) (BASELINE configs[4] "fp16 MFMA attention path"; not the reference's arithmetic).
+ * A pre-pass converts q (times scale log2 e), k, v, dO once into 16-bit operand arrays in `ws` (buddy_flash_attention16_workspace floats: token-major
+ * rows and channel-major transposes, T padded to 128); the kernels stream them through LDS by DMA and keep the softmax in registers (csrc/attn16.hip). */
+long long buddy_flash_attention16_workspace(int B, int T, int C);
+int buddy_flash_attention16_fwd(const float* q, const float* k, const float* v, float* O, float* lse, int B, int T, int C, float scale, int prec,
+                                float* ws, void* stream);
+int buddy_flash_attention16_bwd(const float* q, const float* k, const float* v, const float* O, const float* dO, const float* lse, float* delta,
+                                float* dq, float* dk, float* dv, int B, int T, int C, float scale, int prec, float* ws, void* stream);
 /* The same fp32 kernels with their sequential loop (keys in fwd / dq, queries in dk / dv) split over `splits` workgroups per row block and the partial
  * results combined in fixed split order (no atomics): what the network uses when T / 64 workgroups per utterance would leave most of the 256 CUs idle
  * -- ONE utterance at a time is the reference's own shape (testing/tester.py:132-153).  buddy_flash_attention_splits = the count the network picks: a

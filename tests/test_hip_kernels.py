@@ -569,10 +569,17 @@ def test_flash_attention_fwd_bwd(lib, B, T, Cc, prec):
     q = q * 1.5                                                   # some peaky rows
     scale = Cc ** -0.5
     O = torch.empty_like(q); lse = torch.empty(B, T, device="cuda")
-    _lib.check(lib.buddy_flash_attention_fwd(P(q), P(k), P(v), P(O), P(lse), B, T, Cc, scale, prec, S()))
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     delta = torch.empty(B, T, device="cuda")
-    _lib.check(lib.buddy_flash_attention_bwd(P(q), P(k), P(v), P(O), P(dO), P(lse), P(delta), P(dq), P(dk), P(dv), B, T, Cc, scale, prec, S()))
+    if prec == 0:
+        _lib.check(lib.buddy_flash_attention_fwd(P(q), P(k), P(v), P(O), P(lse), B, T, Cc, scale, 0, S()))
+        _lib.check(lib.buddy_flash_attention_bwd(P(q), P(k), P(v), P(O), P(dO), P(lse), P(delta), P(dq), P(dk), P(dv), B, T, Cc, scale, 0, S()))
+        assert lib.buddy_flash_attention_fwd(P(q), P(k), P(v), P(O), P(lse), B, T, Cc, scale, 1, S()) != 0       # 16-bit operands: the entries below
+    else:
+        ws = torch.empty(lib.buddy_flash_attention16_workspace(B, T, Cc), device="cuda")
+        _lib.check(lib.buddy_flash_attention16_fwd(P(q), P(k), P(v), P(O), P(lse), B, T, Cc, scale, prec, P(ws), S()))
+        _lib.check(lib.buddy_flash_attention16_bwd(P(q), P(k), P(v), P(O), P(dO), P(lse), P(delta), P(dq), P(dk), P(dv), B, T, Cc, scale, prec, P(ws), S()))
+        assert lib.buddy_flash_attention16_fwd(P(q), P(k), P(v), P(O), P(lse), B, T, Cc, scale, prec, None, S()) != 0   # no workspace: argument error
     torch.cuda.synchronize()
     qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
     w = torch.softmax(torch.einsum("bic,bjc->bij", qd, kd) * scale, dim=-1)

@@ -13,8 +13,13 @@ for B, T in ((8, 2048), (4, 15040)):
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     fl = 4.0 * B * T * T * C
     for prec in (0, 1, 2):
-        f = lambda: _lib.check(lib.buddy_flash_attention_fwd(P(q), P(k), P(v), P(O), P(lse), B, T, C, C ** -0.5, prec, S()))
-        b = lambda: _lib.check(lib.buddy_flash_attention_bwd(P(q), P(k), P(v), P(O), P(dO), P(lse), P(dl), P(dq), P(dk), P(dv), B, T, C, C ** -0.5, prec, S()))
+        if prec == 0:
+            f = lambda: _lib.check(lib.buddy_flash_attention_fwd(P(q), P(k), P(v), P(O), P(lse), B, T, C, C ** -0.5, 0, S()))
+            b = lambda: _lib.check(lib.buddy_flash_attention_bwd(P(q), P(k), P(v), P(O), P(dO), P(lse), P(dl), P(dq), P(dk), P(dv), B, T, C, C ** -0.5, 0, S()))
+        else:       # 16-bit operands: pre-pass + kernels (csrc/attn16.hip)
+            ws = torch.empty(lib.buddy_flash_attention16_workspace(B, T, C), device="cuda")
+            f = lambda: _lib.check(lib.buddy_flash_attention16_fwd(P(q), P(k), P(v), P(O), P(lse), B, T, C, C ** -0.5, prec, P(ws), S()))
+            b = lambda: _lib.check(lib.buddy_flash_attention16_bwd(P(q), P(k), P(v), P(O), P(dO), P(lse), P(dl), P(dq), P(dk), P(dv), B, T, C, C ** -0.5, prec, P(ws), S()))
         out = []
         for fn in (f, b):
             fn(); torch.cuda.synchronize(); t = time.perf_counter()
