@@ -25,8 +25,10 @@ import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL across processes); must be set before HIP starts
 
+_T_PROC = time.perf_counter()
 import numpy as np
 import torch
+_IMPORT_TORCH_S = time.perf_counter() - _T_PROC     # first import on a fresh box pages the image in (1-2 min), later ones ~1.5 s
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -38,16 +40,18 @@ PEAK_FP32_MFMA = 157.3   # TFLOP/s, MI355X dense fp32 matrix peak (MI355X_MICROA
 PEAK_BF16_MFMA = 2500.0  # TFLOP/s, MI355X dense bf16 matrix peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 
 
-SETUP = {}     # wall times of the one-off set-up pieces of the FIRST stack (rank-local): reported as `cold_start`
+SETUP = {"import_torch_s": _IMPORT_TORCH_S}     # wall times of the one-off set-up pieces of the FIRST stack (rank-local): reported as `cold_start`
 
 
-def build_stack(args_ns, device, B, first_utt, net=None, tester_cfg="blind_dereverberation_BUDDy", blind=True, T=None, length=None, extra=(), attention=None):
+def build_stack(args_ns, device, B, first_utt, net=None, tester_cfg="blind_dereverberation_BUDDy", blind=True, T=None, length=None, extra=(), attention=None,
+                shipped=False):
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
     from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
     from buddy_amd.testing.tester import Tester
-    ov = [f"tester.sampling_params.T={T or args_ns.T}"] + list(extra)
-    if tester_cfg != "only_unconditional":
+    # shipped: the tester yaml exactly as it ships (blind: wpe_scaled warm start, T = 201) -- no overrides of the sampler's settings
+    ov = ([] if shipped else [f"tester.sampling_params.T={T or args_ns.T}"]) + list(extra)
+    if tester_cfg != "only_unconditional" and not shipped:
         ov.append("tester.posterior_sampling.warm_initialization.mode=reverb_scaled")
     if getattr(args_ns, "attention", None):
         ov.append(f"+network.attention={args_ns.attention}")
@@ -56,6 +60,10 @@ def build_stack(args_ns, device, B, first_utt, net=None, tester_cfg="blind_derev
     args = compose(tester=tester_cfg, overrides=ov)
     L = length or args_ns.length
     if net is None:
+        t0 = time.perf_counter()
+        from buddy_amd import _lib as _l
+        _l.require_gpu()
+        SETUP["lib_load_s"] = time.perf_counter() - t0            # dlopen of libbuddy_hip.so: registers the gfx950 code object with the HIP runtime
         t0 = time.perf_counter()
         net = instantiate(args.network)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(0, args.network.nf).items()})
@@ -75,9 +83,14 @@ def build_stack(args_ns, device, B, first_utt, net=None, tester_cfg="blind_derev
     tester = Tester(args, net, edm, test_set=None, device=device, in_training=True)
     if tester_cfg == "only_unconditional":
         return args, net, edm, tester, None, None, None
+    t0 = time.perf_counter()
     items = [(synth_clean(first_utt + u, L), synth_rir(first_utt + u, 8000), f"utt{first_utt + u}.wav") for u in range(B)]
+    SETUP.setdefault("synth_inputs_s", time.perf_counter() - t0)    # numpy: synthetic clean signals and RIRs of the first stack
     torch.manual_seed(1234 + first_utt)
+    t0 = time.perf_counter()
     seg, y, op, _ = tester.prepare_batch(items, blind=blind)
+    torch.cuda.synchronize()
+    SETUP.setdefault("prepare_batch_s", time.perf_counter() - t0)   # y = clean * RIR through the HIP FIR, the blind operator handle (first stack)
     return args, net, edm, tester, seg, y, op
 
 
@@ -338,7 +351,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (--backend, default nccl = RCCL) even with one rank and run the "
                     "end-of-run gather through it: exercises communicator set-up and the collective on a 1-GPU box")
     ap.add_argument("--legs", default="auto", help="extra untimed-from-`value` legs (BASELINE.md section 3): comma list of informed,informed_b1,blind_b1,"
-                    "forward_only,longform,full_run or 'all' / 'none'; auto = all at N=1 with the default workload, full_run only otherwise")
+                    "forward_only,longform,full_run,shipped or 'all' / 'none'; auto = all at N=1 with the default workload, full_run only otherwise")
     a = ap.parse_args()
     if a.cpu_baseline_only:
         print(json.dumps(cpu_baseline(a.length, a.cpu_baseline_only, a.cpu_reps, a.cpu_utt, a.cpu_mode)))
@@ -373,8 +386,13 @@ def main():
     if world > 1 and a.backend == "nccl" and world > torch.cuda.device_count():
         raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {torch.cuda.device_count()} (--backend gloo lets ranks share a GPU for smoke tests)")
     dev_index = local_rank % torch.cuda.device_count()     # == local_rank on a real node; lets 2 gloo ranks share one GPU in smoke tests
+    t0 = time.perf_counter()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    torch.cuda.init()
+    torch.zeros(1, device=device).add_(1.0)                # HIP context + torch's own code objects + the first kernel launch of the process
+    torch.cuda.synchronize()
+    SETUP["hip_context_s"] = time.perf_counter() - t0
     dist = None
     dist_init_ms = 0.0
     if world > 1 or a.force_dist:
@@ -437,7 +455,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("stack ready; warmup")
+    # every set-up piece goes to stderr too (the driver keeps the tail of stderr; the JSON line's `cold_start` object lies beyond its 2000 characters)
+    log("stack ready: " + ", ".join(f"{k} {v:.2f}" for k, v in SETUP.items()) + f", stack_build_s {stack_build_s:.2f} (= lib_load + module_build + cold_start "
+        "[create + first forward incl. the arena hipMalloc] + synth_inputs + prepare_batch + Tester/replica objects)")
+    log("warmup")
     first_step_ms = None
     for k in range(a.warmup):
         t0 = time.perf_counter()
@@ -468,7 +489,11 @@ def main():
     dom_ms = (C.c_double * 3)(); dom_fl, dom_bi, dom_bo, dom_bg, dom_n = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_longlong()
     _lib.check(lib.buddy_prof_collect_wino4(dom_ms, C.byref(dom_fl), C.byref(dom_bi), C.byref(dom_bo), C.byref(dom_bg), C.byref(dom_n)))
     el = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
+    per_rank_ms = [elapsed / a.steps * 1e3]
     if dist is not None:
+        each = [torch.empty_like(el) for _ in range(world)]
+        dist.all_gather(each, el.clone())
+        per_rank_ms = [float(e.item()) / a.steps * 1e3 for e in each]          # the spread `ms_per_step` is the maximum of
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -521,9 +546,9 @@ def main():
     # ---- further legs, each its own untimed-from-`value` region on a replica of the same network -------------------------
     default_workload = (B == 8 and a.length == 64000)
     if a.legs == "auto":
-        want = {"informed", "informed_b1", "blind_b1", "forward_only", "longform", "full_run"} if (world == 1 and default_workload) else {"full_run"}
+        want = {"informed", "informed_b1", "blind_b1", "forward_only", "longform", "full_run", "shipped"} if (world == 1 and default_workload) else {"full_run"}
     elif a.legs == "all":
-        want = {"informed", "informed_b1", "blind_b1", "forward_only", "longform", "full_run"}
+        want = {"informed", "informed_b1", "blind_b1", "forward_only", "longform", "full_run", "shipped"}
     else:
         want = {w for w in a.legs.split(",") if w and w != "none"}
     legs = {}
@@ -596,6 +621,28 @@ def main():
             legs["longform_480000_B4_f16"]["value_in_4s_units"] = legs["longform_480000_B4_f16"]["value"] * 7.5
             del r_
             torch.cuda.empty_cache()
+
+    if "shipped" in want:        # the reference's own shape (testing/tester.py:132-153, test_blind_dereverberation.sh:18): ONE utterance, the shipped yaml unchanged
+        t0 = time.perf_counter()
+        args_s, _, _, tester_s, _, y_s, op_s = build_stack(a, device, 1, rank, net0[0], shipped=True)
+        ps_ = args_s.tester.posterior_sampling
+        assert ps_.warm_initialization.mode == "wpe_scaled" and args_s.tester.sampling_params.T == 201 and ps_.blind_hp.op_updates_per_step == 10
+        assert tester_s.sampler.noise is None            # torch RNG, no injected streams
+        torch.cuda.synchronize()
+        setup_s = time.perf_counter() - t0
+        barrier()
+        t0 = time.perf_counter()
+        pred_s = tester_s.sampler.predict_conditional(y_s, op_s, shape=(1, a.length), blind=True)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        assert torch.isfinite(pred_s).all(), "shipped run diverged"
+        legs["full_run_B1_shipped"] = {"wall_s": wall, "T": 201, "ms_per_step": wall / 201 * 1e3, "value": world * 201 / wall, "unit": "utterance-steps/s",
+                                       "setup_s": setup_s, "length": a.length,
+                                       "config": "conf/tester/blind_dereverberation_BUDDy.yaml UNCHANGED (wpe_scaled warm start, T = 201, order 1, 10 operator updates per "
+                                                 "step), ONE utterance, torch RNG: Sampler.predict_conditional wall time incl. bind, the WPE warm start on the GPU and "
+                                                 "the final sync; setup_s = prepare_batch + replica handle before it"}
+        log(f"leg full_run_B1_shipped: {wall:.2f} s for T=201 = {wall / 201 * 1e3:.2f} ms/step (set-up {setup_s:.2f} s)")
+        del tester_s, y_s, op_s, pred_s
 
     # ---- one REAL run end to end: predict_conditional over the whole T-step schedule, init included; then the end-of-run gather ---------------
     full_run = None
@@ -711,6 +758,8 @@ def main():
                            "utterances) samples them as two concurrent sub-batches = `concurrent_sub_batches`") if S == 1 else f"{S} concurrent sub-batches",
             "cold_start": {"cold_start_s": SETUP.get("cold_start_s"), "first_step_ms": first_step_ms, "module_build_s": SETUP.get("module_build_s"),
                            "stack_build_s": stack_build_s, "weight_store_bytes": net0[0].weight_bytes(),
+                           "import_torch_s": SETUP.get("import_torch_s"), "hip_context_s": SETUP.get("hip_context_s"), "lib_load_s": SETUP.get("lib_load_s"),
+                           "synth_inputs_s": SETUP.get("synth_inputs_s"), "prepare_batch_s": SETUP.get("prepare_batch_s"),
                            "what": "cold_start_s = buddy_ncsnpp_create (parameter upload, small packs) + the first forward of the batch, which prepares on the "
                                    "GPU the one operand form each 3x3 convolution uses (wprep.hip); first_step_ms = the first sampler step (arena dry run, "
                                    "data-gradient forms, operator hipGraph capture); module_build_s = torch-side module construction + synthetic state dict "
@@ -718,7 +767,7 @@ def main():
             "legs": legs, "full_run": full_run, "rccl_selftest": rccl_selftest, "dist_init_ms": dist_init_ms,
             "network_algorithmic_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
             "gather_ms": gather_ms, "gather_first_call_ms": gather_first_ms, "gather_bytes_per_rank": int(out.numel() * 4),
-            "gather_backend": (a.backend if dist is not None else None),
+            "gather_backend": (a.backend if dist is not None else None), "per_rank_ms_per_step": per_rank_ms,
             # dominant kernel: the batched Winograd-domain GEMMs of the 3x3 convolutions.  bf16x3 (default): every fp32 multiply-add is SIX bf16 MFMA
             # multiply-adds -> achieved = 6 x the fp32-equivalent rate, against the bf16 matrix peak; the fp32-equivalent rate against the fp32 matrix
             # peak is beside it (the kernel replaces v_mfma_f32_32x32x2_f32 at equal accuracy; --gemm fp32 is the reference run)

@@ -82,6 +82,9 @@ _SIGS = {
     "buddy_ncsnpp_set_fir": (C.c_int, [C.c_void_p, C.c_int]),
     "buddy_ncsnpp_set_gemm": (C.c_int, [C.c_void_p, C.c_int]),
     "buddy_ncsnpp_set_attention": (C.c_int, [C.c_void_p, C.c_int]),
+    "buddy_options_check": (C.c_int, []),
+    "buddy_ncsnpp_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "buddy_ncsnpp_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "buddy_flash_attention_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "buddy_flash_attention_bwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float,
                                             C.c_int, C.c_void_p]),
@@ -138,6 +141,11 @@ def load():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
         _lib = lib
+        rc = lib.buddy_options_check()     # a misspelt BUDDY_* switch fails here, loudly, not somewhere inside a launcher
+        if rc != 0:
+            msg = lib.buddy_last_error().decode()
+            _lib = None
+            raise BuddyHipError(f"libbuddy_hip: {msg}")
     return _lib
 
 

@@ -370,7 +370,7 @@ bool flash_attn_supported(int C) { return C == 64 || C == 128 || C == 256; }
 // BUDDY_ATTN_SPLIT=n forces n (1 = never split).
 int flash_attn_splits(int B, int T) {
   (void)B;
-  static const int force = getenv("BUDDY_ATTN_SPLIT") ? atoi(getenv("BUDDY_ATTN_SPLIT")) : 0;
+  const int force = cur_opt().attn_split;
   const int nb = cdiv(T, BC);
   const long long wgs = (long long)cdiv(T, BR);
   int ns = force > 0 ? force : (int)(256 / (wgs > 0 ? wgs : 1));
@@ -399,7 +399,7 @@ void launch_flash_attn_fwd(const float* q, const float* k, const float* v, float
     return;
   }
   // fp32: 128-row workgroups (8 waves) once there are enough of them to fill the chip, 64-row ones otherwise (BUDDY_ATTN_NW=4|8 forces one)
-  static const int force_nw = getenv("BUDDY_ATTN_NW") ? atoi(getenv("BUDDY_ATTN_NW")) : 0;
+  const int force_nw = cur_opt().attn_nw;
   const bool wide = force_nw ? force_nw == 8 : (long long)cdiv(T, 128) * B >= 256;
   const dim3 grid8(cdiv(T, 128), B), block8(512);
 #define FA_FWD(CC)                                                                                                           \

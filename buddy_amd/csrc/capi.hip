@@ -394,6 +394,9 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
   return finish();
 }
 
+int buddy_options_check(void) { return options_check(); }
+int buddy_ncsnpp_set_option(void* h, const char* key, int value) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_set_option((Net*)h, key, value); }
+int buddy_ncsnpp_get_option(void* h, const char* key, int* value) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_get_option((Net*)h, key, value); }
 int buddy_ncsnpp_set_gemm(void* h, int mode) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_set_gemm((Net*)h, mode); }
 int buddy_ncsnpp_set_attention(void* h, int mode) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_set_attention((Net*)h, mode); }
 int buddy_ncsnpp_set_fir(void* h, int fir) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_set_fir((Net*)h, fir); }

@@ -14,6 +14,26 @@
 
 namespace buddy {
 
+// ---- launcher options (options.hip): per handle, defaults from the validated BUDDY_* environment ----------------------
+struct Options {
+  int conv;            // 3x3 convolution form: 0 by shape (F(6x6) / F(4x4) three-pass, fused F(2x2), direct), 1 direct, 2 wino2, 3 wino4
+  int gemm;            // Winograd-domain GEMM arithmetic: 1 bf16x3 (default), 0 fp32 MFMA
+  int attn;            // attention core 0 .. 4 (net.hip)
+  int gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr;                 // fusions of the network graph (A/B switches, default 1)
+  int attn_split, attn_nw;                                                           // fp32 attention: forced loop-split count / forward tile height (0 = by shape)
+  int igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos, wgemm_epi, wgemm_dma;              // GEMM kernels
+  int wino_epi, wino_abl, wino_geo, w6_xcd;                                          // Winograd kernels
+  int gn_fast, c2in4, c2out_tiled;                                                   // GroupNorm / 2-channel convolutions
+  int fir_lds, op_graph;                                                             // blind operator
+};
+const Options& default_options();           // process defaults (environment)
+int options_check();                        // BUDDY_ERR_ARG (+ set_error) when the environment holds an unknown BUDDY_* name or a bad value
+const Options& cur_opt();                   // options of the handle whose call runs on this thread (the defaults outside one)
+struct OptScope { const Options* prev; explicit OptScope(const Options* o); ~OptScope(); OptScope(const OptScope&) = delete; };
+int option_set(Options& o, const char* key, int value);
+int option_get(const Options& o, const char* key, int* value);
+const char* prof_dump_path();               // BUDDY_PROF_DUMP
+
 // ---- implicit-GEMM (conv3x3 / conv1x1 / plain GEMM) -------------------------------------------------
 // C[m][n] = out_scale * ( alpha * sum_k A[m][k] * Bt[n][k] + bias_n[n] + bias_m[m] + bias_bn[b(m)][n] + res[...] )
 struct IgemmParams {

@@ -313,7 +313,7 @@ int igemm_prof_collect(double ms[2], double flops[2], long long launches[2], dou
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return 1;
     const int c = r.taps == 9 ? 0 : 1;
-    static FILE* dump = getenv("BUDDY_PROF_DUMP") ? fopen(getenv("BUDDY_PROF_DUMP"), "w") : nullptr;   // per-launch shapes for tools/gemm_shapes.py
+    static FILE* dump = prof_dump_path() ? fopen(prof_dump_path(), "w") : nullptr;   // per-launch shapes for tools/gemm_shapes.py
     if (dump) setvbuf(dump, nullptr, _IOLBF, 0);
     if (dump) fprintf(dump, "%d %d %d %d %d %d %.6f\n", r.kind, r.taps, r.M, r.N, r.K, r.batch, t);
     ms[c] += t; flops[c] += r.flops; launches[c] += 1; bytes[c] += r.bytes; exec_flops[c] += r.exec_flops;
@@ -398,7 +398,7 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
     if (p.bias_n) wide = wide && al16(p.bias_n);
     if (p.bias_bn) wide = wide && al16(p.bias_bn) && (p.ld_bias_bn % 4 == 0);
     if (p.res_mode) wide = wide && al16(p.res) && (p.ldRes % 4 == 0);
-    static const bool force_scalar = getenv("BUDDY_IGEMM_EPI") && atoi(getenv("BUDDY_IGEMM_EPI")) == 0;   // A/B switch
+    const bool force_scalar = cur_opt().igemm_epi == 0;   // A/B switch
     pw.wide_epi = (wide && !force_scalar) ? 1 : 0;
   }
   ProfRec rec{};
@@ -413,7 +413,7 @@ void launch_igemm(const IgemmParams& p, int taps, bool transA, bool transB, int 
   struct Fin { ProfRec& r; hipStream_t s; ~Fin() { if (g_prof_on) { (void)hipEventRecord(r.e1, s); g_prof.push_back(r); } } } fin{rec, st};
   // V: 0 = next-tile global loads issued before the MFMA block, 2 = after its first quarter (default; +4 % measured,
   // profiles/README.md), 4 = double-buffered LDS, one barrier per K step (slower: 2 blocks/CU).  A/B switch for the 3x3 kernel:
-  static const int variant = getenv("BUDDY_IGEMM_VARIANT") ? atoi(getenv("BUDDY_IGEMM_VARIANT")) : 2;
+  const int variant = cur_opt().igemm_variant;
   if (taps == 9) {
     if (variant == 0) hipLaunchKernelGGL((igemm_kernel<9, false, false, 0>), grid, block, 0, st, pw);
     else if (variant == 4) hipLaunchKernelGGL((igemm_kernel<9, false, false, 4>), grid, block, 0, st, pw);

@@ -170,8 +170,8 @@ struct Net {
   const float* k_cin = nullptr; const float* k_cskip = nullptr; const float* k_cout = nullptr;
 
   int rsv_B = 0, rsv_L = 0, rsv_vjp = -1;   // shape the arena was last sized for (the sizing dry run is skipped while it still fits)
-  int attn_mode = 4;           // see attn_mode_from_env()
-  int gemm_mode = 1;           // Winograd-domain GEMM arithmetic: 1 = bf16x3 (exact three-way split, default), 0 = fp32 MFMA; BUDDY_GEMM=fp32|bf16x3
+  Options opt;                 // this handle's launcher options (options.hip): attention core, GEMM arithmetic, every A/B switch; from the environment
+                               // defaults at creation, changed with buddy_ncsnpp_set_option; the launchers read it through cur_opt() while a call runs
   bool prep_failed = false;    // a lazily prepared weight form could not be built (out of memory): the call reports it
   bool fir = false;            // fir=True: FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257)
   float* w4_scratch = nullptr; size_t w4_cap = 0, w4_need = 0;   // V / M buffers of the three-pass F(4x4,3x3) convolutions (floats)
@@ -216,17 +216,6 @@ static const PSpec* find_spec(const std::vector<PSpec>& v, const std::string& n)
   return nullptr;
 }
 
-static int attn_mode_from_env();
-static int gemm_mode_from_env(int* mode) {
-  *mode = 1;
-  if (const char* g = getenv("BUDDY_GEMM")) {
-    const std::string v = g;
-    if (v == "fp32") *mode = 0;
-    else if (v == "bf16x3" || v.empty()) *mode = 1;
-    else { set_error("BUDDY_GEMM must be 'fp32' or 'bf16x3' (got '" + v + "')"); return BUDDY_ERR_ARG; }
-  }
-  return BUDDY_OK;
-}
 
 // Build the shared weight store: the raw parameters go to the device once (every tensor start aligned to 256 B); the host prepares only the
 // small operands (2-channel convolutions, transposed 1x1 / NIN matrices, the Dense_0 stack, the windowed DFT bases: ~4 M floats).  The 3x3
@@ -242,6 +231,18 @@ static int weights_create(const float* hp, long long n, const NetCfg& cfg, std::
     int cmax = 0;
     for (int l = 0; l < cfg.nlev; ++l) cmax = std::max(cmax, cfg.nf * cfg.ch_mult[l]);
     if (2 * cmax > 1024) { set_error("nf * max(ch_mult) must be <= 512 (concatenated skip tensors of up to 1024 channels)"); return BUDDY_ERR_ARG; }
+  }
+  // GroupNorm kernels (stand-alone and fused) normalise float4 channel quads with ONE group's statistics: min(C / 4, 32) groups must give a
+  // multiple of four channels per group for EVERY normalised tensor, skip concatenations included -- C <= 128 (four per group) or C % 128 == 0.
+  // nf = 32 and nf = 128 with the reference's multipliers satisfy it; e.g. nf = 64, ch_mult (1,2,2,2) has a 192-channel concatenation (six per group)
+  for (const PSpec& ps : N->specs) {
+    if (ps.name.find("GroupNorm_") == std::string::npos) continue;        // the pyramid GroupNorms have the widths of the blocks' GroupNorm_1
+    const int C = ps.shape[0];
+    if (C % 4 || (C > 128 && C % 128)) {
+      set_error("unsupported width: a GroupNorm over " + std::to_string(C) + " channels (" + ps.name + ") has " + std::to_string(C / (C / 4 < 32 ? C / 4 : 32)) +
+                " channels per group; the kernels need a multiple of 4 (C <= 128 or C % 128 == 0)");
+      return BUDDY_ERR_ARG;
+    }
   }
   const int Fb = cfg.n_fft / 2 + 1, Kp = (cfg.n_fft + 3) / 4 * 4;
   if (Fb % (1 << (cfg.nlev - 1))) { set_error("frequency bins not divisible by 2^(levels-1)"); return BUDDY_ERR_ARG; }
@@ -412,8 +413,8 @@ static int net_from_weights(std::shared_ptr<Weights> Wp, Net** out) {
   Net* N = new Net();
   N->W = std::move(Wp);
   N->cfg = N->W->cfg;
-  N->attn_mode = attn_mode_from_env();
-  if (int rc = gemm_mode_from_env(&N->gemm_mode)) { delete N; return rc; }
+  if (int rc = options_check()) { delete N; return rc; }      // an unknown BUDDY_* variable or a bad value fails loudly here
+  N->opt = default_options();
   N->Fb = N->cfg.n_fft / 2 + 1;
   N->Kp = (N->cfg.n_fft + 3) / 4 * 4;
   N->pad = N->cfg.n_fft / 2;
@@ -432,7 +433,7 @@ int net_create(const float* hp, long long n, const NetCfg& cfg, Net** out) {
 int net_replica(Net* src, Net** out) {
   Net* N = nullptr;
   if (int rc = net_from_weights(src->W, &N)) return rc;
-  N->attn_mode = src->attn_mode; N->gemm_mode = src->gemm_mode; N->fir = src->fir;
+  N->opt = src->opt; N->fir = src->fir;
   *out = N;
   return BUDDY_OK;
 }
@@ -451,8 +452,14 @@ int net_weight_bytes(Net* N, long long* params, long long* packed, long long* la
   return BUDDY_OK;
 }
 
-int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 4) { set_error("attention mode must be 0..4"); return BUDDY_ERR_ARG; } N->attn_mode = mode; N->rsv_vjp = -1; return BUDDY_OK; }
-int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 1) { set_error("gemm mode must be 0 (fp32 MFMA) or 1 (bf16x3)"); return BUDDY_ERR_ARG; } N->gemm_mode = mode; N->rsv_vjp = -1; return BUDDY_OK; }
+int net_set_option(Net* N, const char* key, int value) {
+  if (int rc = option_set(N->opt, key, value)) return rc;
+  N->rsv_vjp = -1;             // options change which temporaries a call allocates: size the arena again
+  return BUDDY_OK;
+}
+int net_get_option(Net* N, const char* key, int* value) { return option_get(N->opt, key, value); }
+int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 4) { set_error("attention mode must be 0..4"); return BUDDY_ERR_ARG; } return net_set_option(N, "attention", mode); }
+int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 1) { set_error("gemm mode must be 0 (fp32 MFMA) or 1 (bf16x3)"); return BUDDY_ERR_ARG; } return net_set_option(N, "gemm", mode); }
 int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; return BUDDY_OK; }
 void net_destroy(Net* N) {
   if (!N) return;
@@ -551,11 +558,8 @@ struct Conv3 {
 // fusions on the low-resolution geometry.
 static bool conv3_up_ok(Net* N, int B, int H, int W, int Cin, int Cout) {
   if (H < 7 || W < 7) return false;
-  static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
-  static const bool on = mode.empty() && !(getenv("BUDDY_GN_FUSE") && atoi(getenv("BUDDY_GN_FUSE")) == 0) &&
-                         !(getenv("BUDDY_GN_FUSE_BWDIN") && atoi(getenv("BUDDY_GN_FUSE_BWDIN")) == 0) &&
-                         !(getenv("BUDDY_GN_FUSE_BWD") && atoi(getenv("BUDDY_GN_FUSE_BWD")) == 0) &&
-                         !(getenv("BUDDY_UPCONV") && atoi(getenv("BUDDY_UPCONV")) == 0);     // A/B switch
+  const Options& o = N->opt;
+  const bool on = o.conv == 0 && o.gn_fuse && o.gn_fuse_bwdin && o.gn_fuse_bwd && o.upconv;     // A/B switches
   if (!on || Cin % 8 || Cout % 8 || H < 6 || W < 6) return false;
   IgemmParams p = ig_base();
   p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.ldC = Cout; p.ld_bias_bn = 4;
@@ -569,10 +573,10 @@ static int conv3(Net* N, const Conv3& c) {
   // Winograd forms exist for channel counts that are multiples of 8 (every ResBlock convolution of the supported family)
   const bool wino_ok = c.w != nullptr && c.w->raw != nullptr && Cin % 8 == 0 && Cout % 8 == 0;
   const W4Gn* gn = c.gn; float* gn_tmp = c.gn_tmp; Tens* stat_out = c.stat_out; const W4Gn* bwd_gn = c.bwd_gn; const bool direct = c.direct;
-  // BUDDY_CONV = direct | wino2 | wino4 | (default) three-pass F(6x6,3x3) on the large layers, three-pass F(4x4,3x3) where the shape allows,
+  // option conv = 1 direct | 2 wino2 | 3 wino4 | 0 (default) three-pass F(6x6,3x3) on the large layers, three-pass F(4x4,3x3) where the shape allows,
   // else fused F(2x2,3x3), else direct
-  static const std::string mode = getenv("BUDDY_CONV") ? getenv("BUDDY_CONV") : "";
-  static const bool use_wino = mode != "direct", use_wino4 = mode != "direct" && mode != "wino2", use_wino6 = use_wino4 && mode != "wino4";
+  const int cmode = N->opt.conv;
+  const bool use_wino = cmode != 1, use_wino4 = cmode != 1 && cmode != 2, use_wino6 = use_wino4 && cmode != 3;
   if (N->dry()) {
     if (use_wino4 && wino_ok && H % 4 == 0 && W % 4 == 0) {
       const size_t need = (size_t)36 * ((size_t)B * H * W / 16) * (size_t)(Cin + Cout);
@@ -589,7 +593,7 @@ static int conv3(Net* N, const Conv3& c) {
     IgemmParams p = ig_base();
     p.A0 = a; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = c.out; p.ldC = Cout;
     p.bias_n = c.bias; p.bias_bn = c.bias_bn; p.ld_bias_bn = c.ld_bn; p.rows_per_batch = H * W; p.alpha = c.alpha; p.out_scale = c.out_scale;
-    const bool x3 = N->gemm_mode == 1 && wgemm_supported((c.up == 1 ? 4 : 1) * Cout, (c.up == 2 ? 4 : 1) * Cin);
+    const bool x3 = N->opt.gemm == 1 && wgemm_supported((c.up == 1 ? 4 : 1) * Cout, (c.up == 2 ? 4 : 1) * Cin);
     const WVar* wv = conv_weights(N, *c.w, c.dgrad, 61, x3);
     if (!wv || N->w4_scratch == nullptr) { if (wv) { N->prep_failed = true; set_error("convolution scratch buffer missing"); } return -1; }
     long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf, c.up);
@@ -611,10 +615,10 @@ static int conv3(Net* N, const Conv3& c) {
   p.Bt = nullptr; p.ldB = 9 * Cin; p.C = c.out; p.ldC = Cout;
   p.bias_n = c.bias; p.bias_bn = c.bias_bn; p.ld_bias_bn = c.ld_bn; p.rows_per_batch = H * W;
   p.res = c.res; p.ldRes = c.ldRes; p.res_mode = c.res_mode; p.alpha = c.alpha; p.out_scale = c.out_scale;
-  static const bool fuse_gn = !(getenv("BUDDY_GN_FUSE") && atoi(getenv("BUDDY_GN_FUSE")) == 0);
+  const bool fuse_gn = N->opt.gn_fuse != 0;
   const bool w6 = use_wino6 && wino_ok && N->w4_scratch != nullptr && wino6_supported(p) && wino6_pays(p);
   const bool w4 = !w6 && use_wino4 && wino_ok && N->w4_scratch != nullptr && wino4_supported(p);
-  static const bool fuse_bwd_in = !(getenv("BUDDY_GN_FUSE_BWDIN") && atoi(getenv("BUDDY_GN_FUSE_BWDIN")) == 0);
+  const bool fuse_bwd_in = N->opt.gn_fuse_bwdin != 0;
   if (gn != nullptr && gn->da != nullptr && !(w6 && fuse_gn && fuse_bwd_in)) {       // GroupNorm backward as the input: only F(6x6,3x3) fuses it
     Dst2 d; d.p0 = gn_tmp; d.p1 = nullptr; d.C0 = Cin; d.ld0 = Cin; d.ld1 = 0; d.acc0 = 0; d.acc1 = 0;
     launch_gn_bwd_apply(gn->x, gn->stats, gn->gamma, gn->beta, gn->da, B, H, W, Cin, gn->G, 0, gn->silu, nullptr, 0, 0.f, gn->red, d, N->st);
@@ -624,13 +628,13 @@ static int conv3(Net* N, const Conv3& c) {
     launch_gn_apply(gn->x, gn->stats, gn->gamma, gn->beta, B, H, W, Cin, gn->G, 0, gn->silu, gn_tmp, nullptr, N->st);
     p.A0 = gn_tmp; gn = nullptr;
   }
-  const bool x3 = N->gemm_mode == 1 && wgemm_supported(Cout, Cin);     // the batched GEMM pass in bf16x3 arithmetic: only the stage image is needed
+  const bool x3 = N->opt.gemm == 1 && wgemm_supported(Cout, Cin);     // the batched GEMM pass in bf16x3 arithmetic: only the stage image is needed
   if (w6) {
     const WVar* wv = conv_weights(N, *c.w, c.dgrad, 6, x3);
     if (!wv) return -1;
     const float* U6 = wv->u; const void* U6x = x3 ? wv->x : nullptr;
     long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf);
-    static const bool fuse_bwd = !(getenv("BUDDY_GN_FUSE_BWD") && atoi(getenv("BUDDY_GN_FUSE_BWD")) == 0);
+    const bool fuse_bwd = N->opt.gn_fuse_bwd != 0;
     const bool want_bwd = bwd_gn != nullptr && fuse_gn && fuse_bwd;
     const int sc = ((stat_out != nullptr && fuse_gn) || want_bwd) ? wino6_stat_chunks(p) : 0;
     const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;
@@ -667,7 +671,7 @@ static int conv3(Net* N, const Conv3& c) {
 }
 // a plain row-major GEMM against a registered [N][K] weight (1x1 convolution, NIN) in bf16x3 arithmetic when the handle's mode asks for it
 static bool try_wgemm(Net* N, const IgemmParams& p) {
-  if (N->gemm_mode != 1 || p.bias_m || p.bias_bn || p.res_mode || p.out_scale != 1.f || p.sA || p.sC) return false;
+  if (N->opt.gemm != 1 || p.bias_m || p.bias_bn || p.res_mode || p.out_scale != 1.f || p.sA || p.sC) return false;
   const auto it = N->W->w3.find(p.Bt);
   if (it == N->W->w3.end() || p.ldB != p.Cin || it->second.N != p.N || it->second.K != p.Cin) return false;
   if (!wgemm_general_supported(p.N, p.Cin, p.A1 ? p.C0 : 0, p.ldA0, p.A1 ? p.ldA1 : 0, p.ldC, p.A0, p.A1, p.C, p.bias_n)) return false;
@@ -764,8 +768,8 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       // (wgemm.hip GNB): the block's input gradient in one launch, neither the 1x1 result nor a separate apply pass in HBM
       const W3Img* c2i = nullptr;
       const float* c2a = dout;                               // A operand of that GEMM (the pooled gradient for the sub-pixel up block)
-      static const bool fuse_c2_on = !(getenv("BUDDY_C2_FUSE") && atoi(getenv("BUDDY_C2_FUSE")) == 0);     // A/B switch
-      if (fuse_c2_on && Rp->has_c2 && !firm && (mode == 0 || (mode == 2 && up6)) && n->gemm_mode == 1 && Cin % 4 == 0 && (Cin / G0) % 4 == 0) {
+      const bool fuse_c2_on = n->opt.c2_fuse != 0;     // A/B switch
+      if (fuse_c2_on && Rp->has_c2 && !firm && (mode == 0 || (mode == 2 && up6)) && n->opt.gemm == 1 && Cin % 4 == 0 && (Cin / G0) % 4 == 0) {
         const auto it = n->W->w3.find(Rp->c2.wb);
         if (it != n->W->w3.end() && it->second.N == Cin && it->second.K == Cout && wgemm_gnbwd_supported(Cin, Cout, Cout, src_of(x), d0, dout, dout))
           c2i = &it->second;
@@ -864,18 +868,13 @@ static void gemm_b(Net* N, const float* A, int ldA, long long sA, bool tA, const
 // never exists).  Measured at B = 8, T = 2048 (tools/ab_env.sh BUDDY_ATTN flash matrix): 65.4 -> 64.6 ms/step: six plain batched GEMMs at 100+ TFLOP/s
 // beat kernels that run one wave per SIMD.  The choice depends on T alone: a row's arithmetic does not depend on the batch it is in.
 // 0 = flash, fp32 operands; 1 / 2 = flash with bf16 / f16 MFMA operands (opt-in fast mode); 3 = always the materialised form.
-// Initialised from BUDDY_ATTN (auto | matrix | flash | bf16 | f16), changed per handle with buddy_ncsnpp_set_attention.
+// Default from BUDDY_ATTN (auto | matrix | flash | bf16 | f16; options.hip), changed per handle with buddy_ncsnpp_set_attention / _set_option.
 constexpr int ATTN_MATRIX_MAX_T = 4096;
-static int attn_mode_from_env() {
-  const char* e = getenv("BUDDY_ATTN");
-  const std::string m = e ? e : "";
-  return m == "matrix" ? 3 : m == "bf16" ? 1 : m == "f16" ? 2 : m == "flash" ? 0 : 4;
-}
 static bool attn_use_flash(const Net* N, int C, int T) {
-  if (!flash_attn_supported(C) || N->attn_mode == 3) return false;
-  return N->attn_mode != 4 || T > ATTN_MATRIX_MAX_T;
+  if (!flash_attn_supported(C) || N->opt.attn == 3) return false;
+  return N->opt.attn != 4 || T > ATTN_MATRIX_MAX_T;
 }
-static int attn_prec(const Net* N) { return N->attn_mode == 1 || N->attn_mode == 2 ? N->attn_mode : 0; }
+static int attn_prec(const Net* N) { return N->opt.attn == 1 || N->opt.attn == 2 ? N->opt.attn : 0; }
 
 static Tens* attnblock_flash(Net* N, const AttnW& A, Tens* x, bool rec) {
   const int B = x->B, H = x->H, W = x->W, C = A.C, T = H * W, G = gn_groups(C);
@@ -977,7 +976,7 @@ static Tens* attnblock(Net* N, const AttnW& A, Tens* x, bool rec) {
       float* dq = n->tmp(B * TC); float* dk = n->tmp(B * TC); float* dhn = n->tmp(B * TC);
       // P^T and dS^T by a tiled transpose (T % 32 == 0): the two products that need them then take the row-major-A kernel (and its half-height tiles when
       // the grid is small) instead of the doubly transposed one (272 us per launch at B = 8 against 41 + ~150)
-      static const bool use_tr = !(getenv("BUDDY_ATTN_TR") && atoi(getenv("BUDDY_ATTN_TR")) == 0);     // A/B switch
+      const bool use_tr = n->opt.attn_tr != 0;     // A/B switch
       const bool tr = use_tr && T % 32 == 0;
       float* Tr = tr ? n->tmp(B * TT) : nullptr;
       gemm_b(n, dout, C, 0, false, Ap->Wn[3], C, 0, false, dO, C, 0, B * T, C, C, nullptr, nullptr, INV_SQRT2, 0, 1);
@@ -1207,6 +1206,7 @@ static void run_vjp(Net* N, const float* cot, float* gx) {
 }
 
 int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes) {
+  OptScope scope(&N->opt);
   Arena saved = N->arena;
   N->w4_need = 0;
   N->arena = Arena(); N->arena.dry = true;
@@ -1238,6 +1238,7 @@ int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes) {
 int net_forward(Net* N, const float* x, const float* cnoise, const float* cin_b, const float* cskip_b, const float* cout_b, float* y, int B, int L,
                 int save, hipStream_t st) {
   if (B < 1 || L < N->cfg.n_fft) { set_error("bad B or L"); return BUDDY_ERR_ARG; }
+  OptScope scope(&N->opt);          // the launchers of this call read THIS handle's options
   const int T = 1 + L / N->cfg.hop, Tp = (T + 15) / 16 * 16;
   if (Tp % (1 << (N->cfg.nlev - 1))) { set_error("frames not divisible"); return BUDDY_ERR_ARG; }
   int rc = BUDDY_OK;
@@ -1256,6 +1257,7 @@ int net_forward(Net* N, const float* x, const float* cnoise, const float* cin_b,
 
 int net_vjp(Net* N, const float* cot, float* gx, hipStream_t st) {
   if (!N->have_tape) { set_error("vjp without a saved forward"); return BUDDY_ERR_STATE; }
+  OptScope scope(&N->opt);
   N->st = st;
   run_vjp(N, cot, gx);
   if (N->arena.overflow) { set_error("arena overflow"); return BUDDY_ERR_STATE; }

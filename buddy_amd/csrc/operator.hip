@@ -1273,7 +1273,7 @@ struct BlindOp {
   }
   void update_H() { cons_forward(); }
   bool fir_lds_ok() const {
-    static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
+    const bool lds = cur_opt().fir_lds != 0;
     return lds && big_lds && Nf == FIR_NF;
   }
   // Y0 = FIR(X0, H) and, when X1b is given, Y1 = FIR(X1b, H) in the same launch (LDS kernel only)
@@ -1296,7 +1296,7 @@ struct BlindOp {
     hipLaunchKernelGGL(fir_gradh_lds_kernel, dim3((FB + FL_BINS - 1) / FL_BINS, U, (Nf + GL_TAPS - 1) / GL_TAPS), dim3(256), 0, st, sg, GH, Nf, accumulate);
   }
   void gradh(const float* X, long long xs, const float* GY, int Tn, int accumulate) {
-    static const bool lds = !(getenv("BUDDY_FIR_LDS") && atoi(getenv("BUDDY_FIR_LDS")) == 0);
+    const bool lds = cur_opt().fir_lds != 0;
     if (lds) gradh2(X, xs, GY, Tn, nullptr, 0, nullptr, 0, accumulate);
     else
       hipLaunchKernelGGL(fir_gradh_kernel, dim3(U * ((Nf + FT - 1) / FT) * ((FB + GH_F - 1) / GH_F)), dim3(256), 0, st, X, xs, GY, GH, U, Tn, Nf, accumulate);
@@ -1691,7 +1691,7 @@ int blindop_optimize(BlindOp* o, const float* x_den, const float* noise, float t
                      float b2, float wd, hipStream_t st) {
   o->st = st;
   const int U = o->U;
-  static const bool want_graph = !(getenv("BUDDY_OP_GRAPH") && atoi(getenv("BUDDY_OP_GRAPH")) == 0);
+  const bool want_graph = cur_opt().op_graph != 0;
   const bool use_graph = want_graph && n_iters > 0 && o->adam_step + n_iters < BlindOp::MAXSTEP;
   if (!use_graph) {
     for (int it = 0; it < n_iters; ++it)

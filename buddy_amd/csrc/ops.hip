@@ -939,7 +939,7 @@ void launch_gn_apply(Src2 x, const float* stats, const float* gamma, const float
   const long long total = (long long)B * (mode == 1 ? (H / 2) * (W / 2) : H * W) * (C / 4);
   const double n_in = (double)B * H * W * C, n_out = mode == 1 ? n_in / 4 : (mode == 2 ? n_in * 4 : n_in);
   prof_hbm_begin(4.0 * (n_in + n_out + (pooled_raw ? n_out : 0.0)), st);   // read x, write the (resampled) activation
-  static const bool fast = !(getenv("BUDDY_GN_FAST") && atoi(getenv("BUDDY_GN_FAST")) == 0);
+  const bool fast = cur_opt().gn_fast != 0;
   if (fast && mode == 0 && C % 4 == 0 && C / 4 <= 256) {
     GnFast a = gn_fast(H * W, C, G);
     hipLaunchKernelGGL(gn_apply_m0_kernel, dim3((H * W + a.ppc - 1) / a.ppc, B), dim3(a.q * a.pl), 0, st, x, stats, gamma, beta, a, silu, out);
@@ -970,7 +970,7 @@ void launch_gn_bwd_apply(Src2 x, const float* stats, const float* gamma, const f
   // reads x and da again, writes dx (+ reads the extra gradient)
   prof_hbm_begin(4.0 * (n_in + n_da + n_in + (extra_mode ? (extra_mode == 2 ? n_in / 4 : n_in) : 0.0)), st);
   const long long total = (long long)B * H * W * (C / 4);
-  static const bool fast = !(getenv("BUDDY_GN_FAST") && atoi(getenv("BUDDY_GN_FAST")) == 0);
+  const bool fast = cur_opt().gn_fast != 0;
   if (fast && mode == 0 && extra_mode != 2 && C % 4 == 0 && C / 4 <= 256) {
     GnFast g = gn_fast(H * W, C, G);
     const bool ex = extra_mode == 1 && extra != nullptr, acc = dx.acc0 != 0 || (dx.p1 != nullptr && dx.acc1 != 0);
@@ -1043,7 +1043,7 @@ void launch_conv_c2in(const float* x, const float* w, const float* bias, const f
     const int ppb = 256 / (Cout / 4);
     long long g = ((long long)B * H * W + ppb - 1) / ppb;
     if (g > 256 * 8) g = 256 * 8;
-    static const bool four = !(getenv("BUDDY_C2IN4") && atoi(getenv("BUDDY_C2IN4")) == 0);
+    const bool four = cur_opt().c2in4 != 0;
     if (taps == 9 && four && W % 4 == 0) {
       long long g4 = ((long long)B * H * (W / 4) + ppb - 1) / ppb;
       if (g4 > 256 * 16) g4 = 256 * 16;
@@ -1065,7 +1065,7 @@ void launch_conv_c2out(const float* x, int ldX, const float* w, const float* bia
   const int ppb = 256 / (Cin / 4);
   long long groups = ((long long)B * H * W + ppb - 1) / ppb;
   int grid = (int)(groups < 256 * 8 ? groups : 256 * 8);
-  static const bool tiled = !(getenv("BUDDY_C2OUT_TILED") && atoi(getenv("BUDDY_C2OUT_TILED")) == 0);
+  const bool tiled = cur_opt().c2out_tiled != 0;
   if (taps == 9 && tiled && Cin % C2O_CK == 0 && ldX % 4 == 0) {
     const int blocks = B * ((H + C2O_TH - 1) / C2O_TH) * ((W + C2O_TW - 1) / C2O_TW);
     hipLaunchKernelGGL(conv_c2out_tiled_kernel, dim3(blocks), dim3(256), 0, st, x, ldX, w, bias, up_add, y, B, H, W, Cin, accumulate);

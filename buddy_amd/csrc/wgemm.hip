@@ -101,7 +101,9 @@ __device__ __forceinline__ float dsilu_g(float z) {
 // out[row][c] = alpha * (A W^T)[row][c] + rstd * (dxhat - m1 - xhat * m2), dxhat = da * act'(z) * gamma -- the block's whole input gradient.  The separate
 // apply kernel read x, da and the materialised 1x1 result and wrote dx (5 C-channel streams with the GEMM's store); here the epilogue reads x and da and
 // writes dx (3).  x / out are two-source / two-destination channel views split at a multiple of 128 (a column block never straddles).
-template <bool GEN, bool EPI, bool GNB = false>
+// DMA: the weight stage goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: the stage image is linear, a wave moves 1 KB per instruction) instead
+// of through 24 staging registers and six ds_write_b128 per thread and stage
+template <bool GEN, bool EPI, bool GNB = false, bool DMA = false>
 __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -156,14 +158,25 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
 #pragma unroll
     for (int j = 0; j < 6; ++j) Bs[buf * (STAGE_BYTES / 16) + j * WNT] = rb[j];
   };
+  const int wuni = __builtin_amdgcn_readfirstlane(wid);
+  auto dmaB = [&](int s, int buf) {                            // wave w, instruction j: bytes [(256 j + 64 w) * 16, + 1024) of the stage, lane-linear
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bg + (long long)s * (STAGE_BYTES / 16) + j * WNT),
+                                       (__attribute__((address_space(3))) void*)(smem + buf * STAGE_BYTES + (j * WNT + wuni * 64) * 16), 16, 0, 0);
+  };
 
   loadA(0);
-  loadB(0);
-  storeB(0);
+  if (DMA) { dmaB(0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  else { loadB(0); storeB(0); }
   __syncthreads();
   for (int s = 0; s < S; ++s) {
     const float4 ca[4] = {ra[0], ra[1], ra[2], ra[3]};
-    if (s + 1 < S) { loadA(s + 1); loadB(s + 1); }           // stage s + 1 is in flight under the 48 MFMAs of stage s
+    if (s + 1 < S) {                                           // stage s + 1 is in flight under the 48 MFMAs of stage s
+      loadA(s + 1);
+      if (DMA) dmaB(s + 1, (s + 1) & 1);                       // that buffer was last read in stage s - 1: every wave is past its barrier
+      else loadB(s + 1);
+    }
     const unsigned char* Bcur = smem + (s & 1) * STAGE_BYTES + lane * 16;
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
@@ -181,7 +194,8 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][PB[t]], av.p[PA[t]], acc[cb], 0, 0, 0);
     }
-    if (s + 1 < S) storeB((s + 1) & 1);                        // that buffer was last read in stage s - 1: every wave is past its barrier
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s + 1 have landed (the barrier covers the other waves')
+    else if (s + 1 < S) storeB((s + 1) & 1);                   // that buffer was last read in stage s - 1: every wave is past its barrier
     __syncthreads();
   }
 
@@ -336,7 +350,7 @@ void launch_wgemm_bf16x3_general(const float* A0, int ldA0, const float* A1, int
   a.A1 = A1; a.C0 = A1 ? C0 : K; a.ldA0 = ldA0; a.ldA1 = ldA1; a.ldC = ldC; a.bias_n = bias_n; a.alpha = alpha; a.accumulate = accumulate;
   a.pz = 0; a.gx = 0;
   const dim3 grid((unsigned)(cdiv((int)M, WBM) * a.NB), 1, 1);
-  static const bool direct_store = getenv("BUDDY_WGEMM_GEN_EPI") && atoi(getenv("BUDDY_WGEMM_GEN_EPI")) == 0;      // A/B switch: 32-byte-piece stores
+  const bool direct_store = cur_opt().wgemm_gen_epi == 0;      // A/B switch: 32-byte-piece stores
   if (direct_store) hipLaunchKernelGGL((wgemm_bf16x3_kernel<true, false>), grid, dim3(WNT), 0, st, a);
   else hipLaunchKernelGGL((wgemm_bf16x3_kernel<true, true>), grid, dim3(WNT), 0, st, a);
 }
@@ -366,13 +380,14 @@ void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt,
   a.V = V; a.U3 = reinterpret_cast<const unsigned char*>(U3); a.M = M;
   a.Mt = (int)Mt; a.Cin = Cin; a.Cout = Cout; a.S = Cin / WKS; a.NB = Cout / WBN;
   a.sV = Mt * Cin; a.sM = Mt * Cout;
-  static const bool by_pos = !(getenv("BUDDY_WGEMM_XCDPOS") && atoi(getenv("BUDDY_WGEMM_XCDPOS")) == 0);     // A/B switch
+  const bool by_pos = cur_opt().wgemm_xcdpos != 0;     // A/B switch
   const int gx = cdiv((int)Mt, WBM) * a.NB;
   const bool fold = by_pos && P % 8 == 0 && (long long)gx * P < (1LL << 31);
   a.pz = fold ? P : 0; a.gx = gx;
   const dim3 grid(fold ? (unsigned)(gx * P) : (unsigned)gx, 1, fold ? 1u : (unsigned)P);
-  static const bool direct_store = getenv("BUDDY_WGEMM_EPI") && atoi(getenv("BUDDY_WGEMM_EPI")) == 0;      // A/B switch: 32-byte-piece stores (+0.3 ... 1.9 % slower)
+  const bool direct_store = cur_opt().wgemm_epi == 0;      // A/B switch: 32-byte-piece stores (+0.3 ... 1.9 % slower)
   if (direct_store) hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, false>), grid, dim3(WNT), 0, st, a);
+  else if (cur_opt().wgemm_dma) hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true, false, true>), grid, dim3(WNT), 0, st, a);
   else hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true>), grid, dim3(WNT), 0, st, a);
 }
 

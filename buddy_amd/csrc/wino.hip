@@ -279,14 +279,14 @@ void launch_wino(const IgemmParams& p_in, const float* Uw, hipStream_t st) {
     if (p.bias_n) wide = wide && al16(p.bias_n);
     if (p.bias_bn) wide = wide && al16(p.bias_bn) && (p.ld_bias_bn % 4 == 0);
     if (p.res_mode) wide = wide && al16(p.res) && (p.ldRes % 4 == 0);
-    static const bool force_scalar = getenv("BUDDY_WINO_EPI") && atoi(getenv("BUDDY_WINO_EPI")) == 0;     // A/B switch
+    const bool force_scalar = cur_opt().wino_epi == 0;     // A/B switch
     p.wide_epi = (wide && !force_scalar) ? 1 : 0;
   }
   if (!g_zero_page) { (void)hipMalloc(&g_zero_page, 256); (void)hipMemset(g_zero_page, 0, 256); }
   const int B = p.M / (p.H * p.W);
   const int TH = p.H / 2, TW = p.W / 2;
-  static const int abl = getenv("BUDDY_WINO_ABL") ? atoi(getenv("BUDDY_WINO_ABL")) : 0;     // timing ablations (wrong results): 1 no MFMA, 2 no patch reads, 3 no DMA
-  static const int geo = getenv("BUDDY_WINO_GEO") ? atoi(getenv("BUDDY_WINO_GEO")) : 42;    // 42: 4-wave workgroups, 2 per CU (default, fastest); 82: 8-wave workgroups
+  const int abl = cur_opt().wino_abl;     // timing ablations (wrong results): 1 no MFMA, 2 no patch reads, 3 no DMA
+  const int geo = cur_opt().wino_geo;    // 42: 4-wave workgroups, 2 per CU (default, fastest); 82: 8-wave workgroups
   const float* z = g_zero_page;
   if (TH % 8 == 0 && geo / 10 == 8) {
     const int grid = B * (TH / 8) * (TW / BTX) * (p.N / WN);

@@ -316,7 +316,7 @@ W6Geo geometry(const IgemmParams& p, int C, int up = 0) {
   const int q = C / 4;
   g.QC = q >= 32 ? 32 : (q > 16 ? 32 : (q > 8 ? 16 : (q > 4 ? 8 : (q > 2 ? 4 : (q > 1 ? 2 : 1)))));
   g.TPB = 32 / g.QC;
-  static const int xcd = !(getenv("BUDDY_W6_XCD") && atoi(getenv("BUDDY_W6_XCD")) == 0);     // A/B switch of the XCD-aware tile order of the input transform
+  const int xcd = cur_opt().w6_xcd != 0;     // A/B switch of the XCD-aware tile order of the input transform
   g.xcd = xcd;
   g.Cl = C;
   return g;

@@ -114,8 +114,17 @@ class NCSNppTime(nn.Module):
         if gemm is not None and gemm not in self.GEMM_MODES:
             raise NotImplementedError(f"gemm must be one of {sorted(self.GEMM_MODES)}")
         self.gemm = gemm
+        self._options = {}              # per-handle launcher options set through set_option (build extension; keys: include/buddy_hip.h)
         self.fir = bool(fir)            # FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257); no parameters
         self._specs = module_specs(self.nf, self.ch_mult, self.num_res_blocks)
+        # The architecture family (reference ncsnpp.py:184-270) is built for any level / block count (fixtures net_cm12_rb2, net_cm1122_rb1), with one
+        # restriction of the GroupNorm kernels: they normalise float4 channel quads with one group's statistics, so every normalised tensor -- skip
+        # concatenations included -- needs a multiple of 4 channels per group: C <= 128 or C % 128 == 0 (min(C // 4, 32) groups).  nf = 32 / 128 with the
+        # reference's multipliers fit; nf = 64, ch_mult (1, 2, 2, 2) has a 192-channel concatenation (six per group) and is refused here.
+        bad = sorted({shape[0] for name, shape, kind, _ in self._specs if kind == "gamma" and (shape[0] % 4 or (shape[0] > 128 and shape[0] % 128))})
+        if bad:
+            raise NotImplementedError(f"NCSNppTime (MI355X): unsupported width nf={self.nf}, ch_mult={self.ch_mult}: GroupNorm over {bad} channels "
+                                      "(channels per group must be a multiple of 4: C <= 128 or C % 128 == 0)")
         # parameter containers under the reference names
         n_mod = 1 + max(int(n.split(".")[1]) for n, *_ in self._specs if n.startswith("all_modules."))
         self.all_modules = nn.ModuleList([_Bag() for _ in range(n_mod)])
@@ -169,6 +178,8 @@ class NCSNppTime(nn.Module):
             _lib.check(lib.buddy_ncsnpp_replica(self._parent._get_handle(), C.byref(h)))
             if self.attention is not None:      # per-handle setting: a replica may run another attention core on the shared weights
                 _lib.check(lib.buddy_ncsnpp_set_attention(h, self.ATTENTION_MODES[self.attention]))
+            for k, v in self._options.items():
+                _lib.check(lib.buddy_ncsnpp_set_option(h, k.encode(), int(v)))
             self._handle = h
         if self._handle is None:
             lib = _lib.require_gpu()
@@ -183,8 +194,23 @@ class NCSNppTime(nn.Module):
                 _lib.check(lib.buddy_ncsnpp_set_attention(h, self.ATTENTION_MODES[self.attention]))
             if self.gemm is not None:
                 _lib.check(lib.buddy_ncsnpp_set_gemm(h, self.GEMM_MODES[self.gemm]))
+            for k, v in self._options.items():
+                _lib.check(lib.buddy_ncsnpp_set_option(h, k.encode(), int(v)))
             self._handle = h
         return self._handle
+
+    def set_option(self, key, value):
+        """Per-handle launcher option (``buddy_ncsnpp_set_option``: fusion / layout A/B switches, attention core, GEMM arithmetic; an unknown key or
+        a value out of range raises).  Applies to this module's handle only -- a replica made afterwards starts from the same settings."""
+        self._options[str(key)] = int(value)
+        if getattr(self, "_handle", None) is not None:
+            _lib.check(_lib.load().buddy_ncsnpp_set_option(self._handle, str(key).encode(), int(value)))
+        return self
+
+    def get_option(self, key):
+        v = C.c_int()
+        _lib.check(_lib.load().buddy_ncsnpp_get_option(self._get_handle(), str(key).encode(), C.byref(v)))
+        return v.value
 
     def replica(self, attention=None):
         """A second module on the SAME parameters and the same prepared device weights (``buddy_ncsnpp_replica``: reference-counted, read-only)
@@ -194,6 +220,7 @@ class NCSNppTime(nn.Module):
         if attention is not None and attention not in self.ATTENTION_MODES:   # validate BEFORE copying: a half-built copy still holds the parent's handle
             raise NotImplementedError(f"attention must be one of {sorted(self.ATTENTION_MODES)}")
         r = copy.copy(self)                     # shallow: shares _parameters / _modules (the nn.Parameters themselves)
+        r.__dict__["_options"] = dict(self._options)
         r.__dict__["_handle"] = None            # first thing: the copy must never own (and on collection destroy) the parent's library handle
         if attention is not None:
             r.attention = attention

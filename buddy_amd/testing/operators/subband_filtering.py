@@ -285,7 +285,11 @@ class BlindSubbandFiltering(SubbandFiltering):
             if self.noise is None:
                 noise = torch.randn(n_it, self.U, Lr, device=self.device)      # the reference draws this one on the device too (randn_like(rir_time))
             else:
-                noise = torch.stack([torch.stack([n.randn((Lr,)) for n in self.noise]) for _ in range(n_it)]).to(self.device)
+                # injected per-utterance streams (tests, the float64 arbiter runs): drawn on the host in reference call order, ONE pinned buffer and
+                # ONE asynchronous copy per step -- a pageable .to(device) makes the host wait for the whole queue, i.e. drains the GPU every step
+                host = torch.stack([torch.stack([n.randn((Lr,)) for n in self.noise]) for _ in range(n_it)]).contiguous()
+                cuda = torch.device(self.device).type == "cuda"
+                noise = (host.pin_memory() if cuda else host).to(self.device, non_blocking=cuda)
             noise = noise.contiguous()
         t_op = max(min(float(t), self.reg.crop_sigma_max), self.reg.crop_sigma_min)
         xd = x_den.contiguous().float()

@@ -190,6 +190,16 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
  * The transposes are the other direction times 4 resp. 1/4.  buddy_ncsnpp_set_fir switches a network handle to this resampling (no parameters). */
 int buddy_fir_resample2(const float* x, float* y, int B, int H, int W, int C, int up, float scale, int accumulate, void* stream);
 int buddy_ncsnpp_set_fir(void* handle, int fir);
+/* Per-handle launcher options -- "no hidden global state" (SURVEY.md 8(b)): every switch a launcher consults (attention core, GEMM arithmetic, the
+ * fusion / layout A/B switches) is a field of the handle's option struct; two handles in one process may differ.  Keys (csrc/options.hip): conv, gemm,
+ * attention, gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr, attn_split, attn_nw, igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos,
+ * wgemm_epi, wgemm_dma, wino_epi, wino_abl, wino_geo, w6_xcd, gn_fast, c2in4, c2out_tiled, fir_lds, op_graph.  An unknown key or a value out of range is
+ * BUDDY_ERR_ARG.  A handle starts from the process defaults = the BUDDY_<KEY> environment variables, parsed and validated in ONE place at handle
+ * creation: an unknown BUDDY_* variable or a bad value makes buddy_ncsnpp_create fail with a message naming it.  Set options before the first forward or
+ * between calls (the activation arena is sized again). */
+int buddy_options_check(void);   /* the environment check alone (no GPU needed): BUDDY_OK, or BUDDY_ERR_ARG with buddy_last_error() naming the variable */
+int buddy_ncsnpp_set_option(void* handle, const char* key, int value);
+int buddy_ncsnpp_get_option(void* handle, const char* key, int* value);
 /* attention core of a network handle: 4 = auto (default; fp32: the materialised T x T form while T <= 4096, the online-softmax kernels beyond -- a
  * function of T alone); 0 = online-softmax kernels, fp32 operands; 1 / 2 = the same with bf16 / f16 MFMA operands (opt-in fast mode, fp32 accumulate
  * + fp32 softmax); 3 = always the materialised T x T matrix.  Initial value from BUDDY_ATTN = auto | flash | bf16 | f16 | matrix. */

@@ -144,8 +144,8 @@ def gen_edm_sched():
     save("edm_sched", **out)
 
 
-def _net_fixture(name, nf, n_fft, hop, L, B, seed, with_taps):
-    net = build_ref_net(nf, n_fft, hop, seed)
+def _net_fixture(name, nf, n_fft, hop, L, B, seed, with_taps, ch_mult=(1, 2, 2, 2), num_res_blocks=1):
+    net = build_ref_net(nf, n_fft, hop, seed, ch_mult, num_res_blocks)
     rs = np.random.RandomState(seed + 100)
     x = torch.from_numpy((0.5 * rs.standard_normal((B, 1, L))).astype(np.float32))
     cn = torch.from_numpy(rs.uniform(-2.0, 0.3, size=(B,)).astype(np.float32))
@@ -164,6 +164,9 @@ def _net_fixture(name, nf, n_fft, hop, L, B, seed, with_taps):
         h.remove()
     arrs = dict(x=x.detach(), cnoise=cn, cot=cot, y=y.detach(), vjp=g,
                 meta=np.array([nf, n_fft, hop, L, B, seed]))
+    if tuple(ch_mult) != (1, 2, 2, 2) or num_res_blocks != 1:       # the shipped fixtures keep their exact bytes
+        arrs["ch_mult"] = np.array(ch_mult)
+        arrs["num_res_blocks"] = np.array(num_res_blocks)
     for i, t in taps.items():
         arrs[f"tap{i}_mean"] = t.mean()
         arrs[f"tap{i}_absmax"] = t.abs().max()
@@ -173,6 +176,12 @@ def _net_fixture(name, nf, n_fft, hop, L, B, seed, with_taps):
 
 def gen_net_small():
     _net_fixture("net_small", nf=32, n_fft=126, hop=32, L=4096, B=2, seed=3, with_taps=True)
+
+
+def gen_net_arch():
+    """the constructor is parametric (reference networks/ncsnpp.py:50-52,184-270): two members of the family besides the shipped (1,2,2,2) / 1 block"""
+    _net_fixture("net_cm12_rb2", nf=32, n_fft=126, hop=32, L=4096, B=2, seed=21, with_taps=True, ch_mult=(1, 2), num_res_blocks=2)
+    _net_fixture("net_cm1122_rb1", nf=32, n_fft=126, hop=32, L=4096, B=2, seed=22, with_taps=True, ch_mult=(1, 1, 2, 2), num_res_blocks=1)
 
 
 def gen_net_full():
@@ -471,7 +480,7 @@ def gen_fir():
     save("net_small_fir", **arrs)
 
 
-GENS = dict(edm_sched=gen_edm_sched, net_small=gen_net_small, net_full=gen_net_full, ops=gen_ops,
+GENS = dict(edm_sched=gen_edm_sched, net_small=gen_net_small, net_arch=gen_net_arch, net_full=gen_net_full, ops=gen_ops,
             e2e_informed=gen_e2e_informed, e2e_blind=gen_e2e_blind, e2e_uncond=gen_uncond,
             opt=gen_opt, e2e_blind_o2=gen_e2e_blind_o2, e2e_blind10=gen_e2e_blind10, config1=gen_config1, fir=gen_fir)
 

@@ -64,6 +64,21 @@ def test_two_ranks_equal_single_process(tmp_path):
     assert err < 1e-4, err
 
 
+def test_eight_ranks_64_utterance_partition(tmp_path):
+    """BASELINE configs[2]'s partition at its real rank count on the CPU: 64 utterances over eight gloo ranks (u -> rank u mod 8, eight per rank,
+    sampled as ONE batch of eight per rank like a GPU rank does), one all_gather; every row equals the utterance sampled alone (per-utterance
+    semantics: results do not depend on the world size or on which utterances share a batch)."""
+    n_utts, L = 64, 2048
+    out_path = str(tmp_path / "gathered8.pt")
+    mp.spawn(_worker, args=(8, _free_port(), n_utts, L, out_path), nprocs=8, join=True)
+    gathered = torch.load(out_path)
+    assert gathered.shape == (n_utts, L) and torch.isfinite(gathered).all()
+    for u in (0, 7, 8, 13, 42, 63):        # spot rows of different ranks / batch positions against the utterance on its own
+        single = _sample([u], L)[0]
+        err = float((gathered[u] - single).abs().max() / single.abs().max())
+        assert err < 1e-4, (u, err)
+
+
 def _ragged_worker(rank, world, port, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     sys.path.insert(0, ROOT)

@@ -160,6 +160,13 @@ def test_bench_line_contract():
         assert leg["ms_per_step"] > 0 and leg["value"] > 0 and leg["unit"] == "utterance-steps/s" and leg["config"], name
     assert j["legs"]["longform_480000_B4"]["attention"]
     assert j["legs"]["forward_only"]["forward_evals_per_s"] > j["score_evals_per_s"]          # a forward costs less than forward + VJP + operator update
+    # round 5: the reference's own shape -- ONE utterance through the shipped yaml (wpe_scaled, T = 201, 10 updates), torch RNG --
+    # and every set-up piece of the cold start, in the line and (for the driver's tail) on stderr
+    sh = j["legs"]["full_run_B1_shipped"]
+    assert sh["T"] == 201 and 0.5 < sh["wall_s"] < 20.0 and abs(sh["ms_per_step"] - sh["wall_s"] / 201 * 1e3) < 1e-6 and "UNCHANGED" in sh["config"]
+    for k in ("import_torch_s", "hip_context_s", "lib_load_s", "module_build_s", "cold_start_s", "synth_inputs_s", "prepare_batch_s", "stack_build_s"):
+        assert cs[k] is not None and cs[k] >= 0.0, k
+    assert "stack ready: import_torch_s" in r.stderr and "leg full_run_B1_shipped" in r.stderr
     fr = j["full_run"]
     assert fr["T"] == 50 and fr["batch_per_gpu"] == 8 and 1.0 < fr["wall_s"] < 30.0 and abs(fr["utterance_steps_per_s"] - 400 / fr["wall_s"]) < 1e-6 * 400
     rs = j["rccl_selftest"]

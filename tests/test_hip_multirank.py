@@ -19,7 +19,8 @@ def _free_port():
     return p
 
 
-def _run(rank, world):
+def _run(rank, world, lengths=None):
+    lengths = LENGTHS if lengths is None else lengths
     sys.path.insert(0, ROOT)
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
@@ -31,21 +32,21 @@ def _run(rank, world):
     net = instantiate(args.network)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(2, 32).items()})
     net = net.cuda().eval()
-    items = [(synth_clean(u, L), synth_rir(u, 1500), f"u{u}.wav") for u, L in enumerate(LENGTHS)]
+    items = [(synth_clean(u, L), synth_rir(u, 1500), f"u{u}.wav") for u, L in enumerate(lengths)]
     t = Tester(args, net, instantiate(args.diff_params), test_set=items, device="cuda", in_training=True, batch_size=1, rank=rank, world_size=world)
     t.noise_factory = lambda names: [NoiseStream(700 + int(n[1:-4])) for n in names]
     t.test_dereverberation("blind_dereverberation", blind=True)
     return t.gathered
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, lengths=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from buddy_amd import dist as bd
     bd.init(backend="gloo")
-    g = _run(rank, world)
+    g = _run(rank, world, lengths)
     if rank == 0:
         torch.save(g, out_path)
     dist.barrier()
@@ -61,6 +62,42 @@ def test_two_ranks_one_gpu_equal_single_process(tmp_path):
     for (n, a), (_, b), L in zip(got, ref, LENGTHS):
         assert a.shape == (L,) and torch.isfinite(a).all()
         assert torch.equal(a, b), (n, float((a - b).abs().max()))
+
+
+def test_eight_ranks_64_utterances_one_gpu_equal_single_process(tmp_path):
+    """BASELINE configs[2] at its real rank count: 64 utterances of ragged lengths over EIGHT ranks (u -> rank u mod 8, eight per rank) sharing
+    the one GPU of the test box (gloo control plane; RCCL wants a device per rank), one end-of-run gather: rank 0 holds all 64 rows in utterance
+    order, bit-identical to the single-process run.  nf = 32 keeps eight activation arenas small; the partition, the ragged gather and the
+    per-utterance noise streams are the full-size ones."""
+    lengths = [4096 + 512 * ((5 * u) % 9) + 37 * (u % 4) for u in range(64)]          # 4096 .. 8303 samples, 33 distinct lengths
+    out_path = str(tmp_path / "g8.pt")
+    mp.spawn(_worker, args=(8, _free_port(), out_path, lengths), nprocs=8, join=True)
+    got = torch.load(out_path)
+    ref = _run(0, 1, lengths)
+    assert [n for n, _ in got] == [n for n, _ in ref] == [f"u{u}" for u in range(64)]
+    for (n, a), (_, b), L in zip(got, ref, lengths):
+        assert a.shape == (L,) and torch.isfinite(a).all()
+        assert torch.equal(a, b), (n, float((a - b).abs().max()))
+
+
+def test_bench_eight_gloo_ranks_on_one_gpu():
+    """`python bench.py --gpus 8 --backend gloo ...`: the driver's N = 8 launch path (self-launcher, RANK / WORLD_SIZE environment, barrier + max over
+    ranks timing, end-of-run gather) with eight ranks sharing the one GPU: ONE JSON line, n_gpus 8, the per-rank step times it is the max of."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--batch", "1", "--length", "16000", "--steps", "2", "--warmup", "1",
+           "--legs", "none", "--no-cpu-baseline", "--also-concurrent", "0", "--no-rccl-selftest"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    per = j["per_rank_ms_per_step"]
+    assert len(per) == 8 and abs(max(per) - j["ms_per_step"]) < 1e-6 * j["ms_per_step"] + 1e-9
+    assert abs(j["value"] - 8 * 1 * 1e3 / j["ms_per_step"]) < 1e-6 * j["value"]
+    print(f"8 gloo ranks on one GPU: {j['ms_per_step']:.1f} ms/step (max), per rank {[round(v, 1) for v in per]}")
 
 
 def test_concurrent_sub_batches_equal_single_batch():

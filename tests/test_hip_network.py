@@ -18,15 +18,16 @@ def rel(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
-def build(nf, n_fft, hop, seed, fir=False, attention=None, gemm=None):
+def build(nf, n_fft, hop, seed, fir=False, attention=None, gemm=None, ch_mult=(1, 2, 2, 2), num_res_blocks=1):
     from buddy_amd.config import load_yaml, CONF_DIR, AttrDict
     from buddy_amd.networks.ncsnpp import NCSNppTime
     from buddy_amd.synth import synth_state_dict
     cfg = load_yaml(os.path.join(CONF_DIR, "network", "ncsnpp.yaml"))
     cfg.pop("_target_")
-    cfg.update(nf=nf, fir=fir, attention=attention, gemm=gemm, stft=AttrDict(n_fft=n_fft, hop_length=hop, center=True))
+    cfg.update(nf=nf, fir=fir, attention=attention, gemm=gemm, ch_mult=list(ch_mult), num_res_blocks=num_res_blocks,
+               stft=AttrDict(n_fft=n_fft, hop_length=hop, center=True))
     net = NCSNppTime(**cfg)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(seed, nf).items()})
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(seed, nf, tuple(ch_mult), num_res_blocks).items()})
     return net.cuda().eval()
 
 
@@ -52,6 +53,32 @@ def test_forward_vjp_vs_golden(golden, name):
     gx, = torch.autograd.grad(y, x, torch.from_numpy(g["cot"]).cuda())
     e = rel(gx.cpu().numpy(), g["vjp"])
     assert e < TOL, f"vjp rel err {e}"
+
+
+@pytest.mark.parametrize("attention", ["matrix", "flash"])
+@pytest.mark.parametrize("gemm", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("name", ["net_cm12_rb2", "net_cm1122_rb1"])
+def test_architecture_family_vs_golden(golden, name, gemm, attention):
+    """The constructor is parametric (reference networks/ncsnpp.py:50-52,184-270: ch_mult, num_res_blocks, nf); csrc/net.hip builds the module list
+    for any level / block count.  Two members besides the shipped (1, 2, 2, 2) / 1 block, recorded from the reference: forward, input-VJP and the
+    per-module statistics, in both GEMM arithmetics and both fp32 attention forms."""
+    g = golden(name)
+    nf, n_fft, hop, L, B, seed = [int(v) for v in g["meta"]]
+    ch_mult, nrb = tuple(int(c) for c in g["ch_mult"]), int(g["num_res_blocks"])
+    net = build(nf, n_fft, hop, seed, gemm=gemm, attention=attention, ch_mult=ch_mult, num_res_blocks=nrb)
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = net(x, torch.from_numpy(g["cnoise"]).cuda())
+    bad, n = [], 0
+    for k in sorted(g.files):
+        if k.startswith("tap") and k.endswith("_absmax"):
+            i = int(k[3:-7]); t = net.tap(i); n += 1
+            if abs(float(t.abs().max()) - float(g[k])) > 2e-3 * float(g[k]) or abs(float(t.std()) - float(g[f"tap{i}_std"])) > 2e-3 * float(g[f"tap{i}_std"]):
+                bad.append((i, float(t.abs().max()), float(g[k])))
+    assert n >= 12 and not bad, f"per-module statistics off (idx, absmax, ref): {bad[:6]}"
+    gx, = torch.autograd.grad(y, x, torch.from_numpy(g["cot"]).cuda())
+    ey, eg = rel(y.detach().cpu().numpy(), g["y"]), rel(gx.cpu().numpy(), g["vjp"])
+    print(name, gemm, attention, f"forward {ey:.2e} vjp {eg:.2e}")
+    assert ey < TOL and eg < TOL
 
 
 @pytest.mark.parametrize("attention,tol", [("matrix", TOL), ("flash", TOL), ("f16", 1e-3), ("bf16", 5e-3)])
@@ -168,38 +195,33 @@ def test_cold_start_budget_and_shared_replica():
     print(f"cold start {cold * 1e3:.0f} ms, replica first forward {warm * 1e3:.0f} ms, weight store {wb2}")
 
 
-_AB_SCRIPT = r"""
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from tests.test_hip_network import build
-net = build(128, 510, 128, 0)
-rs = np.random.RandomState(11)
-L, B = 32768, 2
-x = torch.from_numpy((0.3 * rs.standard_normal((B, L))).astype(np.float32)).cuda().requires_grad_(True)
-cn = torch.tensor([-0.3, -1.2]).cuda()
-cot = torch.from_numpy(rs.standard_normal((B, L)).astype(np.float32)).cuda()
-y = net(x, cn)
-g, = torch.autograd.grad(y, x, cot)
-np.savez(sys.argv[2], y=y.detach().cpu().numpy(), g=g.cpu().numpy())
-"""
-
-
-def test_fused_round4_paths_equal_plain_paths(tmp_path):
-    """The two structural fusions of round 4 -- the up blocks' Conv_0 in sub-pixel form (BUDDY_UPCONV) and the skip path's 1x1 data-gradient GEMM with
-    the GroupNorm_0 backward apply as its epilogue (BUDDY_C2_FUSE) -- against the same build with both switched off (the plain three-pass convolution
-    on the materialised upsampled tensor; separate GEMM and apply launches), full-width network, forward and input-VJP.  Both sides are fp32
-    evaluations of the same function in a different summation order: 2e-5 of the abs-max (each holds 5e-4 against the reference fixtures)."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "ab.py"
-    script.write_text(_AB_SCRIPT)
+def test_fused_round4_paths_equal_plain_paths():
+    """The two structural fusions of round 4 -- the up blocks' Conv_0 in sub-pixel form (option upconv) and the skip path's 1x1 data-gradient GEMM with
+    the GroupNorm_0 backward apply as its epilogue (option c2_fuse) -- against the plain paths (three-pass convolution on the materialised upsampled
+    tensor; separate GEMM and apply launches), full-width network, forward and input-VJP.  Both run IN ONE PROCESS on two handles of the same weights
+    (per-handle options, round 5: buddy_ncsnpp_set_option).  Both sides are fp32 evaluations of the same function in a different summation order:
+    2e-5 of the abs-max (each holds 5e-4 against the reference fixtures).  Unknown keys / values are refused."""
+    from buddy_amd import _lib
+    net = build(128, 510, 128, 0)
+    plain = net.replica().set_option("upconv", 0).set_option("c2_fuse", 0)
+    rs = np.random.RandomState(11)
+    L, B = 32768, 2
+    cn = torch.tensor([-0.3, -1.2]).cuda()
+    cot = torch.from_numpy(rs.standard_normal((B, L)).astype(np.float32)).cuda()
+    x0 = torch.from_numpy((0.3 * rs.standard_normal((B, L))).astype(np.float32)).cuda()
     outs = {}
-    for tag, env_over in (("fused", {}), ("plain", {"BUDDY_UPCONV": "0", "BUDDY_C2_FUSE": "0"})):
-        env = dict(os.environ, **env_over)
-        out = tmp_path / f"{tag}.npz"
-        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=env, timeout=600)
-        outs[tag] = np.load(out)
-    ey, eg = rel(outs["fused"]["y"], outs["plain"]["y"]), rel(outs["fused"]["g"], outs["plain"]["g"])
+    for tag, n in (("fused", net), ("plain", plain), ("fused_again", net)):       # interleaved: the handles do not disturb each other
+        x = x0.clone().requires_grad_(True)
+        y = n(x, cn)
+        g, = torch.autograd.grad(y, x, cot)
+        outs[tag] = (y.detach().cpu().numpy(), g.cpu().numpy())
+    assert net.get_option("upconv") == 1 and plain.get_option("upconv") == 0 and plain.get_option("c2_fuse") == 0
+    assert np.array_equal(outs["fused"][0], outs["fused_again"][0]) and np.array_equal(outs["fused"][1], outs["fused_again"][1])
+    ey, eg = rel(outs["fused"][0], outs["plain"][0]), rel(outs["fused"][1], outs["plain"][1])
     print(f"fused vs plain round-4 paths: forward {ey:.2e}, vjp {eg:.2e}")
-    assert not np.array_equal(outs["fused"]["g"], outs["plain"]["g"]), "the switches did not change the path"
+    assert not np.array_equal(outs["fused"][1], outs["plain"][1]), "the options did not change the path"
     assert ey < 2e-5 and eg < 2e-5
+    with pytest.raises(_lib.BuddyHipError):
+        net.set_option("upconvv", 0)
+    with pytest.raises(_lib.BuddyHipError):
+        net.set_option("attention", 9)

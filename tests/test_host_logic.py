@@ -92,6 +92,44 @@ def test_targets_resolve_and_state_dict_names():
     assert edm.sigma_data == 0.05
 
 
+def test_environment_switches_are_validated_in_one_place():
+    """BUDDY_* variables are only the DEFAULTS of the per-handle options, parsed and validated in csrc/options.hip: a misspelt name or a bad value
+    fails loudly at library load (and at handle creation), known names load; the sources read the environment in one place."""
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); from buddy_amd import _lib; _lib.load(); print('loaded')" % ROOT
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("BUDDY_")}
+        e.update(env)
+        return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=300)
+    ok = run(BUDDY_UPCONV="0", BUDDY_ATTN="f16", BUDDY_GEMM="fp32", BUDDY_CONV="wino4")
+    assert ok.returncode == 0 and "loaded" in ok.stdout, ok.stderr[-800:]
+    bad = run(BUDDY_UPCONVV="0")
+    assert bad.returncode != 0 and "unknown variable BUDDY_UPCONVV" in bad.stderr
+    bad = run(BUDDY_ATTN="fp16")
+    assert bad.returncode != 0 and "bad value 'fp16' for BUDDY_ATTN" in bad.stderr
+    bad = run(BUDDY_GN_FUSE="2")
+    assert bad.returncode != 0 and "BUDDY_GN_FUSE" in bad.stderr
+    import glob
+    n = sum(open(f).read().count("getenv(") for f in glob.glob(os.path.join(ROOT, "buddy_amd", "csrc", "*.hip")))
+    assert n <= 3, n
+
+
+def test_architecture_family_accepts_and_refuses():
+    """the constructor takes the reference's ch_mult / num_res_blocks / nf (networks/ncsnpp.py:50-52,184-270): the members pinned by fixtures build
+    with the reference's state-dict names; a width whose GroupNorms would not have a multiple of 4 channels per group is refused, not mis-computed"""
+    import pytest as _pt
+    from buddy_amd.networks.ncsnpp import NCSNppTime
+    from buddy_amd.synth import module_specs
+    stft = {"n_fft": 126, "hop_length": 32, "center": True}
+    for nf, cm, nrb in ((32, (1, 2), 2), (32, (1, 1, 2, 2), 1), (128, (1, 2, 2, 2), 1), (32, (1, 2, 2, 2), 2)):
+        net = NCSNppTime(stft=stft, nf=nf, ch_mult=cm, num_res_blocks=nrb)
+        assert list(net.state_dict()) == [n for n, *_ in module_specs(nf, cm, nrb)]
+    for nf, cm in ((64, (1, 2, 2, 2)), (64, (1, 1, 2, 2)), (96, (1, 2))):
+        with _pt.raises(NotImplementedError, match="GroupNorm over"):
+            NCSNppTime(stft=stft, nf=nf, ch_mult=cm, num_res_blocks=1)
+
+
 def test_schedule_gamma_edm_scalars(golden):
     g = golden("edm_sched")
     for tester in ["blind_dereverberation_BUDDy", "informed_dereverberation_DPS", "only_unconditional"]:
