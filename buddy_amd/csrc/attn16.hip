@@ -54,6 +54,17 @@ __device__ __forceinline__ float half_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// acc *= alpha with the accumulator tile staying in the ACCUMULATOR registers (AGPRs) for the compiler: any plain VALU statement on the tile makes hipcc keep
+// the loop-carried accumulators in arch VGPRs and copy all of them to / from the accumulator file around the MFMAs of EVERY iteration (128 + 128 moves per
+// key block in the first build) -- the rescale is rare (deferred), so its read / multiply / write triple lives inside the asm statement
+__device__ __forceinline__ void scale_acc(f32x16& o, float alpha) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float x = o[r], t;
+    asm("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32_e32 %1, %2, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1" : "+a"(x), "=&v"(t) : "v"(alpha));
+    o[r] = x;
+  }
+}
 
 // XOR swizzle of the 16-byte slot index of an LDS row with SL slots: rows 512 / 256 B -> row & 15, 128 B -> (row >> 1) & 7, 64 B -> (row >> 2) & 3:
 // the 16 lanes of a ds_read_b128 group (16 consecutive-mod-16 rows, same logical slot) land on 16 different 16-byte bank slots
@@ -63,22 +74,72 @@ template <int SL> __device__ __forceinline__ int swz(int row) { return SL >= 16 
 __device__ __forceinline__ void glds16(const void* g, char* lds) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
-// stage an R-row x SL-slot tile (row r of the source at gsrc + r * ld elements) into its swizzled LDS image; 4 waves, R * SL / 256 DMAs per wave
+// stage an R-row x SL-slot tile (row r of the source at base + r * ld elements) into its swizzled LDS image; 4 waves, R * SL / 256 DMAs per wave.
+// The per-lane part of the source address is loop-invariant (TileOff, 32-bit byte offsets computed once); the block origin is a wave-uniform pointer, so
+// a DMA is `global_load_lds_dwordx4 v_off, s[base]` with nothing per-lane to advance between blocks (as 64-bit per-lane pointers they cost two VGPRs
+// and one add per DMA instruction and block: 32 VGPRs in the dk / dv kernel)
+template <int R, int SL> struct TileOff { unsigned o[R * SL / 256]; };
 template <int R, int SL, typename T16>
-__device__ __forceinline__ void stage_tile(const T16* __restrict__ gsrc, long long ld, char* lds, int w, int lane) {
+__device__ __forceinline__ TileOff<R, SL> tile_offsets(long long ld, int w, int lane) {
   constexpr int NI = R * SL / 256;
   static_assert(R * SL % 256 == 0, "whole DMA rounds per wave");
+  TileOff<R, SL> t;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int p0 = (w * NI + i) * 64, p = p0 + lane, r = p / SL, sp = p % SL, sg = sp ^ swz<SL>(r);
-    glds16(gsrc + (long long)r * ld + sg * 8, lds + p0 * 16);
+    const int p = (w * NI + i) * 64 + lane, r = p / SL, sp = p % SL, sg = sp ^ swz<SL>(r);
+    t.o[i] = (unsigned)(((long long)r * ld + sg * 8) * (long long)sizeof(T16));
   }
+  return t;
+}
+template <int R, int SL, typename T16>
+__device__ __forceinline__ void stage_tile(const T16* __restrict__ base, const TileOff<R, SL>& t, char* lds, int w) {
+  constexpr int NI = R * SL / 256;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) glds16(reinterpret_cast<const char*>(base) + t.o[i], lds + (w * NI + i) * 1024);
 }
 // A fragment (32 rows x 16 k) of a row-major [rows][C] tile: lane (row = r0 + (lane & 31), hi = lane >> 5) reads k = 16 kk + 8 hi .. + 7
 template <int SL, typename T16>
 __device__ __forceinline__ typename V8<T16>::t frag_rows(const char* tile, int row, int fsw, int kk, int hi) {
   return *reinterpret_cast<const typename V8<T16>::t*>(tile + row * (SL * 16) + (((2 * kk + hi) ^ fsw) << 4));
 }
+
+// The MFMA phases are written as explicit software pipelines: N fragment reads through a ring of D register sets, the read of item i + D issued right
+// behind the MFMA of item i -- hipcc otherwise emits `ds_read_b128 -> s_waitcnt lgkmcnt(0) -> v_mfma` into ONE register set for every MFMA (the LDS
+// latency fully exposed, round 5 first build: 0.25 of peak) and its scheduler re-serialises a plain source-level pipeline, so every step is fenced with
+// sched_barrier(0); items are ordered so that consecutive MFMAs go to different accumulators (a dependent
+// 32x32x16 MFMA issues every 64 cycles, an independent one every 32).
+// A kernel-argument scalar load still pending when the loop is entered (an output pointer first used after it) keeps the LGKM counter "out of order" for
+// hipcc's wait-count pass, which then drains the whole ring (lgkmcnt(0)) at every wait instead of counting (lgkmcnt(D - 1)): retire them before the loop
+// with a wait the pass sees (vmcnt / expcnt fields at their maxima)
+#define RETIRE_SMEM() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define FA16_PIPE(N, D, LOAD, MMA)                                   \
+  {                                                                  \
+    v8 fr_[D];                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < (D); ++i_) fr_[i_] = LOAD(i_); \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < (N); ++i_) {             \
+      MMA(i_, fr_[i_ % (D)]);                                        \
+      if (i_ + (D) < (N)) fr_[i_ % (D)] = LOAD(i_ + (D));            \
+      __builtin_amdgcn_sched_barrier(0);                             \
+    }                                                                \
+  }
+// The same in BATCHES of D for the kernels where hipcc's wait-count pass only ever emits lgkmcnt(0) (forward, dq: every wait drains all reads in
+// flight, so a ring stalls for a full LDS latency every D MFMAs): two register batches; batch b + 1 is requested right behind the FIRST MFMA of batch b
+// -- the one wait per batch (in front of that MFMA) finds only batch b outstanding, issued D - 1 MFMAs earlier.
+#define FA16_BATCH(N, D, LOAD, MMA)                                  \
+  {                                                                  \
+    static_assert((N) % (D) == 0, "whole batches");                  \
+    v8 fr_[2][D];                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < (D); ++i_) fr_[0][i_] = LOAD(i_); \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    _Pragma("unroll") for (int b_ = 0; b_ < (N) / (D); ++b_) {       \
+      MMA(b_ * (D), fr_[b_ & 1][0]);                                 \
+      if (b_ + 1 < (N) / (D)) { _Pragma("unroll") for (int i_ = 0; i_ < (D); ++i_) fr_[(b_ + 1) & 1][i_] = LOAD((b_ + 1) * (D) + i_); } \
+      __builtin_amdgcn_sched_barrier(0);                             \
+      _Pragma("unroll") for (int i_ = 1; i_ < (D); ++i_) { MMA(b_ * (D) + i_, fr_[b_ & 1][i_]); } \
+      __builtin_amdgcn_sched_barrier(0);                             \
+    }                                                                \
+  }
 
 // ---------------------------------------------------------------------------------------------------------------- operand pre-pass
 // src fp32 [B][T][C] -> rows [B][Tp][C] and / or trans [B][C][Tp] (16-bit, times mult; tokens >= T zero; trans: token order permuted inside 16s)
@@ -158,26 +219,30 @@ __global__ __launch_bounds__(256, 1) void fa16_fwd_kernel(const T16* __restrict_
   for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
   float m = -INFINITY, l = 0.f;
   const int fk = swz<SLK>(lq), fv = swz<SLV>(lq);
+  const TileOff<BN, SLK> ok = tile_offsets<BN, SLK, T16>(C, w, lane);
+  const TileOff<C, SLV> ov = tile_offsets<C, SLV, T16>(Tp, w, lane);
   if (jlo < jhi) {
-    stage_tile<BN, SLK, T16>(Kb + (long long)jlo * C, C, smem, w, lane);
-    stage_tile<C, SLV, T16>(Vb + jlo, Tp, smem + KT, w, lane);
+    stage_tile<BN, SLK, T16>(Kb + (long long)jlo * C, ok, smem, w);
+    stage_tile<C, SLV, T16>(Vb + jlo, ov, smem + KT, w);
   }
+  RETIRE_SMEM();
   int it = 0;
   for (int j0 = jlo; j0 < jhi; j0 += BN, ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (j0 + BN < jhi) {
       char* nb = smem + ((it + 1) & 1) * BUF;
-      stage_tile<BN, SLK, T16>(Kb + (long long)(j0 + BN) * C, C, nb, w, lane);
-      stage_tile<C, SLV, T16>(Vb + j0 + BN, Tp, nb + KT, w, lane);
+      stage_tile<BN, SLK, T16>(Kb + (long long)(j0 + BN) * C, ok, nb, w);
+      stage_tile<C, SLV, T16>(Vb + j0 + BN, ov, nb + KT, w);
     }
     const char* kb = smem + (it & 1) * BUF;
     const char* vb = kb + KT;
     f32x16 s[2] = {zero16(), zero16()};
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) s[t] = mma32(frag_rows<SLK, T16>(kb, 32 * t + lq, fk, kk, hi), qf[kk], s[t]);
+#define LD_(i) frag_rows<SLK, T16>(kb, 32 * ((i) & 1) + lq, fk, (i) >> 1, hi)
+#define MM_(i, f) s[(i) & 1] = mma32(f, qf[(i) >> 1], s[(i) & 1])
+    FA16_BATCH(2 * KS, 8, LD_, MM_)
+#undef LD_
+#undef MM_
     if (j0 + BN > T) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -193,10 +258,9 @@ __global__ __launch_bounds__(256, 1) void fa16_fwd_kernel(const T16* __restrict_
     if (__any(mn > m + RESCALE_THR)) {              // wave-uniform: rescale EVERYTHING accumulated at the old maximum, exactly once
       const float alpha = fexp2(m - mn);
       l *= alpha;
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last P V MFMAs have long retired; the asm reads below are not hazard-checked by hipcc
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      for (int dt = 0; dt < DT; ++dt) scale_acc(o[dt], alpha);
       m = mn;
     }
     v8 pf[4];
@@ -210,11 +274,11 @@ __global__ __launch_bounds__(256, 1) void fa16_fwd_kernel(const T16* __restrict_
         pf[2 * t + (r >> 3)][r & 7] = (T16)p;
       }
     l += ls;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        o[dt] = mma32(*reinterpret_cast<const v8*>(vb + (32 * dt + lq) * (SLV * 16) + (((2 * c + hi) ^ fv) << 4)), pf[c], o[dt]);
+#define LD_(i) *reinterpret_cast<const v8*>(vb + (32 * ((i) % DT) + lq) * (SLV * 16) + (((2 * ((i) / DT) + hi) ^ fv) << 4))
+#define MM_(i, f) o[(i) % DT] = mma32(f, pf[(i) / DT], o[(i) % DT])
+    FA16_BATCH(4 * DT, (DT >= 8 ? 8 : DT), LD_, MM_)
+#undef LD_
+#undef MM_
   }
   const float lt = half_sum(l), inv = 1.f / lt;
   if (qrow < T) {
@@ -255,40 +319,46 @@ __global__ __launch_bounds__(256, 1) void fa16_dq_kernel(const T16* __restrict__
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) acc[dt] = zero16();
   const int fk = swz<SLK>(lq), ft = swz<SLT>(lq);
-  stage_tile<BN, SLK, T16>(Kb, C, smem, w, lane);
-  stage_tile<BN, SLK, T16>(Vb, C, smem + RT, w, lane);
-  stage_tile<C, SLT, T16>(Ktb, Tp, smem + 2 * RT, w, lane);
+  const TileOff<BN, SLK> orow = tile_offsets<BN, SLK, T16>(C, w, lane);
+  const TileOff<C, SLT> otr = tile_offsets<C, SLT, T16>(Tp, w, lane);
+  stage_tile<BN, SLK, T16>(Kb, orow, smem, w);
+  stage_tile<BN, SLK, T16>(Vb, orow, smem + RT, w);
+  stage_tile<C, SLT, T16>(Ktb, otr, smem + 2 * RT, w);
+  RETIRE_SMEM();
   int it = 0;
   for (int j0 = 0; j0 < T; j0 += BN, ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (j0 + BN < T) {
+    {                                                    // unconditional (the last iteration re-stages its own block into the idle buffer): the loop
+      const int jn = j0 + BN < T ? j0 + BN : j0;         // body stays ONE basic block, which hipcc's wait-count pass needs for counted lgkmcnt waits
       char* nb = smem + ((it + 1) & 1) * BUF;
-      stage_tile<BN, SLK, T16>(Kb + (long long)(j0 + BN) * C, C, nb, w, lane);
-      stage_tile<BN, SLK, T16>(Vb + (long long)(j0 + BN) * C, C, nb + RT, w, lane);
-      stage_tile<C, SLT, T16>(Ktb + j0 + BN, Tp, nb + 2 * RT, w, lane);
+      stage_tile<BN, SLK, T16>(Kb + (long long)jn * C, orow, nb, w);
+      stage_tile<BN, SLK, T16>(Vb + (long long)jn * C, orow, nb + RT, w);
+      stage_tile<C, SLT, T16>(Ktb + jn, otr, nb + 2 * RT, w);
     }
     const char* kb = smem + (it & 1) * BUF;
     const char* vb = kb + RT;
     const char* tb = kb + 2 * RT;
-    f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) s = mma32(frag_rows<SLK, T16>(kb, lq, fk, kk, hi), qf[kk], s);
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) dp = mma32(frag_rows<SLK, T16>(vb, lq, fk, kk, hi), df[kk], dp);
+    f32x16 sd[2] = {zero16(), zero16()};              // [0] S^T, [1] dP^T: two independent accumulation chains, interleaved
+#define LD_(i) frag_rows<SLK, T16>(((i) & 1) ? vb : kb, lq, fk, (i) >> 1, hi)
+#define MM_(i, f) sd[(i) & 1] = mma32(f, ((i) & 1) ? df[(i) >> 1] : qf[(i) >> 1], sd[(i) & 1])
+    FA16_BATCH(2 * KS, 8, LD_, MM_)
+#undef LD_
+#undef MM_
+    const f32x16 s = sd[0], dp = sd[1];
     v8 gf[2];
-    const bool tail = j0 + BN > T;
-#pragma unroll
+    const int kleft = T - j0 - 4 * hi;                 // keys >= T (the zero pad rows of K / V): G = 0.  Branch-free: a tail-only branch splits the loop body
+#pragma unroll                                         // into basic blocks and hipcc's wait-count pass then drains the fragment ring at every wait
     for (int r = 0; r < 16; ++r) {
       float g = fexp2(s[r] - l2) * (dp[r] - dl);
-      if (tail && j0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= T) g = 0.f;
+      g = ((r & 3) + 8 * (r >> 2) < kleft) ? g : 0.f;
       gf[r >> 3][r & 7] = (T16)g;
     }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        acc[dt] = mma32(*reinterpret_cast<const v8*>(tb + (32 * dt + lq) * (SLT * 16) + (((2 * h + hi) ^ ft) << 4)), gf[h], acc[dt]);
+#define LD_(i) *reinterpret_cast<const v8*>(tb + (32 * ((i) % DT) + lq) * (SLT * 16) + (((2 * ((i) / DT) + hi) ^ ft) << 4))
+#define MM_(i, f) acc[(i) % DT] = mma32(f, gf[(i) / DT], acc[(i) % DT])
+    FA16_BATCH(2 * DT, (DT >= 8 ? 8 : DT), LD_, MM_)
+#undef LD_
+#undef MM_
   }
   if (qrow < T) {
     float* orow = dq + ((long long)b * T + qrow) * C;
@@ -310,17 +380,20 @@ __global__ __launch_bounds__(256, 1) void fa16_dkv_kernel(const T16* __restrict_
                                                          const float* __restrict__ L2p, const float* __restrict__ Dp, float* __restrict__ dk,
                                                          float* __restrict__ dv, int T, int Tp) {
   typedef typename V8<T16>::t v8;
-  constexpr int BN = 32, KS = C / 16, DT = C / 32, SLK = C / 8, SLT = BN / 8, RT = BN * C * 2, BUF = 4 * RT;
+  constexpr int BN = 32, KS = C / 16, DT = C / 32, SLK = C / 8, SLT = BN / 8, RT = BN * C * 2, BUF = 4 * RT + 256;   // + the block's 32 L2 and 32 D values
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), b = blockIdx.y;
   const int lq = lane & 31, hi = lane >> 5;
   const int krow = blockIdx.x * 128 + 32 * w + lq;
+  // the row statistics of a query block ride with its tiles: lanes 0-7 of wave 0 move the 32 L2 values, lanes 8-15 the 32 D values (one exec-masked DMA;
+  // held in registers across the S / dP phase they cost 32 VGPRs the 256-accumulator kernel does not have)
+  auto stage_ld = [&](int i0n, char* dst) {
+    if (w == 0 && lane < 16) glds16((lane < 8 ? L2p + (long long)b * Tp + i0n + 4 * lane : Dp + (long long)b * Tp + i0n + 4 * (lane - 8)), dst);
+  };
   const T16* Qb = Qh + (long long)b * Tp * C;
   const T16* Ob = dOh + (long long)b * Tp * C;
   const T16* Qtb = Qt + (long long)b * C * Tp;
   const T16* Otb = dOt + (long long)b * C * Tp;
-  const float* L2b = L2p + (long long)b * Tp;
-  const float* Db = Dp + (long long)b * Tp;
   v8 kf[KS], vf[KS];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
@@ -331,41 +404,48 @@ __global__ __launch_bounds__(256, 1) void fa16_dkv_kernel(const T16* __restrict_
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) { gk[dt] = zero16(); gv[dt] = zero16(); }
   const int fk = swz<SLK>(lq), ft = swz<SLT>(lq);
-  stage_tile<BN, SLK, T16>(Qb, C, smem, w, lane);
-  stage_tile<BN, SLK, T16>(Ob, C, smem + RT, w, lane);
-  stage_tile<C, SLT, T16>(Qtb, Tp, smem + 2 * RT, w, lane);
-  stage_tile<C, SLT, T16>(Otb, Tp, smem + 3 * RT, w, lane);
+  const TileOff<BN, SLK> orow = tile_offsets<BN, SLK, T16>(C, w, lane);
+  const TileOff<C, SLT> otr = tile_offsets<C, SLT, T16>(Tp, w, lane);
+  stage_tile<BN, SLK, T16>(Qb, orow, smem, w);
+  stage_tile<BN, SLK, T16>(Ob, orow, smem + RT, w);
+  stage_tile<C, SLT, T16>(Qtb, otr, smem + 2 * RT, w);
+  stage_tile<C, SLT, T16>(Otb, otr, smem + 3 * RT, w);
+  stage_ld(0, smem + 4 * RT);
+  RETIRE_SMEM();
   int it = 0;
   for (int i0 = 0; i0 < T; i0 += BN, ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (i0 + BN < T) {
       char* nb = smem + ((it + 1) & 1) * BUF;
-      stage_tile<BN, SLK, T16>(Qb + (long long)(i0 + BN) * C, C, nb, w, lane);
-      stage_tile<BN, SLK, T16>(Ob + (long long)(i0 + BN) * C, C, nb + RT, w, lane);
-      stage_tile<C, SLT, T16>(Qtb + i0 + BN, Tp, nb + 2 * RT, w, lane);
-      stage_tile<C, SLT, T16>(Otb + i0 + BN, Tp, nb + 3 * RT, w, lane);
+      stage_tile<BN, SLK, T16>(Qb + (long long)(i0 + BN) * C, orow, nb, w);
+      stage_tile<BN, SLK, T16>(Ob + (long long)(i0 + BN) * C, orow, nb + RT, w);
+      stage_tile<C, SLT, T16>(Qtb + i0 + BN, otr, nb + 2 * RT, w);
+      stage_tile<C, SLT, T16>(Otb + i0 + BN, otr, nb + 3 * RT, w);
+      stage_ld(i0 + BN, nb + 4 * RT);
     }
     const char* qb = smem + (it & 1) * BUF;
     const char* ob = qb + RT;
     const char* qtb = qb + 2 * RT;
     const char* otb = qb + 3 * RT;
-    // the 16 query rows of this lane's accumulator registers: i0 + 8 g + 4 hi + (0..3), g = 0..3 (pad rows: L2 = +inf -> P = 0)
-    float4 l4[4], d4[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      l4[g] = *reinterpret_cast<const float4*>(L2b + i0 + 8 * g + 4 * hi);
-      d4[g] = *reinterpret_cast<const float4*>(Db + i0 + 8 * g + 4 * hi);
-    }
-    f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) s = mma32(frag_rows<SLK, T16>(qb, lq, fk, kk, hi), kf[kk], s);
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) dp = mma32(frag_rows<SLK, T16>(ob, lq, fk, kk, hi), vf[kk], dp);
+    // the fragment addresses are recomputed per block (opaque copies of the swizzle terms): hoisted out of the loop they are ~24 loop-invariant VGPRs,
+    // which this kernel (256 accumulators + 128 resident operand registers) pays for with spilled K / V fragments reloaded from scratch in every block
+    int fk_ = fk, ft_ = ft;
+    asm volatile("" : "+v"(fk_), "+v"(ft_));
+    f32x16 sd[2] = {zero16(), zero16()};              // [0] S, [1] dP
+#define LD_(i) frag_rows<SLK, T16>(((i) & 1) ? ob : qb, lq, fk_, (i) >> 1, hi)
+#define MM_(i, f) sd[(i) & 1] = mma32(f, ((i) & 1) ? vf[(i) >> 1] : kf[(i) >> 1], sd[(i) & 1])
+    FA16_PIPE(2 * KS, 4, LD_, MM_)
+#undef LD_
+#undef MM_
+    const f32x16 s = sd[0], dp = sd[1];
     v8 pf[2], gf[2];
+    // the 16 query rows of this lane's accumulator registers: i0 + 8 g + 4 hi + (0..3), g = 0..3 (pad rows: L2 = +inf -> P = 0)
+    const char* ldt = qb + 4 * RT;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float lv[4] = {l4[g].x, l4[g].y, l4[g].z, l4[g].w}, dv4[4] = {d4[g].x, d4[g].y, d4[g].z, d4[g].w};
+      const float4 l4 = *reinterpret_cast<const float4*>(ldt + (8 * g + 4 * hi) * 4), d4 = *reinterpret_cast<const float4*>(ldt + 128 + (8 * g + 4 * hi) * 4);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
@@ -374,14 +454,12 @@ __global__ __launch_bounds__(256, 1) void fa16_dkv_kernel(const T16* __restrict_
         gf[r >> 3][r & 7] = (T16)(p * (dp[r] - dv4[e]));
       }
     }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int off = (32 * dt + lq) * (SLT * 16) + (((2 * h + hi) ^ ft) << 4);
-        gv[dt] = mma32(*reinterpret_cast<const v8*>(otb + off), pf[h], gv[dt]);
-        gk[dt] = mma32(*reinterpret_cast<const v8*>(qtb + off), gf[h], gk[dt]);
-      }
+    // items: (h, dt, which): dv^T[dt] += dO^T P, dk^T[dt] += Qs^T G; consecutive MFMAs on different accumulators
+#define LD_(i) *reinterpret_cast<const v8*>((((i) & 1) ? qtb : otb) + (32 * (((i) >> 1) % DT) + lq) * (SLT * 16) + (((2 * ((i) / (2 * DT)) + hi) ^ ft_) << 4))
+#define MM_(i, f) { if ((i) & 1) gk[((i) >> 1) % DT] = mma32(f, gf[(i) / (2 * DT)], gk[((i) >> 1) % DT]); else gv[((i) >> 1) % DT] = mma32(f, pf[(i) / (2 * DT)], gv[((i) >> 1) % DT]); }
+    FA16_PIPE(4 * DT, 4, LD_, MM_)
+#undef LD_
+#undef MM_
   }
   if (krow < T) {
     float* krow_p = dk + ((long long)b * T + krow) * C;
