@@ -101,9 +101,10 @@ __device__ __forceinline__ float dsilu_g(float z) {
 // out[row][c] = alpha * (A W^T)[row][c] + rstd * (dxhat - m1 - xhat * m2), dxhat = da * act'(z) * gamma -- the block's whole input gradient.  The separate
 // apply kernel read x, da and the materialised 1x1 result and wrote dx (5 C-channel streams with the GEMM's store); here the epilogue reads x and da and
 // writes dx (3).  x / out are two-source / two-destination channel views split at a multiple of 128 (a column block never straddles).
-// DMA: the weight stage goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: the stage image is linear, a wave moves 1 KB per instruction) instead
-// of through 24 staging registers and six ds_write_b128 per thread and stage
-template <bool GEN, bool EPI, bool GNB = false, bool DMA = false>
+// Measured and rejected in round 5 (profiles/README.md): the weight stage by LDS-DMA instead of through 24 staging registers + six ds_write_b128 (152
+// instead of 168 VGPRs, +-0.5 %); s_setprio(1) around the MFMA bursts (the builtin fences hipcc's read / MFMA interleave: 0.50 -> 0.76 ms); any run-time
+// branch inside the K loop (same effect: 65 -> 81 ms/step).
+template <bool GEN, bool EPI, bool GNB = false>
 __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -158,25 +159,14 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
 #pragma unroll
     for (int j = 0; j < 6; ++j) Bs[buf * (STAGE_BYTES / 16) + j * WNT] = rb[j];
   };
-  const int wuni = __builtin_amdgcn_readfirstlane(wid);
-  auto dmaB = [&](int s, int buf) {                            // wave w, instruction j: bytes [(256 j + 64 w) * 16, + 1024) of the stage, lane-linear
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bg + (long long)s * (STAGE_BYTES / 16) + j * WNT),
-                                       (__attribute__((address_space(3))) void*)(smem + buf * STAGE_BYTES + (j * WNT + wuni * 64) * 16), 16, 0, 0);
-  };
 
   loadA(0);
-  if (DMA) { dmaB(0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-  else { loadB(0); storeB(0); }
+  loadB(0);
+  storeB(0);
   __syncthreads();
   for (int s = 0; s < S; ++s) {
     const float4 ca[4] = {ra[0], ra[1], ra[2], ra[3]};
-    if (s + 1 < S) {                                           // stage s + 1 is in flight under the 48 MFMAs of stage s
-      loadA(s + 1);
-      if (DMA) dmaB(s + 1, (s + 1) & 1);                       // that buffer was last read in stage s - 1: every wave is past its barrier
-      else loadB(s + 1);
-    }
+    if (s + 1 < S) { loadA(s + 1); loadB(s + 1); }           // stage s + 1 is in flight under the 48 MFMAs of stage s
     const unsigned char* Bcur = smem + (s & 1) * STAGE_BYTES + lane * 16;
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
@@ -194,8 +184,7 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][PB[t]], av.p[PA[t]], acc[cb], 0, 0, 0);
     }
-    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s + 1 have landed (the barrier covers the other waves')
-    else if (s + 1 < S) storeB((s + 1) & 1);                   // that buffer was last read in stage s - 1: every wave is past its barrier
+    if (s + 1 < S) storeB((s + 1) & 1);                        // that buffer was last read in stage s - 1: every wave is past its barrier
     __syncthreads();
   }
 
@@ -387,7 +376,6 @@ void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt,
   const dim3 grid(fold ? (unsigned)(gx * P) : (unsigned)gx, 1, fold ? 1u : (unsigned)P);
   const bool direct_store = cur_opt().wgemm_epi == 0;      // A/B switch: 32-byte-piece stores (+0.3 ... 1.9 % slower)
   if (direct_store) hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, false>), grid, dim3(WNT), 0, st, a);
-  else if (cur_opt().wgemm_dma) hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true, false, true>), grid, dim3(WNT), 0, st, a);
   else hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true>), grid, dim3(WNT), 0, st, a);
 }
 
