@@ -614,7 +614,7 @@ def main():
         legs["longform_480000_B4"]["value_in_4s_units"] = legs["longform_480000_B4"]["value"] * 7.5
         del r_
         torch.cuda.empty_cache()
-        if not a.attention:      # ... and as configs[4] words it: "fp16 MFMA attention path" (opt-in fast mode, DESIGN.md section 7: inside the 0.1 dB gate)
+        if not a.attention:      # ... and as configs[4] words it: "fp16 MFMA attention path" (opt-in fast mode, DESIGN.md section 4.3: inside the 0.1 dB gate)
             r_ = stack_runner("blind_dereverberation_BUDDy", 4, True, a.T, length=480000, attention="f16")
             time_leg("longform_480000_B4_f16", r_, 4, 3, 1, {"config": "as longform_480000_B4 with the attention kernels on f16 MFMA operands (fp32 accumulation and softmax "
                                                                        "statistics) -- the 'fp16 MFMA attention path' BASELINE configs[4] names; everything else fp32", "attention": "f16"})

@@ -867,7 +867,7 @@ static void gemm_b(Net* N, const float* A, int ldA, long long sA, bool tA, const
 // the matrix is small -- T <= ATTN_MATRIX_MAX_T: 16.8 MB / utterance at 4 s -- and the online-softmax (flash) kernels beyond (905 MB / utterance at 30 s
 // never exists).  Measured at B = 8, T = 2048 (tools/ab_env.sh BUDDY_ATTN flash matrix): 65.4 -> 64.6 ms/step: six plain batched GEMMs at 100+ TFLOP/s
 // beat kernels that run one wave per SIMD.  The choice depends on T alone: a row's arithmetic does not depend on the batch it is in.
-// 0 = flash, fp32 operands; 1 / 2 = flash with bf16 / f16 MFMA operands (opt-in fast mode, DESIGN.md section 7); 3 = always the materialised form.
+// 0 = flash, fp32 operands; 1 / 2 = flash with bf16 / f16 MFMA operands (opt-in fast mode, DESIGN.md section 4.3); 3 = always the materialised form.
 // Default from BUDDY_ATTN (auto | matrix | flash | bf16 | f16; options.hip), changed per handle with buddy_ncsnpp_set_attention / _set_option.
 constexpr int ATTN_MATRIX_MAX_T = 4096;
 static bool attn_use_flash(const Net* N, int C, int T) {

@@ -105,7 +105,7 @@ class NCSNppTime(nn.Module):
         assert bool(get("center")), "center=False not supported"
         self.nf, self.ch_mult, self.num_res_blocks = int(nf), tuple(int(c) for c in ch_mult), int(num_res_blocks)
         # attention core: None = library default (BUDDY_ATTN, else "auto": fp32, materialised while T <= 4096, flash beyond); "auto" | "flash" | "bf16" | "f16" | "matrix" (build extension, not a reference key:
-        # bf16 / f16 are the opt-in fast mode of DESIGN.md section 7)
+        # bf16 / f16 are the opt-in fast mode of DESIGN.md section 4.3)
         if attention is not None and attention not in self.ATTENTION_MODES:
             raise NotImplementedError(f"attention must be one of {sorted(self.ATTENTION_MODES)}")
         self.attention = attention

@@ -1,7 +1,7 @@
 """Long-form policy (BASELINE config 5; not in the reference, which samples one ``(1, L)`` clip per call, testing/tester.py:153).
 
 Default = UN-CHUNKED: the whole utterance goes through the sampler in one piece -- with the flash attention kernel the 30 s case needs
-no 905 MB attention matrix and fits the 288 GB of one MI355X many times over.  For inputs beyond what one GPU
+no 905 MB attention matrix and fits the 288 GB of one MI355X many times over (profiles/DESIGN_history_r01-r04.md section 5, "Long form").  For inputs beyond what one GPU
 should hold, or to turn one very long recording into a batch (utterance-parallel over chunks, also across ranks), the clip is cut into
 equal-length, overlapping chunks that are sampled as independent utterances (own noise stream, own blind operator / RIR estimate) and
 cross-faded back with linear ramps over the overlaps (a partition of unity: chunking the identity returns the input exactly)."""
@@ -62,7 +62,7 @@ def predict_chunked(sample_batch, y, chunk, overlap, level_match=False):
     (``constraint_speech_magnitude``, reference EulerHeunSamplerDPS.py:127-129) -- per CHUNK here, so a chunk that is mostly a pause would come
     back as loud as a chunk of running speech and the cross-fade would mix segments of different gains.  With ``level_match`` each chunk's
     estimate is scaled by std(y_chunk) / std(y_clip) (the observation's own level profile) before the merge, which restores one gain for the clip;
-    what remains chunk-specific is the RIR estimate (one operator per chunk), see DESIGN.md section 5.  Residual bias: the gain profile is the
+    what remains chunk-specific is the RIR estimate (one operator per chunk), see profiles/DESIGN_history_r01-r04.md section 5.  Residual bias: the gain profile is the
     OBSERVATION's, and reverberation fills pauses, so a pause comes back louder than in the clean signal (measured pause / speech level 0.107
     against 0.052 in the input of tests/test_hip_cli.py's clip).  Chunks are never padded (equal chunks, the last one starts at L - chunk), so
     every std is over valid samples."""

@@ -41,7 +41,7 @@ class Tester:
         self.results = []
         # a batch of >= 2 * sub_batches utterances is sampled as that many concurrent sub-batches on their own HIP streams
         # (testing/concurrent.py; better occupancy); 1 = one batch, one stream.  Default ("auto", tester.sub_batches absent): 2 whenever
-        # a group has >= 4 utterances -- the measured optimum (+5 %; 4 loses), DESIGN.md section 6.  Results equal the single-batch run
+        # a group has >= 4 utterances -- the measured optimum (+4-5 %; 4 loses: profiles/r05_sub_batch_sweep.txt).  Results equal the single-batch run
         # row for row only with per-utterance noise streams (noise_factory); with the torch RNG the draw ORDER differs between the two
         # modes, so tester.sub_batches=1 is the way to reproduce a same-seed run of an earlier round.  The second sub-batch's network is a
         # replica: it shares the prepared weights and costs only its activation arena
