@@ -364,6 +364,7 @@ void launch_wgemm_bf16x3_gnbwd(const float* A, int ldA, const void* W3, long lon
 }
 
 void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st) {
+  if (cur_opt().wgemm_v2 && wgemm2_pays(Mt, Cout, P)) { launch_wgemm2_bf16x3(V, U3, M, Mt, Cout, Cin, P, st); return; }
   WgemmArgs a{};
   a.A1 = nullptr; a.C0 = Cin; a.ldA0 = Cin; a.ldA1 = 0; a.ldC = Cout; a.bias_n = nullptr; a.alpha = 1.f; a.accumulate = 0;
   a.V = V; a.U3 = reinterpret_cast<const unsigned char*>(U3); a.M = M;
