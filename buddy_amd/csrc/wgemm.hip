@@ -103,7 +103,9 @@ __device__ __forceinline__ float dsilu_g(float z) {
 // writes dx (3).  x / out are two-source / two-destination channel views split at a multiple of 128 (a column block never straddles).
 // Measured and rejected in round 5 (profiles/README.md): the weight stage by LDS-DMA instead of through 24 staging registers + six ds_write_b128 (152
 // instead of 168 VGPRs, +-0.5 %); s_setprio(1) around the MFMA bursts (the builtin fences hipcc's read / MFMA interleave: 0.50 -> 0.76 ms); any run-time
-// branch inside the K loop (same effect: 65 -> 81 ms/step).
+// branch inside the K loop (same effect: 65 -> 81 ms/step); a from-scratch large-tile kernel (tools/probes/wgemm2_large_tile.hip: 256-row workgroups, one wave
+// per SIMD, both operands by LDS-DMA, cross-stage split pipelining): bit-identical and within +-5 % on every shape -- two unrelated structures, one
+// throughput: the shape is bounded by the power budget of its instruction mix (pipe 49 % busy at 2.06 GHz; a register-only loop: 100 % at 1.57 GHz).
 template <bool GEN, bool EPI, bool GNB = false>
 __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
@@ -364,7 +366,6 @@ void launch_wgemm_bf16x3_gnbwd(const float* A, int ldA, const void* W3, long lon
 }
 
 void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st) {
-  if (cur_opt().wgemm_v2 && wgemm2_pays(Mt, Cout, P)) { launch_wgemm2_bf16x3(V, U3, M, Mt, Cout, Cin, P, st); return; }
   WgemmArgs a{};
   a.A1 = nullptr; a.C0 = Cin; a.ldA0 = Cin; a.ldA1 = 0; a.ldC = Cout; a.bias_n = nullptr; a.alpha = 1.f; a.accumulate = 0;
   a.V = V; a.U3 = reinterpret_cast<const unsigned char*>(U3); a.M = M;

@@ -1,3 +1,9 @@
+// EXPERIMENT, not product (round 5; measured and rejected -- profiles/README.md "Dominant GEMM, round 5"): a from-scratch large-tile form of the batched
+// bf16x3 GEMM (256-row workgroups, one wave per SIMD, both operands by inline-asm LDS-DMA, three-deep V ring, the next stage's split inside the MFMA blocks,
+// peeled tail).  Bit-identical to csrc/wgemm.hip and within +-5 % of it on every shape (0.58 vs 0.54 ms at K = N = 128, 0.915 vs 0.94 at K = 512): two
+// structurally unrelated kernels land on the same throughput, which (with the 49 %-busy pipe at 2.06 GHz against 100 % at 1.57 GHz for a register-only loop)
+// says the shape is bounded by the power budget of its instruction mix, not by a schedule.  Kept for the record; to build it, copy it next to wgemm.hip, add it
+// to build.sh, declare wgemm2_pays / launch_wgemm2_bf16x3 in common.h and call them from launch_wgemm_bf16x3 (tools/wgemm_v2_check.py compares the two).
 // Winograd-domain batched GEMM  M[p] (tiles x Cout) = V[p] (tiles x Cin) . U[p]^T  in bf16x3 arithmetic, LARGE-TILE form (round 5) for the big layers:
 // the same products in the same order as wgemm.hip's kernel (bit-identical results: every fp32 operand split exactly into three bf16 terms, six
 // v_mfma_f32_32x32x16_bf16 products per 16 k, smallest terms first, fp32 accumulation over k ascending), restructured around what limits that kernel:
