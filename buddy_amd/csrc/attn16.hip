@@ -108,10 +108,6 @@ __device__ __forceinline__ typename V8<T16>::t frag_rows(const char* tile, int r
 // latency fully exposed, round 5 first build: 0.25 of peak) and its scheduler re-serialises a plain source-level pipeline, so every step is fenced with
 // sched_barrier(0); items are ordered so that consecutive MFMAs go to different accumulators (a dependent
 // 32x32x16 MFMA issues every 64 cycles, an independent one every 32).
-// A kernel-argument scalar load still pending when the loop is entered (an output pointer first used after it) keeps the LGKM counter "out of order" for
-// hipcc's wait-count pass, which then drains the whole ring (lgkmcnt(0)) at every wait instead of counting (lgkmcnt(D - 1)): retire them before the loop
-// with a wait the pass sees (vmcnt / expcnt fields at their maxima)
-#define RETIRE_SMEM() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define FA16_PIPE(N, D, LOAD, MMA)                                   \
   {                                                                  \
     v8 fr_[D];                                                       \
@@ -225,7 +221,6 @@ __global__ __launch_bounds__(256, 1) void fa16_fwd_kernel(const T16* __restrict_
     stage_tile<BN, SLK, T16>(Kb + (long long)jlo * C, ok, smem, w);
     stage_tile<C, SLV, T16>(Vb + jlo, ov, smem + KT, w);
   }
-  RETIRE_SMEM();
   int it = 0;
   for (int j0 = jlo; j0 < jhi; j0 += BN, ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -324,7 +319,6 @@ __global__ __launch_bounds__(256, 1) void fa16_dq_kernel(const T16* __restrict__
   stage_tile<BN, SLK, T16>(Kb, orow, smem, w);
   stage_tile<BN, SLK, T16>(Vb, orow, smem + RT, w);
   stage_tile<C, SLT, T16>(Ktb, otr, smem + 2 * RT, w);
-  RETIRE_SMEM();
   int it = 0;
   for (int j0 = 0; j0 < T; j0 += BN, ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -411,7 +405,6 @@ __global__ __launch_bounds__(256, 1) void fa16_dkv_kernel(const T16* __restrict_
   stage_tile<C, SLT, T16>(Qtb, otr, smem + 2 * RT, w);
   stage_tile<C, SLT, T16>(Otb, otr, smem + 3 * RT, w);
   stage_ld(0, smem + 4 * RT);
-  RETIRE_SMEM();
   int it = 0;
   for (int i0 = 0; i0 < T; i0 += BN, ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
