@@ -315,6 +315,35 @@ def measure_peaks(lib, device):
     return out
 
 
+def f16x2_roofline(gemm_tf, alg_bytes, ms_total, peaks):
+    """roofline object of the dominant kernel in f16x2 arithmetic (the default): the level-0 launches (K = 128: 56 % of the FLOPs) are HBM-bound on the V read +
+    M write of the three-pass form, the 256-channel ones matrix-bound; `bound` is the side with the larger fraction of its nominal peak, both are in the object."""
+    hbm = alg_bytes / (ms_total * 1e-3) / 1e9 if ms_total > 0 else 0.0
+    mf = 3.0 * gemm_tf
+    side_h = {"achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS}
+    side_m = {"achieved": mf, "peak": PEAK_BF16_MFMA, "unit": "TFLOP/s", "frac": mf / PEAK_BF16_MFMA}
+    use_h = side_h["frac"] >= side_m["frac"]
+    r = {"bound": "hbm" if use_h else "mfma",
+         "kernel": "wgemm_f16x2_kernel -- the batched GEMMs M[pos] = V[pos] U[pos]^T of the three-pass Winograd F(6x6,3x3) convolutions (64 positions; 94 % of the "
+                   "network's algorithmic FLOPs) in f16x2 arithmetic: both fp32 operands scaled by a power of two and split into two f16 terms, three "
+                   "v_mfma_f32_32x32x16_f16 products per 16 k, fp32 accumulate"}
+    r.update(side_h if use_h else side_m)
+    r["achieved_note"] = ("ALGORITHMIC bytes per launch (V read once + M written once + weights once = 4 * positions * tiles * (Cin + Cout) + the stage images) / "
+                          "average launch duration" if use_h else
+                          "EXECUTED f16 MFMA FLOPs per launch (3 x 2 * positions * tiles * Cin * Cout) / average launch duration") + \
+                         ", HIP events on the launch stream inside the timed region (every launch of every other step)"
+    r["mfma_side" if use_h else "hbm_side"] = dict(side_m if use_h else side_h, note=(
+        "executed f16 MFMA FLOPs (3 x 2 * positions * tiles * Cin * Cout) / time against the 2.5 PFLOP/s dense f16 peak" if use_h else
+        "algorithmic bytes (V read once, M written once, weights once) / time"))
+    r["peak_measured_on_box"] = peaks.get("hbm_copy_GBps") if use_h else peaks.get("bf16_mfma_tflops")
+    r["frac_of_measured_peak"] = (r["achieved"] / r["peak_measured_on_box"]) if r["peak_measured_on_box"] else None
+    r["peak_measured_note"] = ("a device-to-device copy kernel on this box (read + write, the GEMM's own mix)" if use_h else
+                               "a pure 16-bit MFMA loop on random operand bits on this box: the chip clocks to its power budget")
+    r["fp32_equivalent_tflops"] = gemm_tf
+    r["frac_of_fp32_matrix_peak"] = gemm_tf / PEAK_FP32_MFMA
+    return r
+
+
 def conv_source_stamp():
     """sha1 over the sources of the dominant kernel group: a PMC summary is only quoted if it was measured on these exact kernels"""
     import hashlib
@@ -339,7 +368,7 @@ def main():
                     "in a second region and report it as `concurrent_sub_batches` (0 = skip)")
     ap.add_argument("--attention", default=None, choices=["auto", "flash", "matrix", "bf16", "f16"], help="attention core of the network (default: the library's, "
                     "auto: fp32, materialised for T <= 4096, online softmax beyond; bf16 / f16 = the opt-in fast mode that passed the 0.1 dB gate, profiles/r02_attention_modes.json)")
-    ap.add_argument("--gemm", default=None, choices=["bf16x3", "fp32"], help="arithmetic of the Winograd-domain GEMMs (default: the library's, bf16x3 = exact "
+    ap.add_argument("--gemm", default=None, choices=["bf16x3", "fp32", "f16x2"], help="arithmetic of the Winograd-domain GEMMs (default: the library's, f16x2; bf16x3 = exact "
                     "three-way bf16 split of the fp32 operands, six bf16 MFMA products, fp32 accumulate; fp32 = v_mfma_f32_32x32x2_f32, the reference run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rccl-selftest", action="store_true", help="skip the one-rank RCCL bring-up at the end of an N=1 run")
@@ -730,7 +759,7 @@ def main():
         a36 = max(1, int(w4_n.value))
         # HBM bytes of the dominant kernel: separate rocprofv3 --pmc passes of this same command (counters cannot be read in-process),
         # summarised by tools/pmc_summary.py; quoted only if measured on the kernels that are running now (source stamp)
-        gemm_mode = a.gemm or ("fp32" if os.environ.get("BUDDY_GEMM", "") == "fp32" else "bf16x3")
+        gemm_mode = {0: "fp32", 1: "bf16x3", 2: "f16x2"}[int(net0[0].get_option("gemm"))]      # what the handle ran with (--gemm, BUDDY_GEMM, or the library default)
         traffic, traffic_group, traffic_src = None, None, "no PMC summary for the current kernel sources (tools/pmc_summary.py writes profiles/conv_traffic_pmc.json)"
         tp = os.path.join(ROOT, "profiles", "conv_traffic_pmc.json")
         stamp = conv_source_stamp()
@@ -748,7 +777,8 @@ def main():
             "metric": f"diffusion steps/sec ({a.length / 16000:g} s@16 kHz utterance, blind Euler-Heun DPS, order 1, 10 operator updates/step)",
             "value": n_utt_steps / elapsed, "unit": "utterance-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (bf16x3 exact split in the Winograd-domain GEMMs)" if gemm_mode == "bf16x3" else "f32"), "data": "synthetic (seeded clean/RIR/weights; random-init NCSN++ 27.7 M params)",
+            "dtype": {"bf16x3": "f32 (bf16x3 exact split in the Winograd-domain GEMMs)", "fp32": "f32",
+                      "f16x2": "f32 (Winograd-domain GEMM operands as two-term f16 splits, 2^-22, fp32 accumulation)"}[gemm_mode], "data": "synthetic (seeded clean/RIR/weights; random-init NCSN++ 27.7 M params)",
             "config": {"workload": f"blind DPS sampler step, B={B} utterances/GPU x {a.length} samples ({a.length / 16000:g} s@16 kHz), T={a.T}-step schedule, "
                                    f"NCSN++ nf=128 STFT 510/128" + (" (BASELINE.json configs[1])" if (B == 8 and a.length == 64000) else ""),
                        "batch_per_gpu": B, "length": a.length, "T": a.T, "order": 1, "op_updates_per_step": 10,
@@ -771,7 +801,8 @@ def main():
             # dominant kernel: the batched Winograd-domain GEMMs of the 3x3 convolutions.  bf16x3 (default): every fp32 multiply-add is SIX bf16 MFMA
             # multiply-adds -> achieved = 6 x the fp32-equivalent rate, against the bf16 matrix peak; the fp32-equivalent rate against the fp32 matrix
             # peak is beside it (the kernel replaces v_mfma_f32_32x32x2_f32 at equal accuracy; --gemm fp32 is the reference run)
-            "roofline": ({"bound": "mfma", "kernel": "wgemm_bf16x3_kernel -- the batched GEMMs M[pos] = V[pos] U[pos]^T of the three-pass Winograd 3x3 convolutions "
+            "roofline": (f16x2_roofline(gemm_tf, dom_bg.value, dom_ms[1], peaks) if gemm_mode == "f16x2" else
+                         {"bound": "mfma", "kernel": "wgemm_bf16x3_kernel -- the batched GEMMs M[pos] = V[pos] U[pos]^T of the three-pass Winograd 3x3 convolutions "
                                                      "(64 positions, F(6x6,3x3), on the large layers; 36, F(4x4,3x3), on the small ones; 94 % of the network's "
                                                      "algorithmic FLOPs) in bf16x3 arithmetic: exact three-way bf16 split of both fp32 operands, six "
                                                      "v_mfma_f32_32x32x16_bf16 products per 16 k, fp32 accumulate",

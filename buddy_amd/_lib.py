@@ -51,6 +51,10 @@ _SIGS = {
     "buddy_wgemm_packed_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "buddy_wgemm_pack_weights": (C.c_int, [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_gemm_winograd_domain_bf16x3": (C.c_int, [_f32p, C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_wgemm_f16x2_packed_bytes": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "buddy_wgemm_f16x2_pack_weights": (C.c_int, [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_gemm_winograd_domain_f16x2": (C.c_int, [_f32p, C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "buddy_abs_max_bits": (C.c_int, [_f32p, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),
     "buddy_gemm_bf16x3": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_void_p, _f32p, C.c_int, C.c_longlong, C.c_int, C.c_int, _f32p, C.c_float,
                                     C.c_int, C.c_void_p]),
     "buddy_conv3x3": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -172,6 +172,28 @@ int buddy_gemm_winograd_domain_bf16x3(const float* V, const void* U3, float* Mo,
   return finish();
 }
 
+long long buddy_wgemm_f16x2_packed_bytes(int positions, int Cout, int Cin) {
+  return (positions < 1 || positions > 64 || !wgemm_f16x2_supported(Cout, Cin)) ? 0 : (long long)wgemm_f16x2_packed_bytes(positions, Cout, Cin);
+}
+int buddy_wgemm_f16x2_pack_weights(const float* U, void* U2, int positions, int Cout, int Cin, void* stream) {
+  if (!U || !U2 || positions < 1 || positions > 64 || !wgemm_f16x2_supported(Cout, Cin)) { set_error("bad arguments (positions <= 64, Cout % 128, Cin % 64)"); return BUDDY_ERR_ARG; }
+  wgemm_f16x2_pack_weights(U, U2, positions, Cout, Cin, (hipStream_t)stream);
+  return finish();
+}
+int buddy_gemm_winograd_domain_f16x2(const float* V, const void* U2, float* Mo, int tiles, int Cout, int Cin, int positions, const unsigned* vmax,
+                                     int tiles_per_utt, void* stream) {
+  if (!V || !U2 || !Mo || !vmax || tiles < 1 || tiles_per_utt < 32 || tiles % tiles_per_utt || positions < 1 || positions > 64 || !wgemm_f16x2_supported(Cout, Cin)) {
+    set_error("bad arguments (positions <= 64, Cout % 128, Cin % 64, tiles a multiple of tiles_per_utt >= 32)"); return BUDDY_ERR_ARG;
+  }
+  launch_wgemm_f16x2(V, U2, Mo, tiles, Cout, Cin, positions, vmax, tiles_per_utt, (hipStream_t)stream);
+  return finish();
+}
+int buddy_abs_max_bits(const float* x, int groups, int segments, long long seg_len, unsigned* out, void* stream) {
+  if (!x || !out || groups < 1 || segments < 1 || seg_len < 1) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  launch_abs_max_bits(x, groups, segments, seg_len, out, (hipStream_t)stream);
+  return finish();
+}
+
 int buddy_gemm_bf16x3(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W3, float* Cm, int ldC, long long M, int N, int K,
                       const float* bias_n, float alpha, int accumulate, void* stream) {
   if (!A0 || !W3 || !Cm || M < 1 || !wgemm_general_supported(N, K, A1 ? C0 : 0, ldA0, A1 ? ldA1 : 0, ldC, A0, A1, Cm, bias_n)) {

@@ -58,6 +58,13 @@ bool wgemm_supported(int Cout, int Cin);
 size_t wgemm_packed_bytes(int P, int Cout, int Cin);
 void wgemm_pack_weights(const float* U_dev, void* U3_dev, int P, int Cout, int Cin, hipStream_t st);
 void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st);
+bool wgemm_f16x2_supported(int Cout, int Cin);
+size_t wgemm_f16x2_packed_bytes(int P, int Cout, int Cin);
+void wgemm_f16x2_pack_weights(const float* U_dev, void* U2_dev, int P, int Cout, int Cin, hipStream_t st);
+// f16x2 GEMM: the abs-max of V per utterance is kept as VMAX_SUB partial maxima (float bit patterns), one per 128-byte line: [utterance][VMAX_SUB][VMAX_STRIDE]
+constexpr int VMAX_SUB = 64, VMAX_STRIDE = 32;
+void launch_abs_max_bits(const float* x, int groups, int segments, long long seg_len, unsigned* out, hipStream_t st);
+void launch_wgemm_f16x2(const float* V, const void* U2, float* M, long long Mt, int Cout, int Cin, int P, const unsigned* vmax, int tiles_per_utt, hipStream_t st);
 bool wgemm_general_supported(int N, int K, int C0, int ldA0, int ldA1, int ldC, const void* A0, const void* A1, const void* C, const void* bias);
 void launch_wgemm_bf16x3_general(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W3, float* C, int ldC, long long M, int N, int K,
                                  const float* bias_n, float alpha, int accumulate, hipStream_t st);
@@ -95,9 +102,10 @@ int wino6_stat_chunks(const IgemmParams& p, int up = 0);
 double wino6_exec_ratio(const IgemmParams& p, int up = 0);
 //   bwd_gn (with stat) -- data-gradient convolutions: the output is the gradient w.r.t. act(GroupNorm(bwd_gn->x)); the partials are the two sums
 //           of that GroupNorm's backward, (dxhat, dxhat * xhat), instead of (sum, sum of squares)
+//   U6x, xform, vmax -- the GEMM pass on the stage image U6x: xform 1 bf16x3, 2 f16x2 (vmax: B zeroed slots for the abs-max of V per utterance)
 //   up -- sub-pixel forms of conv3x3(nearest-upsample x2) (1) and of its data-gradient (2); p describes the LOW resolution (wino6.hip)
 void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn = nullptr, double* stat = nullptr,
-                  const W4Gn* bwd_gn = nullptr, const void* U6x = nullptr, int up = 0);
+                  const W4Gn* bwd_gn = nullptr, const void* U6x = nullptr, int up = 0, int xform = 1, unsigned* vmax = nullptr);
 void wino6_transform_weights(const float* wt_host, int Cout, int Cin, float* U6_host);
 // device-side weight preparation (wprep.hip): raw torch OIHW [O][I][3][3] -> the operand form of one kernel variant (kind 0 direct [Co][9][Ci],
 // 2 F(2x2) [Ci/8][16][Co][8], 4 F(4x4) [36][Co][Ci], 6 F(6x6) [64][Co][Ci]) for the forward (Co = O, Ci = I) or the data-gradient direction

@@ -109,7 +109,7 @@ struct Arena {
 };
 
 // One prepared operand form of a 3x3 convolution's weights: u = fp32 (direct / Winograd-domain), x = the bf16x3 stage image of u (wgemm.hip)
-struct WVar { float* u = nullptr; void* x = nullptr; };
+struct WVar { float* u = nullptr; void* x = nullptr; void* x2 = nullptr; };   // fp32 form, bf16x3 stage image, f16x2 stage image
 // raw: the torch OIHW tensor on the device.  3x3 convolutions of the ResBlocks get their operand forms LAZILY (conv_weights below): one
 // (direction, kernel variant, arithmetic) per layer is ever built for a given workload, on the GPU (wprep.hip).  wf / wb: forms prepared at
 // creation (the small 2-channel convolutions, 1x1 convolutions)
@@ -175,6 +175,9 @@ struct Net {
   bool prep_failed = false;    // a lazily prepared weight form could not be built (out of memory): the call reports it
   bool fir = false;            // fir=True: FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257)
   float* w4_scratch = nullptr; size_t w4_cap = 0, w4_need = 0;   // V / M buffers of the three-pass F(4x4,3x3) convolutions (floats)
+  // gemm = f16x2: abs-max of V per (convolution of this call, utterance): VMAX_SLOTS x B x [VMAX_SUB][VMAX_STRIDE] words (common.h), zeroed at the start of every call
+  unsigned* vmax = nullptr; size_t vmax_cap = 0; int vslot = 0;
+  int vslot_need[2] = {0, 0};  // slots a forward / an input-VJP call used on the reserved shape (0: not known yet, zero all of them)
   bool dry() const { return arena.dry; }
   Tens* mk(int B_, int H, int W, int C, bool grad) {
     pool.emplace_back();
@@ -459,26 +462,28 @@ int net_set_option(Net* N, const char* key, int value) {
 }
 int net_get_option(Net* N, const char* key, int* value) { return option_get(N->opt, key, value); }
 int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 4) { set_error("attention mode must be 0..4"); return BUDDY_ERR_ARG; } return net_set_option(N, "attention", mode); }
-int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 1) { set_error("gemm mode must be 0 (fp32 MFMA) or 1 (bf16x3)"); return BUDDY_ERR_ARG; } return net_set_option(N, "gemm", mode); }
+int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 2) { set_error("gemm mode must be 0 (fp32 MFMA), 1 (bf16x3) or 2 (f16x2)"); return BUDDY_ERR_ARG; } return net_set_option(N, "gemm", mode); }
 int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; return BUDDY_OK; }
 void net_destroy(Net* N) {
   if (!N) return;
   if (N->w4_scratch) (void)hipFree(N->w4_scratch);
+  if (N->vmax) (void)hipFree(N->vmax);
   if (N->arena.base) (void)hipFree(N->arena.base);
   if (N->inv_env) (void)hipFree(N->inv_env);
   delete N;
 }
 
 // The operand form `kind` (0 direct, 2 / 4 / 6 = Winograd F(kind x kind, 3x3), 61 = F(6x6,3x3) of the sub-pixel up form) of a 3x3 convolution for one direction, built on first use on
-// the GPU from the raw OIHW tensor (wprep.hip) and cached in the shared store.  want_x: the bf16x3 stage image (the fp32 form is then only a
-// staging buffer, reused for the next layer); otherwise the fp32 form itself is kept.  The preparing stream is drained before the pointer is
+// the GPU from the raw OIHW tensor (wprep.hip) and cached in the shared store.  want_x: 1 the bf16x3 / 2 the f16x2 stage image (the fp32 form is then only a
+// staging buffer, reused for the next layer); 0: the fp32 form itself is kept.  The preparing stream is drained before the pointer is
 // published, so a replica on another stream may use it at once.
-static const WVar* conv_weights(Net* N, const ConvW& c, bool dgrad, int kind, bool want_x) {
+constexpr int VMAX_SLOTS = 192;                     // 3x3 convolutions per call (the shipped network: 46 forward, 46 + the up forms backward)
+static const WVar* conv_weights(Net* N, const ConvW& c, bool dgrad, int kind, int want_x) {
   Weights* Wt = N->W.get();
   const int ki = kind == 0 ? 0 : kind == 2 ? 1 : kind == 4 ? 2 : kind == 6 ? 3 : 4;
   WVar& v = c.var[dgrad ? 1 : 0][ki];
   std::lock_guard<std::mutex> lk(Wt->mu);
-  if (want_x ? v.x != nullptr : v.u != nullptr) return &v;
+  if (want_x == 2 ? v.x2 != nullptr : want_x ? v.x != nullptr : v.u != nullptr) return &v;
   const int ph = kind == 61 ? 4 : 1;                          // sub-pixel up form: four phase kernels per output channel (wprep.hip)
   const int Co = dgrad ? c.cin : ph * c.cout, Ci = dgrad ? ph * c.cout : c.cin;
   const size_t nfl = (size_t)conv3_weight_floats(c.cout, c.cin, kind);
@@ -502,13 +507,14 @@ static const WVar* conv_weights(Net* N, const ConvW& c, bool dgrad, int kind, bo
   void* x = nullptr;
   if (want_x) {
     const int P = kind == 4 ? 36 : 64;
-    const size_t bytes = wgemm_packed_bytes(P, Co, Ci);
+    const size_t bytes = want_x == 2 ? wgemm_f16x2_packed_bytes(P, Co, Ci) : wgemm_packed_bytes(P, Co, Ci);
     if (hipMalloc(&x, bytes) != hipSuccess) { N->prep_failed = true; set_error("out of memory preparing convolution weights"); return nullptr; }
     Wt->lazy_allocs.push_back(x); Wt->lazy_bytes += bytes;
-    wgemm_pack_weights(u, x, P, Co, Ci, st);
+    if (want_x == 2) wgemm_f16x2_pack_weights(u, x, P, Co, Ci, st);
+    else wgemm_pack_weights(u, x, P, Co, Ci, st);
   }
   (void)hipStreamSynchronize(st);
-  if (want_x) v.x = x; else v.u = u;
+  if (want_x == 2) v.x2 = x; else if (want_x) v.x = x; else v.u = u;
   ++Wt->lazy_count;
   return &v;
 }
@@ -556,6 +562,11 @@ struct Conv3 {
 // The BigGAN up block's Conv_0 (layerspp.py:246-257: h = upsample(act(GroupNorm_0(x))), Conv_0(h)) as one three-pass convolution on the low-resolution
 // grid: no upsampled activation in HBM, V 4x smaller, the data-gradient's M and da 4x smaller.  Needs the F(6x6,3x3) path with the GroupNorm
 // fusions on the low-resolution geometry.
+// the next convolution's abs-max slots (one per utterance; zeroed by begin_call)
+static unsigned* vmax_slot(Net* N, int B) {
+  if (N->vmax == nullptr || N->vslot >= VMAX_SLOTS || (size_t)(N->vslot + 1) * B * VMAX_SUB * VMAX_STRIDE > N->vmax_cap) { N->prep_failed = true; set_error("abs-max slots of the f16x2 GEMM exhausted"); return nullptr; }
+  return N->vmax + (size_t)(N->vslot++) * B * VMAX_SUB * VMAX_STRIDE;
+}
 static bool conv3_up_ok(Net* N, int B, int H, int W, int Cin, int Cout) {
   if (H < 7 || W < 7) return false;
   const Options& o = N->opt;
@@ -593,8 +604,11 @@ static int conv3(Net* N, const Conv3& c) {
     IgemmParams p = ig_base();
     p.A0 = a; p.ldA0 = Cin; p.Cin = Cin; p.H = H; p.W = W; p.M = B * H * W; p.N = Cout; p.C = c.out; p.ldC = Cout;
     p.bias_n = c.bias; p.bias_bn = c.bias_bn; p.ld_bias_bn = c.ld_bn; p.rows_per_batch = H * W; p.alpha = c.alpha; p.out_scale = c.out_scale;
-    const bool x3 = N->opt.gemm == 1 && wgemm_supported((c.up == 1 ? 4 : 1) * Cout, (c.up == 2 ? 4 : 1) * Cin);
+    int x3 = wgemm_supported((c.up == 1 ? 4 : 1) * Cout, (c.up == 2 ? 4 : 1) * Cin) ? N->opt.gemm : 0;     // 1 bf16x3, 2 f16x2
+    if (x3 == 2 && !wgemm_f16x2_supported((c.up == 1 ? 4 : 1) * Cout, (c.up == 2 ? 4 : 1) * Cin)) x3 = 1;
     const WVar* wv = conv_weights(N, *c.w, c.dgrad, 61, x3);
+    unsigned* vm = x3 == 2 ? vmax_slot(N, B) : nullptr;
+    if (x3 == 2 && !vm) return -1;
     if (!wv || N->w4_scratch == nullptr) { if (wv) { N->prep_failed = true; set_error("convolution scratch buffer missing"); } return -1; }
     long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf, c.up);
     const bool want_bwd = c.up == 2 && bwd_gn != nullptr;
@@ -604,7 +618,7 @@ static int conv3(Net* N, const Conv3& c) {
     const double xr = wino6_exec_ratio(p, c.up);
     igemm_prof_record(pr, 9, 1, N->st, true, xr);
     launch_wino6(p, wv->u, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, (stat && want_bwd) ? bwd_gn : nullptr,
-                 x3 ? wv->x : nullptr, c.up);
+                 x3 == 2 ? wv->x2 : x3 ? wv->x : nullptr, c.up, x3, vm);
     igemm_prof_record(pr, 9, 1, N->st, false, xr);
     if (stat && (want_bwd || direct)) return sc;
     if (stat && stat_out) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
@@ -628,11 +642,14 @@ static int conv3(Net* N, const Conv3& c) {
     launch_gn_apply(gn->x, gn->stats, gn->gamma, gn->beta, B, H, W, Cin, gn->G, 0, gn->silu, gn_tmp, nullptr, N->st);
     p.A0 = gn_tmp; gn = nullptr;
   }
-  const bool x3 = N->opt.gemm == 1 && wgemm_supported(Cout, Cin);     // the batched GEMM pass in bf16x3 arithmetic: only the stage image is needed
+  const bool x3 = N->opt.gemm >= 1 && wgemm_supported(Cout, Cin);     // the batched GEMM pass in split arithmetic: only the stage image is needed
   if (w6) {
-    const WVar* wv = conv_weights(N, *c.w, c.dgrad, 6, x3);
+    const int xf = !x3 ? 0 : (N->opt.gemm == 2 && !wgemm_f16x2_supported(Cout, Cin)) ? 1 : N->opt.gemm;     // 1 bf16x3, 2 f16x2
+    const WVar* wv = conv_weights(N, *c.w, c.dgrad, 6, xf);
     if (!wv) return -1;
-    const float* U6 = wv->u; const void* U6x = x3 ? wv->x : nullptr;
+    unsigned* vm = xf == 2 ? vmax_slot(N, B) : nullptr;
+    if (xf == 2 && !vm) return -1;
+    const float* U6 = wv->u; const void* U6x = xf == 2 ? wv->x2 : xf ? wv->x : nullptr;
     long long vf = 0, mf = 0; wino6_scratch(p, &vf, &mf);
     const bool fuse_bwd = N->opt.gn_fuse_bwd != 0;
     const bool want_bwd = bwd_gn != nullptr && fuse_gn && fuse_bwd;
@@ -640,12 +657,12 @@ static int conv3(Net* N, const Conv3& c) {
     const bool stat = sc > 0 && (long long)sc * Cout <= 256LL * 1024;
     const double xr = wino6_exec_ratio(p);
     igemm_prof_record(p, 9, 1, N->st, true, xr);
-    launch_wino6(p, U6, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, (stat && want_bwd) ? bwd_gn : nullptr, U6x);
+    launch_wino6(p, U6, N->w4_scratch, N->w4_scratch + vf, N->st, gn, stat ? N->partial : nullptr, (stat && want_bwd) ? bwd_gn : nullptr, U6x, 0, xf, vm);
     igemm_prof_record(p, 9, 1, N->st, false, xr);
     if (stat && (want_bwd || direct)) return sc;
     if (stat && stat_out) { launch_csum_collapse(N->partial, sc, B, Cout, stat_out->csum, N->st); stat_out->has_csum = true; }
   } else if (w4) {
-    const WVar* wv = conv_weights(N, *c.w, c.dgrad, 4, x3);
+    const WVar* wv = conv_weights(N, *c.w, c.dgrad, 4, x3 ? 1 : 0);       // F(4x4,3x3): the small layers stay on bf16x3 in both split modes
     if (!wv) return -1;
     const float* U4 = wv->u; const void* U4x = x3 ? wv->x : nullptr;
     long long vf = 0, mf = 0; wino4_scratch(p, &vf, &mf);
@@ -671,7 +688,7 @@ static int conv3(Net* N, const Conv3& c) {
 }
 // a plain row-major GEMM against a registered [N][K] weight (1x1 convolution, NIN) in bf16x3 arithmetic when the handle's mode asks for it
 static bool try_wgemm(Net* N, const IgemmParams& p) {
-  if (N->opt.gemm != 1 || p.bias_m || p.bias_bn || p.res_mode || p.out_scale != 1.f || p.sA || p.sC) return false;
+  if (N->opt.gemm < 1 || p.bias_m || p.bias_bn || p.res_mode || p.out_scale != 1.f || p.sA || p.sC) return false;
   const auto it = N->W->w3.find(p.Bt);
   if (it == N->W->w3.end() || p.ldB != p.Cin || it->second.N != p.N || it->second.K != p.Cin) return false;
   if (!wgemm_general_supported(p.N, p.Cin, p.A1 ? p.C0 : 0, p.ldA0, p.A1 ? p.ldA1 : 0, p.ldC, p.A0, p.A1, p.C, p.bias_n)) return false;
@@ -769,7 +786,7 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
       const W3Img* c2i = nullptr;
       const float* c2a = dout;                               // A operand of that GEMM (the pooled gradient for the sub-pixel up block)
       const bool fuse_c2_on = n->opt.c2_fuse != 0;     // A/B switch
-      if (fuse_c2_on && Rp->has_c2 && !firm && (mode == 0 || (mode == 2 && up6)) && n->opt.gemm == 1 && Cin % 4 == 0 && (Cin / G0) % 4 == 0) {
+      if (fuse_c2_on && Rp->has_c2 && !firm && (mode == 0 || (mode == 2 && up6)) && n->opt.gemm >= 1 && Cin % 4 == 0 && (Cin / G0) % 4 == 0) {
         const auto it = n->W->w3.find(Rp->c2.wb);
         if (it != n->W->w3.end() && it->second.N == Cin && it->second.K == Cout && wgemm_gnbwd_supported(Cin, Cout, Cout, src_of(x), d0, dout, dout))
           c2i = &it->second;
@@ -1231,6 +1248,13 @@ int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes) {
     HIPCHK(hipMalloc(&N->arena.base, need));
     N->arena.cap = need;
   }
+  if (N->opt.gemm == 2 && N->vmax_cap < (size_t)VMAX_SLOTS * B * VMAX_SUB * VMAX_STRIDE) {
+    if (N->vmax) (void)hipFree(N->vmax);
+    N->vmax = nullptr; N->vmax_cap = 0;
+    HIPCHK(hipMalloc(&N->vmax, (size_t)VMAX_SLOTS * B * VMAX_SUB * VMAX_STRIDE * 4));
+    N->vmax_cap = (size_t)VMAX_SLOTS * B * VMAX_SUB * VMAX_STRIDE;
+  }
+  N->vslot_need[0] = N->vslot_need[1] = 0;
   N->rsv_B = B; N->rsv_L = L; N->rsv_vjp = with_vjp != 0;
   return BUDDY_OK;
 }
@@ -1248,7 +1272,9 @@ int net_forward(Net* N, const float* x, const float* cnoise, const float* cin_b,
   if (rc) return rc;
   N->st = st;
   N->arena.dry = false; N->arena.overflow = false;
+  if (N->opt.gemm == 2) { HIPCHK(hipMemsetAsync(N->vmax, 0, (size_t)(N->vslot_need[0] ? N->vslot_need[0] : VMAX_SLOTS) * B * VMAX_SUB * VMAX_STRIDE * 4, st)); N->vslot = 0; }
   run_forward(N, x, cnoise, cin_b, cskip_b, cout_b, y, B, L, save != 0);
+  N->vslot_need[0] = N->vslot;
   if (N->arena.overflow) { set_error("arena overflow"); return BUDDY_ERR_STATE; }
   if (N->prep_failed) { N->prep_failed = false; return BUDDY_ERR_HIP; }
   HIPCHK(hipGetLastError());
@@ -1259,7 +1285,9 @@ int net_vjp(Net* N, const float* cot, float* gx, hipStream_t st) {
   if (!N->have_tape) { set_error("vjp without a saved forward"); return BUDDY_ERR_STATE; }
   OptScope scope(&N->opt);
   N->st = st;
+  if (N->opt.gemm == 2) { HIPCHK(hipMemsetAsync(N->vmax, 0, (size_t)(N->vslot_need[1] ? N->vslot_need[1] : VMAX_SLOTS) * N->rsv_B * VMAX_SUB * VMAX_STRIDE * 4, st)); N->vslot = 0; }
   run_vjp(N, cot, gx);
+  N->vslot_need[1] = N->vslot;
   if (N->arena.overflow) { set_error("arena overflow"); return BUDDY_ERR_STATE; }
   if (N->prep_failed) { N->prep_failed = false; return BUDDY_ERR_HIP; }
   HIPCHK(hipGetLastError());

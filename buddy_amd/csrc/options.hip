@@ -25,11 +25,11 @@ struct Entry {
   const Word* words;    // symbolic values (environment only), terminated by {nullptr, 0}
 };
 const Word kConvWords[] = {{"", 0}, {"direct", 1}, {"wino2", 2}, {"wino4", 3}, {nullptr, 0}};
-const Word kGemmWords[] = {{"fp32", 0}, {"bf16x3", 1}, {nullptr, 0}};
+const Word kGemmWords[] = {{"fp32", 0}, {"bf16x3", 1}, {"f16x2", 2}, {nullptr, 0}};
 const Word kAttnWords[] = {{"flash", 0}, {"bf16", 1}, {"f16", 2}, {"matrix", 3}, {"auto", 4}, {nullptr, 0}};
 const Entry kTable[] = {
     {"conv", "BUDDY_CONV", &Options::conv, 0, 3, 0, kConvWords},
-    {"gemm", "BUDDY_GEMM", &Options::gemm, 0, 1, 1, kGemmWords},
+    {"gemm", "BUDDY_GEMM", &Options::gemm, 0, 2, 2, kGemmWords},
     {"attention", "BUDDY_ATTN", &Options::attn, 0, 4, 4, kAttnWords},
     {"gn_fuse", "BUDDY_GN_FUSE", &Options::gn_fuse, 0, 1, 1, nullptr},
     {"gn_fuse_bwdin", "BUDDY_GN_FUSE_BWDIN", &Options::gn_fuse_bwdin, 0, 1, 1, nullptr},

@@ -18,7 +18,9 @@
 //  * LDS is double-buffered: ONE barrier per K-stage of 48 MFMAs per wave; global loads for stage s + 1 are issued before the MFMAs of stage s;
 //  * the accumulator is C^T (weights as the MFMA's first operand): a lane holds 4 consecutive output channels of one row -> 16-byte stores.
 #include "common.h"
+#include <algorithm>
 #include <cstdint>
+#include <type_traits>
 #include <cstdlib>
 
 namespace buddy {
@@ -86,6 +88,8 @@ struct WgemmArgs {
   const float* A1; int C0, ldA0, ldA1, ldC; const float* bias_n; float alpha; int accumulate;
   // GNB epilogue (general form): C = alpha * A W^T + the GroupNorm backward's apply pass, written to a two-destination view
   Src2 gxv; Dst2 gd; const float* gda; const float* gstats; const float* gred; const float* ggamma; const float* gbeta; int gG, gsilu, gHW;
+  // f16x2 form: per-utterance abs-max of V (float bits, written by the input transform), rows per utterance, per-position inverse weight scales
+  const unsigned* vmax; int tpu; const float* uinv;
 };
 
 __device__ __forceinline__ float dsilu_g(float z) {
@@ -318,9 +322,247 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_bf16x3_kernel(const WgemmArgs a)
       *reinterpret_cast<float4*>(dst + cb * 32 + 8 * g) = v;
     }
 }
+
+// ------------------------------------------------------------------------------------------------ f16x2 form of the batched GEMM
+// Arithmetic.  Every fp32 operand is scaled by a power of two (exact) and split into TWO f16 terms by round-to-nearest, x s = hi + lo (11 + 11
+// significant bits: |x s - hi - lo| <= 2^-23 |x s|), and the product is accumulated in fp32 as  lo*hi + hi*lo + hi*hi  on v_mfma_f32_32x32x16_f16 (f16 x f16
+// products are exact in fp32; the dropped term lo*lo is <= 2^-22 of a product).  Three MFMAs per 16 k instead of six: half the matrix-pipe cycles of bf16x3 and
+// 4 instead of 6 operand bytes per weight, for operands good to 2^-22 instead of 2^-24 -- against float64 a whole F(6x6,3x3) convolution moves from 117 dB
+// (exact products) to 114 dB, the level of plain fp32 accumulation.  f16 has 5 exponent bits, hence the scales: the weights carry one power of
+// two per position (their abs-max -> [2^14, 2^15), applied when packing; the inverse is in the image's tail), V one per UTTERANCE (abs-max collected by the
+// input transform with an atomic max, the power of two derived here from its exponent field), so that an utterance's result does not depend on its batch;
+// lo is a normal f16 for |x s| >= 2^-3, i.e. 2^-18 of the abs-max; below that the representation error is absolute, <= 2^-25 = 2^-40 of the abs-max.
+// Same workgroup / wave tiling, staging, XCD order and epilogue as wgemm_bf16x3_kernel<false, true>; a stage image is 16 KB ([k chunk][column block][plane]
+// [lane] x 16 B), 24 MFMAs per wave and barrier.
+// LDS-DMA of 16 bytes per lane as inline asm: source = uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset, LDS destination = M0 + 16 * lane
+__device__ __forceinline__ void glds16_asm(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+constexpr int STAGE2_BYTES = WBN * WKS * 4;                   // 16 KB: 2 k-chunks x 4 column blocks x 2 planes x 1 KB
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+struct Split2 { f16x8 p[2]; };
+__device__ __forceinline__ Split2 split2(const float4 a, const float4 b, float s) {
+  const float x[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
+  Split2 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 h = (_Float16)x[i];
+    r.p[0][i] = h;
+    r.p[1][i] = (_Float16)(x[i] - (float)h);
+  }
+  return r;
+}
+// the power of two that takes an abs-max (float bits) into [2^14, 2^15), and its inverse; exponent fields outside [15, 253] are clamped (zero / tiny / huge
+// tensors: the scale stays a finite normal number)
+__device__ __forceinline__ void pow2_scale(unsigned bits, float& s, float& inv) {
+  int e = (int)((bits >> 23) & 0xFF);
+  e = e < 15 ? 15 : (e > 253 ? 253 : e);
+  s = __uint_as_float((unsigned)(268 - e) << 23);
+  inv = __uint_as_float((unsigned)(e - 14) << 23);
+}
+
+// abs-max of every position's weight matrix -> umax[p] (float bits)
+__global__ __launch_bounds__(256) void wgemm_umax_kernel(const float* __restrict__ U, unsigned* __restrict__ umax, long long per) {
+  const float* u = U + (long long)blockIdx.x * per;
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < per; i += 256) m = fmaxf(m, fabsf(u[i]));
+  __shared__ float red[256];
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+  if (threadIdx.x == 0) umax[blockIdx.x] = __float_as_uint(red[0]);
+}
+// out[u][VMAX_SUB][VMAX_STRIDE]: partial maxima (bit patterns) of |x| over x[g][u][0 .. seg_len), g < groups; grid (chunks, segments), out zeroed before
+__global__ __launch_bounds__(256) void abs_max_bits_kernel(const float* __restrict__ x, int groups, int segments, long long seg_len, unsigned* __restrict__ out) {
+  const int u = blockIdx.y;
+  float m = 0.f;
+  for (int g = 0; g < groups; ++g) {
+    const float* s = x + ((long long)g * segments + u) * seg_len;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < seg_len; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(s[i]));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out + ((long long)u * VMAX_SUB + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (VMAX_SUB - 1))) * VMAX_STRIDE, __float_as_uint(m));
+}
+// U fp32 [P][Cout][Cin] -> stage images [P][Cout/128][Cin/32][2][4][2][64] x 16 B, then P inverse scales (floats); one thread per 16-byte element
+__global__ __launch_bounds__(256) void wgemm_pack2_kernel(const float* __restrict__ U, u32x4* __restrict__ out, const unsigned* __restrict__ umax, int P, int Cout,
+                                                          int Cin) {
+  const long long n16 = (long long)P * Cout * Cin * 4 / 16;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < P) { float s, inv; pow2_scale(umax[i], s, inv); reinterpret_cast<float*>(out + n16)[i] = inv; }
+  if (i >= n16) return;
+  const int lane = (int)(i & 63);
+  long long r = i >> 6;
+  const int q = (int)(r & 1); r >>= 1;
+  const int cb = (int)(r & 3); r >>= 2;
+  const int kc = (int)(r & 1); r >>= 1;
+  const int S = Cin / WKS, NB = Cout / WBN;
+  const int s = (int)(r % S); r /= S;
+  const int nb = (int)(r % NB); r /= NB;
+  const int p = (int)r;
+  const int n = nb * WBN + cb * 32 + (lane & 31), k = s * WKS + 16 * (lane >> 5) + 8 * kc;
+  const float* src = U + ((long long)p * Cout + n) * Cin + k;
+  float sc, inv; pow2_scale(umax[p], sc, inv);
+  const Split2 sp = split2(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4), sc);
+  out[i] = (u32x4)sp.p[q];
+}
+
+template <bool EPI>
+__global__ __launch_bounds__(WNT, 3) void wgemm_f16x2_kernel(const WgemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * STAGE2_BYTES > 4 * 32 * 68 * 4) ? 2 * STAGE2_BYTES : 4 * 32 * 68 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int lid, p;                                                 // XCD-aware order: see wgemm_bf16x3_kernel
+  if (a.pz > 0) {
+    const int orig = blockIdx.x, xcd = orig & 7, k = orig >> 3;
+    lid = k % a.gx; p = xcd + 8 * (k / a.gx);
+  } else {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    p = blockIdx.z;
+  }
+  const int nb = lid % a.NB, m0 = (lid / a.NB) * WBM;
+  const float* __restrict__ V = a.V + (long long)p * a.sV;
+  const unsigned char* __restrict__ U2 = a.U3 + ((long long)p * a.NB + nb) * a.S * STAGE2_BYTES;
+  const int S = a.S;
+
+  int row = m0 + wid * 32 + (lane & 31);
+  const bool row_ok = row < a.Mt;
+  if (!row_ok) row = a.Mt - 1;
+  // the utterance's abs-max = the maximum of its VMAX_SUB partial words: one word per lane, a wave-wide maximum; a wave's 32 rows touch at most two utterances
+  // (tpu >= 32)
+  float sv, inv;
+  {
+    const int r0 = min(m0 + wid * 32, a.Mt - 1), r1 = min(m0 + wid * 32 + 31, a.Mt - 1), b0 = r0 / a.tpu, b1 = r1 / a.tpu;
+    // agent-scope atomic loads: the words were written by agent-scope atomics (executed at the memory side); a plain load may hit a stale line of this XCD's L2
+    unsigned mb0 = __hip_atomic_load(a.vmax + ((long long)b0 * VMAX_SUB + lane) * VMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int o = 32; o > 0; o >>= 1) mb0 = max(mb0, (unsigned)__shfl_xor((int)mb0, o));
+    unsigned mb1 = mb0;
+    if (b1 != b0) {
+      mb1 = __hip_atomic_load(a.vmax + ((long long)b1 * VMAX_SUB + lane) * VMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int o = 32; o > 0; o >>= 1) mb1 = max(mb1, (unsigned)__shfl_xor((int)mb1, o));
+    }
+    pow2_scale(row / a.tpu == b0 ? mb0 : mb1, sv, inv);
+  }
+  inv *= a.uinv[p];
+  // uniform bases + 32-bit per-lane byte offsets: the loads are `global_load_dwordx4 v, v_off, s[base]` -- no 64-bit per-lane address arithmetic per stage
+  const unsigned aoff = (unsigned)(((long long)row * a.Cin + 16 * (lane >> 5)) * 4), boff = (unsigned)tid * 16u;
+  const char* Vb = reinterpret_cast<const char*>(V);
+  const char* Ub = reinterpret_cast<const char*>(U2);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  // Two K-stages of A in flight (the stage is half as long as bf16x3's: one stage of prefetch no longer covers the HBM latency), the loop unrolled by two
+  // so that each register set keeps its name.  The weights' stage image goes global -> LDS by LDS-DMA written as inline asm (no staging registers, no
+  // ds_write pass; invisible to hipcc's wait-count pass, which would otherwise drain every load in flight before the first ds_read): it is requested BEFORE the
+  // A loads of the stage and waited for by ONE counted `s_waitcnt vmcnt(4)` in front of the barrier, which leaves those four A loads in flight.
+  float4 ra[2][4];
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem + wid * 1024);
+  auto loadA = [&](int s, float4 (&r)[4]) {
+    const char* base = Vb + (long long)s * (WKS * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const float4*>(base + aoff + 16 * j);
+  };
+  auto dmaB = [&](int s) {
+    const void* base = uniform_ptr(Ub + (long long)s * STAGE2_BYTES);
+    const unsigned l = lds0 + (s & 1) * STAGE2_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16_asm(base, boff + j * (WNT * 16), l + j * (WNT * 16));
+  };
+  // NB / NA (compile time): this stage requests the weights of stage s + 1 / the A rows of stage s + 2 (the last two stages are peeled: behind a run-time `if`
+  // the wait-count pass must assume the loads were skipped and waits for everything in flight).
+  auto stage = [&](int s, float4 (&r)[4], auto nb_, auto na_) {
+    constexpr bool NB = decltype(nb_)::value, NA = decltype(na_)::value;
+    // the stage's A rows are split FIRST (their registers are then dead and the reload below lands in place: with a copy kept for later, hipcc renames
+    // the reload's destination and moves it back at the loop's back edge -- behind a vmcnt(0))
+    const Split2 av[2] = {split2(r[0], r[1], sv), split2(r[2], r[3], sv)};
+    if (NB) dmaB(s + 1);
+    if (NA) loadA(s + 2, r);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* Bcur = smem + (s & 1) * STAGE2_BYTES + lane * 16;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      f16x8 b[4][2];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[cb][q] = *reinterpret_cast<const f16x8*>(Bcur + ((kc * 4 + cb) * 2 + q) * FRAG);
+      constexpr int PB[3] = {1, 0, 0}, PA[3] = {0, 1, 0};     // smallest terms first: lo*hi, hi*lo, hi*hi (B plane, A plane)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[cb][PB[t]], av[kc].p[PA[t]], acc[cb], 0, 0, 0);
+    }
+    if (NB) { if (NA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __syncthreads();
+  };
+
+  dmaB(0);
+  loadA(0, ra[0]);
+  loadA(1, ra[1]);                                             // S is even (wgemm_f16x2_supported)
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  int s = 0;
+  for (; s + 2 < S; s += 2) {
+    stage(s, ra[0], std::true_type{}, std::true_type{});
+    stage(s + 1, ra[1], std::true_type{}, std::true_type{});
+  }
+  stage(s, ra[0], std::true_type{}, std::false_type{});
+  stage(s + 1, ra[1], std::false_type{}, std::false_type{});
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] *= inv;               // the accumulator is C^T: a lane holds ONE row, so one (utterance, position) scale
+
+  if (EPI) {
+    constexpr int SP = 68;
+    float* St = reinterpret_cast<float*>(smem) + wid * (32 * SP);
+    const int rr = lane >> 4, c4 = (lane & 15) * 4;
+    float* Mrow = a.M + (long long)p * a.sM + (long long)(m0 + wid * 32) * a.Cout + nb * WBN;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(St + (lane & 31) * SP + cl * 32 + 8 * g + 4 * (lane >> 5)) =
+              make_float4(acc[2 * hb + cl][4 * g], acc[2 * hb + cl][4 * g + 1], acc[2 * hb + cl][4 * g + 2], acc[2 * hb + cl][4 * g + 3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = 4 * it + rr;
+        const float4 v = *reinterpret_cast<const float4*>(St + r * SP + c4);
+        if (m0 + wid * 32 + r < a.Mt) *reinterpret_cast<float4*>(Mrow + (long long)r * a.Cout + hb * 64 + c4) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  if (!row_ok) return;
+  float* dst = a.M + (long long)p * a.sM + (long long)row * a.Cout + nb * WBN + 4 * (lane >> 5);
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(dst + cb * 32 + 8 * g) = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+}
 }  // namespace
 
 bool wgemm_supported(int Cout, int Cin) { return Cout % WBN == 0 && Cin % WKS == 0; }
+bool wgemm_f16x2_supported(int Cout, int Cin) { return Cout % WBN == 0 && Cin % (2 * WKS) == 0; }    // an even number of K-stages
 size_t wgemm_packed_bytes(int P, int Cout, int Cin) { return (size_t)P * Cout * Cin * 6; }
 
 void wgemm_pack_weights(const float* U_dev, void* U3_dev, int P, int Cout, int Cin, hipStream_t st) {
@@ -379,6 +621,36 @@ void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt,
   const bool direct_store = cur_opt().wgemm_epi == 0;      // A/B switch: 32-byte-piece stores (+0.3 ... 1.9 % slower)
   if (direct_store) hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, false>), grid, dim3(WNT), 0, st, a);
   else hipLaunchKernelGGL((wgemm_bf16x3_kernel<false, true>), grid, dim3(WNT), 0, st, a);
+}
+
+// f16x2 form
+// image = P * Cout * Cin * 4 bytes of stage images + 256 bytes (the positions' inverse scales, floats) + 256 bytes (their abs-max bit patterns); P <= 64
+size_t wgemm_f16x2_packed_bytes(int P, int Cout, int Cin) { return (size_t)P * Cout * Cin * 4 + 512; }
+void wgemm_f16x2_pack_weights(const float* U_dev, void* U2_dev, int P, int Cout, int Cin, hipStream_t st) {
+  unsigned* umax_scratch = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(U2_dev) + (size_t)P * Cout * Cin * 4 + 256);
+  hipLaunchKernelGGL(wgemm_umax_kernel, dim3((unsigned)P), dim3(256), 0, st, U_dev, umax_scratch, (long long)Cout * Cin);
+  const long long n16 = (long long)P * Cout * Cin * 4 / 16;
+  hipLaunchKernelGGL(wgemm_pack2_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, U_dev, reinterpret_cast<u32x4*>(U2_dev), umax_scratch, P, Cout, Cin);
+}
+void launch_abs_max_bits(const float* x, int groups, int segments, long long seg_len, unsigned* out, hipStream_t st) {
+  (void)hipMemsetAsync(out, 0, (size_t)segments * VMAX_SUB * VMAX_STRIDE * 4, st);
+  const unsigned chunks = (unsigned)std::min<long long>(256, (seg_len + 2047) / 2048);
+  hipLaunchKernelGGL(abs_max_bits_kernel, dim3(chunks, (unsigned)segments), dim3(256), 0, st, x, groups, segments, seg_len, out);
+}
+// vmax: [utterance][VMAX_SUB][VMAX_STRIDE] partial abs-maxima (float bits) of V; an utterance = tiles_per_utt (>= 32) consecutive rows
+void launch_wgemm_f16x2(const float* V, const void* U2, float* M, long long Mt, int Cout, int Cin, int P, const unsigned* vmax, int tiles_per_utt, hipStream_t st) {
+  WgemmArgs a{};
+  a.V = V; a.U3 = reinterpret_cast<const unsigned char*>(U2); a.M = M;
+  a.Mt = (int)Mt; a.Cin = Cin; a.Cout = Cout; a.S = Cin / WKS; a.NB = Cout / WBN;
+  a.sV = Mt * Cin; a.sM = Mt * Cout;
+  a.vmax = vmax; a.tpu = tiles_per_utt; a.uinv = reinterpret_cast<const float*>(a.U3 + (size_t)P * Cout * Cin * 4);
+  const bool by_pos = cur_opt().wgemm_xcdpos != 0;
+  const int gx = cdiv((int)Mt, WBM) * a.NB;
+  const bool fold = by_pos && P % 8 == 0 && (long long)gx * P < (1LL << 31);
+  a.pz = fold ? P : 0; a.gx = gx;
+  const dim3 grid(fold ? (unsigned)(gx * P) : (unsigned)gx, 1, fold ? 1u : (unsigned)P);
+  if (cur_opt().wgemm_epi == 0) hipLaunchKernelGGL((wgemm_f16x2_kernel<false>), grid, dim3(WNT), 0, st, a);
+  else hipLaunchKernelGGL((wgemm_f16x2_kernel<true>), grid, dim3(WNT), 0, st, a);
 }
 
 }  // namespace buddy

@@ -80,7 +80,7 @@ struct W6Geo { int B, H, W, TH, TW, QC, TPB; long long Mt; int xcd; int Cl; };  
 //       (py, px) starts at (7 ty - py, 7 tx - px) (the even phase reads rows i, i + 1 of its image, the odd one i - 1, i).  Single source.
 template <int GN, bool S2D = false, int TS = 6>
 __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__ x, int ldX, const W4Gn gn, float* __restrict__ V, int Cin,
-                                                       const W6Geo geo) {
+                                                       const W6Geo geo, unsigned* __restrict__ vmax) {
   __shared__ float4 lds[32 * 64];
   const int tid = threadIdx.x, QC = geo.QC;
   const int ql = tid % QC, col = (tid / QC) & 7, tl = tid / (QC * 8);
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
     for (int r = 0; r < 8; ++r) lds[(tl * 64 + r * 8 + col) * QC + ql] = t[r];
   }
   __syncthreads();
+  float vm = 0.f;
   if (live) {
     const int r = col;                                       // this thread's row in the second phase
     float4 d[8], t[8];
@@ -169,6 +170,30 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
     const long long ps = geo.Mt * Cin;
 #pragma unroll
     for (int j = 0; j < 8; ++j) st4(out + (long long)(r * 8 + j) * ps, t[j]);
+    if (vmax) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vm = fmaxf(fmaxf(vm, fmaxf(fabsf(t[j].x), fabsf(t[j].y))), fmaxf(fabsf(t[j].z), fabsf(t[j].w)));
+    }
+  }
+  // f16x2 GEMM (wgemm.hip): the abs-max of V per UTTERANCE, from which the GEMM derives its power-of-two operand scale.  Device-scope atomics execute at
+  // the memory side on this part (~250 ns each, serialised per address: one atomic per (tile, row) group onto one word per utterance cost 0.95 ms per
+  // launch, r05g), so: ONE atomic max per tile (workgroup-level reduction through LDS) onto one of VMAX_SUB partial words per utterance, each in its own
+  // 128-byte line; the GEMM combines the partial words.  On the float's bit pattern: non-negative floats order like unsigned integers.
+  if (vmax) {
+    __shared__ float wmx[256];
+    for (int o = QC >> 1; o > 0; o >>= 1) vm = fmaxf(vm, __shfl_xor(vm, o));
+    if (ql == 0) wmx[tl * 8 + col] = vm;
+    __syncthreads();
+    if (tid < geo.TPB) {
+      const long long tw = (long long)bx * geo.TPB + tid;
+      if (tw < geo.Mt) {
+        float m = wmx[tid * 8];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) m = fmaxf(m, wmx[tid * 8 + j]);
+        const int bw = (int)(tw / ((long long)geo.TW * geo.TH)), sub = (int)((tw + 13 * by) & (VMAX_SUB - 1));
+        atomicMax(vmax + ((long long)bw * VMAX_SUB + sub) * VMAX_STRIDE, __float_as_uint(m));
+      }
+    }
   }
 }
 
@@ -362,7 +387,9 @@ double wino6_exec_ratio(const IgemmParams& p, int up) {       // executed / dire
 // up = 2: its data-gradient: p.Cin = channels of the (2H, 2W) gradient, read space-to-depth as 4 Cin channels; output (H, W, N).  U6: [64][N][4 Cin].
 // p.H, p.W, p.M describe the LOW resolution in both.
 void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hipStream_t st, const W4Gn* gn, double* stat, const W4Gn* bwd_gn,
-                  const void* U6x, int up) {
+                  const void* U6x, int up, int xform, unsigned* vmax) {
+  // xform: the arithmetic of the stage image U6x: 1 = bf16x3, 2 = f16x2 (then vmax: one zeroed slot per utterance for this launch's abs-max of V)
+  if (xform != 2) vmax = nullptr;
   const int CinG = up == 2 ? 4 * p.Cin : p.Cin, NG = up == 1 ? 4 * p.N : p.N;       // K and N of the batched GEMM
   W6Geo gi = geometry(p, CinG, up), go = geometry(p, NG, up);
   gi.Cl = p.Cin; go.Cl = p.N;
@@ -374,15 +401,15 @@ void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hi
   if (prof_gemm) { (void)hipEventCreate(&ev[1]); (void)hipEventCreate(&ev[2]); }
   const dim3 grid_in((unsigned)((Mt + gi.TPB - 1) / gi.TPB), (unsigned)((CinG / 4 + gi.QC - 1) / gi.QC));
   if (up == 2) {
-    if (gn && gn->da) hipLaunchKernelGGL((w6_input_kernel<2, true, 7>), grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, CinG, gi);
-    else hipLaunchKernelGGL((w6_input_kernel<0, true, 7>), grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, CinG, gi);
+    if (gn && gn->da) hipLaunchKernelGGL((w6_input_kernel<2, true, 7>), grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, CinG, gi, vmax);
+    else hipLaunchKernelGGL((w6_input_kernel<0, true, 7>), grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, CinG, gi, vmax);
   } else if (up == 1) {
-    if (gn) hipLaunchKernelGGL((w6_input_kernel<1, false, 7>), grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
-    else hipLaunchKernelGGL((w6_input_kernel<0, false, 7>), grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, p.Cin, gi);
+    if (gn) hipLaunchKernelGGL((w6_input_kernel<1, false, 7>), grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi, vmax);
+    else hipLaunchKernelGGL((w6_input_kernel<0, false, 7>), grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, p.Cin, gi, vmax);
   }
-  else if (gn && gn->da) hipLaunchKernelGGL(w6_input_kernel<2>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
-  else if (gn) hipLaunchKernelGGL(w6_input_kernel<1>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi);
-  else hipLaunchKernelGGL(w6_input_kernel<0>, grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, p.Cin, gi);
+  else if (gn && gn->da) hipLaunchKernelGGL(w6_input_kernel<2>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi, vmax);
+  else if (gn) hipLaunchKernelGGL(w6_input_kernel<1>, grid_in, dim3(256), 0, st, (const float*)nullptr, 0, *gn, V, p.Cin, gi, vmax);
+  else hipLaunchKernelGGL(w6_input_kernel<0>, grid_in, dim3(256), 0, st, p.A0, p.ldA0, W4Gn{}, V, p.Cin, gi, vmax);
   if (prof || prof_gemm) (void)hipEventRecord(ev[1], st);
   IgemmParams g; std::memset(&g, 0, sizeof(g));
   g.A0 = V; g.ldA0 = CinG; g.sA = Mt * CinG; g.Cin = CinG;
@@ -391,7 +418,8 @@ void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hi
   g.M = (int)Mt; g.N = NG; g.H = 1; g.W = 1; g.rows_per_batch = 1; g.alpha = 1.f; g.out_scale = 1.f;
   g.tag = 36;                                                 // the Winograd-domain batched GEMM instantiation (36 or 64 positions)
   igemm_prof_enable(0);
-  if (U6x != nullptr && wgemm_supported(NG, CinG)) launch_wgemm_bf16x3(V, U6x, Mb, Mt, NG, CinG, 64, st);
+  if (U6x != nullptr && xform == 2 && wgemm_supported(NG, CinG)) launch_wgemm_f16x2(V, U6x, Mb, Mt, NG, CinG, 64, vmax, gi.TH * gi.TW, st);
+  else if (U6x != nullptr && wgemm_supported(NG, CinG)) launch_wgemm_bf16x3(V, U6x, Mb, Mt, NG, CinG, 64, st);
   else launch_igemm(g, 1, false, false, 64, st);
   igemm_prof_enable(plevel);
   if (prof || prof_gemm) (void)hipEventRecord(ev[2], st);

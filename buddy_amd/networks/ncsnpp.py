@@ -65,7 +65,7 @@ class _NetFn(torch.autograd.Function):
 
 class NCSNppTime(nn.Module):
     ATTENTION_MODES = {"flash": 0, "bf16": 1, "f16": 2, "matrix": 3, "auto": 4}
-    GEMM_MODES = {"fp32": 0, "bf16x3": 1}
+    GEMM_MODES = {"fp32": 0, "bf16x3": 1, "f16x2": 2}
 
     def __init__(self, stft=None, nonlinearity="swish", nf=128, ch_mult=(1, 2, 2, 2), num_res_blocks=1,
                  attn_resolutions=(0,), resamp_with_conv=True, time_conditional=True, fir=False,
@@ -109,8 +109,8 @@ class NCSNppTime(nn.Module):
         if attention is not None and attention not in self.ATTENTION_MODES:
             raise NotImplementedError(f"attention must be one of {sorted(self.ATTENTION_MODES)}")
         self.attention = attention
-        # arithmetic of the Winograd-domain GEMMs (build extension): None = library default (BUDDY_GEMM, else "bf16x3": exact three-way bf16
-        # split of the fp32 operands, fp32-equal accuracy); "fp32" = v_mfma_f32_32x32x2_f32
+        # arithmetic of the Winograd-domain GEMMs (build extension): None = library default (BUDDY_GEMM, else "f16x2": power-of-two-scaled two-term
+        # f16 split of the fp32 operands, 2^-22, three f16 MFMA products); "bf16x3" = exact three-way bf16 split, six products; "fp32" = v_mfma_f32_32x32x2_f32
         if gemm is not None and gemm not in self.GEMM_MODES:
             raise NotImplementedError(f"gemm must be one of {sorted(self.GEMM_MODES)}")
         self.gemm = gemm

@@ -105,6 +105,21 @@ int buddy_gemm_winograd_domain(const float* V, const float* U, float* M, int til
 long long buddy_wgemm_packed_bytes(int positions, int Cout, int Cin);
 int buddy_wgemm_pack_weights(const float* U, void* U3, int positions, int Cout, int Cin, void* stream);
 int buddy_gemm_winograd_domain_bf16x3(const float* V, const void* U3, float* M, int tiles, int Cout, int Cin, int positions, void* stream);
+/* The same products in "f16x2" arithmetic (csrc/wgemm.hip; network option gemm = "f16x2"): every fp32 operand scaled by a power of two and split into
+ * two f16 terms (22 significant bits), three f16 MFMA products (lo*hi + hi*lo + hi*hi), fp32 accumulation -- half the matrix-pipe cycles of bf16x3 for operands
+ * good to 2^-22 instead of 2^-24.  U2 = buddy_wgemm_f16x2_packed_bytes(...) bytes filled by buddy_wgemm_f16x2_pack_weights (one power of two per position;
+ * positions <= 64, Cout % 128 == 0, Cin % 64 == 0, else 0).
+ * The rows of V are `tiles` = utterances * tiles_per_utt (tiles_per_utt >= 32); vmax holds the abs-max of V per utterance (over all positions) as 64
+ * partial maxima, float bit patterns, one per 128-byte line: unsigned [utterances][64][32], word 0 of each line used (buddy_abs_max_bits fills it; the
+ * three-pass convolutions collect it inside their input transform with one atomic max per tile): the power of two of V's scale is derived from the exponent
+ * field of the largest, so an utterance's result does not depend on the rest of the batch. */
+long long buddy_wgemm_f16x2_packed_bytes(int positions, int Cout, int Cin);
+int buddy_wgemm_f16x2_pack_weights(const float* U, void* U2, int positions, int Cout, int Cin, void* stream);
+int buddy_gemm_winograd_domain_f16x2(const float* V, const void* U2, float* M, int tiles, int Cout, int Cin, int positions, const unsigned* vmax,
+                                     int tiles_per_utt, void* stream);
+/* out [segments][64][32]: partial maxima (bit patterns, word 0 of each 128-byte line) of |x| over segment u of every one of `groups` equally spaced blocks:
+ * x is [groups][segments][seg_len] floats (V: groups = positions, segments = utterances, seg_len = tiles_per_utt * Cin); out is overwritten. */
+int buddy_abs_max_bits(const float* x, int groups, int segments, long long seg_len, unsigned* out, void* stream);
 /* The 1x1 convolutions / NIN layers (layers.py:100-106, 548-557) on the same kernel: C (M x N, row stride ldC) = alpha * [A0 | A1] W^T + bias_n
  * (+ C if accumulate); the K input channels come from A0 (first C0, row stride ldA0) and, if A1 != NULL, A1 (the rest, ldA1) -- the U-Net's
  * channel concatenation is never materialised.  W3 = buddy_wgemm_pack_weights(W [N][K], ., 1, N, K).  N % 128, K % 32, C0 % 32 == 0. */

@@ -140,12 +140,15 @@ def test_bench_line_contract():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in j, k
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
-    assert "configs[1]" in j["config"]["workload"] and j["config"]["batch_per_gpu"] == 8 and j["config"]["gemm"] in ("bf16x3", "fp32")
+    assert "configs[1]" in j["config"]["workload"] and j["config"]["batch_per_gpu"] == 8 and j["config"]["gemm"] in ("f16x2", "bf16x3", "fp32")
     assert abs(j["value"] - 8 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
     rf = j["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches"):
         assert k in rf, k
-    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] == "TFLOP/s" and 0.0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] == {"mfma": "TFLOP/s", "hbm": "GB/s"}[rf["bound"]] and 0.0 < rf["frac"] <= 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["peak"] == {"mfma": 2500.0, "hbm": 8000.0}[rf["bound"]]
+    other = rf["mfma_side" if rf["bound"] == "hbm" else "hbm_side"]            # the other roofline of the same launches is beside it
+    assert 0.0 < other["frac"] <= rf["frac"]
     assert rf["launches"] == 80                      # all 80 launches of the dominant kernel on the one sampled step
     if rf["traffic"] is not None:                    # quoted only when the stamped PMC summary matches the kernel sources
         assert 0.5e9 < rf["traffic"] < 3e9 and rf["traffic_conv_group_over_fused_form"] > 1.0

@@ -79,6 +79,48 @@ def test_winograd_domain_gemm_bf16x3(lib, tiles, Cout, Cin, P_):
     assert lib.buddy_wgemm_packed_bytes(2, 96, 128) == 0 and lib.buddy_wgemm_packed_bytes(2, 128, 48) == 0
 
 
+@pytest.mark.parametrize("utts,tpu,Cout,Cin,P_", [(3, 100, 128, 128, 3), (2, 500, 256, 384, 2), (1, 129, 256, 64, 5), (4, 1024, 128, 512, 2)])
+def test_winograd_domain_gemm_f16x2(lib, utts, tpu, Cout, Cin, P_):
+    """buddy_gemm_winograd_domain_f16x2 (two-way f16 split of power-of-two-scaled operands, three f16 MFMA products, fp32 accumulate; csrc/wgemm.hip)
+    against fp64.  The operands are good to 2^-22, so the bound is 4x the bf16x3 / fp32 kernels' (8e-5 of the abs-max; measured beside them); utterances of
+    very different level in one batch (per-utterance scale), weights and rows spanning decades, ragged row counts, and the batch-independence of an
+    utterance's result, bit for bit."""
+    from buddy_amd import _lib
+    tiles = utts * tpu
+    g = torch.Generator(device="cpu").manual_seed(tiles + Cout + Cin)
+    level = torch.tensor([1.0, 3e-4, 2e3, 17.0])[:utts].repeat_interleave(tpu)[None, :, None]
+    V = (torch.randn(P_, tiles, Cin, generator=g) * torch.exp(2.0 * torch.randn(P_, tiles, 1, generator=g)) * level).cuda()
+    U = (torch.randn(P_, Cout, Cin, generator=g) * torch.exp(1.5 * torch.randn(P_, 1, Cin, generator=g)) * 1e-2).cuda()
+    ref = torch.einsum("pmk,pnk->pmn", V.double(), U.double())
+    nbytes = int(lib.buddy_wgemm_f16x2_packed_bytes(P_, Cout, Cin))
+    assert nbytes == P_ * Cout * Cin * 4 + 512
+    U2 = torch.empty(nbytes // 4, dtype=torch.int32, device="cuda")
+    _lib.check(lib.buddy_wgemm_f16x2_pack_weights(P(U), U2.data_ptr(), P_, Cout, Cin, S()))
+    vmax = torch.empty(utts, 64, 32, dtype=torch.int32, device="cuda")      # 64 partial maxima per utterance, one per 128-byte line (include/buddy_hip.h)
+    _lib.check(lib.buddy_abs_max_bits(P(V), P_, utts, tpu * Cin, vmax.data_ptr(), S()))
+    assert torch.equal(vmax.view(torch.float32)[:, :, 0].amax(dim=1), V.reshape(P_, utts, -1).abs().amax(dim=(0, 2)))
+    M2 = torch.full((P_, tiles, Cout), 7.0, device="cuda")
+    _lib.check(lib.buddy_gemm_winograd_domain_f16x2(P(V), U2.data_ptr(), P(M2), tiles, Cout, Cin, P_, vmax.data_ptr(), tpu, S()))
+    M1 = torch.empty(P_, tiles, Cout, device="cuda")
+    _lib.check(lib.buddy_gemm_winograd_domain(P(V), P(U), P(M1), tiles, Cout, Cin, P_, S()))
+    torch.cuda.synchronize()
+    # every utterance against ITS abs-max (the levels differ by 7 decades)
+    worst2 = worst1 = 0.0
+    for u in range(utts):
+        sl = slice(u * tpu, (u + 1) * tpu)
+        worst2 = max(worst2, rel(M2[:, sl], ref[:, sl])); worst1 = max(worst1, rel(M1[:, sl], ref[:, sl]))
+    rr = lambda X: float(((X.double() - ref).abs().amax(dim=2) / ref.abs().amax(dim=2)).max())
+    print(f"utts={utts} tiles/utt={tpu} Cout={Cout} Cin={Cin}: f16x2 {worst2:.2e} (worst row {rr(M2):.2e}), fp32 MFMA {worst1:.2e} (worst row {rr(M1):.2e})")
+    assert worst2 < 8e-5 and rr(M2) < 2e-3          # a row 2^-18 below its utterance's abs-max keeps >= 2^-22 * 2^... of absolute accuracy (see wgemm.hip)
+    # utterance 0 alone == utterance 0 inside the batch
+    V0 = V[:, :tpu].contiguous()
+    M0 = torch.empty(P_, tpu, Cout, device="cuda")
+    _lib.check(lib.buddy_gemm_winograd_domain_f16x2(P(V0), U2.data_ptr(), P(M0), tpu, Cout, Cin, P_, vmax.data_ptr(), tpu, S()))
+    torch.cuda.synchronize()
+    assert torch.equal(M0, M2[:, :tpu])
+    assert lib.buddy_wgemm_f16x2_packed_bytes(2, 96, 128) == 0 and lib.buddy_wgemm_f16x2_packed_bytes(65, 128, 128) == 0 and lib.buddy_wgemm_f16x2_packed_bytes(2, 128, 96) == 0
+
+
 @pytest.mark.parametrize("M,N,K,C0", [(1000, 128, 384, 256), (4097, 256, 256, 0), (300, 128, 64, 32)])
 def test_gemm_bf16x3_general_form(lib, M, N, K, C0):
     """buddy_gemm_bf16x3 (the 1x1 convolutions / NINs on the bf16x3 kernel): two-source A (channel concatenation split at C0; 0 = one source), bias,

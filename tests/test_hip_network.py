@@ -56,7 +56,7 @@ def test_forward_vjp_vs_golden(golden, name):
 
 
 @pytest.mark.parametrize("attention", ["matrix", "flash"])
-@pytest.mark.parametrize("gemm", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "fp32"])
 @pytest.mark.parametrize("name", ["net_cm12_rb2", "net_cm1122_rb1"])
 def test_architecture_family_vs_golden(golden, name, gemm, attention):
     """The constructor is parametric (reference networks/ncsnpp.py:50-52,184-270: ch_mult, num_res_blocks, nf); csrc/net.hip builds the module list
@@ -139,9 +139,10 @@ def test_batch_independence_and_determinism():
     assert torch.equal(y, y1)
 
 
-@pytest.mark.parametrize("gemm", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "fp32"])
 def test_gemm_modes_vs_golden(golden, gemm):
-    """NCSNppTime(gemm=...): the Winograd-domain GEMMs in bf16x3 arithmetic (default: exact three-way bf16 split, six bf16 MFMA products) and on
+    """NCSNppTime(gemm=...): the Winograd-domain GEMMs in f16x2 arithmetic (default: two-term f16 split of power-of-two-scaled operands, three f16 MFMA
+    products), in bf16x3 arithmetic (exact three-way bf16 split, six bf16 MFMA products) and on
     the fp32 MFMA hold the SAME tolerance against the full-width reference fixture; both errors are printed side by side."""
     g = golden("net_full")
     nf, n_fft, hop, L, B, seed = [int(v) for v in g["meta"]]

@@ -5,7 +5,10 @@ kernel's duration in shader clocks), SQ_WAVE_CYCLES / SQ_WAIT_ANY / SQ_WAIT_INST
 GRBM_GUI_ACTIVE comes summed over the 8 XCDs (one GRBM each; 8.3e6 "cycles" for a 0.46 ms launch), so per-XCD cycles = GUI_ACTIVE / 8:
 MFMA utilisation = MFMA busy cycles / (GUI_ACTIVE / 8 x 1024 SIMDs); effective clock = GUI_ACTIVE / 8 / kernel duration (CSV timestamps)."""
 import csv, json, sys
-KEY = sys.argv[3] if len(sys.argv) > 3 else "wgemm_bf16x3_kernel<false"     # kernel-name substring (fp32 reference run: "2, 2, 36>")
+KEY = sys.argv[3] if len(sys.argv) > 3 else None     # kernel-name substring; default: the batched GEMM that ran (f16x2, else bf16x3; fp32 reference run: "2, 2, 36>")
+if KEY is None:
+    names = {r["Kernel_Name"] for r in csv.DictReader(open(sys.argv[1]))}
+    KEY = "wgemm_f16x2_kernel" if any("wgemm_f16x2_kernel" in k for k in names) else "wgemm_bf16x3_kernel<false"
 tot, n, dur = {}, {}, 0.0
 seen = set()
 for r in csv.DictReader(open(sys.argv[1])):

@@ -5,9 +5,9 @@ w4_output_kernel); their counters are summed and divided by the number of convol
 bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> doubled here."""
 import csv, hashlib, json, os, sys
 
-GROUP = ("input transform (w6_input_kernel, w4_input_kernel)", "batched GEMM (wgemm_bf16x3_kernel / igemm_kernel<...,36>)",
+GROUP = ("input transform (w6_input_kernel, w4_input_kernel)", "batched GEMM (wgemm_f16x2_kernel / wgemm_bf16x3_kernel / igemm_kernel<...,36>)",
          "output transform (w6_output_kernel, w4_output_kernel)")
-MATCH = {GROUP[0]: ("w6_input_kernel", "w4_input_kernel"), GROUP[1]: ("2, 2, 36>", "wgemm_bf16x3_kernel<false"), GROUP[2]: ("w6_output_kernel", "w4_output_kernel")}   # not the <..., true, ...> instantiation: the 1x1 convolutions
+MATCH = {GROUP[0]: ("w6_input_kernel", "w4_input_kernel"), GROUP[1]: ("2, 2, 36>", "wgemm_bf16x3_kernel<false", "wgemm_f16x2_kernel"), GROUP[2]: ("w6_output_kernel", "w4_output_kernel")}   # not the <..., true, ...> instantiation: the 1x1 convolutions
 
 
 def per_kernel(path, counter):
