@@ -559,6 +559,140 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_f16x2_kernel(const WgemmArgs a) 
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<float4*>(dst + cb * 32 + 8 * g) = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
 }
+
+// 64 rows per wave (two 32-row tiles; workgroup = 256 rows x 128 columns, 128 accumulators per lane, two workgroups per CU): every weight fragment read from LDS
+// feeds two MFMAs per product term instead of one (the 32-row form reads 0.67 fragments per MFMA) and a barrier separates 48 instead of 24 MFMAs per wave.  One K-stage of A in flight (a stage is 48 MFMAs per wave), reloaded in place after the split; the rest as wgemm_f16x2_kernel<true>.
+__global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_rt2_kernel(const WgemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * STAGE2_BYTES > 4 * 32 * 68 * 4) ? 2 * STAGE2_BYTES : 4 * 32 * 68 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int lid, p;
+  if (a.pz > 0) {
+    const int orig = blockIdx.x, xcd = orig & 7, k = orig >> 3;
+    lid = k % a.gx; p = xcd + 8 * (k / a.gx);
+  } else {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    p = blockIdx.z;
+  }
+  const int nb = lid % a.NB, m0 = (lid / a.NB) * (2 * WBM);
+  const float* __restrict__ V = a.V + (long long)p * a.sV;
+  const unsigned char* __restrict__ U2 = a.U3 + ((long long)p * a.NB + nb) * a.S * STAGE2_BYTES;
+  const int S = a.S;
+
+  int row[2];
+  float sv[2], inv[2];
+  unsigned aoff[2];
+  {
+    const int r0 = min(m0 + wid * 64, a.Mt - 1), r1 = min(m0 + wid * 64 + 63, a.Mt - 1), b0 = r0 / a.tpu, b1 = r1 / a.tpu;     // tpu >= 64: at most two utterances
+    unsigned mb0 = __hip_atomic_load(a.vmax + ((long long)b0 * VMAX_SUB + lane) * VMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int o = 32; o > 0; o >>= 1) mb0 = max(mb0, (unsigned)__shfl_xor((int)mb0, o));
+    unsigned mb1 = mb0;
+    if (b1 != b0) {
+      mb1 = __hip_atomic_load(a.vmax + ((long long)b1 * VMAX_SUB + lane) * VMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int o = 32; o > 0; o >>= 1) mb1 = max(mb1, (unsigned)__shfl_xor((int)mb1, o));
+    }
+    const float ui = a.uinv[p];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      row[t] = min(m0 + wid * 64 + t * 32 + (lane & 31), a.Mt - 1);
+      pow2_scale(row[t] / a.tpu == b0 ? mb0 : mb1, sv[t], inv[t]);
+      inv[t] *= ui;
+      aoff[t] = (unsigned)(((long long)row[t] * a.Cin + 16 * (lane >> 5)) * 4);
+    }
+  }
+  const unsigned boff = (unsigned)tid * 16u;
+  const char* Vb = reinterpret_cast<const char*>(V);
+  const char* Ub = reinterpret_cast<const char*>(U2);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+  float4 ra[2][4];
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem + wid * 1024);
+  auto loadA = [&](int s) {
+    const char* base = Vb + (long long)s * (WKS * 4);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ra[t][j] = *reinterpret_cast<const float4*>(base + aoff[t] + 16 * j);
+  };
+  auto dmaB = [&](int s) {
+    const void* base = uniform_ptr(Ub + (long long)s * STAGE2_BYTES);
+    const unsigned l = lds0 + (s & 1) * STAGE2_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16_asm(base, boff + j * (WNT * 16), l + j * (WNT * 16));
+  };
+  auto stage = [&](int s, auto nx_) {
+    constexpr bool NX = decltype(nx_)::value;                  // stage s + 1 exists: request its weights and A rows
+    Split2 av[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) av[t][kc] = split2(ra[t][2 * kc], ra[t][2 * kc + 1], sv[t]);
+    if (NX) { dmaB(s + 1); loadA(s + 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* Bcur = smem + (s & 1) * STAGE2_BYTES + lane * 16;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      f16x8 b[4][2];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[cb][q] = *reinterpret_cast<const f16x8*>(Bcur + ((kc * 4 + cb) * 2 + q) * FRAG);
+      constexpr int PB[3] = {1, 0, 0}, PA[3] = {0, 1, 0};
+#pragma unroll
+      for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) acc[t][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[cb][PB[tm]], av[t][kc].p[PA[tm]], acc[t][cb], 0, 0, 0);
+    }
+    if (NX) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // the four weight DMAs have landed, the eight A loads stay in flight
+    __syncthreads();
+  };
+  dmaB(0);
+  loadA(0);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  int s = 0;
+  for (; s + 1 < S; ++s) stage(s, std::true_type{});
+  stage(s, std::false_type{});
+
+  constexpr int SP = 68;
+  float* St = reinterpret_cast<float*>(smem) + wid * (32 * SP);
+  const int rr = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int rb = m0 + wid * 64 + t * 32;
+    float* Mrow = a.M + (long long)p * a.sM + (long long)rb * a.Cout + nb * WBN;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(St + (lane & 31) * SP + cl * 32 + 8 * g + 4 * (lane >> 5)) =
+              make_float4(acc[t][2 * hb + cl][4 * g] * inv[t], acc[t][2 * hb + cl][4 * g + 1] * inv[t], acc[t][2 * hb + cl][4 * g + 2] * inv[t],
+                          acc[t][2 * hb + cl][4 * g + 3] * inv[t]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = 4 * it + rr;
+        const float4 v = *reinterpret_cast<const float4*>(St + r * SP + c4);
+        if (rb + r < a.Mt) *reinterpret_cast<float4*>(Mrow + (long long)r * a.Cout + hb * 64 + c4) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
 }  // namespace
 
 bool wgemm_supported(int Cout, int Cin) { return Cout % WBN == 0 && Cin % WKS == 0; }
@@ -645,11 +779,15 @@ void launch_wgemm_f16x2(const float* V, const void* U2, float* M, long long Mt, 
   a.sV = Mt * Cin; a.sM = Mt * Cout;
   a.vmax = vmax; a.tpu = tiles_per_utt; a.uinv = reinterpret_cast<const float*>(a.U3 + (size_t)P * Cout * Cin * 4);
   const bool by_pos = cur_opt().wgemm_xcdpos != 0;
-  const int gx = cdiv((int)Mt, WBM) * a.NB;
+  // 64-row waves (wgemm_f16x2_rt2_kernel): 4-6 % faster on every shape of the shipped network (tools/wgemm_modes_bench.py, profiles/README.md r05i); option
+  // wgemm_rt 1 = the 32-row kernel (A/B switch)
+  const bool rt2 = tiles_per_utt >= 64 && cur_opt().wgemm_epi != 0 && cur_opt().wgemm_rt != 1;
+  const int gx = cdiv((int)Mt, rt2 ? 2 * WBM : WBM) * a.NB;
   const bool fold = by_pos && P % 8 == 0 && (long long)gx * P < (1LL << 31);
   a.pz = fold ? P : 0; a.gx = gx;
   const dim3 grid(fold ? (unsigned)(gx * P) : (unsigned)gx, 1, fold ? 1u : (unsigned)P);
-  if (cur_opt().wgemm_epi == 0) hipLaunchKernelGGL((wgemm_f16x2_kernel<false>), grid, dim3(WNT), 0, st, a);
+  if (rt2) hipLaunchKernelGGL(wgemm_f16x2_rt2_kernel, grid, dim3(WNT), 0, st, a);
+  else if (cur_opt().wgemm_epi == 0) hipLaunchKernelGGL((wgemm_f16x2_kernel<false>), grid, dim3(WNT), 0, st, a);
   else hipLaunchKernelGGL((wgemm_f16x2_kernel<true>), grid, dim3(WNT), 0, st, a);
 }
 
