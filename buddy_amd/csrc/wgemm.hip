@@ -1,8 +1,9 @@
-// Winograd-domain batched GEMM  M[p] (tiles x Cout) = V[p] (tiles x Cin) . U[p]^T (Cout x Cin),  p < positions,  in "bf16x3" arithmetic:
-// the middle pass of the three-pass 3x3 convolutions (reference ddpm_conv3x3, networks/ncsnpp_utils/layers.py:119-126) -- 94 % of the
-// score network's FLOPs.
+// Winograd-domain batched GEMM  M[p] (tiles x Cout) = V[p] (tiles x Cin) . U[p]^T (Cout x Cin),  p < positions: the middle pass of the three-pass 3x3
+// convolutions (reference ddpm_conv3x3, networks/ncsnpp_utils/layers.py:119-126) -- 94 % of the score network's FLOPs -- in two split arithmetics on the
+// 16-bit matrix pipe: "f16x2" (the default since round 5: wgemm_f16x2_kernel / wgemm_f16x2_rt2_kernel, second half of this file) and "bf16x3" (this kernel;
+// also the general form of the 1x1 convolutions / NIN layers / DFT GEMMs and the ResBlock skip path's fused GroupNorm-backward form in both modes).
 //
-// Arithmetic.  Every fp32 operand is split EXACTLY into three bf16 terms by truncation, x = hi + mid + lo (8 + 8 + 8 significant bits), and
+// bf16x3 arithmetic.  Every fp32 operand is split EXACTLY into three bf16 terms by truncation, x = hi + mid + lo (8 + 8 + 8 significant bits), and
 // the product is accumulated in fp32 as  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are
 // exact in fp32; the dropped terms mid*lo, lo*mid, lo*lo are <= 2^-23 of a product, the fp32 rounding level).  Six bf16 MFMAs (32 cycles, 16 k)
 // replace eight fp32 MFMAs (64 cycles, 2 k each): 2.67x fewer matrix-pipe cycles per multiply-add at the accuracy of the fp32 path
