@@ -175,8 +175,8 @@ struct Net {
   bool prep_failed = false;    // a lazily prepared weight form could not be built (out of memory): the call reports it
   bool fir = false;            // fir=True: FIR (1,3,3,1) resampling instead of nearest / box (reference up_or_down_sampling.py:195-257)
   float* w4_scratch = nullptr; size_t w4_cap = 0, w4_need = 0;   // V / M buffers of the three-pass F(4x4,3x3) convolutions (floats)
-  // gemm = f16x2: abs-max of V per (convolution of this call, utterance): VMAX_SLOTS x B x [VMAX_SUB][VMAX_STRIDE] words (common.h), zeroed at the start of every call
-  unsigned* vmax = nullptr; size_t vmax_cap = 0; int vslot = 0;
+  // gemm = f16x2: abs-max of V per (convolution of this call, utterance): vslots x B x [VMAX_SUB][VMAX_STRIDE] words (common.h), zeroed at the start of every call
+  unsigned* vmax = nullptr; size_t vmax_cap = 0; int vslot = 0, vslots = 0, vdry = 0;   // vslots: convolutions per call counted by the sizing dry run
   int vslot_need[2] = {0, 0};  // slots a forward / an input-VJP call used on the reserved shape (0: not known yet, zero all of them)
   bool dry() const { return arena.dry; }
   Tens* mk(int B_, int H, int W, int C, bool grad) {
@@ -477,7 +477,6 @@ void net_destroy(Net* N) {
 // the GPU from the raw OIHW tensor (wprep.hip) and cached in the shared store.  want_x: 1 the bf16x3 / 2 the f16x2 stage image (the fp32 form is then only a
 // staging buffer, reused for the next layer); 0: the fp32 form itself is kept.  The preparing stream is drained before the pointer is
 // published, so a replica on another stream may use it at once.
-constexpr int VMAX_SLOTS = 192;                     // 3x3 convolutions per call (the shipped network: 46 forward, 46 + the up forms backward)
 static const WVar* conv_weights(Net* N, const ConvW& c, bool dgrad, int kind, int want_x) {
   Weights* Wt = N->W.get();
   const int ki = kind == 0 ? 0 : kind == 2 ? 1 : kind == 4 ? 2 : kind == 6 ? 3 : 4;
@@ -564,7 +563,7 @@ struct Conv3 {
 // fusions on the low-resolution geometry.
 // the next convolution's abs-max slots (one per utterance; zeroed by begin_call)
 static unsigned* vmax_slot(Net* N, int B) {
-  if (N->vmax == nullptr || N->vslot >= VMAX_SLOTS || (size_t)(N->vslot + 1) * B * VMAX_SUB * VMAX_STRIDE > N->vmax_cap) { N->prep_failed = true; set_error("abs-max slots of the f16x2 GEMM exhausted"); return nullptr; }
+  if (N->vmax == nullptr || N->vslot >= N->vslots || (size_t)(N->vslot + 1) * B * VMAX_SUB * VMAX_STRIDE > N->vmax_cap) { N->prep_failed = true; set_error("abs-max slots of the f16x2 GEMM exhausted"); return nullptr; }
   return N->vmax + (size_t)(N->vslot++) * B * VMAX_SUB * VMAX_STRIDE;
 }
 static bool conv3_up_ok(Net* N, int B, int H, int W, int Cin, int Cout) {
@@ -581,6 +580,7 @@ static bool conv3_up_ok(Net* N, int B, int H, int W, int Cin, int Cout) {
 static int conv3(Net* N, const Conv3& c) {
   const float* a = c.a; const int B = c.B, H = c.H, W = c.W, Cin = c.Cin, Cout = c.Cout;
   if (N->prep_failed) return -1;      // an earlier convolution of this call could not be prepared: launch nothing more on its unwritten output, the call reports the error
+  if (N->dry()) ++N->vdry;            // convolutions per call: the abs-max slots of the f16x2 GEMM are sized from this count
   // Winograd forms exist for channel counts that are multiples of 8 (every ResBlock convolution of the supported family)
   const bool wino_ok = c.w != nullptr && c.w->raw != nullptr && Cin % 8 == 0 && Cout % 8 == 0;
   const W4Gn* gn = c.gn; float* gn_tmp = c.gn_tmp; Tens* stat_out = c.stat_out; const W4Gn* bwd_gn = c.bwd_gn; const bool direct = c.direct;
@@ -1230,8 +1230,11 @@ int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes) {
   // the dry run takes the allocation sequence of the form with per-utterance EDM scalars (a superset of the one without): the pointers
   // only have to be non-null, nothing is dereferenced or launched while arena.dry is set
   static const float dry_scalars[1] = {0.f};
+  N->vdry = 0;
   run_forward(N, nullptr, nullptr, dry_scalars, dry_scalars, dry_scalars, nullptr, B, L, with_vjp != 0);
+  const int conv_fwd = N->vdry;
   if (with_vjp) run_vjp(N, nullptr, nullptr);
+  const int conv_slots = std::max(conv_fwd, N->vdry - conv_fwd) + 1;
   const size_t need = N->arena.peak + (1 << 20);
   N->arena = saved;
   N->pool.clear(); N->tape.clear(); N->taps.clear(); N->have_tape = false;
@@ -1248,11 +1251,12 @@ int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes) {
     HIPCHK(hipMalloc(&N->arena.base, need));
     N->arena.cap = need;
   }
-  if (N->opt.gemm == 2 && N->vmax_cap < (size_t)VMAX_SLOTS * B * VMAX_SUB * VMAX_STRIDE) {
+  N->vslots = conv_slots;
+  if (N->opt.gemm == 2 && N->vmax_cap < (size_t)conv_slots * B * VMAX_SUB * VMAX_STRIDE) {
     if (N->vmax) (void)hipFree(N->vmax);
     N->vmax = nullptr; N->vmax_cap = 0;
-    HIPCHK(hipMalloc(&N->vmax, (size_t)VMAX_SLOTS * B * VMAX_SUB * VMAX_STRIDE * 4));
-    N->vmax_cap = (size_t)VMAX_SLOTS * B * VMAX_SUB * VMAX_STRIDE;
+    HIPCHK(hipMalloc(&N->vmax, (size_t)conv_slots * B * VMAX_SUB * VMAX_STRIDE * 4));
+    N->vmax_cap = (size_t)conv_slots * B * VMAX_SUB * VMAX_STRIDE;
   }
   N->vslot_need[0] = N->vslot_need[1] = 0;
   N->rsv_B = B; N->rsv_L = L; N->rsv_vjp = with_vjp != 0;
@@ -1272,7 +1276,7 @@ int net_forward(Net* N, const float* x, const float* cnoise, const float* cin_b,
   if (rc) return rc;
   N->st = st;
   N->arena.dry = false; N->arena.overflow = false;
-  if (N->opt.gemm == 2) { HIPCHK(hipMemsetAsync(N->vmax, 0, (size_t)(N->vslot_need[0] ? N->vslot_need[0] : VMAX_SLOTS) * B * VMAX_SUB * VMAX_STRIDE * 4, st)); N->vslot = 0; }
+  if (N->opt.gemm == 2) { HIPCHK(hipMemsetAsync(N->vmax, 0, (size_t)(N->vslot_need[0] ? N->vslot_need[0] : N->vslots) * B * VMAX_SUB * VMAX_STRIDE * 4, st)); N->vslot = 0; }
   run_forward(N, x, cnoise, cin_b, cskip_b, cout_b, y, B, L, save != 0);
   N->vslot_need[0] = N->vslot;
   if (N->arena.overflow) { set_error("arena overflow"); return BUDDY_ERR_STATE; }
@@ -1285,7 +1289,7 @@ int net_vjp(Net* N, const float* cot, float* gx, hipStream_t st) {
   if (!N->have_tape) { set_error("vjp without a saved forward"); return BUDDY_ERR_STATE; }
   OptScope scope(&N->opt);
   N->st = st;
-  if (N->opt.gemm == 2) { HIPCHK(hipMemsetAsync(N->vmax, 0, (size_t)(N->vslot_need[1] ? N->vslot_need[1] : VMAX_SLOTS) * N->rsv_B * VMAX_SUB * VMAX_STRIDE * 4, st)); N->vslot = 0; }
+  if (N->opt.gemm == 2) { HIPCHK(hipMemsetAsync(N->vmax, 0, (size_t)(N->vslot_need[1] ? N->vslot_need[1] : N->vslots) * N->rsv_B * VMAX_SUB * VMAX_STRIDE * 4, st)); N->vslot = 0; }
   run_vjp(N, cot, gx);
   N->vslot_need[1] = N->vslot;
   if (N->arena.overflow) { set_error("arena overflow"); return BUDDY_ERR_STATE; }

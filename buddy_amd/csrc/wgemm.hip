@@ -370,16 +370,16 @@ __device__ __forceinline__ void pow2_scale(unsigned bits, float& s, float& inv) 
   inv = __uint_as_float((unsigned)(e - 14) << 23);
 }
 
-// abs-max of every position's weight matrix -> umax[p] (float bits)
+// abs-max of every position's weight matrix -> umax[p] (float bits); grid (chunks, P), umax zeroed before
 __global__ __launch_bounds__(256) void wgemm_umax_kernel(const float* __restrict__ U, unsigned* __restrict__ umax, long long per) {
-  const float* u = U + (long long)blockIdx.x * per;
+  const float* u = U + (long long)blockIdx.y * per;
   float m = 0.f;
-  for (long long i = threadIdx.x; i < per; i += 256) m = fmaxf(m, fabsf(u[i]));
-  __shared__ float red[256];
-  red[threadIdx.x] = m;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
-  if (threadIdx.x == 0) umax[blockIdx.x] = __float_as_uint(red[0]);
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < per; i += (long long)gridDim.x * 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(u + i);                      // per = Cout * Cin, a multiple of 4
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(umax + blockIdx.y, __float_as_uint(m));
 }
 // out[u][VMAX_SUB][VMAX_STRIDE]: partial maxima (bit patterns) of |x| over x[g][u][0 .. seg_len), g < groups; grid (chunks, segments), out zeroed before
 __global__ __launch_bounds__(256) void abs_max_bits_kernel(const float* __restrict__ x, int groups, int segments, long long seg_len, unsigned* __restrict__ out) {
@@ -763,7 +763,8 @@ void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt,
 size_t wgemm_f16x2_packed_bytes(int P, int Cout, int Cin) { return (size_t)P * Cout * Cin * 4 + 512; }
 void wgemm_f16x2_pack_weights(const float* U_dev, void* U2_dev, int P, int Cout, int Cin, hipStream_t st) {
   unsigned* umax_scratch = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(U2_dev) + (size_t)P * Cout * Cin * 4 + 256);
-  hipLaunchKernelGGL(wgemm_umax_kernel, dim3((unsigned)P), dim3(256), 0, st, U_dev, umax_scratch, (long long)Cout * Cin);
+  (void)hipMemsetAsync(umax_scratch, 0, 256, st);
+  hipLaunchKernelGGL(wgemm_umax_kernel, dim3(16, (unsigned)P), dim3(256), 0, st, U_dev, umax_scratch, (long long)Cout * Cin);
   const long long n16 = (long long)P * Cout * Cin * 4 / 16;
   hipLaunchKernelGGL(wgemm_pack2_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, U_dev, reinterpret_cast<u32x4*>(U2_dev), umax_scratch, P, Cout, Cin);
 }

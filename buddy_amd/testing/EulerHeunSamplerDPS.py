@@ -6,7 +6,7 @@ Batched: ``y`` may be ``(B, L)``; every reduction the reference takes over "the 
 is elementwise -- so row b of a batched run equals the reference's B=1 run on utterance b.
 The likelihood loss and its gradient w.r.t. the Tweedie estimate come from the operator's library handle (one call), autograd then
 continues through the hand-written HIP network VJP (``NCSNppTime`` is an autograd Function).  The operator update (``optimize_op``) is one
-library call.  No torch-op operator / Adam path exists in the product (tests/torchops/sampler.py holds that form for host-logic tests)."""
+library call.  No torch-op operator / Adam path exists in the product (oracle/batched/sampler.py holds that form for host-logic tests)."""
 from __future__ import annotations
 
 import torch

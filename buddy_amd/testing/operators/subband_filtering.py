@@ -6,7 +6,7 @@ cross-utterance coupling anywhere).
 HIP only.  Parameters, Adam state, the filter H and every intermediate live inside a ``buddy_blindop_*`` handle of ``libbuddy_hip.so``
 (hand-written forward + analytic backward kernels, one library call per ``optimize_op``).  There is no torch-op implementation in the product:
 constructing the operator without a GPU raises ``BuddyHipError``.  The torch-op restatement used by the CPU host-logic tests and by the
-on-GPU autograd cross-checks lives in ``tests/torchops/operators.py``.
+on-GPU autograd cross-checks lives in ``oracle/batched/operators.py``.
 """
 from __future__ import annotations
 

@@ -5,7 +5,7 @@ The product evaluates the likelihood loss and its gradient INSIDE ``libbuddy_hip
 adjoints), so ``get_loss`` here resolves and VALIDATES a loss block of the config and returns its specification; the one supported loss is
 the shipped ``l2_comp_stft_summean`` with compression factor 0.667 (``conf/tester/*.yaml``; reference ``losses.py:59-64``).  Anything else
 raises ``NotImplementedError`` -- there is no torch-op evaluation path in the product (the formulas as torch expressions live in
-``tests/torchops/losses.py``).  Per-utterance semantics: the library returns one loss per utterance and their sum, so gradients decouple
+``oracle/batched/losses.py``).  Per-utterance semantics: the library returns one loss per utterance and their sum, so gradients decouple
 per utterance."""
 from __future__ import annotations
 

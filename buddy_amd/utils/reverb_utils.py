@@ -4,7 +4,7 @@
 (``buddy_fir``): the same linear convolution the reference evaluates through a 2^17-point complex FFT, exact to
 fp32 round-off, with its transpose as the autograd backward.  ``hilbert`` / ``minimum_phase_version`` (reference :3-23) run inside the
 blind operator's library handle (25 856-point FFT kernels, ``BlindSubbandFiltering.minimum_phase``); their torch restatement is test
-infrastructure (``tests/torchops/operators.py``)."""
+infrastructure (``oracle/batched/operators.py``)."""
 from __future__ import annotations
 
 import torch

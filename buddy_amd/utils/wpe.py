@@ -8,7 +8,7 @@ restates its published algorithm (Nakatani et al. 2010; Drude et al. 2018, batch
 UNPINNED against the package itself; checked on the GPU against the independent numpy oracle ``oracle/wpe_ref.py``.
 The whole estimate is ONE library call (``buddy_wpe_dereverb``, ``csrc/wpe.hip``): hand-written complex128 STFT, the iterations (inverse
 power, correlation matrix, Cholesky solve, prediction filter; one workgroup per (utterance, bin) row) and the overlap-add iSTFT.  There is
-no CPU form in the product: a CPU tensor raises ``BuddyHipError`` (the torch restatement used by host-logic tests lives in ``tests/torchops``)."""
+no CPU form in the product: a CPU tensor raises ``BuddyHipError`` (the torch restatement used by host-logic tests lives in ``oracle/batched``)."""
 from __future__ import annotations
 
 import torch

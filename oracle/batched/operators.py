@@ -75,36 +75,12 @@ class StftOnly(OperatorSTFT):
         self._init_stft(op_hp, sample_rate, device)
 
 
-def hilbert(h):
-    """reference reverb_utils.py:3-7: window [2]*ceil(N/2) ++ [0]*floor(N/2), DC/Nyquist not special-cased."""
-    n = h.size(-1)
-    window = 2 * torch.heaviside(torch.linspace(-1, 1, steps=n), values=torch.ones(1)).to(h.device)
-    window = torch.flip(window, dims=(-1,))
-    return torch.fft.ifft(window * torch.fft.fft(h))
-
-
-def minimum_phase_version(h):
-    """reference reverb_utils.py:9-23 (batched over leading dims)."""
-    T = h.size(-1)
-    h = F.pad(h, (0, T))
-    H = torch.fft.fft(h)
-    log_abs = torch.log(torch.abs(H) + 1e-8)
-    phase = -torch.imag(hilbert(log_abs))
-    e = torch.exp(1j * phase)
-    out = torch.real(torch.fft.ifft(torch.abs(H).type(e.dtype) * e))
-    return out[..., :-T]
+from oracle.operators_ref import hilbert_ref as hilbert, minimum_phase_ref as minimum_phase_version, linear_interp as _linear_interp_kc   # noqa: E402
 
 
 def linear_interp(knots, values, query):
-    """Piecewise-linear interpolation over ``knots`` evaluated at ``query`` -- what the reference obtains from
-    ``torchcde.LinearInterpolation(torchcde.linear_interpolation_coeffs(v), t=knots).evaluate(query)``
-    (subband_filtering.py:233-235; third-party, restated from API semantics).  values (..., K), returns (..., Q)."""
-    K = knots.shape[0]
-    idx = (torch.bucketize(query, knots) - 1).clamp(0, K - 2)
-    t0, t1 = knots[idx], knots[idx + 1]
-    frac = (query - t0) / (t1 - t0)
-    v0, v1 = values[..., idx], values[..., idx + 1]
-    return v0 + frac * (v1 - v0)
+    """values (..., K) -> (..., Q): the oracle's piecewise-linear interpolation (restated from torchcde's API semantics, parity unpinned) on one channel."""
+    return _linear_interp_kc(knots, values.unsqueeze(-1), query).squeeze(-1)
 
 
 class SubbandFiltering(Operator, OperatorSTFT):

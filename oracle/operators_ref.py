@@ -18,13 +18,13 @@ def hilbert_ref(h):
     """reference utils/reverb_utils.py:3-7 -- window is [2]*N/2 ++ [0]*N/2 (DC/Nyquist NOT special-cased;
     torch.heaviside(linspace(-1,1,N), 1) flipped)."""
     n = h.shape[-1]
-    window = 2 * torch.heaviside(torch.linspace(-1, 1, steps=n), values=torch.ones(1))
+    window = 2 * torch.heaviside(torch.linspace(-1, 1, steps=n), values=torch.ones(1)).to(h.device)
     window = torch.flip(window, dims=(-1,))
     return torch.fft.ifft(window * torch.fft.fft(h))
 
 
 def minimum_phase_ref(h):
-    """reference utils/reverb_utils.py:9-23."""
+    """reference utils/reverb_utils.py:9-23 (batched over leading dims)."""
     T = h.shape[-1]
     h = F.pad(h, (0, T))
     H = torch.fft.fft(h)
@@ -32,7 +32,7 @@ def minimum_phase_ref(h):
     phase = -torch.imag(hilbert_ref(log_abs))
     e = torch.exp(1j * phase)
     out = torch.real(torch.fft.ifft(torch.abs(H).type(e.dtype) * e))
-    return out[:-T]
+    return out[..., :-T]
 
 
 def fast_apply_rir_ref(y, filt):

@@ -21,8 +21,8 @@ def _sample(utts, L):
     sys.path.insert(0, ROOT)
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
-    from tests.torchops.operators import BlindSubbandFiltering
-    from tests.torchops.sampler import EulerHeunSamplerDPSTorch
+    from oracle.batched.operators import BlindSubbandFiltering
+    from oracle.batched.sampler import EulerHeunSamplerDPSTorch
     from oracle.sampler_ref import NoiseStream
     from tests.test_host_logic import _ToyNet
     torch.set_num_threads(2)

@@ -579,7 +579,7 @@ def test_row_ops(lib):
 
 def test_wpe_kernel_vs_torch_restatement(lib):
     """buddy_wpe (one workgroup per frequency bin, Cholesky in LDS, complex128) vs the torch restatement of the same algorithm."""
-    from tests.torchops import wpe
+    from oracle.batched import wpe
     from buddy_amd.utils.wpe import wpe_hip
     g = torch.Generator(device="cpu").manual_seed(11)
     L = 16000

@@ -1,5 +1,5 @@
 """GPU parity of the hand-written blind operator (buddy_blindop_*: analytic forward/backward, fused Adam loop) against the
-torch-op restatement of the same reference code (tests/torchops: autograd, rocFFT, torch's Adam -- test infrastructure, not product) on the
+torch-op restatement of the same reference code (oracle/batched: autograd, rocFFT, torch's Adam -- test infrastructure, not product) on the
 same device, inputs and noise draws; that restatement is pinned to the reference fixtures by tests/test_host_logic.py.  Tolerances
 relative to abs-max."""
 import numpy as np
@@ -17,7 +17,7 @@ def rel(a, b):
 def make_ops(U, L, seed=40):
     from buddy_amd.config import compose
     from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering
-    from tests.torchops.operators import BlindSubbandFiltering as BlindSubbandFilteringTorch
+    from oracle.batched.operators import BlindSubbandFiltering as BlindSubbandFilteringTorch
     from oracle.sampler_ref import NoiseStream
     args = compose(overrides=["tester.posterior_sampling.warm_initialization.mode=reverb_scaled"])
     op_hp = args.tester.informed_dereverberation.op_hp
@@ -53,7 +53,7 @@ def test_forward_pieces():
 
 
 def test_likelihood_loss_and_gradient():
-    from tests.torchops.losses import get_loss
+    from oracle.batched.losses import get_loss
     U, L = 2, 16000
     args, opt, oph, nt, nh = make_ops(U, L)
     ps = args.tester.posterior_sampling
@@ -71,7 +71,7 @@ def test_likelihood_loss_and_gradient():
 
 def test_parameter_gradients():
     from buddy_amd import _lib
-    from tests.torchops.losses import get_loss
+    from oracle.batched.losses import get_loss
     U, L = 2, 16000
     args, opt, oph, nt, nh = make_ops(U, L)
     ps = args.tester.posterior_sampling
@@ -101,7 +101,7 @@ def test_parameter_gradients():
 def test_parameter_gradients_without_regulariser():
     """noise == NULL: the reconstruction term alone (the path that does not share its launches with the regulariser chain)"""
     from buddy_amd import _lib
-    from tests.torchops.losses import get_loss
+    from oracle.batched.losses import get_loss
     U, L = 2, 16000
     args, opt, oph, nt, nh = make_ops(U, L)
     ps = args.tester.posterior_sampling
@@ -131,7 +131,7 @@ def test_optimize_loop_matches_torch_adam():
     ps = args.tester.posterior_sampling
     x, y = signals(U, L)
     args.tester.posterior_sampling.blind_hp.op_updates_per_step = 3
-    from tests.torchops.sampler import EulerHeunSamplerDPSTorch
+    from oracle.batched.sampler import EulerHeunSamplerDPSTorch
     smp_t = EulerHeunSamplerDPSTorch(torch.nn.Identity(), instantiate(args.diff_params), args)
     smp_h = instantiate(args.tester.sampler, torch.nn.Identity(), instantiate(args.diff_params), args)
     assert type(smp_h).__name__ == "EulerHeunSamplerDPS"
@@ -157,7 +157,7 @@ def test_informed_likelihood_loss_and_gradient():
     from buddy_amd.config import compose
     from buddy_amd.synth import synth_rir
     from buddy_amd.testing.operators.reverb import RIROperator
-    from tests.torchops.losses import get_loss
+    from oracle.batched.losses import get_loss
     U, L = 2, 16000
     args = compose(tester="informed_dereverberation_DPS")
     ps = args.tester.posterior_sampling
@@ -169,7 +169,7 @@ def test_informed_likelihood_loss_and_gradient():
     xh = xd.clone().requires_grad_(True)
     rec_h = op.hip_rec_loss(xh)
     gh, = torch.autograd.grad(rec_h, xh)
-    from tests.torchops.operators import StftOnly
+    from oracle.batched.operators import StftOnly
     st = StftOnly(args.tester.informed_dereverberation.op_hp, 16000, "cuda")     # the loss formula's STFT through torch; the FIR is the HIP kernel (autograd Function)
     xt = xd.clone().requires_grad_(True)
     rec_t = get_loss(ps.rec_loss, operator=st)(y, op.degradation(xt))

@@ -66,9 +66,9 @@ def _run_blind(g, extra, backend):
         smp = instantiate(args.tester.sampler, net, edm, args)
         op = BlindSubbandFiltering(args.tester.informed_dereverberation.op_hp, 16000, num_utts=1, noise=ns, device="cuda", length=meta[1])
         assert hasattr(op, "hip_optimize")
-    else:                                # cross-check: the torch-op restatement (tests/torchops) around the same HIP network
-        from tests.torchops.operators import BlindSubbandFiltering
-        from tests.torchops.sampler import EulerHeunSamplerDPSTorch
+    else:                                # cross-check: the torch-op restatement (oracle/batched) around the same HIP network
+        from oracle.batched.operators import BlindSubbandFiltering
+        from oracle.batched.sampler import EulerHeunSamplerDPSTorch
         smp = EulerHeunSamplerDPSTorch(net, edm, args)
         op = BlindSubbandFiltering(args.tester.informed_dereverberation.op_hp, 16000, num_utts=1, noise=ns, device="cuda")
     smp.noise = ns
@@ -82,7 +82,7 @@ def _run_blind(g, extra, backend):
 @pytest.mark.parametrize("backend", ["hip", "torch"])
 def test_blind_dps_vs_reference_fixture(golden, backend):
     """backend "hip": the hand-written operator (csrc/operator.hip -- what the bench and the Tester run); "torch": the torch-op restatement
-    of tests/torchops (test infrastructure) driving the same HIP network."""
+    of oracle/batched (test infrastructure) driving the same HIP network."""
     g = golden("e2e_blind")
     p, op, smp = _run_blind(g, ["tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
                                 "tester.posterior_sampling.blind_hp.op_updates_per_step=3"], backend)

@@ -147,10 +147,10 @@ def test_schedule_gamma_edm_scalars(golden):
 
 
 def test_blind_operator_vs_golden_and_batching(golden):
-    """the batched torch-op restatement (tests/torchops: test infrastructure since round 4) against the reference fixtures; it is what the
+    """the batched torch-op restatement (oracle/batched: test infrastructure since round 4) against the reference fixtures; it is what the
     host-logic tests below and the on-GPU autograd cross-checks of the HIP operator stand on"""
-    from tests.torchops.operators import BlindSubbandFiltering
-    from tests.torchops.losses import get_loss
+    from oracle.batched.operators import BlindSubbandFiltering
+    from oracle.batched.losses import get_loss
     from oracle.sampler_ref import NoiseStream
     g = golden("ops")
     args = compose()
@@ -206,9 +206,9 @@ class _ToyNet(torch.nn.Module):
 def test_batched_blind_dps_equals_oracle_per_utterance():
     """Row b of the batched sampler == the oracle's (reference-faithful) B=1 run of utterance b.  The product sampler's control flow
     (schedule, stochastic step, per-utterance reductions, noise-stream order, Euler update) with the operator / likelihood through torch ops
-    (tests/torchops/sampler.py) -- on a GPU those three hooks are library calls."""
-    from tests.torchops.operators import BlindSubbandFiltering
-    from tests.torchops.sampler import EulerHeunSamplerDPSTorch
+    (oracle/batched/sampler.py) -- on a GPU those three hooks are library calls."""
+    from oracle.batched.operators import BlindSubbandFiltering
+    from oracle.batched.sampler import EulerHeunSamplerDPSTorch
     from oracle import operators_ref as O, sampler_ref as S
     ov = ["tester.sampling_params.T=3", "tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
           "tester.posterior_sampling.blind_hp.op_updates_per_step=2"]
@@ -254,7 +254,7 @@ def test_unconditional_sampler_equals_oracle():
 
 def test_wpe_restated_roundtrip_and_dereverb():
     """nara_wpe restatement (parity unpinned): STFT/iSTFT round trip is exact and WPE removes late reverberation of a bursty source."""
-    from tests.torchops import wpe
+    from oracle.batched import wpe
     rs = np.random.RandomState(0)
     n = 16000
     env = (np.sin(2 * np.pi * 3 * np.arange(n) / 16000) > 0.6).astype(np.float64)
@@ -272,8 +272,8 @@ def test_wpe_restated_roundtrip_and_dereverb():
 def test_wpe_oracle_conventions_and_independent_restatements_agree():
     """oracle/wpe_ref.py (numpy, test infrastructure) against the conventions it cites -- frame count of the fading + padded STFT, exact
     STFT -> iSTFT round trip at ragged lengths, zero prediction filter for a white input's delayed taps within statistics -- and against
-    the separately written torch form of the same published algorithm (tests/torchops/wpe.py; two restatements, one algorithm: 1e-6)."""
-    from tests.torchops import wpe
+    the separately written torch form of the same published algorithm (oracle/batched/wpe.py; two restatements, one algorithm: 1e-6)."""
+    from oracle.batched import wpe
     from oracle import wpe_ref
     rs = np.random.RandomState(3)
     for n in (700, 12345, 16000, 64000):

@@ -8,7 +8,7 @@ import csv, json, sys
 KEY = sys.argv[3] if len(sys.argv) > 3 else None     # kernel-name substring; default: the batched GEMM that ran (f16x2, else bf16x3; fp32 reference run: "2, 2, 36>")
 if KEY is None:
     names = {r["Kernel_Name"] for r in csv.DictReader(open(sys.argv[1]))}
-    KEY = "wgemm_f16x2_kernel" if any("wgemm_f16x2_kernel" in k for k in names) else "wgemm_bf16x3_kernel<false"
+    KEY = "wgemm_f16x2_" if any("wgemm_f16x2_" in k for k in names) else "wgemm_bf16x3_kernel<false"
 tot, n, dur = {}, {}, 0.0
 seen = set()
 for r in csv.DictReader(open(sys.argv[1])):
@@ -28,6 +28,6 @@ out = {"kernel": KEY + " (batched Winograd-domain GEMMs)", "launches": launches,
        "note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace over "
                "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --also-concurrent 0`; v_mfma_f32_32x32x2_f32 issues every 64 cycles per SIMD, so "
                "utilisation 1.0 = the 157.3 TFLOP/s nominal rate at 2.4 GHz; achieved TFLOP/s = utilisation x 157.3 x (effective clock / 2.4).  "
-               "v_mfma_f32_32x32x16_bf16 (the bf16x3 kernel) issues every 32 cycles: utilisation 1.0 = 2.5 PFLOP/s bf16 = 417 TFLOP/s fp32-equivalent"}
+               "v_mfma_f32_32x32x16_bf16 / _f16 (the bf16x3 / f16x2 kernels) issue every 32 cycles: utilisation 1.0 = 2.5 PFLOP/s = 417 (bf16x3) / 833 (f16x2) TFLOP/s fp32-equivalent"}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out)[:1200])
