@@ -350,6 +350,8 @@ constexpr int STAGE2_BYTES = WBN * WKS * 4;                   // 16 KB: 2 k-chun
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 struct Split2 { f16x8 p[2]; };
+// x s = hi + lo by round-to-nearest.  Measured and rejected (round 5, same box A/B): lo as ONE v_fma_mixlo/hi_f16 per element through inline asm (64 instead of
+// 116 VALU instructions per 48 MFMAs; bit-identical) -- 1.5 % SLOWER on the 256-channel shapes: the vector ALU is not what the kernel waits for.
 __device__ __forceinline__ Split2 split2(const float4 a, const float4 b, float s) {
   const float x[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
   Split2 r;
