@@ -1,5 +1,5 @@
-"""Is the batched bf16x3 GEMM power-limited?  The same launch on random, sign-constant and zero operands (identical instruction stream and memory traffic;
-only the switching activity differs).  usage: python tools/wgemm_power_probe.py [Mt N K]"""
+"""Is the batched Winograd-domain GEMM power-limited?  The same launch on random, sign-constant and zero operands (identical instruction stream and memory
+traffic; only the switching activity differs), in both split arithmetics.  usage: python tools/wgemm_power_probe.py [Mt N K]   (Mt = 8 x tiles per utterance)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,4 +17,14 @@ for name, gen in (("random N(0,1)", lambda *s: torch.randn(*s, device="cuda")), 
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(20): f()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
-    print(f"{name:22s} Mt={Mt} N={N} K={K}: {dt*1e3:.3f} ms  {12.0*nb*Mt*N*K/dt/1e12:.0f} TF bf16", flush=True)
+    U2 = torch.empty(int(lib.buddy_wgemm_f16x2_packed_bytes(nb, N, K)) // 4, dtype=torch.int32, device="cuda")
+    _lib.check(lib.buddy_wgemm_f16x2_pack_weights(P(Bt), U2.data_ptr(), nb, N, K, S()))
+    vmax = torch.empty(8, 64, 32, dtype=torch.int32, device="cuda")
+    _lib.check(lib.buddy_abs_max_bits(P(A), nb, 8, (Mt // 8) * K, vmax.data_ptr(), S()))
+    f2 = lambda: _lib.check(lib.buddy_gemm_winograd_domain_f16x2(P(A), U2.data_ptr(), P(Cm), Mt, N, K, nb, vmax.data_ptr(), Mt // 8, S()))
+    for _ in range(3): f2()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20): f2()
+    torch.cuda.synchronize(); d2 = (time.perf_counter() - t) / 20
+    print(f"{name:22s} Mt={Mt} N={N} K={K}: bf16x3 {dt*1e3:.3f} ms {12.0*nb*Mt*N*K/dt/1e12:.0f} TF | f16x2 {d2*1e3:.3f} ms {6.0*nb*Mt*N*K/d2/1e12:.0f} TF "
+          f"{4.0*nb*Mt*(N+K)/d2/1e9:.0f} GB/s", flush=True)
