@@ -16,12 +16,19 @@ def _on_device(device):
     if device is None:
         yield
         return
+    # torch's GPU kernels are not run-to-run reproducible by default (atomic accumulation orders): two float64 executions of the informed T = 50
+    # chain came out 74 dB apart (round 5), a noise floor right where the build is measured (69-72 dB).  The arbiter runs with torch's deterministic
+    # algorithms: the float64 run is then bit-reproducible and the comparison means something.
     prev = torch.get_default_device()
+    det, cd, cb = torch.are_deterministic_algorithms_enabled(), torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark
+    warn = torch.is_deterministic_algorithms_warn_only_enabled()
     torch.set_default_device(device)
+    torch.use_deterministic_algorithms(True, warn_only=True); torch.backends.cudnn.deterministic = True; torch.backends.cudnn.benchmark = False
     try:
         yield
     finally:
         torch.set_default_device(prev)
+        torch.use_deterministic_algorithms(det, warn_only=warn); torch.backends.cudnn.deterministic = cd; torch.backends.cudnn.benchmark = cb
 
 
 def overrides(T, updates, nf):

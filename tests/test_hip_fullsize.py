@@ -330,5 +330,6 @@ def test_precision_budget_informed_T50_vs_fp64(net):
     s = _sd(pred[0].cpu(), x64[-1])
     dc = _sd(pred[0].cpu(), clean) - _sd(x64[-1], clean)
     print(f"informed T=50 order 2, full size: SI-SDR(build; float64 run) {s:.1f} dB, delta SI-SDR to clean {dc:+.5f} dB")
-    assert s > 68.0                                                   # measured r03: 72.7 dB, delta -0.0007 dB
+    # measured r03: 72.7 dB; round 5 (f16x2 GEMMs, float64 arbiter made reproducible: it was 74 dB from ITSELF run to run): 70.5 dB; bf16x3 71.2, fp32 MFMA 72.1
+    assert s > 68.0
     assert abs(dc) < 0.01
