@@ -139,6 +139,34 @@ def test_batch_independence_and_determinism():
     assert torch.equal(y, y1)
 
 
+def test_f16x2_utterance_does_not_depend_on_its_batch():
+    """Full width (the f16x2 batched GEMMs run: 128 / 256 channels), utterances FOUR DECADES apart in level in one batch: the power-of-two scale of the
+    transformed inputs is per utterance (abs-max collected by the input transform), so row b of the batched forward + VJP equals the B = 1 call bit for bit,
+    whatever shares the batch; and the quiet utterance keeps its accuracy (against the fp32-MFMA handle, relative to ITS abs-max)."""
+    net = build(128, 510, 128, 3)
+    assert net.get_option("gemm") == 2                      # the library default
+    ref = build(128, 510, 128, 3, gemm="fp32")
+    rs = np.random.RandomState(4)
+    x = torch.from_numpy((0.3 * rs.standard_normal((3, 16000))).astype(np.float32))
+    x[1] *= 1e-2; x[2] *= 1e2
+    cot = torch.from_numpy(rs.standard_normal((3, 16000)).astype(np.float32)).cuda()
+    cn = torch.tensor([-1.0, -0.5, 0.1], device="cuda")
+    def run(n, xs, cs, ct):
+        xg = xs.cuda().requires_grad_(True)
+        y = n(xg, cs)
+        g, = torch.autograd.grad(y, xg, ct)
+        return y.detach(), g
+    y, g = run(net, x, cn, cot)
+    for b in range(3):
+        y1, g1 = run(net, x[b:b + 1], cn[b:b + 1], cot[b:b + 1])
+        assert torch.equal(y[b:b + 1], y1) and torch.equal(g[b:b + 1], g1), b
+    yr, gr = run(ref, x, cn, cot)
+    for b in range(3):
+        ey, eg = rel(y[b].cpu().numpy(), yr[b].cpu().numpy()), rel(g[b].cpu().numpy(), gr[b].cpu().numpy())
+        print(f"utterance {b} (level {float(x[b].abs().max()):.1e}): f16x2 vs fp32 MFMA forward {ey:.2e} vjp {eg:.2e}")
+        assert ey < TOL and eg < TOL
+
+
 @pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "fp32"])
 def test_gemm_modes_vs_golden(golden, gemm):
     """NCSNppTime(gemm=...): the Winograd-domain GEMMs in f16x2 arithmetic (default: two-term f16 split of power-of-two-scaled operands, three f16 MFMA
