@@ -160,6 +160,10 @@ def test_f16x2_utterance_does_not_depend_on_its_batch():
     for b in range(3):
         y1, g1 = run(net, x[b:b + 1], cn[b:b + 1], cot[b:b + 1])
         assert torch.equal(y[b:b + 1], y1) and torch.equal(g[b:b + 1], g1), b
+    alt = net.replica()
+    alt.set_option("wgemm_rt", 1)                           # the 32-row-per-wave kernel: another tiling of the same sums in the same order
+    ya, ga = run(alt, x, cn, cot)
+    assert torch.equal(y, ya) and torch.equal(g, ga)
     yr, gr = run(ref, x, cn, cot)
     for b in range(3):
         ey, eg = rel(y[b].cpu().numpy(), yr[b].cpu().numpy()), rel(g[b].cpu().numpy(), gr[b].cpu().numpy())
