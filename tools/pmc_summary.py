@@ -35,5 +35,28 @@ out["source_stamp"] = _h.hexdigest()[:12]
 out["fetch_bytes_per_launch"] = sum(v["fetch"] for v in out["per_kernel_bytes_per_convolution"].values())
 out["write_bytes_per_launch"] = sum(v["write"] for v in out["per_kernel_bytes_per_convolution"].values())
 out["hbm_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+
+
+def whole_run(path, counter):
+    """every kernel of the run except the peak micro-benchmarks and the runtime's copy / fill kernels (set-up): counter sum, busy time, dispatches"""
+    tot, dur, seen = 0.0, 0.0, set()
+    for r in csv.DictReader(open(path)):
+        n = r["Kernel_Name"]
+        if r["Counter_Name"] != counter or "ubench" in n or "__amd_rocclr" in n or "pack" in n or "prep" in n:
+            continue
+        tot += float(r["Counter_Value"])
+        if r.get("Dispatch_Id") not in seen and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            seen.add(r.get("Dispatch_Id")); dur += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    return tot * 1024, dur * 1e-9, len(seen)
+
+
+fb, fd, fn = whole_run(sys.argv[1], "FETCH_SIZE")
+wb, wd, wn = whole_run(sys.argv[2], "WRITE_SIZE")
+out["whole_run"] = {"fetch_bytes_x2": 2 * fb, "write_bytes": wb, "kernel_busy_s": (fd + wd) / 2, "dispatches": fn,
+                    "avg_hbm_GBps_while_busy": (2 * fb + wb) / ((fd + wd) / 2) / 1e9 if fd + wd > 0 else None,
+                    "note": "ALL kernels of the profiled run (sampler steps incl. warm-up and the instrumented attribution steps; without the peak micro-benchmarks, "
+                            "weight preparation and the runtime's copy / fill kernels): HBM bytes moved / summed kernel durations = the average HBM rate of the "
+                            "step while the GPU is busy (busy ~ wall: the step has no launch gaps).  FETCH_SIZE x2 is the wide-read correction; kernels with narrow "
+                            "reads are over-counted by it, so this is an upper estimate"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out)[:900])
