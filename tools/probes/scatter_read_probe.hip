@@ -156,6 +156,49 @@ template <int WALK, bool PF> float run7(const float* M, const float* res, float*
   float ms; hipEventElapsedTime(&ms, e0, e1);
   return ms / 10;
 }
+
+// mode 9: no exchange at all -- a THREAD owns a whole tile for one channel pair (64 float2 loads = 512 B per wave and position plane, the separable transform in
+// registers, 36 float2 stores), a wave = 128 channels of one tile, 4 tiles per workgroup, WALK tile groups per workgroup
+__device__ __forceinline__ float2 add2(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+template <int WALK>
+__global__ __launch_bounds__(256) void k9(const float* __restrict__ M, const float* __restrict__ res, float* __restrict__ y, double* __restrict__ st, int Mt) {
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  double s0 = 0, s1 = 0;
+  for (int it = 0; it < WALK; ++it) {
+    const int tile = (blockIdx.x * WALK + it) * 4 + w;
+    if (tile >= Mt) break;
+    float2 m[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[i][j] = *reinterpret_cast<const float2*>(M + ((long long)(i * 8 + j) * Mt + tile) * C + l * 2);
+    float2 t[6][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 6; ++r) t[r][j] = add2(m[r][j], add2(m[r + 1][j], m[r + 2][j]));
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const long long pix = ((long long)tile * 36 + r * 6 + c) * C + l * 2;
+        float2 v = add2(add2(t[r][c], add2(t[r][c + 1], t[r][c + 2])), *reinterpret_cast<const float2*>(res + pix));
+        *reinterpret_cast<float2*>(y + pix) = v;
+        s0 += (double)v.x + (double)v.y; s1 += (double)v.x * v.x + (double)v.y * v.y;
+      }
+  }
+  if (s0 + s1 == 12345.678) st[blockIdx.x * 256 + tid] = s0 + s1;
+}
+template <int WALK> float run9(const float* M, const float* res, float* y, double* st, int Mt) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int g = (Mt + 4 * WALK - 1) / (4 * WALK);
+  hipLaunchKernelGGL((k9<WALK>), dim3(g), dim3(256), 0, 0, M, res, y, st, Mt);
+  hipEventRecord(e0);
+  for (int it = 0; it < 10; ++it) hipLaunchKernelGGL((k9<WALK>), dim3(g), dim3(256), 0, 0, M, res, y, st, Mt);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms / 10;
+}
 template <int MODE> float run(const float* M, const float* res, float* y, double* st, int Mt) {
   const int walk = MODE >= 2 ? TL : 1;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -177,6 +220,8 @@ int main() {
   { const float t6 = run6(M, res, y, st, Mt); printf("mode 6 %-28s %.3f ms  %.0f GB/s\n", "wave-private exchange", t6, (rd + 2 * wr) / t6 / 1e6); }
   { const float a = run7<8, true>(M, res, y, st, Mt), b = run7<2, false>(M, res, y, st, Mt), c = run7<1, false>(M, res, y, st, Mt), d = run7<16, true>(M, res, y, st, Mt);
     printf("mode 7 walk 8 + prefetch %.3f ms %.0f GB/s | walk 2 %.3f ms %.0f | walk 1 %.3f ms %.0f | walk 16 + prefetch %.3f ms %.0f\n", a, (rd + 2 * wr) / a / 1e6, b, (rd + 2 * wr) / b / 1e6, c, (rd + 2 * wr) / c / 1e6, d, (rd + 2 * wr) / d / 1e6); }
+  { const float a = run9<1>(M, res, y, st, Mt), b = run9<2>(M, res, y, st, Mt), c = run9<4>(M, res, y, st, Mt);
+    printf("mode 9 thread-per-(tile, channel pair), no exchange: walk 1 %.3f ms %.0f GB/s | walk 2 %.3f ms %.0f | walk 4 %.3f ms %.0f\n", a, (rd + 2 * wr) / a / 1e6, b, (rd + 2 * wr) / b / 1e6, c, (rd + 2 * wr) / c / 1e6); }
   for (int i = 0; i < 6; ++i) { const double by = rd + wr + (i >= 4 ? wr : 0.0); printf("mode %d %-28s %.3f ms  %.0f GB/s\n", i, nm[i], t[i], by / t[i] / 1e6); }
   return 0;
 }
