@@ -2,6 +2,11 @@
 # MFMA-utilisation / HBM-traffic PMC passes of the 16-bit attention kernels (tools/probes/attn16_probe_base, B = 4 x T = 15 008, C = 256, f16)
 # -> gpurun_out/<tag>_attn16_pmc.json.  Separate passes, --kernel-trace only (MI355X_MICROARCH.md rocprofv3 section).
 TAG=${1:-r05}
+# the probe binary is not tracked: built here from tools/probes/attn16_probe.hip + the product's attn16.hip when missing (hipcc is on the box)
+if [ ! -x tools/probes/attn16_probe_base ]; then
+  F="--offload-arch=gfx950 -O3 -std=c++17 -fno-gpu-rdc -Ibuddy_amd/csrc -Iinclude"
+  hipcc $F -c tools/probes/attn16_probe.hip -o /tmp/attn16_probe.o && hipcc $F -c buddy_amd/csrc/attn16.hip -o /tmp/attn16.o && hipcc --offload-arch=gfx950 /tmp/attn16_probe.o /tmp/attn16.o -o tools/probes/attn16_probe_base || exit 1
+fi
 R=$(pwd); OUT=$R/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 P="$R/tools/probes/attn16_probe_base time 4 15008 256 2 3"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pa_m -o m -- $P > /dev/null 2>&1
