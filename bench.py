@@ -367,7 +367,7 @@ def main():
     ap.add_argument("--also-concurrent", type=int, default=2, help="after the main region, time the same workload as this many concurrent sub-batches "
                     "in a second region and report it as `concurrent_sub_batches` (0 = skip)")
     ap.add_argument("--attention", default=None, choices=["auto", "flash", "matrix", "bf16", "f16"], help="attention core of the network (default: the library's, "
-                    "auto: fp32, materialised for T <= 4096, online softmax beyond; bf16 / f16 = the opt-in fast mode that passed the 0.1 dB gate, profiles/r02_attention_modes.json)")
+                    "auto: fp32, materialised for T <= 4096, online softmax beyond; bf16 / f16 = the opt-in fast mode that passed the 0.1 dB gate, profiles/archive/r02_attention_modes.json)")
     ap.add_argument("--gemm", default=None, choices=["bf16x3", "fp32", "f16x2"], help="arithmetic of the Winograd-domain GEMMs (default: the library's, f16x2; bf16x3 = exact "
                     "three-way bf16 split of the fp32 operands, six bf16 MFMA products, fp32 accumulate; fp32 = v_mfma_f32_32x32x2_f32, the reference run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

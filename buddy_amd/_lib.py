@@ -87,6 +87,7 @@ _SIGS = {
     "buddy_ncsnpp_set_gemm": (C.c_int, [C.c_void_p, C.c_int]),
     "buddy_ncsnpp_set_attention": (C.c_int, [C.c_void_p, C.c_int]),
     "buddy_options_check": (C.c_int, []),
+    "buddy_option_validate": (C.c_int, [C.c_char_p, C.c_int]),
     "buddy_ncsnpp_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "buddy_ncsnpp_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "buddy_flash_attention_fwd": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),

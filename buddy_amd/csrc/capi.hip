@@ -417,6 +417,7 @@ int buddy_groupnorm_act_bwd(const float* x, const float* gamma, const float* bet
 }
 
 int buddy_options_check(void) { return options_check(); }
+int buddy_option_validate(const char* key, int value) { Options o = default_options(); return option_set(o, key, value); }
 int buddy_ncsnpp_set_option(void* h, const char* key, int value) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_set_option((Net*)h, key, value); }
 int buddy_ncsnpp_get_option(void* h, const char* key, int* value) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_get_option((Net*)h, key, value); }
 int buddy_ncsnpp_set_gemm(void* h, int mode) { if (!h) { set_error("null handle"); return BUDDY_ERR_ARG; } return net_set_gemm((Net*)h, mode); }

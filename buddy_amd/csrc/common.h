@@ -17,7 +17,7 @@ namespace buddy {
 // ---- launcher options (options.hip): per handle, defaults from the validated BUDDY_* environment ----------------------
 struct Options {
   int conv;            // 3x3 convolution form: 0 by shape (F(6x6) / F(4x4) three-pass, fused F(2x2), direct), 1 direct, 2 wino2, 3 wino4
-  int gemm;            // Winograd-domain GEMM arithmetic: 1 bf16x3 (default), 0 fp32 MFMA
+  int gemm;            // Winograd-domain GEMM arithmetic: 2 f16x2 (default: two-term f16 splits, 2^-22), 1 bf16x3 (exact split), 0 fp32 MFMA
   int attn;            // attention core 0 .. 4 (net.hip)
   int gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr;                 // fusions of the network graph (A/B switches, default 1)
   int attn_split, attn_nw;                                                           // fp32 attention: forced loop-split count / forward tile height (0 = by shape)

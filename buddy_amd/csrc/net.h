@@ -17,7 +17,7 @@ int net_replica(Net* src, Net** out);      // a second handle sharing src's prep
 int net_weight_bytes(Net* N, long long* params, long long* packed, long long* lazy, int* lazy_forms);   // device bytes of the shared weight store
 int net_set_option(Net* N, const char* key, int value);   // per-handle launcher option (keys: csrc/options.hip); unknown key / bad value -> BUDDY_ERR_ARG
 int net_get_option(Net* N, const char* key, int* value);
-int net_set_gemm(Net* N, int mode);        // Winograd-domain GEMM arithmetic: 1 bf16x3 exact split (default), 0 fp32 MFMA
+int net_set_gemm(Net* N, int mode);        // Winograd-domain GEMM arithmetic: 2 f16x2 (default), 1 bf16x3 exact split, 0 fp32 MFMA
 int net_set_attention(Net* N, int mode);   // 0 flash fp32 (default), 1 bf16 / 2 f16 MFMA operands, 3 materialised T x T
 int net_set_fir(Net* N, int fir);     // fir=True resampling (reference up_or_down_sampling.py:195-257), set before the first forward
 int net_reserve(Net* N, int B, int L, int with_vjp, long long* bytes);

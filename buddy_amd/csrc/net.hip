@@ -458,12 +458,15 @@ int net_weight_bytes(Net* N, long long* params, long long* packed, long long* la
 int net_set_option(Net* N, const char* key, int value) {
   if (int rc = option_set(N->opt, key, value)) return rc;
   N->rsv_vjp = -1;             // options change which temporaries a call allocates: size the arena again
+  // ... and which kernels the recorded backward closures would launch against a tape and arena built under the old ones (abs-max slots, attention
+  // workspace, fused forms): a saved forward does not survive an option change -- vjp reports BUDDY_ERR_STATE until the next forward(save = 1)
+  N->tape.clear(); N->have_tape = false;
   return BUDDY_OK;
 }
 int net_get_option(Net* N, const char* key, int* value) { return option_get(N->opt, key, value); }
 int net_set_attention(Net* N, int mode) { if (mode < 0 || mode > 4) { set_error("attention mode must be 0..4"); return BUDDY_ERR_ARG; } return net_set_option(N, "attention", mode); }
 int net_set_gemm(Net* N, int mode) { if (mode < 0 || mode > 2) { set_error("gemm mode must be 0 (fp32 MFMA), 1 (bf16x3) or 2 (f16x2)"); return BUDDY_ERR_ARG; } return net_set_option(N, "gemm", mode); }
-int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; return BUDDY_OK; }
+int net_set_fir(Net* N, int fir) { N->fir = fir != 0; N->rsv_vjp = -1; N->tape.clear(); N->have_tape = false; return BUDDY_OK; }
 void net_destroy(Net* N) {
   if (!N) return;
   if (N->w4_scratch) (void)hipFree(N->w4_scratch);

@@ -3,14 +3,18 @@
 // Every A/B switch a launcher consults is a field of `Options`.  A network handle carries its own copy (Net::opt, changed with
 // buddy_ncsnpp_set_option(handle, key, value)); while one of its calls runs, an OptScope makes that copy the calling thread's current options, which is
 // what the launchers read (cur_opt()).  Outside a handle call -- the single-kernel entry points of the unit tests -- the process defaults apply.
-// The process defaults come from the environment, parsed and VALIDATED once: a BUDDY_* variable this table does not know, or a value outside its
-// range, makes every handle creation (and buddy_option_check) fail with a message naming it -- a misspelt switch is never silently ignored.
+// The process defaults come from the environment, parsed and VALIDATED once: a value outside its range, or a BUDDY_* name that is a NEAR MISS of a
+// switch of this table (edit distance <= 2: BUDDY_UPCONVV, BUDDY_GN_FUSED), makes every handle creation (and buddy_option_check) fail with a message
+// naming it -- a misspelt switch is never silently ignored.  A BUDDY_* name that resembles none of them (BUDDY_ROOT, BUDDY_DATA: the project is
+// called BUDDy) belongs to somebody else: it is left alone, with one note on stderr.
 #include "common.h"
 #include "net.h"
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 extern char** environ;
 
@@ -59,6 +63,17 @@ const Entry kTable[] = {
 const char* const kOtherEnv[] = {"BUDDY_PROF_DUMP", "BUDDY_BENCH_PROF"};
 
 struct Defaults { Options opt; std::string error; };
+// Levenshtein distance, capped: names of a few tens of characters, called once per unknown variable
+int edit_distance(const std::string& a, const std::string& b) {
+  std::vector<int> prev(b.size() + 1), cur(b.size() + 1);
+  for (size_t j = 0; j <= b.size(); ++j) prev[j] = (int)j;
+  for (size_t i = 1; i <= a.size(); ++i) {
+    cur[0] = (int)i;
+    for (size_t j = 1; j <= b.size(); ++j) cur[j] = std::min(std::min(prev[j] + 1, cur[j - 1] + 1), prev[j - 1] + (a[i - 1] != b[j - 1]));
+    prev.swap(cur);
+  }
+  return prev[b.size()];
+}
 bool parse_value(const Entry& e, const char* text, int* out) {
   if (e.words)
     for (const Word* w = e.words; w->name; ++w)
@@ -87,7 +102,12 @@ const Defaults& defaults() {
         if (!parse_value(e, eq + 1, &v)) { if (r.error.empty()) r.error = "environment: bad value '" + std::string(eq + 1) + "' for " + name; }
         else r.opt.*(e.field) = v;
       }
-      if (!known && r.error.empty()) r.error = "environment: unknown variable " + name + " (the BUDDY_* switches are listed in csrc/options.hip)";
+      if (known) continue;
+      const char* near = nullptr;
+      for (const Entry& e : kTable) if (edit_distance(name, e.env) <= 2) near = e.env;
+      for (const char* o : kOtherEnv) if (edit_distance(name, o) <= 2) near = o;
+      if (near) { if (r.error.empty()) r.error = "environment: unknown variable " + name + " (did you mean " + near + "?  the BUDDY_* switches are listed in csrc/options.hip)"; }
+      else fprintf(stderr, "libbuddy_hip: note: environment variable %s is not one of this library's switches (csrc/options.hip); ignored\n", name.c_str());
     }
     return r;
   }();

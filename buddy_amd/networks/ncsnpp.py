@@ -202,9 +202,11 @@ class NCSNppTime(nn.Module):
     def set_option(self, key, value):
         """Per-handle launcher option (``buddy_ncsnpp_set_option``: fusion / layout A/B switches, attention core, GEMM arithmetic; an unknown key or
         a value out of range raises).  Applies to this module's handle only -- a replica made afterwards starts from the same settings."""
+        lib = _lib.load()
+        _lib.check(lib.buddy_option_validate(str(key).encode(), int(value)))     # BEFORE it is remembered: a rejected entry would be replayed (and
+        if getattr(self, "_handle", None) is not None:                            # rejected) by every later handle and replica of this module
+            _lib.check(lib.buddy_ncsnpp_set_option(self._handle, str(key).encode(), int(value)))
         self._options[str(key)] = int(value)
-        if getattr(self, "_handle", None) is not None:
-            _lib.check(_lib.load().buddy_ncsnpp_set_option(self._handle, str(key).encode(), int(value)))
         return self
 
     def get_option(self, key):

@@ -298,4 +298,3 @@ class BlindSubbandFiltering(SubbandFiltering):
                                                       float(self.hp.weight_decay), _lib.stream_ptr()))
 
 
-BlindSubbandFilteringHIP = BlindSubbandFiltering     # round-1..3 name of the HIP class

@@ -210,18 +210,24 @@ int buddy_ncsnpp_set_fir(void* handle, int fir);
  * attention, gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr, attn_split, attn_nw, igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos,
  * wgemm_epi, wgemm_rt, wino_epi, wino_abl, wino_geo, w6_xcd, gn_fast, c2in4, c2out_tiled, fir_lds, op_graph.  An unknown key or a value out of range is
  * BUDDY_ERR_ARG.  A handle starts from the process defaults = the BUDDY_<KEY> environment variables, parsed and validated in ONE place at handle
- * creation: an unknown BUDDY_* variable or a bad value makes buddy_ncsnpp_create fail with a message naming it.  Set options before the first forward or
- * between calls (the activation arena is sized again). */
+ * creation: a bad value, or an unknown BUDDY_* name within edit distance 2 of a switch (a misspelling), makes buddy_ncsnpp_create fail with a message naming it;
+ * BUDDY_* names that resemble no switch are not this library's and are left alone.  Set options before the first forward or between calls: the
+ * activation arena is sized again and a saved forward is dropped (buddy_ncsnpp_vjp returns BUDDY_ERR_STATE until the next forward with save = 1). */
 int buddy_options_check(void);   /* the environment check alone (no GPU needed): BUDDY_OK, or BUDDY_ERR_ARG with buddy_last_error() naming the variable */
+int buddy_option_validate(const char* key, int value);   /* would buddy_ncsnpp_set_option accept (key, value)?  no handle, no GPU, nothing changed */
 int buddy_ncsnpp_set_option(void* handle, const char* key, int value);
 int buddy_ncsnpp_get_option(void* handle, const char* key, int* value);
 /* attention core of a network handle: 4 = auto (default; fp32: the materialised T x T form while T <= 4096, the online-softmax kernels beyond -- a
  * function of T alone); 0 = online-softmax kernels, fp32 operands; 1 / 2 = the same with bf16 / f16 MFMA operands (opt-in fast mode, fp32 accumulate
  * + fp32 softmax); 3 = always the materialised T x T matrix.  Initial value from BUDDY_ATTN = auto | flash | bf16 | f16 | matrix. */
 int buddy_ncsnpp_set_attention(void* handle, int mode);
-/* Arithmetic of the Winograd-domain GEMMs of the 3x3 convolutions (94 % of the FLOPs): 1 (default) = "bf16x3" -- every fp32 operand split
- * exactly into three bf16 terms, six bf16 MFMA products, fp32 accumulation: the fp32 kernel's accuracy against float64 (unit test) at
- * 2.67x fewer matrix-pipe cycles; 0 = v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains).  Env BUDDY_GEMM=fp32|bf16x3 sets the default. */
+/* Arithmetic of the Winograd-domain GEMMs of the 3x3 convolutions (94 % of the FLOPs):
+ *   2 (default) = "f16x2": both fp32 operands scaled by a power of two and split by round-to-nearest into TWO f16 terms (22 significant bits instead of
+ *       fp32's 24), three f16 MFMA products, fp32 accumulation; measured against float64 it is as close as the exact forms (one denoiser evaluation +
+ *       VJP 117.2 / 113.0 dB), but it is NOT bit-for-bit the fp32 product;
+ *   1 = "bf16x3": every fp32 operand split EXACTLY into three bf16 terms, six bf16 MFMA products, fp32 accumulation: the fp32 kernel's accuracy;
+ *   0 = v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains; the reference run).
+ * The 1x1 / NIN / DFT GEMMs run in bf16x3 in modes 1 and 2.  Env BUDDY_GEMM=fp32|bf16x3|f16x2 sets the process default. */
 int buddy_ncsnpp_set_gemm(void* handle, int mode);
 
 /* single-head attention over T tokens without the T x T matrix (online softmax, fp32 MFMA), token-major q, k, v, O [B][T][C], C in {64,128,256}:

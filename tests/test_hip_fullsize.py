@@ -201,7 +201,7 @@ def _sd(a, b):
 
 
 def test_fullsize_blind_T10_fp64_arbiter(net):
-    """The claim of profiles/r02_arbiter_L64000_T50.json under the driver: full size (L = 64 000, nf = 128), the shipped 10 updates per
+    """The claim of profiles/archive/r02_arbiter_L64000_T50.json under the driver: full size (L = 64 000, nf = 128), the shipped 10 updates per
     step, T = 10, one utterance / noise seed.  Arbiter = the restated algorithm in float64 (oracle.precision; run through torch ops on the
     GPU, the CPU has no fast fp64 convolution); the fp32 oracle runs on the CPU at two thread counts.  The build's per-step deviation
     from the float64 trajectory must not be worse than the worse fp32 oracle's by more than 10 dB (one denoiser evaluation of the build

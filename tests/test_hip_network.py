@@ -258,3 +258,18 @@ def test_fused_round4_paths_equal_plain_paths():
         net.set_option("upconvv", 0)
     with pytest.raises(_lib.BuddyHipError):
         net.set_option("attention", 9)
+    # a rejected entry is not remembered: a replica made afterwards (which replays the module's options onto its new handle) still builds and runs
+    assert "upconvv" not in net._options and net._options.get("attention") != 9
+    with torch.no_grad():
+        assert torch.isfinite(net.replica()(x0, cn)).all()
+    # an option change between a saved forward and its VJP drops the tape (the closures were recorded for the old kernels / workspaces): the VJP
+    # reports a state error instead of launching against a stale arena
+    x = x0.clone().requires_grad_(True)
+    y = net(x, cn)
+    net.set_option("gemm", 1)
+    with pytest.raises(_lib.BuddyHipError, match="saved forward"):
+        torch.autograd.grad(y, x, cot)
+    net.set_option("gemm", 2)
+    x = x0.clone().requires_grad_(True)
+    g2, = torch.autograd.grad(net(x, cn), x, cot)
+    assert np.array_equal(g2.cpu().numpy(), outs["fused"][1])

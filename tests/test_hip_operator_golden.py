@@ -19,12 +19,12 @@ def rel(a, b):
 
 def _make(seed, L, extra=()):
     from buddy_amd.config import compose
-    from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering, BlindSubbandFilteringHIP
+    from buddy_amd.testing.operators.subband_filtering import BlindSubbandFiltering
     from oracle.sampler_ref import NoiseStream
     args = compose(overrides=list(extra))
     ns = [NoiseStream(seed)]
     op = BlindSubbandFiltering(args.tester.informed_dereverberation.op_hp, 16000, num_utts=1, noise=ns, device="cuda", length=L)
-    assert isinstance(op, BlindSubbandFilteringHIP)
+    assert isinstance(op, BlindSubbandFiltering)
     op.update_H(use_noise=True)        # the fixtures construct the operator and then call update_H(use_noise=True), like tester.py:143-146
     return args, op, ns
 

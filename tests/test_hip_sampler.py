@@ -110,7 +110,7 @@ def test_blind_second_order_with_magnitude_constraint(golden):
 def test_blind_T10_shipped_updates_fp64_arbiter(golden):
     """T = 10 schedule with the shipped op_updates_per_step = 10 (conf/tester/blind_dereverberation_BUDDy.yaml:72), HIP operator.
     With ten scale-free Adam updates per step the reference ALGORITHM is chaotic in fp32: the CPU oracle (the reference's own torch
-    kernels) leaves its float64 trajectory at 127 -> 45 -> 18 -> 13 -> 10 dB within four steps (profiles/r02_arbiter_*.json), so a
+    kernels) leaves its float64 trajectory at 127 -> 45 -> 18 -> 13 -> 10 dB within four steps (profiles/archive/r02_arbiter_*.json), so a
     fixture recorded from one fp32 execution cannot be matched sample by sample by ANY other fp32 execution.  The arbiter is the
     algorithm run in float64 (oracle.precision): the build's deviation from that trajectory must stay of the order of the fp32 oracle's
     own (two thread counts = two summation orders) at every step, the first step (before any feedback) must agree to > 100 dB, and the

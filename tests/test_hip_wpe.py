@@ -142,7 +142,7 @@ def test_shipped_blind_config_to_the_end_sanity():
     The chain is chaotic (no sample-wise reference exists after a few steps), so this is the sanity gate a harness run
     needs: finite everywhere, every estimate at the level the speech-magnitude constraint pins (std = speech_scaling), the operator
     parameters inside their projection box, the estimated RIR finite with its direct path in place, the noise streams fully consumed in
-    step.  The measured comparison against the float64 arbiter and the fp32 oracles is profiles/r04_shipped_T201.json (tools/shipped_run.py)."""
+    step.  The measured comparison against the float64 arbiter and the fp32 oracles is profiles/archive/r04_shipped_T201.json (tools/shipped_run.py)."""
     import time
     L, seeds = 64000, [3, 4]
     args, t, ns, items, y, op = _stack(201, 128, L, 2, seeds)

@@ -105,7 +105,9 @@ def test_environment_switches_are_validated_in_one_place():
     ok = run(BUDDY_UPCONV="0", BUDDY_ATTN="f16", BUDDY_GEMM="fp32", BUDDY_CONV="wino4")
     assert ok.returncode == 0 and "loaded" in ok.stdout, ok.stderr[-800:]
     bad = run(BUDDY_UPCONVV="0")
-    assert bad.returncode != 0 and "unknown variable BUDDY_UPCONVV" in bad.stderr
+    assert bad.returncode != 0 and "unknown variable BUDDY_UPCONVV" in bad.stderr and "BUDDY_UPCONV?" in bad.stderr
+    other = run(BUDDY_ROOT="/data/buddy", BUDDY_DATA="x")      # the project is called BUDDy: names that resemble no switch are somebody else's
+    assert other.returncode == 0 and "loaded" in other.stdout and "BUDDY_ROOT is not one of this library's switches" in other.stderr, other.stderr[-800:]
     bad = run(BUDDY_ATTN="fp16")
     assert bad.returncode != 0 and "bad value 'fp16' for BUDDY_ATTN" in bad.stderr
     bad = run(BUDDY_GN_FUSE="2")
@@ -113,6 +115,21 @@ def test_environment_switches_are_validated_in_one_place():
     import glob
     n = sum(open(f).read().count("getenv(") for f in glob.glob(os.path.join(ROOT, "buddy_amd", "csrc", "*.hip")))
     assert n <= 3, n
+
+
+def test_set_option_validates_before_remembering():
+    """NCSNppTime.set_option asks the library (buddy_option_validate: no handle, no GPU) before it stores the entry: a misspelt key or a value out of
+    range raises and leaves the module's option dict -- which every later handle and replica replays -- untouched."""
+    import pytest as _pt
+    from buddy_amd import _lib
+    from buddy_amd.networks.ncsnpp import NCSNppTime
+    net = NCSNppTime(stft={"n_fft": 126, "hop_length": 32, "center": True}, nf=32, ch_mult=(1, 2), num_res_blocks=1)
+    net.set_option("upconv", 0).set_option("gemm", 1)
+    for key, val in (("upconvv", 0), ("attention", 9), ("gemm", -1)):
+        with _pt.raises(_lib.BuddyHipError):
+            net.set_option(key, val)
+    assert net._options == {"upconv": 0, "gemm": 1}
+    assert net.replica()._options == {"upconv": 0, "gemm": 1}
 
 
 def test_architecture_family_accepts_and_refuses():

@@ -12,7 +12,7 @@ difference of SI-SDR-to-clean.  The build passes if its deviation from the fp64 
 
   python tools/arbiter.py oracle --seeds 0-7 [--L 64000 --T 50 --nf 128 --workers 2 --threads 8,4]     # CPU, writes traces
   python tools/arbiter.py build  --seeds 0-7 [...]                                                       # GPU, writes traces
-  python tools/arbiter.py report --seeds 0-7 [...] > profiles/r02_arbiter_*.json
+  python tools/arbiter.py report --seeds 0-7 [...] > profiles/archive/r02_arbiter_*.json
 
 Traces (x_den per step, float32) live under oracle/_ref/arbiter/ (git-ignored scratch that still travels to the GPU box)."""
 import argparse

@@ -8,7 +8,7 @@ start, T = 201, order 1, 10 operator updates per step (reference test_blind_dere
   * a second float64 run with the input scaled by 1 + 1e-13 (the resolution of the arbiter for a chaotic chain).
 
 Every execution is measured against the float64 trajectory: per-step SI-SDR of x_den, SI-SDR of the final estimate to clean.
-    python tools/shipped_run.py > profiles/r04_shipped_T201.json"""
+    python tools/shipped_run.py > profiles/archive/r04_shipped_T201.json"""
 import argparse
 import contextlib
 import json

@@ -2,7 +2,7 @@
 noise) per attention mode -- matrix (materialised T x T, the r01 path), flash (fp32 online softmax, default), bf16 / f16 (16-bit MFMA operands) --
 each in its own process (BUDDY_ATTN is read once), then SI-SDR of every mode against the matrix run and the difference of SI-SDR-to-clean.
 A reduced-precision mode may only be offered as a fast option if |delta SI-SDR to clean| <= 0.1 dB.
-usage: python tools/validate_attention_modes.py [T] [L] > profiles/r02_attention_modes.json"""
+usage: python tools/validate_attention_modes.py [T] [L] > profiles/archive/r02_attention_modes.json"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 """Long-form policy check: one long clip dereverberated un-chunked and as overlapping chunks (testing/longform.py), full informed
 DPS run (T steps, order 2, full-width network on seeded weights): SI-SDR of both estimates to the clean signal and to each other.
-usage: python tools/validate_longform_chunked.py [seconds] [chunk_seconds] [overlap_seconds] [T] > profiles/r02_longform_chunked.json"""
+usage: python tools/validate_longform_chunked.py [seconds] [chunk_seconds] [overlap_seconds] [T] > profiles/archive/r02_longform_chunked.json"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
