@@ -15,6 +15,7 @@ void launch_dps_update(const float* x_hat, const float* x_den, const float* lh, 
                        float t, float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, hipStream_t st);
 void launch_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st);
 void launch_mfma_ubench_bf16(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st);
+int launch_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int nt, int blocks, hipStream_t st);
 void launch_fir(const float* x, const float* h, long long h_stride, float* y, int B, int L, int M, int adjoint, hipStream_t st);
 }
 
@@ -103,6 +104,11 @@ int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream) {
   return BUDDY_OK;
 }
 
+int buddy_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int nt, int blocks, void* stream) {
+  if ((mode != 2 && !src) || !dst || bytes < 16 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) { set_error("hbm_ubench: 16-byte aligned device buffers of >= 16 bytes"); return BUDDY_ERR_ARG; }
+  if (launch_hbm_ubench(src, dst, bytes, mode, nt, blocks, (hipStream_t)stream)) { set_error("hbm_ubench: mode 0 copy | 1 read | 2 write, blocks >= 1"); return BUDDY_ERR_ARG; }
+  return BUDDY_OK;
+}
 int buddy_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, void* stream) {
   if (!seed || !out || !clk) { set_error("null argument"); return BUDDY_ERR_ARG; }
   launch_mfma_ubench(seed, out, blocks, iters, clk, (hipStream_t)stream);

@@ -188,4 +188,51 @@ void launch_mfma_ubench_bf16(const float* seed, float* out, int blocks, int iter
 void launch_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st) {
   hipLaunchKernelGGL(mfma_ubench_kernel, dim3(blocks), dim3(256), 0, st, seed, out, iters, clk);
 }
+
+// ---- calibration micro-benchmark: what this box's HBM sustains for a plain streaming kernel (MI355X_MICROARCH.md: 8.0 TB/s nominal, 6.29 TB/s measured
+// for a float4 copy).  mode 0 copy (n16 x 16 B read + written), 1 read (summed, stored only under a condition that never holds), 2 write; nt: the
+// non-temporal forms of the loads / stores.  Every thread keeps UNROLL independent 16-byte requests in flight; consecutive threads touch consecutive
+// 16-byte words; the grid-stride walks the array once per launch.
+namespace {
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int MODE, bool NT, int UNROLL>
+__global__ __launch_bounds__(256) void hbm_ubench_kernel(const f32x4_t* __restrict__ src, f32x4_t* __restrict__ dst, long long n16) {
+  const long long stride = (long long)gridDim.x * 256;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+    f32x4_t v[UNROLL];
+    if (MODE != 2) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) acc += v[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const f32x4_t w = MODE == 2 ? f32x4_t{1.f, 2.f, 3.f, (float)u} : v[u];
+        if (NT) __builtin_nontemporal_store(w, dst + i + u * stride); else dst[i + u * stride] = w;
+      }
+    }
+  }
+  for (; i < n16; i += stride) {
+    if (MODE == 1) acc += src[i];
+    else dst[i] = MODE == 2 ? f32x4_t{1.f, 2.f, 3.f, 4.f} : src[i];
+  }
+  if (MODE == 1 && acc.x + acc.y + acc.z + acc.w == 1.2345678e30f) dst[0] = acc;
+}
+}  // namespace
+int launch_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int nt, int blocks, hipStream_t st) {
+  const long long n16 = bytes / 16;
+  if (mode < 0 || mode > 2 || blocks < 1 || n16 < 1) return BUDDY_ERR_ARG;
+  const f32x4_t* s = reinterpret_cast<const f32x4_t*>(src); f32x4_t* d = reinterpret_cast<f32x4_t*>(dst);
+#define BUDDY_HBM_UB(M, N) hipLaunchKernelGGL((hbm_ubench_kernel<M, N, 8>), dim3((unsigned)blocks), dim3(256), 0, st, s, d, n16)
+  if (mode == 0) { if (nt) BUDDY_HBM_UB(0, true); else BUDDY_HBM_UB(0, false); }
+  else if (mode == 1) { if (nt) BUDDY_HBM_UB(1, true); else BUDDY_HBM_UB(1, false); }
+  else { if (nt) BUDDY_HBM_UB(2, true); else BUDDY_HBM_UB(2, false); }
+#undef BUDDY_HBM_UB
+  return BUDDY_OK;
+}
 }  // namespace buddy

@@ -565,6 +565,10 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_f16x2_kernel(const WgemmArgs a) 
 
 // 64 rows per wave (two 32-row tiles; workgroup = 256 rows x 128 columns, 128 accumulators per lane, two workgroups per CU): every weight fragment read from LDS
 // feeds two MFMAs per product term instead of one (the 32-row form reads 0.67 fragments per MFMA) and a barrier separates 48 instead of 24 MFMAs per wave.  One K-stage of A in flight (a stage is 48 MFMAs per wave), reloaded in place after the split; the rest as wgemm_f16x2_kernel<true>.
+// NT (A/B switch wgemm_nt): bit 0 = the V rows are read with non-temporal loads (V is read exactly once: it should not displace the weight panels from
+// this XCD's L2), bit 1 = M leaves with non-temporal stores (its reader is the next launch, 0.4 - 1 GB later).
+typedef float f32x4nt __attribute__((ext_vector_type(4)));
+template <int NT>
 __global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_rt2_kernel(const WgemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * STAGE2_BYTES > 4 * 32 * 68 * 4) ? 2 * STAGE2_BYTES : 4 * 32 * 68 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -623,7 +627,10 @@ __global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_rt2_kernel(const WgemmArgs
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ra[t][j] = *reinterpret_cast<const float4*>(base + aoff[t] + 16 * j);
+      for (int j = 0; j < 4; ++j) {
+        if (NT & 1) { const f32x4nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(base + aoff[t] + 16 * j)); ra[t][j] = make_float4(v.x, v.y, v.z, v.w); }
+        else ra[t][j] = *reinterpret_cast<const float4*>(base + aoff[t] + 16 * j);
+      }
   };
   auto dmaB = [&](int s) {
     const void* base = uniform_ptr(Ub + (long long)s * STAGE2_BYTES);
@@ -689,7 +696,10 @@ __global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_rt2_kernel(const WgemmArgs
       for (int it = 0; it < 8; ++it) {
         const int r = 4 * it + rr;
         const float4 v = *reinterpret_cast<const float4*>(St + r * SP + c4);
-        if (rb + r < a.Mt) *reinterpret_cast<float4*>(Mrow + (long long)r * a.Cout + hb * 64 + c4) = v;
+        if (rb + r < a.Mt) {
+          if (NT & 2) __builtin_nontemporal_store(f32x4nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4nt*>(Mrow + (long long)r * a.Cout + hb * 64 + c4));
+          else *reinterpret_cast<float4*>(Mrow + (long long)r * a.Cout + hb * 64 + c4) = v;
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -790,7 +800,14 @@ void launch_wgemm_f16x2(const float* V, const void* U2, float* M, long long Mt, 
   const bool fold = by_pos && P % 8 == 0 && (long long)gx * P < (1LL << 31);
   a.pz = fold ? P : 0; a.gx = gx;
   const dim3 grid(fold ? (unsigned)(gx * P) : (unsigned)gx, 1, fold ? 1u : (unsigned)P);
-  if (rt2) hipLaunchKernelGGL(wgemm_f16x2_rt2_kernel, grid, dim3(WNT), 0, st, a);
+  if (rt2) {
+    switch (cur_opt().wgemm_nt) {
+      case 1: hipLaunchKernelGGL(wgemm_f16x2_rt2_kernel<1>, grid, dim3(WNT), 0, st, a); break;
+      case 2: hipLaunchKernelGGL(wgemm_f16x2_rt2_kernel<2>, grid, dim3(WNT), 0, st, a); break;
+      case 3: hipLaunchKernelGGL(wgemm_f16x2_rt2_kernel<3>, grid, dim3(WNT), 0, st, a); break;
+      default: hipLaunchKernelGGL(wgemm_f16x2_rt2_kernel<0>, grid, dim3(WNT), 0, st, a);
+    }
+  }
   else if (cur_opt().wgemm_epi == 0) hipLaunchKernelGGL((wgemm_f16x2_kernel<false>), grid, dim3(WNT), 0, st, a);
   else hipLaunchKernelGGL((wgemm_f16x2_kernel<true>), grid, dim3(WNT), 0, st, a);
 }

@@ -88,6 +88,12 @@ int buddy_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsi
  * sustains under its power budget, the ceiling of the bf16x3 GEMM */
 int buddy_mfma_ubench_bf16(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, void* stream);
 
+/* calibration: one streaming pass over `bytes` (a multiple of 16, 16-byte aligned device buffers) by `blocks` workgroups of 256 threads, eight independent
+ * 16-byte requests in flight per thread: mode 0 copy src -> dst (bytes read + bytes written), 1 read src (summed in registers), 2 write dst; nt != 0 uses the
+ * non-temporal loads / stores.  The HBM rate a plain kernel reaches on THIS box, next to the nominal 8 TB/s (MI355X_MICROARCH.md records 6.29 TB/s for a
+ * float4 copy): the second denominator of every HBM-bound roofline in bench.py. */
+int buddy_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int nt, int blocks, void* stream);
+
 /* ---- unit-level kernels (the pieces the network is made of; used by the parity tests) ---- */
 /* C[b] = alpha * op(A[b]) op(Bt[b])^T (+ bias_n), row-major; transX = operand stored k-major. replaces torch.einsum/bmm
  * in AttnBlockpp (networks/ncsnpp_utils/layerspp.py:82-86) and NIN (layers.py:548-557). */
@@ -208,7 +214,7 @@ int buddy_ncsnpp_set_fir(void* handle, int fir);
 /* Per-handle launcher options -- "no hidden global state" (SURVEY.md 8(b)): every switch a launcher consults (attention core, GEMM arithmetic, the
  * fusion / layout A/B switches) is a field of the handle's option struct; two handles in one process may differ.  Keys (csrc/options.hip): conv, gemm,
  * attention, gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr, attn_split, attn_nw, igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos,
- * wgemm_epi, wgemm_rt, wino_epi, wino_abl, wino_geo, w6_xcd, gn_fast, c2in4, c2out_tiled, fir_lds, op_graph.  An unknown key or a value out of range is
+ * wgemm_epi, wgemm_rt, wgemm_nt, wino_epi, wino_abl, wino_geo, w6_xcd, gn_fast, c2in4, c2out_tiled, fir_lds, op_graph.  An unknown key or a value out of range is
  * BUDDY_ERR_ARG.  A handle starts from the process defaults = the BUDDY_<KEY> environment variables, parsed and validated in ONE place at handle
  * creation: a bad value, or an unknown BUDDY_* name within edit distance 2 of a switch (a misspelling), makes buddy_ncsnpp_create fail with a message naming it;
  * BUDDY_* names that resemble no switch are not this library's and are left alone.  Set options before the first forward or between calls: the

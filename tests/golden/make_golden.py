@@ -144,12 +144,15 @@ def gen_edm_sched():
     save("edm_sched", **out)
 
 
-def _net_fixture(name, nf, n_fft, hop, L, B, seed, with_taps, ch_mult=(1, 2, 2, 2), num_res_blocks=1):
+def _net_fixture(name, nf, n_fft, hop, L, B, seed, with_taps, ch_mult=(1, 2, 2, 2), num_res_blocks=1, first_row_of=None):
     net = build_ref_net(nf, n_fft, hop, seed, ch_mult, num_res_blocks)
     rs = np.random.RandomState(seed + 100)
     x = torch.from_numpy((0.5 * rs.standard_normal((B, 1, L))).astype(np.float32))
     cn = torch.from_numpy(rs.uniform(-2.0, 0.3, size=(B,)).astype(np.float32))
     cot = torch.from_numpy(rs.standard_normal((B, 1, L)).astype(np.float32))
+    if first_row_of is not None:      # row 0 = the B = 1 fixture's utterance (row independence: its results must not depend on the batch it is in)
+        f1 = np.load(os.path.join(HERE, first_row_of + ".npz"))
+        x[0], cn[0], cot[0] = torch.from_numpy(f1["x"][0]), torch.from_numpy(f1["cnoise"])[0], torch.from_numpy(f1["cot"][0])
     x.requires_grad_(True)
     taps = {}
     hooks = []
@@ -186,6 +189,14 @@ def gen_net_arch():
 
 def gen_net_full():
     _net_fixture("net_full", nf=128, n_fft=510, hop=128, L=16000, B=1, seed=5, with_taps=True)
+
+
+def gen_net_full_64000():
+    """the FULL size pinned against the reference itself (networks/ncsnpp.py:281-449, :498-506) -- nf = 128, STFT 510 / 128,
+    L = 64 000 (BASELINE configs[1]'s utterance length): input, cnoise, cotangent, output, input-VJP and the per-module statistics; and a B = 2
+    batch whose row 0 is that same utterance (row independence at the full size)."""
+    _net_fixture("net_full_64000", nf=128, n_fft=510, hop=128, L=64000, B=1, seed=6, with_taps=True)
+    _net_fixture("net_full_64000_B2", nf=128, n_fft=510, hop=128, L=64000, B=2, seed=6, with_taps=False, first_row_of="net_full_64000")
 
 
 def gen_ops():
@@ -480,7 +491,7 @@ def gen_fir():
     save("net_small_fir", **arrs)
 
 
-GENS = dict(edm_sched=gen_edm_sched, net_small=gen_net_small, net_arch=gen_net_arch, net_full=gen_net_full, ops=gen_ops,
+GENS = dict(edm_sched=gen_edm_sched, net_small=gen_net_small, net_arch=gen_net_arch, net_full=gen_net_full, net_full_64000=gen_net_full_64000, ops=gen_ops,
             e2e_informed=gen_e2e_informed, e2e_blind=gen_e2e_blind, e2e_uncond=gen_uncond,
             opt=gen_opt, e2e_blind_o2=gen_e2e_blind_o2, e2e_blind10=gen_e2e_blind10, config1=gen_config1, fir=gen_fir)
 

@@ -187,6 +187,38 @@ def test_gemm_modes_vs_golden(golden, gemm):
     assert ey < TOL and eg < TOL
 
 
+@pytest.mark.parametrize("gemm", ["f16x2", "bf16x3", "fp32"])
+def test_full_size_vs_reference_fixture(golden, gemm):
+    """SURVEY 8(c).3 / VERDICT r5 item 3: the FULL size against the reference itself (not only against the oracle): nf = 128, STFT 510 / 128,
+    L = 64 000 = BASELINE configs[1]'s utterance (reference networks/ncsnpp.py:281-449, :498-506) -- forward, input-VJP and the per-module statistics,
+    in all three GEMM arithmetics at the SAME 5e-4 bound; then the B = 2 fixture whose row 0 is that utterance: both rows against the reference's
+    batched run, and row 0 bit-identical to the B = 1 call (an utterance's result does not depend on its batch)."""
+    g = golden("net_full_64000")
+    nf, n_fft, hop, L, B, seed = [int(v) for v in g["meta"]]
+    assert (nf, L, B) == (128, 64000, 1)
+    net = build(nf, n_fft, hop, seed, gemm=gemm)
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = net(x, torch.from_numpy(g["cnoise"]).cuda())
+    bad, n = [], 0
+    for k in sorted(g.files):
+        if k.startswith("tap") and k.endswith("_absmax"):
+            i = int(k[3:-7]); t = net.tap(i); n += 1
+            if abs(float(t.abs().max()) - float(g[k])) > 2e-3 * float(g[k]) or abs(float(t.std()) - float(g[f"tap{i}_std"])) > 2e-3 * float(g[f"tap{i}_std"]):
+                bad.append((i, float(t.abs().max()), float(g[k])))
+    assert n >= 18 and not bad, f"per-module statistics off (idx, absmax, ref): {bad[:6]}"
+    gx, = torch.autograd.grad(y, x, torch.from_numpy(g["cot"]).cuda())
+    ey, eg = rel(y.detach().cpu().numpy(), g["y"]), rel(gx.cpu().numpy(), g["vjp"])
+    g2 = golden("net_full_64000_B2")
+    assert np.array_equal(g2["x"][0], g["x"][0]) and g2["x"].shape[0] == 2
+    x2 = torch.from_numpy(g2["x"]).cuda().requires_grad_(True)
+    y2 = net(x2, torch.from_numpy(g2["cnoise"]).cuda())
+    gx2, = torch.autograd.grad(y2, x2, torch.from_numpy(g2["cot"]).cuda())
+    ey2, eg2 = rel(y2.detach().cpu().numpy(), g2["y"]), rel(gx2.cpu().numpy(), g2["vjp"])
+    print(f"L = 64000 vs the reference, gemm={gemm}: B=1 forward {ey:.2e} vjp {eg:.2e}; B=2 forward {ey2:.2e} vjp {eg2:.2e}")
+    assert ey < TOL and eg < TOL and ey2 < TOL and eg2 < TOL
+    assert torch.equal(y2[0].detach(), y[0].detach()) and torch.equal(gx2[0], gx[0]), "row 0 of the batch differs from its B = 1 run"
+
+
 def test_cold_start_budget_and_shared_replica():
     """a network handle must be cheap.  Full-width network (111 MB of parameters): buddy_ncsnpp_create + the first forward
     (which prepares, on the GPU, the ONE operand form each 3x3 convolution uses for this workload) under 1.5 s of wall time here (measured

@@ -34,9 +34,11 @@ def test_edm_schedule_gamma(golden):
         assert np.allclose(getattr(edm, k)(sig).numpy(), g[k], rtol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["net_small", "net_full", "net_cm12_rb2", "net_cm1122_rb1"])
+@pytest.mark.parametrize("name", ["net_small", "net_full", "net_cm12_rb2", "net_cm1122_rb1", "net_full_64000"])
 def test_network_forward_and_vjp(golden, name):
-    """net_cm12_rb2 / net_cm1122_rb1: other members of the architecture family the constructor accepts (reference networks/ncsnpp.py:184-270:
+    """net_full_64000 (round 6): the FULL size -- nf = 128, L = 64 000, BASELINE configs[1]'s utterance -- recorded from the reference
+    itself: the oracle the 64 000-sample GPU tests lean on is pinned at that size too, not only at 16 000.
+    net_cm12_rb2 / net_cm1122_rb1: other members of the architecture family the constructor accepts (reference networks/ncsnpp.py:184-270:
     ch_mult (1, 2) with two blocks per level, nf 32; ch_mult (1, 1, 2, 2) with one, nf 32), recorded from the reference like the shipped ones."""
     g = golden(name)
     nf, n_fft, hop, L, B, seed = [int(v) for v in g["meta"]]
