@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 U_FWD = 1.2501e12   # algorithmic FLOPs of one score-network forward for a 4 s utterance (measured with
                     # torch.utils.flop_counter on the reference); forward + input-VJP = 2 * U_FWD
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E, MI355X_MICROARCH.md
+GUIDE_COPY_GBS = 6290.0      # the same guide's measured float4-copy rate ("8.0 TB/s spec; 6.29 TB/s measured"): the calibrated streaming ceiling
 PEAK_FP32_MFMA = 157.3   # TFLOP/s, MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_BF16_MFMA = 2500.0  # TFLOP/s, MI355X dense bf16 matrix peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 
@@ -299,18 +300,34 @@ def measure_peaks(lib, device):
         out["bf16_mfma_tflops"] = blocks * 4 * 12 * iters * 32768 / (e0.elapsed_time(e1) * 1e-3) / 1e12     # random operand bits, no memory traffic
     except Exception as e:
         out["fp32_mfma_tflops"] = None; out["mfma_error"] = str(e)[:100]
+    # HBM: the library's own float4 streaming kernels (buddy_hbm_ubench: eight 16-byte requests in flight per thread, grid sweep, plain and non-temporal;
+    # round 6 -- rounds 1-5 quoted torch's copy / sum kernels here, whose read-only figure was below their copy figure: a microbenchmark
+    # artefact).  hbm_copy_GBps (read + write, the transforms' and the GEMM's own mix) is the calibrated denominator of every HBM-bound roofline.
     n = 256 * 2 ** 20
     x = torch.randn(n, device=device); y = torch.empty_like(x)
-    for name, fn, nbytes in (("hbm_copy_GBps", lambda: y.copy_(x), 8 * n), ("hbm_add_GBps", lambda: torch.add(x, 1.0, out=y), 8 * n),
-                             ("hbm_read_GBps", lambda: x.sum(), 4 * n)):
+    S = torch.cuda.current_stream().cuda_stream
+
+    def rate(fn, nbytes, reps=6):
         for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
+        for _ in range(reps):
             fn()
         e1.record(); torch.cuda.synchronize()
-        out[name] = nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    for mode, name, moved in ((0, "hbm_copy_GBps", 8 * n), (1, "hbm_read_GBps", 4 * n), (2, "hbm_write_GBps", 4 * n)):
+        best = 0.0
+        for nt in (0, 1):
+            for blocks in (-1, -2, -4, 512, 16384):
+                best = max(best, rate(lambda: _lib.check(lib.buddy_hbm_ubench(x.data_ptr(), y.data_ptr(), 4 * n, mode, nt, blocks, S)), moved))
+        out[name] = best
+    out["hbm_torch_copy_GBps"] = rate(lambda: y.copy_(x), 8 * n)
+    out["hbm_torch_add_GBps"] = rate(lambda: torch.add(x, 1.0, out=y), 8 * n)
+    out["hbm_copy_guide_GBps"] = GUIDE_COPY_GBS
+    out["hbm_note"] = ("hbm_copy / hbm_read / hbm_write: best of the library's float4 streaming kernel (buddy_hbm_ubench; plain and non-temporal; one-shot grids of 1 / 2 / "
+                       "4 words per thread and grid-stride forms of 512 / 16384 workgroups) over 1 GiB on THIS box; hbm_copy_guide = the 6.29 TB/s MI355X_MICROARCH.md records for a float4 copy (not reached on "
+                       "the boxes of this pool: profiles/r06_hbm_ubench.json)")
     del x, y
     return out
 
@@ -337,7 +354,9 @@ def f16x2_roofline(gemm_tf, alg_bytes, ms_total, peaks):
         "algorithmic bytes (V read once, M written once, weights once) / time"))
     r["peak_measured_on_box"] = peaks.get("hbm_copy_GBps") if use_h else peaks.get("bf16_mfma_tflops")
     r["frac_of_measured_peak"] = (r["achieved"] / r["peak_measured_on_box"]) if r["peak_measured_on_box"] else None
-    r["peak_measured_note"] = ("a device-to-device copy kernel on this box (read + write, the GEMM's own mix)" if use_h else
+    if use_h:
+        r["frac_of_guide_copy"] = r["achieved"] / GUIDE_COPY_GBS       # against the 6.29 TB/s float4 copy of MI355X_MICROARCH.md
+    r["peak_measured_note"] = ("the library's float4 copy kernel on this box (buddy_hbm_ubench: read + write, the GEMM's own mix; best of plain / non-temporal over a grid sweep)" if use_h else
                                "a pure 16-bit MFMA loop on random operand bits on this box: the chip clocks to its power budget")
     r["fp32_equivalent_tflops"] = gemm_tf
     r["frac_of_fp32_matrix_peak"] = gemm_tf / PEAK_FP32_MFMA
@@ -380,7 +399,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (--backend, default nccl = RCCL) even with one rank and run the "
                     "end-of-run gather through it: exercises communicator set-up and the collective on a 1-GPU box")
     ap.add_argument("--legs", default="auto", help="extra untimed-from-`value` legs (BASELINE.md section 3): comma list of informed,informed_b1,blind_b1,"
-                    "forward_only,longform,full_run,shipped or 'all' / 'none'; auto = all at N=1 with the default workload, full_run only otherwise")
+                    "forward_only,longform,full_run,shipped,gemm_modes,realclip or 'all' / 'none'; auto = all at N=1 with the default workload, full_run only otherwise")
     a = ap.parse_args()
     if a.cpu_baseline_only:
         print(json.dumps(cpu_baseline(a.length, a.cpu_baseline_only, a.cpu_reps, a.cpu_utt, a.cpu_mode)))
@@ -414,7 +433,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the sampler path has no CPU fallback")
     if world > 1 and a.backend == "nccl" and world > torch.cuda.device_count():
         raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {torch.cuda.device_count()} (--backend gloo lets ranks share a GPU for smoke tests)")
-    dev_index = local_rank % torch.cuda.device_count()     # == local_rank on a real node; lets 2 gloo ranks share one GPU in smoke tests
+    from buddy_amd import dist as bdist_
+    dev_index = bdist_.device_index(local_rank)            # == local_rank on a real node (visible device r of the launcher's list); gloo smoke tests wrap around one GPU
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    # each rank drives ~2 000 launches per step from one Python thread: its own cores, next to its GPU (sysfs numa_node / local_cpulist), disjoint from its peers'
+    placement = bdist_.pin_rank(local_rank, local_world, torch.cuda.device_count()) if world > 1 else {"cpus": None, "numa_cpus": None, "physical_device": None}
     t0 = time.perf_counter()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -424,8 +447,10 @@ def main():
     SETUP["hip_context_s"] = time.perf_counter() - t0
     dist = None
     dist_init_ms = 0.0
+    rccl_env = None
     if world > 1 or a.force_dist:
         import torch.distributed as dist
+        rccl_env = bdist_.rccl_env_defaults()          # before the process group exists: dmabuf IPC, the RCCL version banner (NCCL_DEBUG=VERSION)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:                   # --force-dist on one rank: a private rendezvous
             import socket
@@ -444,6 +469,13 @@ def main():
     def log(msg):
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+    placements = [placement]
+    if dist is not None:
+        placements = [None] * world
+        dist.all_gather_object(placements, placement)
+        log("rccl / device environment: " + ", ".join(f"{k}={v}" for k, v in rccl_env.items() if v is not None))
+        for r_, p_ in enumerate(placements):
+            log(f"rank {r_}: physical device {p_['physical_device']}, cpus {p_['cpus']} (GPU-local NUMA cpus: {p_['numa_cpus']})")
 
     from buddy_amd import _lib
     lib = _lib.require_gpu()
@@ -574,10 +606,12 @@ def main():
 
     # ---- further legs, each its own untimed-from-`value` region on a replica of the same network -------------------------
     default_workload = (B == 8 and a.length == 64000)
+    ALL_LEGS = {"informed", "informed_b1", "blind_b1", "forward_only", "longform", "full_run", "shipped", "gemm_modes", "realclip"}
+    gemm_mode_now = {0: "fp32", 1: "bf16x3", 2: "f16x2"}[int(net0[0].get_option("gemm"))]
     if a.legs == "auto":
-        want = {"informed", "informed_b1", "blind_b1", "forward_only", "longform", "full_run", "shipped"} if (world == 1 and default_workload) else {"full_run"}
+        want = set(ALL_LEGS) if (world == 1 and default_workload) else {"full_run"}
     elif a.legs == "all":
-        want = {"informed", "informed_b1", "blind_b1", "forward_only", "longform", "full_run", "shipped"}
+        want = set(ALL_LEGS)
     else:
         want = {w for w in a.legs.split(",") if w and w != "none"}
     legs = {}
@@ -599,9 +633,11 @@ def main():
                            "warmup": n_warm}, **extra)
         log(f"leg {name}: {legs[name]['ms_per_step']:.2f} ms/step")
 
-    def stack_runner(tester_cfg, Bl, blind, T, length=None, extra=(), attention=None):
-        _, _, _, tester, _, y, op = build_stack(a, device, Bl, rank * Bl, net0[0], tester_cfg=tester_cfg, blind=blind, T=T, length=length, extra=extra,
-                                                attention=attention)
+    def stack_runner(tester_cfg, Bl, blind, T, length=None, extra=(), attention=None, gemm=None):
+        _, net_l, _, tester, _, y, op = build_stack(a, device, Bl, rank * Bl, net0[0], tester_cfg=tester_cfg, blind=blind, T=T, length=length, extra=extra,
+                                                    attention=attention)
+        if gemm is not None:             # per-handle option of the replica: the other arithmetics' operand forms are prepared on first use (shared store)
+            net_l.set_option("gemm", {"fp32": 0, "bf16x3": 1, "f16x2": 2}[gemm])
         return StepRunner(tester, y, op, device, blind=blind)
 
     if "informed" in want:       # (ii) of BASELINE.md section 3: informed sampler, order 2 (two forward+VJP evaluations per step), T=10 schedule
@@ -611,6 +647,23 @@ def main():
                                                 "score_evals_per_step": 2})
         legs["informed_order2"]["score_evals_per_s"] = 2 * legs["informed_order2"]["value"]
         del r_
+    if "gemm_modes" in want and gemm_mode_now == "f16x2":
+        # the exact-arithmetic numbers under the driver -- the SAME workload as `value` (blind, B utterances, order 1, 10 updates) with the
+        # Winograd-domain GEMMs as exact three-way bf16 splits (six products: the fp32 kernel's accuracy) and on the fp32 MFMA (bit-exact FMA chains)
+        for gm in ("bf16x3", "fp32"):
+            r_ = stack_runner("blind_dereverberation_BUDDy", B, True, a.T, gemm=gm)
+            time_leg(f"gemm_{gm}", r_, B, 6, 2, {"config": f"the headline workload (blind step, B={B} x {a.length}) with the Winograd-domain GEMMs in {gm} arithmetic "
+                                                           "(per-handle option `gemm`; default f16x2 = `value`)", "gemm": gm})
+            del r_
+            torch.cuda.empty_cache()
+    if "realclip" in want:       # BASELINE configs[0]'s own geometry: the audio_examples clip has 133 829 samples -> 1 056 frames, 132 rows at the lowest level
+        r_ = stack_runner("informed_dereverberation_DPS", 1, False, 10, length=133829)
+        time_leg("informed_order2_B1_L133829", r_, 1, 6, 2, {"config": "informed DPS, order 2, T=10 schedule, ONE utterance of 133 829 samples = the length of "
+                                                                      "audio_examples/clean/p226 (BASELINE configs[0]; reference conf/tester/informed_dereverberation_DPS.yaml:24), "
+                                                                      "synthetic signal and weights: a geometry that is not a power of two (1 056 frames; tiles overhang on "
+                                                                      "every level)", "score_evals_per_step": 2, "length": 133829})
+        del r_
+        torch.cuda.empty_cache()
     if "informed_b1" in want:    # the reference's own shape: one utterance at a time (testing/tester.py:132-153)
         r_ = stack_runner("informed_dereverberation_DPS", 1, False, 10)
         time_leg("informed_order2_B1", r_, 1, 6, 2, {"config": f"as informed_order2 with B=1 (latency of one utterance; BASELINE configs[0] shape)", "score_evals_per_step": 2})
@@ -798,6 +851,7 @@ def main():
             "network_algorithmic_tflops": n_utt_steps * 2 * U_FWD * (a.length / 64000.0) / elapsed / 1e12,
             "gather_ms": gather_ms, "gather_first_call_ms": gather_first_ms, "gather_bytes_per_rank": int(out.numel() * 4),
             "gather_backend": (a.backend if dist is not None else None), "per_rank_ms_per_step": per_rank_ms,
+            "per_rank_placement": placements if world > 1 else None, "rccl_env": rccl_env,
             # dominant kernel: the batched Winograd-domain GEMMs of the 3x3 convolutions.  bf16x3 (default): every fp32 multiply-add is SIX bf16 MFMA
             # multiply-adds -> achieved = 6 x the fp32-equivalent rate, against the bf16 matrix peak; the fp32-equivalent rate against the fp32 matrix
             # peak is beside it (the kernel replaces v_mfma_f32_32x32x2_f32 at equal accuracy; --gemm fp32 is the reference run)
@@ -836,7 +890,8 @@ def main():
                         "avg_conv_ms": ms[0] / max(1, ln[0]), "convolutions": int(ln[0]), "share_of_step": ms[0] * 1e-3 / attr_elapsed,
                         "transform_passes": {"input_GBps": w4_bi.value / (w4_ms[0] * 1e-3) / 1e9 if w4_ms[0] > 0 else 0.0,
                                              "output_GBps": w4_bo.value / (w4_ms[2] * 1e-3) / 1e9 if w4_ms[2] > 0 else 0.0,
-                                             "peak_GBps": PEAK_HBM_GBS, "share_of_step": (w4_ms[0] + w4_ms[2]) * 1e-3 / attr_elapsed,
+                                             "peak_GBps": PEAK_HBM_GBS, "copy_GBps_on_this_box": peaks.get("hbm_copy_GBps"), "copy_GBps_guide": GUIDE_COPY_GBS,
+                                             "share_of_step": (w4_ms[0] + w4_ms[2]) * 1e-3 / attr_elapsed,
                                              "note": "HBM-bound: input read once + 64/36 (F(6x6,3x3)) or 36/16 (F(4x4,3x3)) transformed values written; the same read + output (and residual) once"},
                         "fused_form_bytes_per_conv": by[0] / max(1, ln[0]),
                         "three_pass_bytes_per_conv": (w4_bi.value + w4_bg.value + w4_bo.value) / a36},
@@ -848,6 +903,8 @@ def main():
             "roofline_hbm": {"bound": "hbm", "kernel": "GroupNorm statistics / apply(+SiLU,+resample) / backward (chan_reduce, gn_apply, gn_bwd_apply)",
                              "achieved": hb_by.value / (hb_ms.value * 1e-3) / 1e9 if hb_ms.value > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": (hb_by.value / (hb_ms.value * 1e-3) / 1e9 / PEAK_HBM_GBS) if hb_ms.value > 0 else 0.0,
+                             "frac_of_measured_copy": (hb_by.value / (hb_ms.value * 1e-3) / 1e9 / peaks["hbm_copy_GBps"]) if (hb_ms.value > 0 and peaks.get("hbm_copy_GBps")) else None,
+                             "frac_of_guide_copy": (hb_by.value / (hb_ms.value * 1e-3) / 1e9 / GUIDE_COPY_GBS) if hb_ms.value > 0 else None,
                              "peak_measured_on_box": {k: v for k, v in peaks.items() if k.startswith("hbm_")},
                              "launch_groups": int(hb_n.value), "kernel_time_share_of_step": hb_ms.value * 1e-3 / attr_elapsed,
                              "note": "algorithmic bytes (every pass reads its inputs and writes its output once) / HIP-event time"},

@@ -1,5 +1,6 @@
 // Sampler-side kernels (gfx950): per-utterance (row) elementwise / reductions and the time-domain RIR operator.
 #include "common.h"
+#include <algorithm>
 
 namespace buddy {
 namespace {
@@ -191,48 +192,59 @@ void launch_mfma_ubench(const float* seed, float* out, int blocks, int iters, un
 
 // ---- calibration micro-benchmark: what this box's HBM sustains for a plain streaming kernel (MI355X_MICROARCH.md: 8.0 TB/s nominal, 6.29 TB/s measured
 // for a float4 copy).  mode 0 copy (n16 x 16 B read + written), 1 read (summed, stored only under a condition that never holds), 2 write; nt: the
-// non-temporal forms of the loads / stores.  Every thread keeps UNROLL independent 16-byte requests in flight; consecutive threads touch consecutive
-// 16-byte words; the grid-stride walks the array once per launch.
+// non-temporal forms of the loads / stores.  A workgroup moves CONTIGUOUS chunks of UNROLL x 256 sixteen-byte words (UNROLL independent requests per
+// thread, consecutive threads on consecutive words) and strides over the array by the grid; blocks <= 0 asks for the one-shot form: exactly one chunk
+// per workgroup, UNROLL = -blocks in {1, 2, 4, 8} (|blocks| = 1 is the classic "one float4 per thread" copy).
 namespace {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int MODE, bool NT, int UNROLL>
 __global__ __launch_bounds__(256) void hbm_ubench_kernel(const f32x4_t* __restrict__ src, f32x4_t* __restrict__ dst, long long n16) {
-  const long long stride = (long long)gridDim.x * 256;
+  const long long chunk = (long long)UNROLL * 256, stride = (long long)gridDim.x * chunk;
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
-    f32x4_t v[UNROLL];
-    if (MODE != 2) {
+  for (long long base = (long long)blockIdx.x * chunk; base < n16; base += stride) {
+    const long long i = base + threadIdx.x;
+    if (base + chunk <= n16) {
+      f32x4_t v[UNROLL];
+      if (MODE != 2) {
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
-    }
-    if (MODE == 1) {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) acc += v[u];
-    } else {
+        for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * 256) : src[i + u * 256];
+      }
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
+        if (MODE == 1) { acc += v[u]; continue; }
         const f32x4_t w = MODE == 2 ? f32x4_t{1.f, 2.f, 3.f, (float)u} : v[u];
-        if (NT) __builtin_nontemporal_store(w, dst + i + u * stride); else dst[i + u * stride] = w;
+        if (NT) __builtin_nontemporal_store(w, dst + i + u * 256); else dst[i + u * 256] = w;
+      }
+    } else {
+      for (long long j = i; j < n16; j += 256) {
+        if (MODE == 1) acc += src[j];
+        else dst[j] = MODE == 2 ? f32x4_t{1.f, 2.f, 3.f, 4.f} : src[j];
       }
     }
   }
-  for (; i < n16; i += stride) {
-    if (MODE == 1) acc += src[i];
-    else dst[i] = MODE == 2 ? f32x4_t{1.f, 2.f, 3.f, 4.f} : src[i];
-  }
   if (MODE == 1 && acc.x + acc.y + acc.z + acc.w == 1.2345678e30f) dst[0] = acc;
+}
+template <int MODE, bool NT>
+void hbm_ubench_launch(const f32x4_t* s, f32x4_t* d, long long n16, int blocks, hipStream_t st) {
+  const int u = blocks > 0 ? 8 : -blocks;
+  const long long chunks = (n16 + (long long)u * 256 - 1) / ((long long)u * 256);
+  const unsigned g = (unsigned)(blocks > 0 ? std::min<long long>(blocks, chunks) : chunks);
+  switch (u) {
+    case 1: hipLaunchKernelGGL((hbm_ubench_kernel<MODE, NT, 1>), dim3(g), dim3(256), 0, st, s, d, n16); break;
+    case 2: hipLaunchKernelGGL((hbm_ubench_kernel<MODE, NT, 2>), dim3(g), dim3(256), 0, st, s, d, n16); break;
+    case 4: hipLaunchKernelGGL((hbm_ubench_kernel<MODE, NT, 4>), dim3(g), dim3(256), 0, st, s, d, n16); break;
+    default: hipLaunchKernelGGL((hbm_ubench_kernel<MODE, NT, 8>), dim3(g), dim3(256), 0, st, s, d, n16);
+  }
 }
 }  // namespace
 int launch_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int nt, int blocks, hipStream_t st) {
   const long long n16 = bytes / 16;
-  if (mode < 0 || mode > 2 || blocks < 1 || n16 < 1) return BUDDY_ERR_ARG;
+  if (mode < 0 || mode > 2 || n16 < 1 || blocks == 0 || (blocks < 0 && blocks != -1 && blocks != -2 && blocks != -4 && blocks != -8) || n16 / 256 > 0x7fffffffLL)
+    return BUDDY_ERR_ARG;
   const f32x4_t* s = reinterpret_cast<const f32x4_t*>(src); f32x4_t* d = reinterpret_cast<f32x4_t*>(dst);
-#define BUDDY_HBM_UB(M, N) hipLaunchKernelGGL((hbm_ubench_kernel<M, N, 8>), dim3((unsigned)blocks), dim3(256), 0, st, s, d, n16)
-  if (mode == 0) { if (nt) BUDDY_HBM_UB(0, true); else BUDDY_HBM_UB(0, false); }
-  else if (mode == 1) { if (nt) BUDDY_HBM_UB(1, true); else BUDDY_HBM_UB(1, false); }
-  else { if (nt) BUDDY_HBM_UB(2, true); else BUDDY_HBM_UB(2, false); }
-#undef BUDDY_HBM_UB
+  if (mode == 0) { if (nt) hbm_ubench_launch<0, true>(s, d, n16, blocks, st); else hbm_ubench_launch<0, false>(s, d, n16, blocks, st); }
+  else if (mode == 1) { if (nt) hbm_ubench_launch<1, true>(s, d, n16, blocks, st); else hbm_ubench_launch<1, false>(s, d, n16, blocks, st); }
+  else { if (nt) hbm_ubench_launch<2, true>(s, d, n16, blocks, st); else hbm_ubench_launch<2, false>(s, d, n16, blocks, st); }
   return BUDDY_OK;
 }
 }  // namespace buddy

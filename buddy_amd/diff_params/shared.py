@@ -19,8 +19,8 @@ class SDE:
         are folded into the STFT / overlap-add kernels; otherwise the generic expression is evaluated."""
         B = xn.shape[0]
         if not torch.is_tensor(t):
-            t = torch.full((1,), float(t), dtype=torch.float32, device=xn.device)      # a fill kernel, not a host-to-device copy
-        t = torch.as_tensor(t, dtype=torch.float32, device=xn.device)
+            t = torch.full((1,), float(t), dtype=xn.dtype, device=xn.device)      # a fill kernel, not a host-to-device copy
+        t = torch.as_tensor(t, dtype=xn.dtype, device=xn.device)               # fp32 in the product; the float64 arbiter runs keep their sigma in float64
         sigma_b = self._std(t).reshape(-1).expand(B) if t.numel() in (1, B) else None
         if sigma_b is None:
             raise ValueError("t must be a scalar or have one entry per batch element")

@@ -57,7 +57,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         x_in.requires_grad = True
         x_den = self.get_Tweedie_estimate(x_in, t)
         if blind:
-            self.optimize_op(x_den.clone().detach(), t)
+            self.optimize_op(x_den.detach(), t)      # the library copies it into the captured graph's input buffer: no clone here
         lh_score, _ = self.get_likelihood_score(x_den, x_in, t)
         x_in.detach_()
         csm = self.args.tester.posterior_sampling.constraint_speech_magnitude
@@ -71,7 +71,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         x_in.requires_grad = True
         x_den = self.get_Tweedie_estimate(x_in, t)
         if blind:
-            self.optimize_op(x_den.clone().detach(), t)
+            self.optimize_op(x_den.detach(), t)      # the library copies it into the captured graph's input buffer: no clone here
         lh_score, _ = self.get_likelihood_score(x_den, x_in, t)
         x_in.detach_()
         return lh_score.detach(), x_den.detach()

@@ -88,9 +88,10 @@ int buddy_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsi
  * sustains under its power budget, the ceiling of the bf16x3 GEMM */
 int buddy_mfma_ubench_bf16(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, void* stream);
 
-/* calibration: one streaming pass over `bytes` (a multiple of 16, 16-byte aligned device buffers) by `blocks` workgroups of 256 threads, eight independent
- * 16-byte requests in flight per thread: mode 0 copy src -> dst (bytes read + bytes written), 1 read src (summed in registers), 2 write dst; nt != 0 uses the
- * non-temporal loads / stores.  The HBM rate a plain kernel reaches on THIS box, next to the nominal 8 TB/s (MI355X_MICROARCH.md records 6.29 TB/s for a
+/* calibration: one streaming pass over `bytes` (a multiple of 16, 16-byte aligned device buffers): mode 0 copy src -> dst (bytes read + bytes written),
+ * 1 read src (summed in registers), 2 write dst; nt != 0 uses the non-temporal loads / stores.  blocks >= 1: that many workgroups of 256 threads stride
+ * over the array in contiguous chunks of 8 x 256 sixteen-byte words (eight independent requests per thread); blocks = -1 | -2 | -4 | -8: the one-shot
+ * form, one chunk of that many words per thread and workgroup (-1 = the classic one-float4-per-thread copy).  The HBM rate a plain kernel reaches on THIS box, next to the nominal 8 TB/s (MI355X_MICROARCH.md records 6.29 TB/s for a
  * float4 copy): the second denominator of every HBM-bound roofline in bench.py. */
 int buddy_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int nt, int blocks, void* stream);
 

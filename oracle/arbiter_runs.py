@@ -67,6 +67,49 @@ def run_blind(seed, L, T, nf, updates, rir_taps, fp64=False, threads=8, weight_s
         torch.set_num_threads(prev)
 
 
+def run_blind_batched(seeds, L, T, nf, updates, rir_taps, fp64=False, weight_seed=0, device="cuda", perturb=0.0):
+    """ALL the utterances ``seeds`` as ONE batch (round 6: the population gate samples 8 seeds; eight B = 1 float64 runs take eight minutes):
+    the batched torch-op sampler / operator of oracle/batched (row b == the B = 1 oracle run of utterance b: tests/test_host_logic.py::
+    test_batched_blind_dps_equals_oracle_per_utterance) around the oracle network, in float64 (the arbiter) or float32 (one more fp32
+    execution through torch's GPU kernels), noise stream 9000 + seed per utterance -> (x_den per step (T, U, L) float32, clean (U, L), n_draws per utterance)"""
+    from buddy_amd.config import compose
+    from buddy_amd.instantiate import instantiate
+    from buddy_amd.synth import synth_state_dict, synth_clean, synth_rir
+    from .batched.operators import BlindSubbandFiltering
+    from .batched.sampler import EulerHeunSamplerDPSTorch
+    args = compose(overrides=overrides(T, updates, nf))
+    with (precision.fp64(device) if fp64 else _on_device(device)), (_on_device(device) if fp64 else contextlib.nullcontext()):
+        dt, dev = torch.get_default_dtype(), torch.get_default_device()
+        P = ncsnpp_ref.to_torch(synth_state_dict(weight_seed, nf))
+        net = lambda z, cn: ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
+        op_hp = args.tester.informed_dereverberation.op_hp
+        cs, ys = [], []
+        for s in seeds:
+            c0 = torch.from_numpy(synth_clean(s, L)).to(device=dev, dtype=dt)
+            c0 = 0.05 * c0 / c0.std()
+            if perturb:
+                c0 = c0 * (1.0 + perturb)
+            oo = O.RIROperatorRef(op_hp)
+            oo.update_params(torch.from_numpy(synth_rir(s, rir_taps)).to(device=dev, dtype=dt))
+            cs.append(c0); ys.append(oo.degradation(c0[None])[0])
+        y0 = torch.stack(ys)
+        ns = [S.NoiseStream(9000 + s) for s in seeds]
+        smp = EulerHeunSamplerDPSTorch(net, instantiate(args.diff_params), args)
+        smp.use_hip_update = False              # the elementwise tail as torch expressions in the run's dtype (the HIP kernels are fp32)
+        smp.noise = ns
+        bo = BlindSubbandFiltering(op_hp, 16000, num_utts=len(seeds), noise=ns, device=str(dev))
+        bo.update_H(use_noise=True)
+        smp.bind(y0, bo, True)
+        sched = smp.create_schedule()
+        tl, gl = sched.tolist(), smp.get_gamma(sched).tolist()
+        x = smp.initialize_x(tuple(y0.shape), dev, sched)
+        tr = []
+        for i in range(T):
+            x, xd = smp.step(x, tl[i], tl[i + 1], gl[i], blind=True)
+            tr.append(xd.detach().float().cpu())
+    return torch.stack(tr), torch.stack(cs).float().cpu(), [n.k for n in ns]
+
+
 def run_informed(seed, L, T, nf, rir_taps, fp64=False, threads=8, weight_seed=0, device=None, order=2):
     """the non-chaotic chain: informed DPS (known RIR, no operator optimisation), order 2 -> (x_den per step (T, L) float32, clean, n_draws)"""
     from buddy_amd.config import compose

@@ -93,7 +93,7 @@ class SubbandFiltering(Operator, OperatorSTFT):
         assert self.n_fft >= self.win_length, "n_fft must be greater than 2*win_length to avoid temporal aliasing"
         self.Nf = self.op_hp.Nf
         self.length_rir = self.hop_length * self.Nf
-        self.time = torch.arange(self.Nf, dtype=torch.float32) / (self.sample_rate / self.hop_length)
+        self.time = torch.arange(self.Nf, dtype=torch.get_default_dtype()) / (self.sample_rate / self.hop_length)
 
     def subband_filtering(self, X, H):
         """Per-band causal FIR along frames (reference :67-74).  X (U,F,T) complex, H (F,Nf) or (U,F,Nf)."""
@@ -123,10 +123,10 @@ class SubbandFiltering(Operator, OperatorSTFT):
     def get_time_RIR(self, excitation=None, H=None):
         """(U, length_rir+1024) estimated time-domain RIR(s) (reference :103-113; U=1 squeezes like the reference)."""
         if excitation is None:
-            x = torch.zeros(int(self.length_rir + 1024), dtype=torch.float32, device=self.device)
+            x = torch.zeros(int(self.length_rir + 1024), dtype=torch.get_default_dtype(), device=self.device)
             x[0] = 1
         else:
-            x = torch.as_tensor(excitation, dtype=torch.float32, device=self.device)
+            x = torch.as_tensor(excitation, dtype=torch.get_default_dtype(), device=self.device)
         Hh = self.H if H is None else H
         U = Hh.shape[0] if Hh.dim() == 3 else 1
         r = self.degradation(x.unsqueeze(0).expand(U, -1), H=Hh)
@@ -167,8 +167,8 @@ class BlindSubbandFiltering(SubbandFiltering):
             wts = [self.num_bands * [float(w)] for w in op_hp.init_params.multiexp_weighting]
         else:
             t60, wts = op_hp.init_params.T60_breakpoints, op_hp.init_params.multiexp_weighting
-        t60 = torch.tensor(t60, dtype=torch.float32, device=self.device)
-        wts = torch.tensor(wts, dtype=torch.float32, device=self.device)
+        t60 = torch.tensor(t60, dtype=torch.get_default_dtype(), device=self.device)
+        wts = torch.tensor(wts, dtype=torch.get_default_dtype(), device=self.device)
         frame_rate = self.sample_rate / op_hp.hop
         decay = 6.908 / (t60 * frame_rate)
         self.num_exponentials = decay.shape[0]
@@ -222,7 +222,7 @@ class BlindSubbandFiltering(SubbandFiltering):
         Nf = len(self.time)
         decay_bp = torch.exp(self.params[0])                                   # (U,E,bands)
         weights = self.params[1]
-        n = torch.arange(0, Nf, device=self.device).float()
+        n = torch.arange(0, Nf, device=self.device).to(torch.get_default_dtype())
         inner = (weights.unsqueeze(-1) * decay_bp.unsqueeze(-1) ** (-n)).sum(1)  # (U,bands,Nf)
         if self.fix_EQ_extremes:
             z = torch.zeros(inner.shape[0], 1, Nf, device=self.device)
@@ -230,7 +230,7 @@ class BlindSubbandFiltering(SubbandFiltering):
         else:
             dm = inner
         dm = torch.log(dm.transpose(1, 2) + 1e-6)                                # (U,Nf,knots)
-        H2 = linear_interp(self.EQ_freqs.to(torch.float32), dm, self.freqs)       # (U,Nf,F)
+        H2 = linear_interp(self.EQ_freqs.to(torch.get_default_dtype()), dm, self.freqs)       # (U,Nf,F)
         H2 = torch.exp(H2.transpose(1, 2))
         assert not torch.isnan(H2).any(), "decay is Nan"
         return H2
@@ -269,8 +269,8 @@ class BlindSubbandFiltering(SubbandFiltering):
         assert self.H.shape[-2] == self.n_fft // 2 + 1 and self.H.shape[-1] == self.Nf
 
     def update_params(self, params_dict):
-        T60s = torch.tensor(params_dict.T60_breakpoints, dtype=torch.float32, device=self.device)
-        w = torch.tensor(params_dict.multiexp_weighting, dtype=torch.float32, device=self.device)
+        T60s = torch.tensor(params_dict.T60_breakpoints, dtype=torch.get_default_dtype(), device=self.device)
+        w = torch.tensor(params_dict.multiexp_weighting, dtype=torch.get_default_dtype(), device=self.device)
         decays = 6.908 / (T60s * (self.sample_rate / self.hop_length))
         assert len(w) == len(T60s)
         self.num_exponentials = len(T60s)

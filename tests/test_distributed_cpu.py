@@ -101,3 +101,71 @@ def test_gather_ragged_rows_two_ranks(tmp_path):
     out_path = str(tmp_path / "ok")
     mp.spawn(_ragged_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
     assert torch.load(out_path + ".0") is True and torch.load(out_path + ".1") is True
+
+
+def _fake_sysfs(root, cards):
+    """cards: list of (vendor, local_cpulist or None, numa_node or None) in drm card order; node cpulists: node0 = 0-7, node1 = 8-15"""
+    for i, (vendor, cpulist, node) in enumerate(cards):
+        d = root / "class" / "drm" / f"card{i}" / "device"
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n")
+        if cpulist is not None:
+            (d / "local_cpulist").write_text(cpulist + "\n")
+        if node is not None:
+            (d / "numa_node").write_text(f"{node}\n")
+    for n, cl in ((0, "0-7"), (1, "8-15")):
+        nd = root / "devices" / "system" / "node" / f"node{n}"
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cl + "\n")
+    (root / "class" / "drm" / "card0-DP-1").mkdir()          # connector entries sit next to the cards in /sys/class/drm
+    return str(root)
+
+
+def test_rank_placement_device_mapping_and_affinity(tmp_path, monkeypatch):
+    """Round 6: what a rank needs on an 8-GPU node before it samples -- its device under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES
+    re-mapping, and its own cores next to its GPU (sysfs numa_node / local_cpulist), disjoint from the other ranks' (each rank drives ~2 000 launches per
+    step from one Python thread).  Pure host logic on a fabricated /sys tree: two sockets x four GPUs, an integrated non-AMD card in between."""
+    sys.path.insert(0, ROOT)
+    from buddy_amd import dist as bd
+    for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    assert bd.visible_device_ids() is None
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7")
+    assert bd.visible_device_ids() == [4, 5, 6, 7]
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "7,6,5,4,3,2,1,0")           # HIP indices count inside the ROCr list
+    assert bd.visible_device_ids() == [3, 2, 1, 0]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert bd.visible_device_ids() == [7, 6, 5, 4, 3, 2, 1, 0]
+    assert [bd.device_index(r, 8) for r in range(8)] == list(range(8)) and [bd.device_index(r, 1) for r in range(3)] == [0, 0, 0]
+    # plan: disjoint, inside the allowed set, GPU-local when the kernel says which cores those are
+    allowed = list(range(16))
+    sets = [bd.plan_affinity(r, 4, allowed, list(range(8, 16))) for r in range(4)]
+    assert all(set(s) <= set(range(8, 16)) and len(s) == 2 for s in sets) and len(set().union(*map(set, sets))) == 8
+    sets = [bd.plan_affinity(r, 8, allowed, None) for r in range(8)]
+    assert len(set().union(*map(set, sets))) == 16 and all(len(s) == 2 for s in sets)
+    assert bd.plan_affinity(0, 8, [3, 5], [3, 5, 7]) == [3] and bd.plan_affinity(1, 8, [3, 5], [0, 1]) in ([5], [3, 5])   # fewer cores than ranks: still a valid set
+    # sysfs: AMD cards only, in card order; local_cpulist first, numa_node as the fall-back
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    sysfs = _fake_sysfs(tmp_path, [("0x1002", "0-7", 0), ("0x1002", None, 0), ("0x8086", "0-15", 0), ("0x1002", "0-7", 0), ("0x1002", "0-7", 0),
+                                   ("0x1002", "8-15", 1), ("0x1002", None, 1), ("0x1002", "8-15", 1), ("0x1002", None, -1)])
+    assert bd._gpu_numa_cpus(0, sysfs) == list(range(8)) and bd._gpu_numa_cpus(1, sysfs) == list(range(8))        # node fall-back
+    assert bd._gpu_numa_cpus(4, sysfs) == list(range(8, 16)) and bd._gpu_numa_cpus(7, sysfs) is None and bd._gpu_numa_cpus(99, sysfs) is None
+    applied = []
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)), raising=False)
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: applied.append(sorted(cpus)), raising=False)
+    recs = [bd.pin_rank(r, 8, 8, sysfs) for r in range(8)]
+    assert [r["physical_device"] for r in recs] == list(range(8)) and applied == [r["cpus"] for r in recs]
+    for r in range(4):
+        assert set(recs[r]["cpus"]) <= set(range(8)) and recs[r]["numa_cpus"] == 8
+    for r in (4, 5, 6):
+        assert set(recs[r]["cpus"]) <= set(range(8, 16))
+    for grp in (recs[:4], recs[4:7]):
+        allc = [c for r in grp for c in r["cpus"]]
+        assert len(allc) == len(set(allc)), "ranks of one socket share cores"
+    assert recs[7]["numa_cpus"] is None and recs[7]["cpus"]                                  # a GPU without a NUMA node: a slice of the allowed set
+    # eight ranks sharing ONE visible GPU (the gloo smoke test of the test box): eight disjoint slices of that GPU's cores
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4")
+    recs = [bd.pin_rank(r, 8, 1, sysfs) for r in range(8)]
+    assert all(r["physical_device"] == 4 for r in recs) and sorted(c for r in recs for c in r["cpus"]) == list(range(8, 16))
+    env = bd.rccl_env_defaults()
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] and os.environ["NCCL_DEBUG"]

@@ -240,21 +240,29 @@ def test_fullsize_blind_T10_fp64_arbiter(net):
         assert dev["build"][i] > min(100.0, min(dev["fp32t16"][i], dev["fp32t8"][i]) - 10.0), (i, dev)
 
 
-def test_fullsize_blind_T50_two_seeds_fp64_arbiter(net):
-    """BASELINE configs[1] as specified, through the WHOLE schedule, under the driver (the 8-seed T = 50 evidence of
-    profiles/r0*_arbiter_L64000_T50.json was builder-run): L = 64 000, nf = 128, T = 50, order 1, 10 operator updates per step, two utterances /
-    noise seeds sampled as one batch.  Arbiter = the restated algorithm in float64 through torch ops on the GPU; the second fp32 execution is the
-    fp32 oracle through torch's own GPU kernels (rocFFT / MIOpen / ATen: other summation orders than the CPU's; 50 CPU steps would take four
-    minutes per seed).  Asserted at every step: the build's SI-SDR to the float64 trajectory is not more than 10 dB below the fp32 oracle's
-    (capped at 100 dB = the fp32 round-off floor), the first step is at that floor, and the final estimates are statistically the same
-    (|delta SI-SDR to clean| of the build against float64 within 3 dB: two float64 executions of this chaotic chain differ by up to ~1.5 dB)."""
+def test_fullsize_blind_T50_population_fp64_arbiter(net):
+    """BASELINE configs[1] as specified, through the WHOLE schedule, at the CURRENT arithmetic, as a POPULATION gate (rounds 3-5
+    gated two seeds at |delta| < 3 dB): L = 64 000, nf = 128, T = 50, order 1, 10 operator updates per step, EIGHT utterances / noise seeds sampled as
+    ONE B = 8 batch by the build -- the headline workload itself.  Arbiter = the restated algorithm in float64 through torch ops on the GPU, batched the
+    same way (oracle.arbiter_runs.run_blind_batched: row b == the B = 1 oracle run of utterance b), executed TWICE (inputs scaled by 1 + 1e-13 the
+    second time): the blind chain is chaotic in the reference's own arithmetic (reference testing/EulerHeunSamplerDPS.py:71-157: ten scale-free Adam
+    steps per diffusion step), so two float64 executions separate, and their separation is the resolution "within 0.1 dB of the reference" can be
+    tested at.  Asserted:
+      * final estimates: median over the 8 utterances of |SI-SDR(build; clean) - SI-SDR(float64; clean)| <= the same median between the two float64
+        executions + 0.1 dB, and its maximum <= 1.5 dB;
+      * every step: the build's SI-SDR to the float64 trajectory is not more than 10 dB below that of one more fp32 execution (the same batched
+        algorithm through torch's own fp32 GPU kernels), capped at 100 dB = the fp32 round-off floor; the first step (before any feedback) is at
+        that floor."""
+    import json
+    import os
+    import time
     from buddy_amd.config import compose
     from buddy_amd.instantiate import instantiate
     from buddy_amd.synth import synth_clean, synth_rir
     from buddy_amd.testing.tester import Tester
-    from oracle.arbiter_runs import run_blind, overrides
+    from oracle.arbiter_runs import run_blind_batched, overrides
     from oracle.sampler_ref import NoiseStream
-    T, nf, up, taps, seeds = 50, 128, 10, 8000, [1, 6]
+    T, nf, up, taps, seeds = 50, 128, 10, 8000, list(range(8))
     args = compose(overrides=overrides(T, up, nf))
     t = Tester(args, net, instantiate(args.diff_params), test_set=None, device="cuda", in_training=True)
     ns = [NoiseStream(9000 + s) for s in seeds]
@@ -266,26 +274,53 @@ def test_fullsize_blind_T50_two_seeds_fp64_arbiter(net):
     tl, gl = sched.tolist(), smp.get_gamma(sched).tolist()
     x = smp.initialize_x(tuple(y.shape), "cuda", sched)
     tr = []
+    t0 = time.time()
     for i in range(T):
         x, xd = smp.step(x, tl[i], tl[i + 1], gl[i], blind=True)
         tr.append(xd.cpu())
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
     assert torch.isfinite(x).all()
+    def batched(**kw):           # two half-batches: torch's autograd keeps every float64 activation of the 36-module network alive (~15 GB per utterance)
+        parts = [run_blind_batched(seeds[lo:lo + 4], L, T, nf, up, taps, **kw) for lo in (0, 4)]
+        torch.cuda.empty_cache()
+        return torch.cat([p[0] for p in parts], dim=1), torch.cat([p[1] for p in parts]), parts[0][2] + parts[1][2]
+    t0 = time.time()
+    a64, clean, k = batched(fp64=True)
+    t_a = time.time() - t0
+    assert k == [n.k for n in ns], "noise streams out of step"
+    b64, _, _ = batched(fp64=True, perturb=1e-13)
+    t0 = time.time()
+    o32, _, k32 = batched(fp64=False)
+    t_o = time.time() - t0
+    assert k32 == k
+    d_build, d_64, d_o32, first = [], [], [], []
     for b, seed in enumerate(seeds):
-        x64, clean, k = run_blind(seed, L, T, nf, up, taps, fp64=True, device="cuda")
-        assert k == ns[b].k, "noise streams out of step"
-        x32, _, k32 = run_blind(seed, L, T, nf, up, taps, device="cuda")
-        assert k32 == k
-        bd = [_sd(tr[i][b], x64[i]) for i in range(T)]
-        od = [_sd(x32[i], x64[i]) for i in range(T)]
-        show = [0, 1, 2, 3, 5, 9, 19, 29, 49]
-        print(f"full size T50 seed {seed}: build      vs float64 per step {[round(bd[i], 1) for i in show]}")
-        print(f"full size T50 seed {seed}: fp32 torch vs float64 per step {[round(od[i], 1) for i in show]}")
-        dc_b, dc_o = _sd(tr[-1][b], clean) - _sd(x64[-1], clean), _sd(x32[-1], clean) - _sd(x64[-1], clean)
-        print(f"full size T50 seed {seed}: delta SI-SDR to clean vs float64: build {dc_b:+.2f} dB, fp32 torch oracle {dc_o:+.2f} dB")
-        assert bd[0] > 105.0
+        ref_c = _sd(a64[-1][b], clean[b])
+        d_build.append(abs(_sd(tr[-1][b], clean[b]) - ref_c))
+        d_64.append(abs(_sd(b64[-1][b], clean[b]) - ref_c))
+        d_o32.append(abs(_sd(o32[-1][b], clean[b]) - ref_c))
+        bd = [_sd(tr[i][b], a64[i][b]) for i in range(T)]
+        od = [_sd(o32[i][b], a64[i][b]) for i in range(T)]
+        first.append(bd[0])
         for i in range(T):
             assert bd[i] > min(100.0, od[i]) - 10.0, (seed, i, bd[i], od[i])
-        assert abs(dc_b) < 3.0, dc_b
+    med = lambda v: float(np.median(v))
+    rep = {"what": "blind DPS, L = 64000, nf = 128, T = 50, order 1, 10 operator updates per step, seeds 0-7 as ONE B = 8 batch; |delta SI-SDR to clean| of the "
+                   "final estimate against the float64 execution (dB), per utterance",
+           "gemm": {0: "fp32", 1: "bf16x3", 2: "f16x2"}[net.get_option("gemm")],
+           "build": [round(v, 3) for v in d_build], "second_float64_execution": [round(v, 3) for v in d_64], "fp32_torch_gpu_kernels": [round(v, 3) for v in d_o32],
+           "median": {"build": med(d_build), "second_float64_execution": med(d_64), "fp32_torch_gpu_kernels": med(d_o32)},
+           "max": {"build": max(d_build), "second_float64_execution": max(d_64), "fp32_torch_gpu_kernels": max(d_o32)},
+           "first_step_SI_SDR_to_float64_dB": [round(v, 1) for v in first],
+           "seconds": {"build_T50_B8": round(t_build, 1), "float64_batched": round(t_a, 1), "fp32_torch_batched": round(t_o, 1)}}
+    print("population gate:", json.dumps(rep))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(rep, open(os.path.join(out, "r06_arbiter_L64000_T50.json"), "w"), indent=1)
+    assert min(first) > 105.0, first
+    assert med(d_build) <= med(d_64) + 0.1, rep["median"]
+    assert max(d_build) <= 1.5, rep["max"]
 
 
 def test_precision_budget_one_denoiser_evaluation_vs_fp64(net):

@@ -35,7 +35,7 @@ def main():
         y = torch.empty_like(x)
         for mode, name, moved in ((0, "copy", 2), (1, "read", 1), (2, "write", 1)):
             for nt in (0, 1):
-                for blocks in (256 * 2, 256 * 4, 256 * 8, 256 * 16, 256 * 32, 256 * 64):
+                for blocks in (-1, -2, -4, -8, 256 * 2, 256 * 8, 256 * 32, 256 * 64, 256 * 256):
                     dt = timed(lambda: _lib.check(lib.buddy_hbm_ubench(x.data_ptr(), y.data_ptr(), n * 4, mode, nt, blocks, S())))
                     r = {"MB": mb, "mode": name, "nt": nt, "blocks": blocks, "GBps": moved * n * 4 / dt / 1e9}
                     out["ubench"].append(r)
