@@ -572,6 +572,22 @@ int buddy_blindop_degrade(void* h, const float* x, float* y, void* stream) { BOP
 int buddy_blindop_time_rir(void* h, float* out, void* stream) { BOP_CHECK(h); if (!out) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_time_rir((BlindOp*)h, out, (hipStream_t)stream); }
 int buddy_blindop_design_filter(void* h, float* A, void* stream) { BOP_CHECK(h); if (!A) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_design_filter((BlindOp*)h, A, (hipStream_t)stream); }
 int buddy_blindop_apply_stft(void* h, const float* x, float* X, void* stream) { BOP_CHECK(h); if (!x || !X) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_apply_stft((BlindOp*)h, x, X, (hipStream_t)stream); }
+int buddy_blindop_degrade_vjp(void* h, const float* x, const float* g_y, float* g_x, float* g_H, void* stream) {
+  BOP_CHECK(h);
+  if (!g_y || (!g_x && !g_H) || (g_H && !x)) { set_error("degrade_vjp: g_y and at least one output; x is needed for g_H"); return BUDDY_ERR_ARG; }
+  return blindop_degrade_vjp((BlindOp*)h, x, g_y, g_x, g_H, (hipStream_t)stream);
+}
+int buddy_blindop_time_rir_vjp(void* h, const float* g_rir, float* g_H, void* stream) { BOP_CHECK(h); if (!g_rir || !g_H) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_time_rir_vjp((BlindOp*)h, g_rir, g_H, (hipStream_t)stream); }
+int buddy_blindop_update_H_vjp(void* h, const float* g_H, float* g_decay, float* g_weights, float* g_phases, void* stream) {
+  BOP_CHECK(h); if (!g_H) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_update_H_vjp((BlindOp*)h, g_H, g_decay, g_weights, g_phases, (hipStream_t)stream);
+}
+int buddy_blindop_stft(void* h, const float* x, int len, float* X, void* stream) { BOP_CHECK(h); if (!x || !X) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_stft_len((BlindOp*)h, x, len, X, (hipStream_t)stream); }
+int buddy_blindop_stft_adjoint(void* h, const float* G, int len, float* g_x, void* stream) { BOP_CHECK(h); if (!G || !g_x) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_stft_len_adj((BlindOp*)h, G, len, g_x, (hipStream_t)stream); }
+int buddy_blindop_stft_loss(void* h, const float* a, const float* b, int len, float weight, float* loss, float* g_a, float* g_b, void* stream) {
+  BOP_CHECK(h); if (!a || !b || !loss) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_stft_loss((BlindOp*)h, a, b, len, weight, loss, g_a, g_b, (hipStream_t)stream);
+}
+int buddy_blindop_set_compression(void* h, float comp) { BOP_CHECK(h); return blindop_set_compression((BlindOp*)h, comp); }
+int buddy_blindop_lengths(void* h, int* L, int* Lr, int* T, int* Td) { BOP_CHECK(h); return blindop_lengths((BlindOp*)h, L, Lr, T, Td); }
 int buddy_blindop_minphase(void* h, const float* hin, float* out, void* stream) { BOP_CHECK(h); if (!hin || !out) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_minphase((BlindOp*)h, hin, out, (hipStream_t)stream); }
 int buddy_blindop_project(void* h, void* stream) { BOP_CHECK(h); return blindop_project((BlindOp*)h, (hipStream_t)stream); }
 int buddy_blindop_get_adam(void* h, float* m_decay, float* v_decay, float* m_weights, float* v_weights, float* m_phases, float* v_phases, int* step,

@@ -22,7 +22,7 @@ struct Options {
   int gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr;                 // fusions of the network graph (A/B switches, default 1)
   int attn_split, attn_nw;                                                           // fp32 attention: forced loop-split count / forward tile height (0 = by shape)
   int igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos, wgemm_epi, wgemm_rt, wgemm_nt;              // GEMM kernels
-  int wino_epi, wino_abl, wino_geo, w6_xcd;                                          // Winograd kernels
+  int wino_epi, wino_abl, wino_geo, w6_xcd, w6_nt;                                          // Winograd kernels
   int gn_fast, c2in4, c2out_tiled;                                                   // GroupNorm / 2-channel convolutions
   int fir_lds, op_graph;                                                             // blind operator
 };

@@ -50,6 +50,14 @@ int blindop_apply_stft(BlindOp* o, const float* x, float* X_ref, hipStream_t st)
 int blindop_minphase(BlindOp* o, const float* h, float* out, hipStream_t st);
 int blindop_project(BlindOp* o, hipStream_t st);
 int blindop_get_adam(BlindOp* o, float* m_decay, float* v_decay, float* m_wts, float* v_wts, float* m_phases, float* v_phases, int* step, hipStream_t st);
+int blindop_degrade_vjp(BlindOp* o, const float* x, const float* g_y, float* g_x, float* g_H_ref, hipStream_t st);
+int blindop_time_rir_vjp(BlindOp* o, const float* g_rir, float* g_H_ref, hipStream_t st);
+int blindop_update_H_vjp(BlindOp* o, const float* g_H_ref, float* g_decay, float* g_wts, float* g_phases_ref, hipStream_t st);
+int blindop_stft_len(BlindOp* o, const float* x, int len, float* X_ref, hipStream_t st);
+int blindop_stft_len_adj(BlindOp* o, const float* G_ref, int len, float* g_x, hipStream_t st);
+int blindop_stft_loss(BlindOp* o, const float* a, const float* b, int len, float weight, float* loss, float* g_a, float* g_b, hipStream_t st);
+int blindop_set_compression(BlindOp* o, float comp);
+int blindop_lengths(BlindOp* o, int* L, int* Lr, int* T, int* Td);
 int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* loss, float* g_x, hipStream_t st);
 int blindop_fir_loss_grad(BlindOp* o, const float* x_den, const float* rir, long long rir_stride, int M, float weight, float* loss, float* g_x,
                           hipStream_t st);

@@ -1112,6 +1112,14 @@ __global__ __launch_bounds__(256) void copy_spec_kernel(const float* X, float* o
     reinterpret_cast<float2*>(out)[((long long)u * FB + f) * T + t] = reinterpret_cast<const float2*>(X + ((long long)u * T + t) * LDSP)[f];
   }
 }
+// reference (U,F,T,2) -> padded frame-major [U][T][LDSP] (pad floats zeroed): the inverse of copy_spec_kernel / copy_h_kernel (T = Nf)
+__global__ __launch_bounds__(256) void spec_from_ref_kernel(const float* in, float* X, int U, int T) {
+  const long long total = (long long)U * T * (LDSP / 2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int f = (int)(i % (LDSP / 2)), t = (int)((i / (LDSP / 2)) % T), u = (int)(i / ((long long)(LDSP / 2) * T));
+    reinterpret_cast<float2*>(X + ((long long)u * T + t) * LDSP)[f] = f < FB ? reinterpret_cast<const float2*>(in)[((long long)u * FB + f) * T + t] : make_float2(0.f, 0.f);
+  }
+}
 // plain minimum-phase output: hm = Re(o)[:Lm] (no direct-path override)
 
 inline int gridf(long long total) { long long g = (total + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1; return (int)g; }
@@ -1554,6 +1562,104 @@ int blindop_get_adam(BlindOp* o, float* m_decay, float* v_decay, float* m_wts, f
   HIPCHK(hipGetLastError());
   return BUDDY_OK;
 }
+
+// ---- the differentiable surface the REFERENCE's own sampler needs (round 6): it autograds through operator.degradation (testing/EulerHeunSamplerDPS.py:61-69),
+// through update_H / get_time_RIR inside optimize_op (:71-113) and through get_loss(...)(y, y_hat) (utils/losses.py:26-71).  Each entry below is the
+// vector-Jacobian product of one of those pieces, built from the adjoint kernels the fused likelihood / optimisation calls already use; the Python classes
+// wrap them as torch.autograd.Function, so an unmodified torch-loop sampler runs on the HIP operator.
+static int frames_of(const BlindOp* o, int len) { return len == o->L ? o->T : (len == o->Lr ? o->Td : -1); }
+// x (U, L), g_y (U, L) -> g_x = (d degrade / d x)^T g_y and / or g_H (U, 513, Nf, 2) = (d degrade / d H)^T g_y, for the CURRENT H
+int blindop_degrade_vjp(BlindOp* o, const float* x, const float* g_y, float* g_x, float* g_H_ref, hipStream_t st) {
+  o->st = st;
+  const int U = o->U, T = o->T, L = o->L;
+  o->istft_adj(g_y, T, WIN + WIN / 2, o->env_T, L, o->norm, o->X2);                         // gradient w.r.t. the filtered spectrogram
+  if (g_H_ref) {
+    o->stft(x, L, WIN, T, 1.f / o->norm, o->X1);
+    o->gradh(o->X1, (long long)T * LDSP, o->X2, T, 0);
+    hipLaunchKernelGGL(copy_h_kernel, dim3(gridf((long long)U * o->Nf * FB)), dim3(256), 0, st, (const float*)o->GH, g_H_ref, U, o->Nf);
+  }
+  if (g_x) {
+    hipLaunchKernelGGL(fir_adjx_kernel, dim3(gridf((long long)U * T * FB)), dim3(256), 0, st, (const float*)o->X2, (const float*)o->H, o->X3, U, T, o->Nf);
+    o->stft_adj(o->X3, L, WIN, T, 1.f / o->norm, g_x);
+  }
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+// g_rir (U, Lr) -> g_H (U, 513, Nf, 2) = (d get_time_RIR / d H)^T g_rir
+int blindop_time_rir_vjp(BlindOp* o, const float* g_rir, float* g_H_ref, hipStream_t st) {
+  o->st = st;
+  o->istft_adj(g_rir, o->Td, WIN + WIN / 2, o->env_d, o->Lr, o->norm, o->X2);
+  o->gradh(o->Xdelta, 0LL, o->X2, o->Td, 0);
+  hipLaunchKernelGGL(copy_h_kernel, dim3(gridf((long long)o->U * o->Nf * FB)), dim3(256), 0, st, (const float*)o->GH, g_H_ref, o->U, o->Nf);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+// g_H (U, 513, Nf, 2) -> gradients of (decay, weights, phases) through cons(design_filter(.) exp(j phases)): the state of the LAST update_H is used
+// (A, the minimum-phase spectra); any output may be NULL
+int blindop_update_H_vjp(BlindOp* o, const float* g_H_ref, float* g_decay, float* g_wts, float* g_phases_ref, hipStream_t st) {
+  o->st = st;
+  const int U = o->U, Nf = o->Nf;
+  hipLaunchKernelGGL(spec_from_ref_kernel, dim3(gridf((long long)U * Nf * (LDSP / 2))), dim3(256), 0, st, g_H_ref, o->GH, U, Nf);
+  o->cons_backward(o->GH);
+  hipLaunchKernelGGL(h0_bwd_knots_kernel, dim3(U * Nf), dim3(256), 0, st, (const float*)o->GFin, (const float*)o->A, (const float*)o->Apre, (const float*)o->phi, o->tabs(),
+                     (const float*)o->dmv, o->gphi, o->gdm, U, o->K, Nf);
+  hipLaunchKernelGGL(design_bwd_params_kernel, dim3(cdiv(U * o->E * o->NB, 4)), dim3(256), 0, st, (const float*)o->gdm, (const float*)o->decay, (const float*)o->wts, o->gdecay, o->gw, U, o->E, o->NB, Nf);
+  const size_t nb = (size_t)U * o->E * o->NB * 4;
+  if (g_decay) HIPCHK(hipMemcpyAsync(g_decay, o->gdecay, nb, hipMemcpyDeviceToDevice, st));
+  if (g_wts) HIPCHK(hipMemcpyAsync(g_wts, o->gw, nb, hipMemcpyDeviceToDevice, st));
+  if (g_phases_ref) hipLaunchKernelGGL(transpose_fk_kernel, dim3(gridf((long long)U * Nf * FB)), dim3(256), 0, st, (const float*)o->gphi, g_phases_ref, U, Nf, 0);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+// apply_stft (:41-52) of signals of the bound length L (T frames) or of the time-RIR length Lr (Td frames), and its adjoint
+int blindop_stft_len(BlindOp* o, const float* x, int len, float* X_ref, hipStream_t st) {
+  o->st = st;
+  const int Tn = frames_of(o, len);
+  if (Tn < 0) { set_error("apply_stft: the handle transforms signals of its bound length or of its time-RIR length only"); return BUDDY_ERR_ARG; }
+  o->stft(x, len, WIN, Tn, 1.f / o->norm, o->X2);
+  hipLaunchKernelGGL(copy_spec_kernel, dim3(gridf((long long)o->U * Tn * FB)), dim3(256), 0, st, (const float*)o->X2, X_ref, o->U, Tn);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+int blindop_stft_len_adj(BlindOp* o, const float* G_ref, int len, float* g_x, hipStream_t st) {
+  o->st = st;
+  const int Tn = frames_of(o, len);
+  if (Tn < 0) { set_error("apply_stft adjoint: the handle transforms signals of its bound length or of its time-RIR length only"); return BUDDY_ERR_ARG; }
+  hipLaunchKernelGGL(spec_from_ref_kernel, dim3(gridf((long long)o->U * Tn * (LDSP / 2))), dim3(256), 0, st, G_ref, o->X3, o->U, Tn);
+  o->stft_adj(o->X3, len, WIN, Tn, 1.f / o->norm, g_x);
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+// loss_u = weight * l2_comp_stft_summean(a_u, b_u) (utils/losses.py:59-64) of two signals of length len in {L, Lr}, with the gradient w.r.t. either
+// argument (NULL: not wanted).  The formula is symmetric in (a, b); each gradient is one pass of the loss kernel against the other side's compressed spectrum.
+int blindop_stft_loss(BlindOp* o, const float* a, const float* b, int len, float weight, float* loss, float* g_a, float* g_b, hipStream_t st) {
+  o->st = st;
+  const int U = o->U, Tn = frames_of(o, len);
+  if (Tn < 0) { set_error("stft loss: signals of the handle's bound length or of its time-RIR length only"); return BUDDY_ERR_ARG; }
+  const dim3 gc(gridf((long long)U * Tn * FB));
+  o->stft(a, len, WIN, Tn, 1.f / o->norm, o->X1);
+  o->stft(b, len, WIN, Tn, 1.f / o->norm, o->X2);
+  if (g_b || !g_a) {
+    hipLaunchKernelGGL(compress_kernel, gc, dim3(256), 0, st, (const float*)o->X1, o->Ybuf, (long long)U * Tn, o->c.comp);
+    o->comp_loss(o->Ybuf, o->X2, g_b ? o->X3 : nullptr, Tn, weight, loss, 0);
+    if (g_b) o->stft_adj(o->X3, len, WIN, Tn, 1.f / o->norm, g_b);
+  }
+  if (g_a) {
+    hipLaunchKernelGGL(compress_kernel, gc, dim3(256), 0, st, (const float*)o->X2, o->Ybuf, (long long)U * Tn, o->c.comp);
+    o->comp_loss(o->Ybuf, o->X1, o->X3, Tn, weight, loss, 0);
+    o->stft_adj(o->X3, len, WIN, Tn, 1.f / o->norm, g_a);
+  }
+  HIPCHK(hipGetLastError());
+  return BUDDY_OK;
+}
+// the compression exponent of the spectral losses, (0, 1]; the cached compressed observation must be set again afterwards (buddy_blindop_set_y)
+int blindop_set_compression(BlindOp* o, float comp) {
+  if (!(comp > 0.f && comp <= 1.f)) { set_error("compression factor must be in (0, 1]"); return BUDDY_ERR_ARG; }
+  if (comp != o->c.comp && o->gexec) { (void)hipGraphExecDestroy(o->gexec); o->gexec = nullptr; }      // the captured loop holds the exponent as a kernel argument
+  o->c.comp = comp;
+  return BUDDY_OK;
+}
+int blindop_lengths(BlindOp* o, int* L, int* Lr, int* T, int* Td) { if (L) *L = o->L; if (Lr) *Lr = o->Lr; if (T) *T = o->T; if (Td) *Td = o->Td; return BUDDY_OK; }
 
 // likelihood: loss_u = w_rec * l2_comp_stft_summean(y, degrade(x_den)), g = d sum_u loss_u / d x_den  (uses the CURRENT H)
 int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* loss, float* g_x, hipStream_t st) {

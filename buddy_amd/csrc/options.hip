@@ -54,6 +54,7 @@ const Entry kTable[] = {
     {"wino_abl", "BUDDY_WINO_ABL", &Options::wino_abl, 0, 3, 0, nullptr},
     {"wino_geo", "BUDDY_WINO_GEO", &Options::wino_geo, 42, 82, 42, nullptr},
     {"w6_xcd", "BUDDY_W6_XCD", &Options::w6_xcd, 0, 1, 1, nullptr},
+    {"w6_nt", "BUDDY_W6_NT", &Options::w6_nt, 0, 1, 1, nullptr},
     {"gn_fast", "BUDDY_GN_FAST", &Options::gn_fast, 0, 1, 1, nullptr},
     {"c2in4", "BUDDY_C2IN4", &Options::c2in4, 0, 1, 1, nullptr},
     {"c2out_tiled", "BUDDY_C2OUT_TILED", &Options::c2out_tiled, 0, 1, 1, nullptr},

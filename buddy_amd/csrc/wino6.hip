@@ -207,7 +207,11 @@ __global__ __launch_bounds__(256) void w6_input_kernel(const float* __restrict__
 // ph = 2 py + px; tile pixel (y, x) of phase ph is pixel (2 y + py, 2 x + px) of the (2H, 2W, N) output (depth-to-space).  The statistics partials
 // of phase ph are chunks [ph * chunks, (ph + 1) * chunks) of 4 * chunks per utterance.  No residual.  TS = 7: tile row r of phase py is row
 // 7 ty + r - py of the phase image (the patch starts at low-resolution row 7 ty - 1 for both phases).
-template <int STAT, bool UP = false, int TS = 6>
+// NTM (A/B switch w6_nt): M is read with non-temporal loads -- every 16-byte piece is read exactly once, in whole 512-byte rows per instruction (the
+// streaming ubench: reads 6.3 -> 7.1 TB/s with them, tools/hbm_bw.py; the GEMM's V rows, read in four partial-line pieces, lost 45 % with them).
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4nt(const float* p) { const f32x4w v = __builtin_nontemporal_load(reinterpret_cast<const f32x4w*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+template <int STAT, bool UP = false, int TS = 6, bool NTM = false>
 __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict__ Mb, const IgemmParams p, const W6Geo geo, int chunks, int TL,
                                                         double* __restrict__ stat, const W4Gn bg) {
   __shared__ float4 lds[32 * TS * 8];
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void w6_output_kernel(const float* __restrict_
       const float* src = Mb + tile * NM + nq;
       float4 m[8], s[TS];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) m[i] = ld4(src + (long long)(i * 8 + col) * ps);
+      for (int i = 0; i < 8; ++i) m[i] = NTM ? ld4nt(src + (long long)(i * 8 + col) * ps) : ld4(src + (long long)(i * 8 + col) * ps);
       at8(m, s);                                             // column: s[:, col] = A^T m[:, col]
 #pragma unroll
       for (int r = 0; r < TS; ++r) lds[(tl * (TS * 8) + r * 8 + col) * QC + ql] = s[r];
@@ -431,6 +435,11 @@ void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hi
   } else if (up == 2) {
     if (stat && bwd_gn) hipLaunchKernelGGL((w6_output_kernel<2, false, 7>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, *bwd_gn);
     else hipLaunchKernelGGL((w6_output_kernel<0, false, 7>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
+  }
+  else if (cur_opt().w6_nt) {
+    if (stat && bwd_gn) hipLaunchKernelGGL((w6_output_kernel<2, false, 6, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, *bwd_gn);
+    else if (stat) hipLaunchKernelGGL((w6_output_kernel<1, false, 6, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, W4Gn{});
+    else hipLaunchKernelGGL((w6_output_kernel<0, false, 6, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
   }
   else if (stat && bwd_gn) hipLaunchKernelGGL(w6_output_kernel<2>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, *bwd_gn);
   else if (stat) hipLaunchKernelGGL(w6_output_kernel<1>, grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, W4Gn{});

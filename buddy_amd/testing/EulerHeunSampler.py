@@ -33,7 +33,7 @@ class EulerHeunSampler(Sampler):
     def stochastic_timestep(self, x, t, gamma, Snoise=1):
         t_hat = t + gamma * t
         epsilon = self._randn(x.shape, x.device) * Snoise     # Snoise from the config never reaches here (reference :41,50)
-        if x.is_cuda and x.dim() == 2:
+        if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and getattr(self, "use_hip_update", True):      # the fused kernels are fp32
             from . import _hipops
             return _hipops.perturb(x, epsilon, float((t_hat ** 2 - t ** 2) ** (1 / 2))), t_hat
         x_hat = x + ((t_hat ** 2 - t ** 2) ** (1 / 2)) * epsilon

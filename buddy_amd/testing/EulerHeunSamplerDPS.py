@@ -95,7 +95,7 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
 
     def step(self, x_i, t_i, t_iplus1, gamma_i, blind=False):
         t_i, t_iplus1, gamma_i = self._scalar(t_i), self._scalar(t_iplus1), self._scalar(gamma_i)
-        if x_i.is_cuda and x_i.dim() == 2 and self.use_hip_update:
+        if x_i.is_cuda and x_i.dim() == 2 and x_i.dtype == torch.float32 and self.use_hip_update:
             return self._step_hip(x_i, t_i, t_iplus1, gamma_i, blind)
         x_hat, t_hat = self.stochastic_timestep(x_i, t_i, gamma_i)
         ode_integrand, x_den = self._guided_eval(x_hat, t_hat, blind)

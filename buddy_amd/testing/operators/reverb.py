@@ -38,17 +38,36 @@ class RIROperator(Operator, OperatorSTFT):
         from .subband_filtering import create_stft_loss_handle
         from ... import _lib
         l, hp = ps.rec_loss, self.op_hp
-        if not (y.is_cuda and y.dim() == 2 and l.name == "l2_comp_stft_summean" and abs(l.compression_factor - 0.667) < 1e-9
+        if not (y.is_cuda and y.dim() == 2 and l.name == "l2_comp_stft_summean" and 0.0 < float(l.compression_factor) <= 1.0
                 and (hp.NFFT, hp.win_length, hp.hop, hp.window) == (1024, 512, 128, "hann") and y.shape[1] >= 1024):
             return False
-        key = (int(y.shape[0]), int(y.shape[1]))
+        h = self._loss_handle(int(y.shape[0]), int(y.shape[1]))
+        self._hip_w = float(l.get("weight", 1.0))
+        _lib.check(_lib.load().buddy_blindop_set_compression(h, float(l.compression_factor)))
+        _lib.check(_lib.load().buddy_blindop_set_y(h, _lib.ptr(y.contiguous().float()), _lib.stream_ptr()))
+        return True
+
+    def _loss_handle(self, U, n):
+        """library handle (STFT-1024/512/128 + compressed-spectrum loss machinery) for (U, n) signals; one is kept, rebuilt when the shape changes"""
+        from .subband_filtering import create_stft_loss_handle
+        hp = self.op_hp
+        if (hp.NFFT, hp.win_length, hp.hop, hp.window) != (1024, 512, 128, "hann") or n < 1024:
+            raise NotImplementedError("the HIP STFT / loss kernels are built for the operator STFT 1024 / 512 / 128 (hann) and signals of >= 1024 samples")
+        key = (int(U), int(n))
         if getattr(self, "_hip_key", None) != key:
             self._hip_release()
             self._hip_h = create_stft_loss_handle(self.sample_rate, key[0], key[1])
             self._hip_key = key
-        self._hip_w = float(l.get("weight", 1.0))
-        _lib.check(_lib.load().buddy_blindop_set_y(self._hip_h, _lib.ptr(y.contiguous().float()), _lib.stream_ptr()))
-        return True
+        return self._hip_h
+
+    def apply_stft(self, x):
+        """reference reverb.py:54-72 -> (U, 513, frames) complex64, differentiable (its adjoint runs in the library): get_loss(...)(y, y_hat) of the
+        reference's own utils/losses.py autograds through it"""
+        from .subband_filtering import _StftFn
+        xx = x.unsqueeze(0) if x.dim() == 1 else x
+        h = self._loss_handle(int(xx.shape[0]), int(xx.shape[1]))
+        T = 1 + (int(xx.shape[1]) + self.win_length) // self.hop_length
+        return torch.view_as_complex(_StftFn.apply(xx, h, T))
 
     def hip_rec_loss(self, x_den):
         from .subband_filtering import _HipFirRecLoss

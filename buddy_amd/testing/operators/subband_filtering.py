@@ -52,6 +52,127 @@ class _HipRecLoss(torch.autograd.Function):
         return gout * g, None, None
 
 
+# ---- the differentiable surface (round 6): the pieces the REFERENCE's own sampler autograds through, each a torch.autograd.Function whose forward and
+# backward are library calls (buddy_blindop_* and their _vjp entries).  H travels between them as its real view (U, 513, Nf, 2): no complex-gradient
+# conventions inside the Functions; ``operator.H`` hands out the complex view.
+class _UpdateHFn(torch.autograd.Function):
+    """H = cons(design_filter(decay, weights) * exp(j phases)) (reference subband_filtering.py:253-285) from the operator's persistent parameter tensors."""
+
+    @staticmethod
+    def forward(ctx, decay, weights, phases, op):
+        lib = _lib.require_gpu()
+        c = lambda t: t.detach().to(op.device).float().contiguous()
+        d, w, p = c(decay), c(weights), c(phases)
+        _lib.check(lib.buddy_blindop_set_params(op._h, _lib.ptr(d), _lib.ptr(w), _lib.ptr(p), 0, _lib.stream_ptr()))
+        _lib.check(lib.buddy_blindop_update_H(op._h, None, _lib.stream_ptr()))
+        H = torch.empty(op.U, op.n_fft // 2 + 1, op.Nf, 2, device=op.device)
+        _lib.check(lib.buddy_blindop_get_H(op._h, _lib.ptr(H), _lib.stream_ptr()))
+        op._h_epoch += 1
+        ctx.op, ctx.epoch = op, op._h_epoch
+        return H
+
+    @staticmethod
+    def backward(ctx, gH):
+        op = ctx.op
+        if ctx.epoch != op._h_epoch:
+            raise _lib.BuddyHipError("backward through a stale update_H: the handle keeps the state of its LAST update_H (call backward before the next one)")
+        E, NB, F = op.num_exponentials, op.num_bands, op.n_fft // 2 + 1
+        gd = torch.empty(op.U, E, NB, device=op.device); gw = torch.empty_like(gd); gp = torch.empty(op.U, F, op.Nf, device=op.device)
+        _lib.check(_lib.load().buddy_blindop_update_H_vjp(op._h, _lib.ptr(gH.contiguous().float()), _lib.ptr(gd), _lib.ptr(gw), _lib.ptr(gp), _lib.stream_ptr()))
+        return gd, gw, gp, None
+
+
+class _DegradeFn(torch.autograd.Function):
+    """y = degradation(x) with the operator's current H (reference :82-101); differentiable w.r.t. x and -- when H carries a graph -- w.r.t. H."""
+
+    @staticmethod
+    def forward(ctx, x, Hr, op):
+        xx = x.contiguous().float()
+        y = torch.empty_like(xx)
+        _lib.check(_lib.require_gpu().buddy_blindop_degrade(op._h, _lib.ptr(xx), _lib.ptr(y), _lib.stream_ptr()))
+        ctx.op, ctx.epoch = op, op._h_epoch
+        ctx.save_for_backward(xx)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        op = ctx.op
+        if ctx.epoch != op._h_epoch:
+            raise _lib.BuddyHipError("backward through a degradation whose H has been rebuilt since (update_H): differentiate before the next update_H")
+        x, = ctx.saved_tensors
+        want_x, want_H = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx = torch.empty_like(x) if want_x else None
+        gH = torch.empty(op.U, op.n_fft // 2 + 1, op.Nf, 2, device=x.device) if want_H else None
+        if want_x or want_H:
+            _lib.check(_lib.load().buddy_blindop_degrade_vjp(op._h, _lib.ptr(x), _lib.ptr(gy.contiguous().float()), _lib.ptr(gx), _lib.ptr(gH), _lib.stream_ptr()))
+        return gx, gH, None
+
+
+class _TimeRirFn(torch.autograd.Function):
+    """get_time_RIR (reference :103-113) = degradation of the unit impulse; differentiable w.r.t. H."""
+
+    @staticmethod
+    def forward(ctx, Hr, op):
+        out = torch.empty(op.U, op.length_rir + 1024, device=op.device)
+        _lib.check(_lib.require_gpu().buddy_blindop_time_rir(op._h, _lib.ptr(out), _lib.stream_ptr()))
+        ctx.op, ctx.epoch = op, op._h_epoch
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        op = ctx.op
+        if ctx.epoch != op._h_epoch:
+            raise _lib.BuddyHipError("backward through a time RIR whose H has been rebuilt since (update_H)")
+        gH = torch.empty(op.U, op.n_fft // 2 + 1, op.Nf, 2, device=op.device)
+        _lib.check(_lib.load().buddy_blindop_time_rir_vjp(op._h, _lib.ptr(g.contiguous().float()), _lib.ptr(gH), _lib.stream_ptr()))
+        return gH, None
+
+
+class _StftFn(torch.autograd.Function):
+    """apply_stft (reference :41-52) -> real view (U, 513, frames, 2); backward = the adjoint transform (library handle ``h`` of the right (U, L))."""
+
+    @staticmethod
+    def forward(ctx, x, h, frames):
+        xx = x.contiguous().float()
+        U, n = xx.shape
+        X = torch.empty(U, 513, frames, 2, device=xx.device)
+        _lib.check(_lib.require_gpu().buddy_blindop_stft(h, _lib.ptr(xx), n, _lib.ptr(X), _lib.stream_ptr()))
+        ctx.h, ctx.n = h, n
+        return X
+
+    @staticmethod
+    def backward(ctx, G):
+        gx = torch.empty(G.shape[0], ctx.n, device=G.device)
+        _lib.check(_lib.load().buddy_blindop_stft_adjoint(ctx.h, _lib.ptr(G.contiguous().float()), ctx.n, _lib.ptr(gx), _lib.stream_ptr()))
+        return gx, None, None
+
+
+class _StftLossFn(torch.autograd.Function):
+    """sum_u weight * l2_comp_stft_summean(a_u, b_u) (reference utils/losses.py:59-64) in ONE library call, gradient w.r.t. whichever side needs it."""
+
+    @staticmethod
+    def forward(ctx, a, b, h, weight, sink):
+        aa, bb = a.contiguous().float(), b.contiguous().float()
+        U, n = aa.shape
+        loss = torch.empty(U, device=aa.device)
+        ga = torch.empty_like(aa) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(bb) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.require_gpu().buddy_blindop_stft_loss(h, _lib.ptr(aa), _lib.ptr(bb), n, float(weight), _lib.ptr(loss), _lib.ptr(ga), _lib.ptr(gb),
+                                                              _lib.stream_ptr()))
+        ctx.save_for_backward(*[t for t in (ga, gb) if t is not None])
+        ctx.have = (ga is not None, gb is not None)
+        if sink is not None:
+            sink.last_loss_per_utt = loss
+        return loss.sum()
+
+    @staticmethod
+    def backward(ctx, gout):
+        saved = list(ctx.saved_tensors)
+        ga = gout * saved.pop(0) if ctx.have[0] else None
+        gb = gout * saved.pop(0) if ctx.have[1] else None
+        return ga, gb, None, None, None
+
+
 def create_stft_loss_handle(sample_rate, num_utts, length):
     """Library handle used only for its STFT-1024/512/128 + compressed-spectrum-loss machinery (informed operator): the blind filter
     parameters of the handle are placeholders."""
@@ -126,6 +247,11 @@ class BlindSubbandFiltering(SubbandFiltering):
                                             int(bool(op_hp.enforce_long_decay_in_second_exponential)), C.byref(h)))
         self._h = h
         self._comp_created = 0.667
+        self._h_epoch = 0             # bumped by every update_H: a saved autograd node of an older H refuses to run its backward
+        self._Hr = None               # H of the last autograd-mode update_H (real view, carries the graph to the parameters)
+        self._pt = None               # persistent parameter tensors (decay, weights, phases) once somebody asked for ``params`` (see there)
+        self._pt_seen = None
+        self._lib_newer = True        # the library's copy changed since the persistent tensors were last filled
         d0 = decay.unsqueeze(0).repeat(self.U, 1, 1).to(self.device).contiguous()
         w0 = torch.tensor(wts, dtype=torch.float32).unsqueeze(0).repeat(self.U, 1, 1).to(self.device).contiguous()
         with torch.no_grad():
@@ -166,17 +292,43 @@ class BlindSubbandFiltering(SubbandFiltering):
         _lib.check(_lib.load().buddy_blindop_get_params(self._h, _lib.ptr(d), _lib.ptr(w), _lib.ptr(p), _lib.stream_ptr()))
         return d, w, p
 
+    # The reference keeps its parameters as torch tensors the sampler's Adam holds on to (``Adam(operator.params + operator.params_phases)``,
+    # EulerHeunSamplerDPS.py:193) and flips ``requires_grad`` on (:78-81).  Here the parameters live in the library handle; ``params`` /
+    # ``params_phases`` hand out PERSISTENT tensors that mirror them: refreshed from the handle when a library call changed it (hip_optimize,
+    # project_params, set_params), pushed into the handle by update_H when torch changed them in place (an optimizer step: tensor._version moved).
+    def _persistent(self):
+        if self._pt is None:
+            self._pt = list(self._get())
+            self._lib_newer = False
+            self._pt_seen = [t._version for t in self._pt]
+        elif self._lib_newer:
+            with torch.no_grad():
+                for t, v in zip(self._pt, self._get()):
+                    t.copy_(v)
+            self._lib_newer = False
+            self._pt_seen = [t._version for t in self._pt]
+        return self._pt
+
+    def _torch_side_changed(self):
+        return self._pt is not None and not self._lib_newer and [t._version for t in self._pt] != self._pt_seen
+
+    def _push_persistent(self):
+        d, w, p = (t.detach().float().contiguous() for t in self._pt)
+        _lib.check(_lib.load().buddy_blindop_set_params(self._h, _lib.ptr(d), _lib.ptr(w), _lib.ptr(p), 0, _lib.stream_ptr()))
+        self._pt_seen = [t._version for t in self._pt]
+
     @property
     def params(self):
-        d, w, _ = self._get()
-        return [d, w]
+        return self._persistent()[:2]
 
     @property
     def params_phases(self):
-        return [self._get()[2]]
+        return self._persistent()[2:]
 
     @property
     def H(self):
+        if self._Hr is not None:          # autograd mode: the tensor the graph runs through
+            return torch.view_as_complex(self._Hr)
         out = torch.empty(self.U, self.n_fft // 2 + 1, self.Nf, 2, device=self.device)
         _lib.check(_lib.load().buddy_blindop_get_H(self._h, _lib.ptr(out), _lib.stream_ptr()))
         return torch.view_as_complex(out)
@@ -189,21 +341,42 @@ class BlindSubbandFiltering(SubbandFiltering):
     def set_params(self, decay=None, weights=None, phases=None, reset_adam=False):
         c = lambda t: None if t is None else t.to(self.device).float().contiguous()
         d, w, p = c(decay), c(weights), c(phases)
+        if self._torch_side_changed():
+            self._push_persistent()       # an in-place torch update that has not reached the handle yet must not be lost under a partial set
         _lib.check(_lib.load().buddy_blindop_set_params(self._h, _lib.ptr(d), _lib.ptr(w), _lib.ptr(p), int(reset_adam), _lib.stream_ptr()))
+        if d is not None or w is not None or p is not None:
+            self._lib_newer = True
 
     def update_H(self, rir=None, H=None, use_noise=False, noise=None, phases=None):
         if rir is not None or H is not None:
             raise NotImplementedError("an externally given H / RIR is the informed scenario (RIROperator); the blind operator designs H from its parameters")
         if phases is not None:
             self.set_params(phases=phases)
+        if not use_noise and self._pt is not None and any(t.requires_grad for t in self._pt) and torch.is_grad_enabled():
+            # the reference's optimize_op (:78-83): parameters flagged requires_grad, then update_H -- H comes out attached to them
+            d, w, p = self._persistent()
+            self._Hr = _UpdateHFn.apply(d, w, p, self)
+            self._pt_seen = [t._version for t in self._pt]
+            return
+        if self._torch_side_changed():
+            self._push_persistent()
         n = None
         if use_noise:
             n = (noise if noise is not None else self._randn((self.length_rir,))).to(self.device).float().contiguous()
         _lib.check(_lib.load().buddy_blindop_update_H(self._h, _lib.ptr(n), _lib.stream_ptr()))
+        self._h_epoch += 1
+        self._Hr = None
+        if use_noise:
+            self._lib_newer = True        # phases := angle(H)
 
     def project_params(self):
         """reference :298-331 on the device-resident parameters (also applied inside buddy_blindop_optimize after every Adam step)"""
+        if self._torch_side_changed():
+            self._push_persistent()
         _lib.check(_lib.load().buddy_blindop_project(self._h, _lib.stream_ptr()))
+        if self._pt is not None:          # the reference projects its tensors in place (:298-331): the persistent mirrors follow
+            self._lib_newer = True
+            self._persistent()
 
     def design_filter(self, correct_OLA=True):
         """reference :241-251 -> (U, F, Nf) magnitudes from the current decay / weights"""
@@ -214,13 +387,13 @@ class BlindSubbandFiltering(SubbandFiltering):
 
     def apply_stft(self, x):
         """reference :41-52 for signals of the bound length: (U, F, T) complex64"""
-        xx = (x.unsqueeze(0) if x.dim() == 1 else x).contiguous().float()
-        if tuple(xx.shape) != (self.U, self.length):
-            raise NotImplementedError(f"the HIP operator transforms (U={self.U}, L={self.length}) signals, got {tuple(xx.shape)}")
-        T = 1 + (self.length + self.win_length) // self.hop_length
-        X = torch.empty(self.U, self.n_fft // 2 + 1, T, 2, device=self.device)
-        _lib.check(_lib.load().buddy_blindop_apply_stft(self._h, _lib.ptr(xx), _lib.ptr(X), _lib.stream_ptr()))
-        return torch.view_as_complex(X)
+        xx = x.unsqueeze(0) if x.dim() == 1 else x
+        n = int(xx.shape[-1])
+        if xx.shape[0] != self.U or n not in (self.length, self.length_rir + 1024):
+            raise NotImplementedError(f"the HIP operator transforms (U={self.U}, L={self.length}) signals and its own time RIRs "
+                                      f"(U, {self.length_rir + 1024}), got {tuple(xx.shape)}")
+        T = 1 + (n + self.win_length) // self.hop_length
+        return torch.view_as_complex(_StftFn.apply(xx, self._h, T))      # differentiable: the reference's get_loss(...) autograds through apply_stft
 
     def minimum_phase(self, h):
         """utils/reverb_utils.py:9-23 at the size cons() uses: h (U, hop * (Nf + 1))"""
@@ -245,15 +418,14 @@ class BlindSubbandFiltering(SubbandFiltering):
     def degradation(self, x, mode="waveform", H=None, detach_operator=False):
         assert mode == "waveform" and H is None
         squeeze = x.dim() == 1
-        xx = (x.unsqueeze(0) if squeeze else x).contiguous().float()
-        y = torch.empty_like(xx)
-        _lib.check(_lib.load().buddy_blindop_degrade(self._h, _lib.ptr(xx), _lib.ptr(y), _lib.stream_ptr()))
+        xx = x.unsqueeze(0) if squeeze else x
+        Hr = self._Hr if (self._Hr is not None and not detach_operator) else None
+        y = _DegradeFn.apply(xx, Hr, self)           # a graph w.r.t. x (likelihood score, :61-69) and, in autograd mode, w.r.t. H (optimize_op, :86)
         return y.squeeze(0) if squeeze else y
 
     def get_time_RIR(self, excitation=None, H=None):
         assert excitation is None and H is None
-        out = torch.empty(self.U, self.length_rir + 1024, device=self.device)
-        _lib.check(_lib.load().buddy_blindop_time_rir(self._h, _lib.ptr(out), _lib.stream_ptr()))
+        out = _TimeRirFn.apply(self._Hr, self)
         return out.squeeze(0) if self.U == 1 else out
 
     # ---- sampler fast paths ----
@@ -262,9 +434,12 @@ class BlindSubbandFiltering(SubbandFiltering):
         # the regulariser is gated like the reference gates it (EulerHeunSamplerDPS.py:94,200): only loss.name == "none" turns it off;
         # RIR_noise_regularization.use is never read there
         reg_loss = ps.RIR_noise_regularization.loss
-        for l in (ps.rec_loss, ps.rec_loss_params) + (() if reg_loss.name == "none" else (reg_loss,)):
-            assert l.name == "l2_comp_stft_summean" and abs(l.compression_factor - self._comp_created) < 1e-9, \
-                "HIP operator supports l2_comp_stft_summean with compression_factor 0.667"
+        used = (ps.rec_loss, ps.rec_loss_params) + (() if reg_loss.name == "none" else (reg_loss,))
+        comps = {float(l.compression_factor) for l in used}
+        if any(l.name != "l2_comp_stft_summean" for l in used) or len(comps) != 1 or not (0.0 < min(comps) <= 1.0):
+            raise NotImplementedError("the HIP operator evaluates l2_comp_stft_summean with ONE compression factor in (0, 1] for the reconstruction, "
+                                      "parameter and regulariser terms (the shipped configs: 0.667 for all three)")
+        self.set_compression(comps.pop())
         self.w_rec = float(ps.rec_loss.get("weight", 1.0))
         self.w_rec_params = float(ps.rec_loss_params.get("weight", 1.0))
         self.w_reg = None if reg_loss.name == "none" else float(reg_loss.get("weight", 1.0))
@@ -272,7 +447,22 @@ class BlindSubbandFiltering(SubbandFiltering):
         self.hp = ps.blind_hp
         yy = y.contiguous().float()
         _lib.check(_lib.load().buddy_blindop_set_y(self._h, _lib.ptr(yy), _lib.stream_ptr()))
+        self._y_bound = yy
         self.set_params(reset_adam=True)          # fresh Adam state, like constructing the optimizer in the reference's predict_conditional (:193)
+
+    def _loss_handle(self, U, n):
+        """library handle whose STFT / loss kernels take (U, n) signals (utils.losses.LossSpec.__call__)"""
+        if U != self.U or n not in (self.length, self.length_rir + 1024):
+            raise NotImplementedError(f"the HIP operator evaluates losses of (U={self.U}, {self.length}) signals and of its time RIRs, got ({U}, {n})")
+        return self._h
+
+    def set_compression(self, c):
+        """compression exponent of the spectral losses (reference utils/losses.py:60-62: any value in (0, 1])"""
+        if abs(float(c) - self._comp_created) > 1e-12:
+            _lib.check(_lib.load().buddy_blindop_set_compression(self._h, float(c)))
+            self._comp_created = float(c)
+            if getattr(self, "_y_bound", None) is not None:       # the cached compressed observation depends on the exponent
+                _lib.check(_lib.load().buddy_blindop_set_y(self._h, _lib.ptr(self._y_bound), _lib.stream_ptr()))
 
     def hip_rec_loss(self, x_den):
         return _HipRecLoss.apply(x_den, self, self.w_rec)
@@ -293,8 +483,11 @@ class BlindSubbandFiltering(SubbandFiltering):
             noise = noise.contiguous()
         t_op = max(min(float(t), self.reg.crop_sigma_max), self.reg.crop_sigma_min)
         xd = x_den.contiguous().float()
+        if self._torch_side_changed():
+            self._push_persistent()
         _lib.check(_lib.load().buddy_blindop_optimize(self._h, _lib.ptr(xd), _lib.ptr(noise), float(t_op), n_it, self.w_rec_params,
                                                       float(self.w_reg or 0.0), float(self.hp.lr_op), float(self.hp.beta1), float(self.hp.beta2),
                                                       float(self.hp.weight_decay), _lib.stream_ptr()))
+        self._h_epoch += 1; self._Hr = None; self._lib_newer = True      # parameters and H moved inside the library
 
 

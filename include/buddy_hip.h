@@ -215,7 +215,7 @@ int buddy_ncsnpp_set_fir(void* handle, int fir);
 /* Per-handle launcher options -- "no hidden global state" (SURVEY.md 8(b)): every switch a launcher consults (attention core, GEMM arithmetic, the
  * fusion / layout A/B switches) is a field of the handle's option struct; two handles in one process may differ.  Keys (csrc/options.hip): conv, gemm,
  * attention, gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr, attn_split, attn_nw, igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos,
- * wgemm_epi, wgemm_rt, wgemm_nt, wino_epi, wino_abl, wino_geo, w6_xcd, gn_fast, c2in4, c2out_tiled, fir_lds, op_graph.  An unknown key or a value out of range is
+ * wgemm_epi, wgemm_rt, wgemm_nt, wino_epi, wino_abl, wino_geo, w6_xcd, w6_nt, gn_fast, c2in4, c2out_tiled, fir_lds, op_graph.  An unknown key or a value out of range is
  * BUDDY_ERR_ARG.  A handle starts from the process defaults = the BUDDY_<KEY> environment variables, parsed and validated in ONE place at handle
  * creation: a bad value, or an unknown BUDDY_* name within edit distance 2 of a switch (a misspelling), makes buddy_ncsnpp_create fail with a message naming it;
  * BUDDY_* names that resemble no switch are not this library's and are left alone.  Set options before the first forward or between calls: the
@@ -317,6 +317,27 @@ int buddy_blindop_time_rir(void* handle, float* rir /*(U, 128*Nf+1024)*/, void* 
 int buddy_blindop_design_filter(void* handle, float* A, void* stream);
 int buddy_blindop_apply_stft(void* handle, const float* x, float* X, void* stream);
 int buddy_blindop_minphase(void* handle, const float* h, float* out, void* stream);
+/* ---- the differentiable surface (round 6): vector-Jacobian products of the pieces the REFERENCE's own sampler autograds through -- operator.degradation
+ * in get_likelihood_score (testing/EulerHeunSamplerDPS.py:61-69), update_H / degradation / get_time_RIR in optimize_op (:71-113), apply_stft inside
+ * get_loss(...)(y, y_hat) (utils/losses.py:26-71).  buddy_amd/testing/operators wraps each as a torch.autograd.Function, so an unmodified torch-loop
+ * sampler (oracle/sampler_ref.py = the reference's control flow) runs on the HIP operator.  H-shaped gradients are (U, 513, Nf, 2) = (d/dRe, d/dIm). */
+/* degradation^T for the CURRENT H: g_x (U, L) and / or g_H from g_y (U, L); x (U, L) is needed for g_H only; either output may be NULL (not both) */
+int buddy_blindop_degrade_vjp(void* handle, const float* x, const float* g_y, float* g_x, float* g_H, void* stream);
+int buddy_blindop_time_rir_vjp(void* handle, const float* g_rir /*(U, 128*Nf+1024)*/, float* g_H, void* stream);      /* get_time_RIR^T */
+/* update_H^T (H = cons(design_filter(decay, weights) exp(j phases)), subband_filtering.py:253-285): gradients of the three parameter tensors in the
+ * reference layouts from g_H, using the state the LAST buddy_blindop_update_H left in the handle; any output may be NULL */
+int buddy_blindop_update_H_vjp(void* handle, const float* g_H, float* g_decay, float* g_weights, float* g_phases, void* stream);
+/* apply_stft (:41-52) of signals of the bound length L (T = 1 + (L + 512) / 128 frames) or of the time-RIR length 128 * Nf + 1024, X (U, 513, frames, 2),
+ * and its adjoint g_x (U, len) from G (U, 513, frames, 2); other lengths are BUDDY_ERR_ARG */
+int buddy_blindop_stft(void* handle, const float* x, int len, float* X, void* stream);
+int buddy_blindop_stft_adjoint(void* handle, const float* G, int len, float* g_x, void* stream);
+/* loss[u] = weight * l2_comp_stft_summean(a_u, b_u) (utils/losses.py:59-64) for two signals of length len (as above) with the gradient w.r.t. either
+ * argument (g_a / g_b (U, len), NULL = not wanted) */
+int buddy_blindop_stft_loss(void* handle, const float* a, const float* b, int len, float weight, float* loss, float* g_a, float* g_b, void* stream);
+/* compression exponent of the spectral losses, (0, 1] (the handle is created with one; the shipped configs use 0.667); call buddy_blindop_set_y again
+ * afterwards: the cached compressed observation depends on it */
+int buddy_blindop_set_compression(void* handle, float compression_factor);
+int buddy_blindop_lengths(void* handle, int* L, int* L_rir, int* frames, int* frames_rir);
 int buddy_blindop_project(void* handle, void* stream);
 int buddy_blindop_get_adam(void* handle, float* m_decay, float* v_decay, float* m_weights, float* v_weights, float* m_phases, float* v_phases,
                            int* step /*host*/, void* stream);

@@ -81,7 +81,11 @@ def run_blind_batched(seeds, L, T, nf, updates, rir_taps, fp64=False, weight_see
     with (precision.fp64(device) if fp64 else _on_device(device)), (_on_device(device) if fp64 else contextlib.nullcontext()):
         dt, dev = torch.get_default_dtype(), torch.get_default_device()
         P = ncsnpp_ref.to_torch(synth_state_dict(weight_seed, nf))
-        net = lambda z, cn: ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
+
+        class _OracleNet(torch.nn.Module):              # the product sampler's constructor calls model.eval()
+            def forward(self, z, cn):
+                return ncsnpp_ref.ncsnpp_time(P, z, cn, 510, 128)
+        net = _OracleNet()
         op_hp = args.tester.informed_dereverberation.op_hp
         cs, ys = [], []
         for s in seeds:

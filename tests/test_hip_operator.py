@@ -183,3 +183,84 @@ def test_informed_likelihood_loss_and_gradient():
     xt = xd.clone().requires_grad_(True)
     gt, = torch.autograd.grad(get_loss(ps.rec_loss, operator=st)(y, op.degradation(xt)), xt)
     assert rel(gh, gt) < 5e-4
+
+
+
+def test_autograd_surface_vs_torch_restatement():
+    """Round 6: the differentiable surface of the product operator (what the reference's own sampler autograds through) against torch autograd of the
+    restatement on the same parameters / inputs: d degradation / d x (likelihood score, EulerHeunSamplerDPS.py:61-69); with the parameter tensors
+    flagged requires_grad, update_H -> degradation + get_time_RIR -> losses -> backward down to (decay, weights, phases) (optimize_op, :78-105);
+    apply_stft and its adjoint for both signal lengths; the callable loss of utils.losses.get_loss for compression factors 0.667 / 0.5 / 1.0 with
+    the gradient w.r.t. either argument."""
+    from buddy_amd.config import AttrDict
+    from buddy_amd.utils.losses import get_loss as get_loss_hip
+    from oracle.batched.losses import get_loss
+    U, L = 2, 16000
+    args, opt, oph, nt, nh = make_ops(U, L)
+    ps = args.tester.posterior_sampling
+    x, y = signals(U, L)
+    w = torch.randn(U, L, device="cuda")
+    # (1) d <w, degradation(x)> / d x
+    xt = x.clone().requires_grad_(True); xh = x.clone().requires_grad_(True)
+    gt, = torch.autograd.grad((w * opt.degradation(xt)).sum(), xt)
+    gh, = torch.autograd.grad((w * oph.degradation(xh)).sum(), xh)
+    assert rel(gh, gt) < 5e-4
+    # (2) apply_stft: value, adjoint, both lengths
+    for sig in (x, oph.get_time_RIR().detach()):
+        st = sig.clone().requires_grad_(True); sh = sig.clone().requires_grad_(True)
+        Xt, Xh = opt.apply_stft(st), oph.apply_stft(sh)
+        assert Xh.shape == Xt.shape and rel(torch.view_as_real(Xh), torch.view_as_real(Xt)) < 2e-5
+        Wc = torch.randn_like(torch.view_as_real(Xt))
+        g1, = torch.autograd.grad((torch.view_as_real(Xt) * Wc).sum(), st)
+        g2, = torch.autograd.grad((torch.view_as_real(Xh) * Wc).sum(), sh)
+        assert rel(g2, g1) < 2e-5
+    # (3) the callable loss, any compression factor, gradient w.r.t. either side
+    for c in (0.667, 0.5, 1.0):
+        la = AttrDict(name="l2_comp_stft_summean", weight=3.0, compression_factor=c)
+        lt, lh = get_loss(la, opt), get_loss_hip(la, oph)
+        a1 = (0.8 * x).requires_grad_(True); b1 = (0.9 * y).requires_grad_(True)
+        a2 = a1.detach().clone().requires_grad_(True); b2 = b1.detach().clone().requires_grad_(True)
+        vt = lt(a1, b1); vh = lh(a2, b2)
+        assert abs(float(vh) - float(vt)) < 2e-4 * abs(float(vt)), (c, float(vh), float(vt))
+        gta, gtb = torch.autograd.grad(vt, (a1, b1)); gha, ghb = torch.autograd.grad(vh, (a2, b2))
+        assert rel(gha, gta) < 2e-3 and rel(ghb, gtb) < 2e-3, (c, rel(gha, gta), rel(ghb, gtb))
+        assert rel(oph.last_loss_per_utt, lt(a1, b1, per_utt=True)) < 2e-4
+    oph.set_compression(0.667)
+    # (4) optimize_op's graph: parameters -> update_H -> degradation / get_time_RIR -> losses -> backward
+    lp, lr = get_loss(ps.rec_loss_params, opt), get_loss(ps.RIR_noise_regularization.loss, opt)
+    lph, lrh = get_loss_hip(ps.rec_loss_params, oph), get_loss_hip(ps.RIR_noise_regularization.loss, oph)
+    for p in opt.params + opt.params_phases:
+        p.requires_grad = True
+    for p in oph.params + oph.params_phases:
+        p.requires_grad = True
+    assert oph.params[0] is oph.params[0], "the parameter tensors must be persistent objects (the sampler's Adam holds on to them)"
+    opt.update_H(); oph.update_H()
+    assert oph.H.requires_grad and rel(torch.view_as_real(oph.H), torch.view_as_real(opt.H)) < 5e-4
+    rt, rh = opt.get_time_RIR(), oph.get_time_RIR()
+    n = torch.randn_like(rt)
+    loss_t = lp(y, opt.degradation(x)) + lr(rt, (rt + 0.004 * n).detach())
+    loss_h = lph(y, oph.degradation(x)) + lrh(rh, (rh + 0.004 * n).detach())
+    assert abs(float(loss_h) - float(loss_t)) < 3e-4 * abs(float(loss_t))
+    gs_t = torch.autograd.grad(loss_t, opt.params + opt.params_phases)
+    loss_h.backward()
+    for got, want, name in zip([p.grad for p in oph.params + oph.params_phases], gs_t, ("decay", "weights", "phases")):
+        assert got is not None and rel(got, want) < 5e-3, (name, rel(got, want))
+    # an in-place optimizer step on the persistent tensors reaches the handle at the next update_H; project_params keeps both sides in step
+    with torch.no_grad():
+        for ph_, pt_ in zip(oph.params + oph.params_phases, opt.params + opt.params_phases):
+            ph_.add_(0.01 * torch.sign(ph_)); pt_.add_(0.01 * torch.sign(pt_))
+    for p in oph.params + opt.params:
+        p.detach_()
+    oph.project_params(); opt.project_params()
+    assert rel(oph.params[0], opt.params[0]) < 1e-6 and rel(oph.params[1], opt.params[1]) < 1e-6
+    opt.update_H(); oph.update_H()
+    assert rel(torch.view_as_real(oph.H.detach()), torch.view_as_real(opt.H.detach())) < 5e-4
+    # a backward through an H that has since been rebuilt is refused, not computed from the wrong state
+    for p in oph.params:
+        p.requires_grad = True
+    oph.update_H()
+    yy = oph.degradation(x)
+    oph.update_H()
+    from buddy_amd import _lib
+    with pytest.raises(_lib.BuddyHipError, match="rebuilt since"):
+        yy.sum().backward()
