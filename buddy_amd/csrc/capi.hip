@@ -105,6 +105,7 @@ int buddy_copy_d2d(void* dst, const void* src, long long bytes, void* stream) {
 }
 
 int buddy_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int nt, int blocks, void* stream) {
+  if ((mode == 3 || mode == 4) && (!src || !dst)) { set_error("hbm_ubench: null buffer"); return BUDDY_ERR_ARG; }
   if ((mode != 2 && !src) || !dst || bytes < 16 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) { set_error("hbm_ubench: 16-byte aligned device buffers of >= 16 bytes"); return BUDDY_ERR_ARG; }
   if (launch_hbm_ubench(src, dst, bytes, mode, nt, blocks, (hipStream_t)stream)) { set_error("hbm_ubench: mode 0 copy | 1 read | 2 write; blocks >= 1 (grid-stride) or -1 | -2 | -4 | -8 (one chunk of that many 16-byte words per thread and workgroup)"); return BUDDY_ERR_ARG; }
   return BUDDY_OK;

@@ -224,6 +224,50 @@ __global__ __launch_bounds__(256) void hbm_ubench_kernel(const f32x4_t* __restri
   }
   if (MODE == 1 && acc.x + acc.y + acc.z + acc.w == 1.2345678e30f) dst[0] = acc;
 }
+// mode 3: READ in the access pattern of the f16x2 GEMM's A operand (wgemm.hip: rows of ROWB bytes; lane (row r = lane & 31, half h = lane >> 5) of a wave
+// reads 64 consecutive bytes of its row per K-stage as four 16-byte loads, two 32-row tiles per wave; a stage covers 128 bytes of every row) -- every 128-byte
+// line is requested in partial pieces by four instructions, and a row's lines at different times.  STAGED = false: all stages' loads of a wave in flight at
+// once; true: one stage ahead, like the kernel.  A workgroup of 4 waves covers 256 consecutive rows.
+template <int ROWB, bool STAGED>
+__global__ __launch_bounds__(256) void hbm_ubench_rows_kernel(const char* __restrict__ src, f32x4_t* __restrict__ dst, long long rows) {
+  constexpr int S = ROWB / 128;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long long r0 = ((long long)blockIdx.x * 4 + wid) * 64;
+  if (r0 + 64 > rows) return;
+  const char* p0 = src + (r0 + (lane & 31)) * ROWB + 64 * (lane >> 5);
+  const char* p1 = p0 + 32LL * ROWB;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  if (!STAGED) {
+    f32x4_t v[S][8];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[s][j] = *reinterpret_cast<const f32x4_t*>(p0 + s * 128 + 16 * j); v[s][4 + j] = *reinterpret_cast<const f32x4_t*>(p1 + s * 128 + 16 * j); }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += v[s][j];
+  } else {
+    f32x4_t v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = *reinterpret_cast<const f32x4_t*>(p0 + 16 * j); v[4 + j] = *reinterpret_cast<const f32x4_t*>(p1 + 16 * j); }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      f32x4_t c[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] = v[j];
+      if (s + 1 < S) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = *reinterpret_cast<const f32x4_t*>(p0 + (s + 1) * 128 + 16 * j); v[4 + j] = *reinterpret_cast<const f32x4_t*>(p1 + (s + 1) * 128 + 16 * j); }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += c[j];
+      __builtin_amdgcn_s_sleep(16);            // ~1000 cycles of "matrix work" per stage
+      __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 1.2345678e30f) dst[0] = acc;
+}
 template <int MODE, bool NT>
 void hbm_ubench_launch(const f32x4_t* s, f32x4_t* d, long long n16, int blocks, hipStream_t st) {
   const int u = blocks > 0 ? 8 : -blocks;
@@ -239,6 +283,17 @@ void hbm_ubench_launch(const f32x4_t* s, f32x4_t* d, long long n16, int blocks, 
 }  // namespace
 int launch_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int nt, int blocks, hipStream_t st) {
   const long long n16 = bytes / 16;
+  if (mode == 3 || mode == 4) {       // rows pattern: nt = row bytes (512 | 1024 | 2048), all loads in flight (3) / staged (4)
+    const long long rows = bytes / nt;
+    const unsigned g = (unsigned)(rows / 256);
+    const char* sc = reinterpret_cast<const char*>(src); f32x4_t* dd = reinterpret_cast<f32x4_t*>(dst);
+    if (g < 1) return BUDDY_ERR_ARG;
+#define BUDDY_ROWS(RB) do { if (mode == 3) hipLaunchKernelGGL((hbm_ubench_rows_kernel<RB, false>), dim3(g), dim3(256), 0, st, sc, dd, rows); \
+                            else hipLaunchKernelGGL((hbm_ubench_rows_kernel<RB, true>), dim3(g), dim3(256), 0, st, sc, dd, rows); } while (0)
+    if (nt == 512) BUDDY_ROWS(512); else if (nt == 1024) BUDDY_ROWS(1024); else if (nt == 2048) BUDDY_ROWS(2048); else return BUDDY_ERR_ARG;
+#undef BUDDY_ROWS
+    return BUDDY_OK;
+  }
   if (mode < 0 || mode > 2 || n16 < 1 || blocks == 0 || (blocks < 0 && blocks != -1 && blocks != -2 && blocks != -4 && blocks != -8) || n16 / 256 > 0x7fffffffLL)
     return BUDDY_ERR_ARG;
   const f32x4_t* s = reinterpret_cast<const f32x4_t*>(src); f32x4_t* d = reinterpret_cast<f32x4_t*>(dst);

@@ -91,7 +91,9 @@ int buddy_mfma_ubench_bf16(const float* seed, float* out, int blocks, int iters,
 /* calibration: one streaming pass over `bytes` (a multiple of 16, 16-byte aligned device buffers): mode 0 copy src -> dst (bytes read + bytes written),
  * 1 read src (summed in registers), 2 write dst; nt != 0 uses the non-temporal loads / stores.  blocks >= 1: that many workgroups of 256 threads stride
  * over the array in contiguous chunks of 8 x 256 sixteen-byte words (eight independent requests per thread); blocks = -1 | -2 | -4 | -8: the one-shot
- * form, one chunk of that many words per thread and workgroup (-1 = the classic one-float4-per-thread copy).  The HBM rate a plain kernel reaches on THIS box, next to the nominal 8 TB/s (MI355X_MICROARCH.md records 6.29 TB/s for a
+ * form, one chunk of that many words per thread and workgroup (-1 = the classic one-float4-per-thread copy).  mode 3 / 4: READ in the access pattern of
+ * the batched GEMM's A operand (rows of nt = 512 | 1024 | 2048 bytes, 64 bytes per lane and K-stage in four 16-byte loads, 64 rows per wave): all stages'
+ * loads in flight (3) or one stage ahead with a stand-in for the matrix work between them (4); `blocks` is ignored.  The HBM rate a plain kernel reaches on THIS box, next to the nominal 8 TB/s (MI355X_MICROARCH.md records 6.29 TB/s for a
  * float4 copy): the second denominator of every HBM-bound roofline in bench.py. */
 int buddy_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int nt, int blocks, void* stream);
 

@@ -249,8 +249,10 @@ def test_fullsize_blind_T50_population_fp64_arbiter(net):
     steps per diffusion step), so two float64 executions separate, and their separation is the resolution "within 0.1 dB of the reference" can be
     tested at.  Asserted:
       * final estimates: median over the 8 utterances of |SI-SDR(build; clean) - SI-SDR(float64; clean)| <= the same median between the two float64
-        executions + 0.1 dB, and its maximum <= 1.5 dB;
-      * every step: the build's SI-SDR to the float64 trajectory is not more than 10 dB below that of one more fp32 execution (the same batched
+        executions + 0.1 dB, and its maximum <= the larger of 1.5 dB and the two float64 executions' own maximum + 0.5 dB (measured round 6: medians
+        0.80 / 0.74 dB, maxima 2.20 / 2.18 dB -- the worst utterance of the population separates two FLOAT64 runs by more than 2 dB; torch's own fp32
+        GPU kernels: 0.66 / 10.5 dB);
+      * every step (first four utterances): the build's SI-SDR to the float64 trajectory is not more than 10 dB below that of one more fp32 execution (the same batched
         algorithm through torch's own fp32 GPU kernels), capped at 100 dB = the fp32 round-off floor; the first step (before any feedback) is at
         that floor."""
     import json
@@ -291,20 +293,21 @@ def test_fullsize_blind_T50_population_fp64_arbiter(net):
     assert k == [n.k for n in ns], "noise streams out of step"
     b64, _, _ = batched(fp64=True, perturb=1e-13)
     t0 = time.time()
-    o32, _, k32 = batched(fp64=False)
+    o32, _, k32 = run_blind_batched(seeds[:4], L, T, nf, up, taps, fp64=False)      # the per-step floor on the first half (80 s for all eight)
     t_o = time.time() - t0
-    assert k32 == k
+    assert k32 == k[:4]
     d_build, d_64, d_o32, first = [], [], [], []
     for b, seed in enumerate(seeds):
         ref_c = _sd(a64[-1][b], clean[b])
         d_build.append(abs(_sd(tr[-1][b], clean[b]) - ref_c))
         d_64.append(abs(_sd(b64[-1][b], clean[b]) - ref_c))
-        d_o32.append(abs(_sd(o32[-1][b], clean[b]) - ref_c))
         bd = [_sd(tr[i][b], a64[i][b]) for i in range(T)]
-        od = [_sd(o32[i][b], a64[i][b]) for i in range(T)]
         first.append(bd[0])
-        for i in range(T):
-            assert bd[i] > min(100.0, od[i]) - 10.0, (seed, i, bd[i], od[i])
+        if b < o32.shape[1]:
+            d_o32.append(abs(_sd(o32[-1][b], clean[b]) - ref_c))
+            od = [_sd(o32[i][b], a64[i][b]) for i in range(T)]
+            for i in range(T):
+                assert bd[i] > min(100.0, od[i]) - 10.0, (seed, i, bd[i], od[i])
     med = lambda v: float(np.median(v))
     rep = {"what": "blind DPS, L = 64000, nf = 128, T = 50, order 1, 10 operator updates per step, seeds 0-7 as ONE B = 8 batch; |delta SI-SDR to clean| of the "
                    "final estimate against the float64 execution (dB), per utterance",
@@ -320,7 +323,7 @@ def test_fullsize_blind_T50_population_fp64_arbiter(net):
         json.dump(rep, open(os.path.join(out, "r06_arbiter_L64000_T50.json"), "w"), indent=1)
     assert min(first) > 105.0, first
     assert med(d_build) <= med(d_64) + 0.1, rep["median"]
-    assert max(d_build) <= 1.5, rep["max"]
+    assert max(d_build) <= max(1.5, max(d_64) + 0.5), rep["max"]
 
 
 def test_precision_budget_one_denoiser_evaluation_vs_fp64(net):
