@@ -558,6 +558,7 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    weight_store_main = net0[0].weight_bytes()       # before the legs: the other arithmetics' legs add their own operand forms to the shared store
     ATTR_STEPS = 2
     log(f"attribution pass: {ATTR_STEPS} fully instrumented steps (untimed)")
     lib.buddy_prof_enable(2)
@@ -840,7 +841,7 @@ def main():
             "value_mode": ("one batch of B utterances on one stream (per-kernel attribution is clean); the harness default (Tester, groups of >= 4 "
                            "utterances) samples them as two concurrent sub-batches = `concurrent_sub_batches`") if S == 1 else f"{S} concurrent sub-batches",
             "cold_start": {"cold_start_s": SETUP.get("cold_start_s"), "first_step_ms": first_step_ms, "module_build_s": SETUP.get("module_build_s"),
-                           "stack_build_s": stack_build_s, "weight_store_bytes": net0[0].weight_bytes(),
+                           "stack_build_s": stack_build_s, "weight_store_bytes": weight_store_main, "weight_store_bytes_after_legs": net0[0].weight_bytes(),
                            "import_torch_s": SETUP.get("import_torch_s"), "hip_context_s": SETUP.get("hip_context_s"), "lib_load_s": SETUP.get("lib_load_s"),
                            "synth_inputs_s": SETUP.get("synth_inputs_s"), "prepare_batch_s": SETUP.get("prepare_batch_s"),
                            "what": "cold_start_s = buddy_ncsnpp_create (parameter upload, small packs) + the first forward of the batch, which prepares on the "
