@@ -105,8 +105,10 @@ _SIGS = {
                                                   C.c_int, _f32p, C.c_void_p]),
     "buddy_axpby_rows": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_void_p]),
     "buddy_perturb": (C.c_int, [_f32p, _f32p, C.c_float, _f32p, C.c_longlong, C.c_void_p]),
-    "buddy_dps_update": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p,
+    "buddy_dps_update": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p,
                                    C.c_int, C.c_int, C.c_void_p]),
+    "buddy_row_scale": (C.c_int, [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "buddy_fill_rows4": (C.c_int, [_f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "buddy_row_moments": (C.c_int, [_f32p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "buddy_blindop_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

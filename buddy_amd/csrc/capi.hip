@@ -11,8 +11,10 @@ namespace buddy {
 void launch_axpby_rows(const float* x, const float* y, const float* a, const float* c, float* out, int B, int L, hipStream_t st);
 void launch_row_moments(const float* x, double* out, int B, int L, hipStream_t st);
 void launch_perturb(const float* x, const float* eps, float scale, float* out, long long n, hipStream_t st);
-void launch_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* den_scale_b, const float* base, const float* d_prev,
+void launch_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* lh_scale_b, const float* den_scale_b, const float* base, const float* d_prev,
                        float t, float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, hipStream_t st);
+void launch_row_scale(const float* x, float* out, int B, int L, int mode, float p0, float p1, hipStream_t st);
+void launch_fill_rows4(float* out, int B, float v0, float v1, float v2, float v3, hipStream_t st);
 void launch_mfma_ubench(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st);
 void launch_mfma_ubench_bf16(const float* seed, float* out, int blocks, int iters, unsigned long long* clk, hipStream_t st);
 int launch_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int nt, int blocks, hipStream_t st);
@@ -509,10 +511,20 @@ int buddy_perturb(const float* x, const float* eps, float scale, float* out, lon
   return finish();
 }
 
-int buddy_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* den_scale, const float* base, const float* d_prev, float t,
-                     float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, void* stream) {
+int buddy_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* lh_scale, const float* den_scale, const float* base,
+                     const float* d_prev, float t, float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, void* stream) {
   if (!x_hat || !x_den || !base || !out || t <= 0.f) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
-  launch_dps_update(x_hat, x_den, lh, den_scale, base, d_prev, t, dt, w_prev, w_cur, out, d_out, x_den_out, B, L, (hipStream_t)stream);
+  launch_dps_update(x_hat, x_den, lh, lh_scale, den_scale, base, d_prev, t, dt, w_prev, w_cur, out, d_out, x_den_out, B, L, (hipStream_t)stream);
+  return finish();
+}
+int buddy_row_scale(const float* x, float* out, int B, int L, int mode, float p0, float p1, void* stream) {
+  if (!x || !out || B < 1 || L < 2 || (mode != 0 && mode != 1) || (mode == 1 && !(p1 > 0.f))) { set_error("row_scale: mode 0 (p0 / std) or 1 (p0 / (norm / p1 + 1e-8)), L >= 2"); return BUDDY_ERR_ARG; }
+  launch_row_scale(x, out, B, L, mode, p0, p1, (hipStream_t)stream);
+  return finish();
+}
+int buddy_fill_rows4(float* out, int B, float v0, float v1, float v2, float v3, void* stream) {
+  if (!out || B < 1) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  launch_fill_rows4(out, B, v0, v1, v2, v3, (hipStream_t)stream);
   return finish();
 }
 

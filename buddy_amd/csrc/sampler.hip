@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void perturb_kernel(const float* x, const floa
 //   d      = -t * (x_den' - x_hat) / t^2 + lh                         (ODE integrand + likelihood score)
 //   out    = base + dt * (w_prev * d_prev + w_cur * d)                (Euler: base = x_hat, w_prev = 0, w_cur = 1; Heun: 0.5 / 0.5)
 // also writes d (for the Heun corrector) and the rescaled x_den'.
-__global__ __launch_bounds__(256) void dps_update_kernel(const float* x_hat, const float* x_den, const float* lh, const float* den_scale_b,
+__global__ __launch_bounds__(256) void dps_update_kernel(const float* x_hat, const float* x_den, const float* lh, const float* lh_scale_b, const float* den_scale_b,
                                                          const float* base, const float* d_prev, float t, float dt, float w_prev, float w_cur,
                                                          float* out, float* d_out, float* x_den_out, int B, int L) {
   const long long n = (long long)B * L;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void dps_update_kernel(const float* x_hat, con
     const float xd = x_den[i] * (den_scale_b ? den_scale_b[b] : 1.f);
     const float score = (xd - x_hat[i]) * inv_t * inv_t;
     float d = -t * score;
-    if (lh) d += lh[i];
+    if (lh) d += lh_scale_b ? lh_scale_b[b] * lh[i] : lh[i];
     float acc = w_cur * d;
     if (d_prev) acc += w_prev * d_prev[i];
     out[i] = base[i] + dt * acc;
@@ -58,6 +58,49 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* x, double
     __syncthreads();
   }
   if (tid == 0) { out[b * 2] = s1[0]; out[b * 2 + 1] = s2[0]; }
+}
+
+// One scalar per utterance from a row's moments, in ONE launch (round 6: the sampler formed these with ~10 tensor expressions per step, each its own
+// 4 us kernel, and an 8-workgroup moments kernel of 100 us): one workgroup of 1024 threads per row, fp64 accumulation.
+//   mode 0: out[b] = p0 / std_b        unbiased standard deviation (Tensor.std()): constraint_speech_magnitude, EulerHeunSamplerDPS.py:127-129
+//   mode 1: out[b] = p0 / (||row_b||_2 / p1 + 1e-8)                                 the guidance normaliser zeta / (normguide + 1e-8), :66-69
+// The float roundings follow the tensor expressions they replace: std / norm rounded to fp32 first, then fp32 division(s).
+__global__ __launch_bounds__(1024) void row_scale_kernel(const float* __restrict__ x, float* __restrict__ out, int L, int mode, float p0, float p1) {
+  __shared__ double s1[1024], s2[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* r = x + (long long)b * L;
+  double a = 0, q = 0;
+  if ((L & 3) == 0 && ((uintptr_t)r & 15) == 0) {
+    const float4* r4 = reinterpret_cast<const float4*>(r);
+    for (int i = tid; i < L / 4; i += 1024) {
+      const float4 v = r4[i];
+      a += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (int i = tid; i < L; i += 1024) { const double v = r[i]; a += v; q += v * v; }
+  }
+  s1[tid] = a; s2[tid] = q;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (tid < off) { s1[tid] += s1[tid + off]; s2[tid] += s2[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (mode == 0) {
+      double var = (s2[0] - s1[0] * s1[0] / L) / (L - 1);
+      if (var < 0) var = 0;
+      out[b] = p0 / (float)sqrt(var);
+    } else {
+      const float nrm = (float)sqrt(s2[0]);
+      out[b] = p0 / (nrm / p1 + 1e-8f);
+    }
+  }
+}
+// out[k][b] = v[k], k < 4: the four EDM preconditioning scalars of one sigma, broadcast over the batch (the host evaluates diff_params/edm.py:44-75 in fp32)
+__global__ void fill_rows4_kernel(float* out, int B, float v0, float v1, float v2, float v3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 4 * B) { const int k = i / B; out[i] = k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : v3; }
 }
 
 // Direct-form FIR, 1024 outputs per block, taps staged through LDS in tiles of 1024.
@@ -109,11 +152,17 @@ void launch_perturb(const float* x, const float* eps, float scale, float* out, l
   long long g = (n + 255) / 256; if (g > 4096) g = 4096;
   hipLaunchKernelGGL(perturb_kernel, dim3((int)g), dim3(256), 0, st, x, eps, scale, out, n);
 }
-void launch_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* den_scale_b, const float* base, const float* d_prev,
+void launch_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* lh_scale_b, const float* den_scale_b, const float* base, const float* d_prev,
                        float t, float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, hipStream_t st) {
   long long g = ((long long)B * L + 255) / 256; if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(dps_update_kernel, dim3((int)g), dim3(256), 0, st, x_hat, x_den, lh, den_scale_b, base, d_prev, t, dt, w_prev, w_cur, out, d_out,
+  hipLaunchKernelGGL(dps_update_kernel, dim3((int)g), dim3(256), 0, st, x_hat, x_den, lh, lh_scale_b, den_scale_b, base, d_prev, t, dt, w_prev, w_cur, out, d_out,
                      x_den_out, B, L);
+}
+void launch_row_scale(const float* x, float* out, int B, int L, int mode, float p0, float p1, hipStream_t st) {
+  hipLaunchKernelGGL(row_scale_kernel, dim3(B), dim3(1024), 0, st, x, out, L, mode, p0, p1);
+}
+void launch_fill_rows4(float* out, int B, float v0, float v1, float v2, float v3, hipStream_t st) {
+  hipLaunchKernelGGL(fill_rows4_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, st, out, B, v0, v1, v2, v3);
 }
 void launch_row_moments(const float* x, double* out, int B, int L, hipStream_t st) {
   hipLaunchKernelGGL(row_moments_kernel, dim3(B), dim3(256), 0, st, x, out, L);

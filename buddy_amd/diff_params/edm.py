@@ -29,6 +29,9 @@ class EDM(SDE):
         return (self.sigma_data ** 2 + sigma ** 2) ** (-0.5)
 
     def cnoise(self, sigma):      # edm.py:69-75
+        if not torch.is_tensor(sigma):      # numpy float32 scalar (SDE.host_scalars)
+            import numpy as np
+            return np.float32(1 / 4) * np.log(np.float32(sigma))
         return (1 / 4) * torch.log(sigma)
 
     def lambda_w(self, sigma):    # edm.py:77-81

@@ -272,6 +272,26 @@ class NCSNppTime(nn.Module):
         cskip[b]*x + cout[b]*net(cin[b]*x, cnoise[b]) (reference diff_params/shared.py:98-120).  x: (B,L); rest (B,)."""
         return _NetFn.apply(x.float(), cnoise.float(), (cin.float(), cskip.float(), cout.float()), self)
 
+    def denoise_saved(self, x, scal4):
+        """The EDM denoiser (as ``denoise_fused``) WITHOUT an autograd graph: forward with the handle's VJP tape kept; pair it with ``input_vjp``.
+        The sampler's fast path (round 6) calls the two library entries directly -- no autograd engine, no ones / sum / mul helper kernels around
+        them.  x (B, L); scal4 (4, B) = rows (cnoise, cin, cskip, cout)."""
+        lib = _lib.require_gpu()
+        x = x.contiguous().float()
+        B, L = x.shape
+        y = torch.empty_like(x)
+        _lib.check(lib.buddy_ncsnpp_forward(self._get_handle(), _lib.ptr(x), _lib.ptr(scal4[0]), _lib.ptr(scal4[1]), _lib.ptr(scal4[2]), _lib.ptr(scal4[3]),
+                                            _lib.ptr(y), B, L, 1, _lib.stream_ptr()))
+        self._fwd_id += 1           # an autograd node of an earlier forward is stale from here on
+        return y
+
+    def input_vjp(self, g):
+        """(d denoise_saved / d x)^T g for the last ``denoise_saved`` (``buddy_ncsnpp_vjp``)"""
+        g = g.contiguous().float()
+        gx = torch.empty_like(g)
+        _lib.check(_lib.load().buddy_ncsnpp_vjp(self._get_handle(), _lib.ptr(g), _lib.ptr(gx), _lib.stream_ptr()))
+        return gx
+
     def tap(self, module_idx):
         """(B, frames, bins, C) copy of all_modules[module_idx]'s output from the last forward (parity tests)."""
         p = C.c_void_p()

@@ -67,30 +67,42 @@ class EulerHeunSamplerDPS(EulerHeunSampler):
         return self.diff_params._ode_integrand(x_in, t, score) + lh_score, x_den
 
     def _eval_parts(self, x_in, t, blind):
-        """network + operator part of one guided evaluation: (likelihood score, raw Tweedie estimate), both detached."""
+        """network + operator part of one guided evaluation -> (likelihood gradient, its per-utterance scale or None, raw Tweedie estimate), detached.
+        Fast path (round 6): the network's saved forward and input-VJP and the operator's loss gradient are called directly -- no autograd graph, no
+        helper kernels -- and the guidance normaliser zeta / (||g|| / sqrt(audio_len) + 1e-8) (:66-69) stays a per-utterance scalar that the fused update
+        applies (``buddy_row_scale`` + ``buddy_dps_update``), instead of five tensor expressions and a scaled copy of the gradient."""
+        from . import _hipops
+        net, op = self.model, self.operator
+        if hasattr(net, "denoise_saved") and hasattr(op, "hip_rec_loss_grad") and not torch.is_tensor(t):
+            sc = self.diff_params.scalars_on_device(t, x_in.shape[0], x_in.device)
+            x_den = net.denoise_saved(x_in, sc)
+            if blind:
+                self.optimize_op(x_den, t)
+            g = net.input_vjp(op.hip_rec_loss_grad(x_den))
+            return g, _hipops.row_scale(g, 1, self.zeta, self.args.exp.audio_len ** 0.5), x_den
         x_in.requires_grad = True
         x_den = self.get_Tweedie_estimate(x_in, t)
         if blind:
-            self.optimize_op(x_den.detach(), t)      # the library copies it into the captured graph's input buffer: no clone here
+            self.optimize_op(x_den.detach(), t)
         lh_score, _ = self.get_likelihood_score(x_den, x_in, t)
         x_in.detach_()
-        return lh_score.detach(), x_den.detach()
+        return lh_score.detach(), None, x_den.detach()
 
     def _step_hip(self, x_i, t_i, t_iplus1, gamma_i, blind):
-        """same arithmetic as step() with the elementwise tail fused into HIP kernels (buddy_perturb / buddy_dps_update)."""
+        """same arithmetic as step() with the elementwise tail fused into HIP kernels (buddy_perturb / buddy_row_scale / buddy_dps_update)."""
         from . import _hipops
         csm = self.args.tester.posterior_sampling.constraint_speech_magnitude
         x_hat, t_hat = self.stochastic_timestep(x_i, t_i, gamma_i)
-        lh, x_den = self._eval_parts(x_hat, t_hat, blind)
-        scale = (csm.speech_scaling / _hipops.row_std(x_den)).reshape(-1) if csm.use else None
+        lh, lhs, x_den = self._eval_parts(x_hat, t_hat, blind)
+        scale = _hipops.row_scale(x_den, 0, csm.speech_scaling) if csm.use else None
         dt = float(t_iplus1 - t_hat)
         if t_iplus1 != 0 and self.order == 2:
-            x_prime, d1, _ = _hipops.dps_update(x_hat, x_den, lh, scale, x_hat, None, float(t_hat), dt, 0.0, 1.0, want_d=True)
-            lh2, x_den2 = self._eval_parts(x_prime, t_iplus1, blind)
+            x_prime, d1, _ = _hipops.dps_update(x_hat, x_den, lh, scale, x_hat, None, float(t_hat), dt, 0.0, 1.0, want_d=True, lh_scale=lhs)
+            lh2, lhs2, x_den2 = self._eval_parts(x_prime, t_iplus1, blind)
             # the reference rescales x_den only in the first evaluation (:127-129); the corrector uses and returns the raw estimate (:139-149)
-            x_next, _, x_den_out = _hipops.dps_update(x_prime, x_den2, lh2, None, x_hat, d1, float(t_iplus1), dt, 0.5, 0.5)
+            x_next, _, x_den_out = _hipops.dps_update(x_prime, x_den2, lh2, None, x_hat, d1, float(t_iplus1), dt, 0.5, 0.5, lh_scale=lhs2)
         else:
-            x_next, _, x_den_out = _hipops.dps_update(x_hat, x_den, lh, scale, x_hat, None, float(t_hat), dt, 0.0, 1.0)
+            x_next, _, x_den_out = _hipops.dps_update(x_hat, x_den, lh, scale, x_hat, None, float(t_hat), dt, 0.0, 1.0, lh_scale=lhs)
         return x_next, x_den_out
 
     def step(self, x_i, t_i, t_iplus1, gamma_i, blind=False):

@@ -73,6 +73,19 @@ class RIROperator(Operator, OperatorSTFT):
         from .subband_filtering import _HipFirRecLoss
         return _HipFirRecLoss.apply(x_den, self, self._hip_w)
 
+    def hip_rec_loss_grad(self, x_den):
+        """d (sum_u weight * rec_loss_u) / d x_den straight from the library (no autograd graph)"""
+        from ... import _lib
+        x = x_den.contiguous().float()
+        rir = self.params.detach().contiguous().float()
+        M = rir.shape[-1]
+        loss = torch.empty(x.shape[0], device=x.device)
+        g = torch.empty_like(x)
+        _lib.check(_lib.load().buddy_blindop_fir_loss_grad(self._hip_h, _lib.ptr(x), _lib.ptr(rir), 0 if rir.dim() == 1 else M, M, float(self._hip_w),
+                                                           _lib.ptr(loss), _lib.ptr(g), _lib.stream_ptr()))
+        self.last_rec_per_utt = loss
+        return g
+
     def _hip_release(self):
         try:
             if getattr(self, "_hip_h", None) is not None:

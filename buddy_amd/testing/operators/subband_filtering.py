@@ -467,6 +467,15 @@ class BlindSubbandFiltering(SubbandFiltering):
     def hip_rec_loss(self, x_den):
         return _HipRecLoss.apply(x_den, self, self.w_rec)
 
+    def hip_rec_loss_grad(self, x_den):
+        """d (sum_u w_rec * rec_loss_u) / d x_den straight from the library (no autograd graph); the per-utterance losses land in ``last_rec_per_utt``"""
+        x = x_den.contiguous().float()
+        loss = torch.empty(self.U, device=x.device)
+        g = torch.empty_like(x)
+        _lib.check(_lib.load().buddy_blindop_rec_loss_grad(self._h, _lib.ptr(x), float(self.w_rec), _lib.ptr(loss), _lib.ptr(g), _lib.stream_ptr()))
+        self.last_rec_per_utt = loss
+        return g
+
     def hip_optimize(self, x_den, t):
         n_it = int(self.hp.op_updates_per_step)
         noise = None

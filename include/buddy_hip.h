@@ -274,10 +274,17 @@ int buddy_axpby_rows(const float* x, const float* y, const float* a, const float
 /* stochastic churn: out = x + scale * eps (EulerHeunSampler.py:41-45, scale = sqrt(t_hat^2 - t^2)) */
 int buddy_perturb(const float* x, const float* eps, float scale, float* out, long long n, void* stream);
 /* fused Euler / Heun update of the DPS sampler (EulerHeunSamplerDPS.py:128-157, edm.py:83-96), per-utterance rows:
- *   x_den' = x_den * den_scale[b] (NULL = 1);  d = -t * (x_den' - x_hat) / t^2 + lh (NULL = 0);
- *   out = base + dt * (w_prev * d_prev (NULL = 0) + w_cur * d);   d_out / x_den_out optional. */
-int buddy_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* den_scale, const float* base, const float* d_prev,
-                     float t, float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, void* stream);
+ *   x_den' = x_den * den_scale[b] (NULL = 1);  d = -t * (x_den' - x_hat) / t^2 + lh_scale[b] (NULL = 1) * lh (NULL = 0);
+ *   out = base + dt * (w_prev * d_prev (NULL = 0) + w_cur * d);   d_out / x_den_out optional.
+ * lh_scale (round 6): the guidance normaliser zeta / (||grad||_2 / sqrt(audio_len) + 1e-8) per utterance (:66-69, buddy_row_scale mode 1), so the raw
+ * likelihood gradient goes in and no scaled copy of it is materialised. */
+int buddy_dps_update(const float* x_hat, const float* x_den, const float* lh, const float* lh_scale, const float* den_scale, const float* base,
+                     const float* d_prev, float t, float dt, float w_prev, float w_cur, float* out, float* d_out, float* x_den_out, int B, int L, void* stream);
+/* one scalar per utterance row of x (B, L), one launch, fp64 accumulation: mode 0: out[b] = p0 / std(x_b) (unbiased, Tensor.std(): the speech-magnitude
+ * constraint, :127-129); mode 1: out[b] = p0 / (||x_b||_2 / p1 + 1e-8) (the guidance normaliser with p0 = zeta, p1 = sqrt(audio_len)) */
+int buddy_row_scale(const float* x, float* out, int B, int L, int mode, float p0, float p1, void* stream);
+/* out[k][b] = v_k, k < 4, b < B: the four EDM preconditioning scalars of one sigma (evaluated on the host in fp32) broadcast over the batch */
+int buddy_fill_rows4(float* out, int B, float v0, float v1, float v2, float v3, void* stream);
 /* per-row sum and sum of squares in double precision: out[b] = {sum, sumsq} */
 int buddy_row_moments(const float* x, double* out, int B, int L, void* stream);
 /* time-domain FIR (direct form) y[b][n] = sum_m h_b[m] x[b][n-m], n < L, h_b = h + b*h_stride (h_stride 0 = shared RIR):
