@@ -129,6 +129,7 @@ _SIGS = {
     "buddy_blindop_stft_adjoint": (C.c_int, [C.c_void_p, _f32p, C.c_int, _f32p, C.c_void_p]),
     "buddy_blindop_stft_loss": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.c_float, _f32p, _f32p, _f32p, C.c_void_p]),
     "buddy_blindop_set_compression": (C.c_int, [C.c_void_p, C.c_float]),
+    "buddy_blindop_set_loss_norm": (C.c_int, [C.c_void_p, C.c_int]),
     "buddy_blindop_lengths": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "buddy_blindop_minphase": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_void_p]),
     "buddy_blindop_project": (C.c_int, [C.c_void_p, C.c_void_p]),

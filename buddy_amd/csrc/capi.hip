@@ -600,6 +600,7 @@ int buddy_blindop_stft_loss(void* h, const float* a, const float* b, int len, fl
   BOP_CHECK(h); if (!a || !b || !loss) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_stft_loss((BlindOp*)h, a, b, len, weight, loss, g_a, g_b, (hipStream_t)stream);
 }
 int buddy_blindop_set_compression(void* h, float comp) { BOP_CHECK(h); return blindop_set_compression((BlindOp*)h, comp); }
+int buddy_blindop_set_loss_norm(void* h, int mode) { BOP_CHECK(h); return blindop_set_loss_norm((BlindOp*)h, mode); }
 int buddy_blindop_lengths(void* h, int* L, int* Lr, int* T, int* Td) { BOP_CHECK(h); return blindop_lengths((BlindOp*)h, L, Lr, T, Td); }
 int buddy_blindop_minphase(void* h, const float* hin, float* out, void* stream) { BOP_CHECK(h); if (!hin || !out) { set_error("null"); return BUDDY_ERR_ARG; } return blindop_minphase((BlindOp*)h, hin, out, (hipStream_t)stream); }
 int buddy_blindop_project(void* h, void* stream) { BOP_CHECK(h); return blindop_project((BlindOp*)h, (hipStream_t)stream); }

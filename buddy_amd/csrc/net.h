@@ -57,6 +57,7 @@ int blindop_stft_len(BlindOp* o, const float* x, int len, float* X_ref, hipStrea
 int blindop_stft_len_adj(BlindOp* o, const float* G_ref, int len, float* g_x, hipStream_t st);
 int blindop_stft_loss(BlindOp* o, const float* a, const float* b, int len, float weight, float* loss, float* g_a, float* g_b, hipStream_t st);
 int blindop_set_compression(BlindOp* o, float comp);
+int blindop_set_loss_norm(BlindOp* o, int mode);
 int blindop_lengths(BlindOp* o, int* L, int* Lr, int* T, int* Td);
 int blindop_rec_loss_grad(BlindOp* o, const float* x_den, float weight, float* loss, float* g_x, hipStream_t st);
 int blindop_fir_loss_grad(BlindOp* o, const float* x_den, const float* rir, long long rir_stride, int M, float weight, float* loss, float* g_x,

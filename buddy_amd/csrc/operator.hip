@@ -1151,6 +1151,7 @@ struct BlindOp {
   float *frames = nullptr, *X1 = nullptr, *X2 = nullptr, *X3 = nullptr, *Ybuf = nullptr, *sig1 = nullptr, *sig2 = nullptr;
   // second scratch set: the RIR-regulariser chain of an iteration shares every launch with the reconstruction chain (param_grads)
   float *frames_b = nullptr, *X2_b = nullptr, *X3_b = nullptr, *Ybuf_b = nullptr; double* partial_b = nullptr;
+  int loss_norm = 0;                 // 0 l2_comp_stft_summean (default), 1 l2_comp_stft_sum, 2 l2_comp_stft_mean
   bool fused_loop = false;           // inside the captured optimisation loop: step counter in design_dm, no loss finalisation, one Adam launch
   bool big_lds = false;              // fir_sb_lds_kernel may take > 64 KB of dynamic LDS (set once at creation, outside any stream capture)
   float *A = nullptr, *Apre = nullptr, *logdm = nullptr, *dmv = nullptr, *gdm = nullptr, *Fin = nullptr, *GFin = nullptr, *GH = nullptr;
@@ -1314,7 +1315,9 @@ struct BlindOp {
   void comp_loss2(const float* Rc0, const float* Xh0, float* G0, int T0, float w0, float* out0, const float* Rc1, const float* Xh1, float* G1, int T1, float w1,
                   float* out1, bool two) {
     LossJobs jobs; std::memset(&jobs, 0, sizeof(jobs));
-    const float k0 = w0 / (float)T0, k1 = two ? w1 / (float)T1 : 0.f;
+    // normalisation of the loss family (utils/losses.py:46-64): summean = mean over frames of the sum over bins (the shipped one), sum, mean over both
+    auto kap = [&](float w, int Tn) { return loss_norm == 0 ? w / (float)Tn : (loss_norm == 1 ? w : w / ((float)Tn * (float)FB)); };
+    const float k0 = kap(w0, T0), k1 = two ? kap(w1, T1) : 0.f;
     jobs.j[0] = LossJob{Rc0, Xh0, G0, partial, T0, k0, LOSS_BLK};
     if (two) jobs.j[1] = LossJob{Rc1, Xh1, G1, partial_b, T1, k1, LOSS_BLK_B};
     hipLaunchKernelGGL(comp_loss_kernel, dim3(LOSS_BLK + (two ? LOSS_BLK_B : 0), U), dim3(256), 0, st, jobs, c.comp);
@@ -1657,6 +1660,13 @@ int blindop_set_compression(BlindOp* o, float comp) {
   if (!(comp > 0.f && comp <= 1.f)) { set_error("compression factor must be in (0, 1]"); return BUDDY_ERR_ARG; }
   if (comp != o->c.comp && o->gexec) { (void)hipGraphExecDestroy(o->gexec); o->gexec = nullptr; }      // the captured loop holds the exponent as a kernel argument
   o->c.comp = comp;
+  return BUDDY_OK;
+}
+// which member of the l2_comp_stft family the loss entries evaluate: 0 summean (utils/losses.py:59-64), 1 sum (:46-50), 2 mean (:52-57)
+int blindop_set_loss_norm(BlindOp* o, int mode) {
+  if (mode < 0 || mode > 2) { set_error("loss normalisation: 0 summean, 1 sum, 2 mean"); return BUDDY_ERR_ARG; }
+  if (mode != o->loss_norm && o->gexec) { (void)hipGraphExecDestroy(o->gexec); o->gexec = nullptr; }      // kappa is a kernel argument of the captured loop
+  o->loss_norm = mode;
   return BUDDY_OK;
 }
 int blindop_lengths(BlindOp* o, int* L, int* Lr, int* T, int* Td) { if (L) *L = o->L; if (Lr) *Lr = o->Lr; if (T) *T = o->T; if (Td) *Td = o->Td; return BUDDY_OK; }

@@ -38,12 +38,15 @@ class RIROperator(Operator, OperatorSTFT):
         from .subband_filtering import create_stft_loss_handle
         from ... import _lib
         l, hp = ps.rec_loss, self.op_hp
-        if not (y.is_cuda and y.dim() == 2 and l.name == "l2_comp_stft_summean" and 0.0 < float(l.compression_factor) <= 1.0
+        from ...utils.losses import NORM_MODE
+        if not (y.is_cuda and y.dim() == 2 and not hasattr(l, "loss_1") and l.name in NORM_MODE and 0.0 < float(l.compression_factor) <= 1.0
                 and (hp.NFFT, hp.win_length, hp.hop, hp.window) == (1024, 512, 128, "hann") and y.shape[1] >= 1024):
             return False
         h = self._loss_handle(int(y.shape[0]), int(y.shape[1]))
         self._hip_w = float(l.get("weight", 1.0))
-        _lib.check(_lib.load().buddy_blindop_set_compression(h, float(l.compression_factor)))
+        self._comp_created, self._loss_norm = float(l.compression_factor), NORM_MODE[l.name]
+        _lib.check(_lib.load().buddy_blindop_set_compression(h, self._comp_created))
+        _lib.check(_lib.load().buddy_blindop_set_loss_norm(h, self._loss_norm))
         _lib.check(_lib.load().buddy_blindop_set_y(h, _lib.ptr(y.contiguous().float()), _lib.stream_ptr()))
         return True
 

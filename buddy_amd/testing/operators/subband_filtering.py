@@ -247,6 +247,7 @@ class BlindSubbandFiltering(SubbandFiltering):
                                             int(bool(op_hp.enforce_long_decay_in_second_exponential)), C.byref(h)))
         self._h = h
         self._comp_created = 0.667
+        self._loss_norm = 0           # member of the l2_comp_stft family the fused calls evaluate (hip_bind): 0 summean
         self._h_epoch = 0             # bumped by every update_H: a saved autograd node of an older H refuses to run its backward
         self._Hr = None               # H of the last autograd-mode update_H (real view, carries the graph to the parameters)
         self._pt = None               # persistent parameter tensors (decay, weights, phases) once somebody asked for ``params`` (see there)
@@ -434,11 +435,16 @@ class BlindSubbandFiltering(SubbandFiltering):
         # the regulariser is gated like the reference gates it (EulerHeunSamplerDPS.py:94,200): only loss.name == "none" turns it off;
         # RIR_noise_regularization.use is never read there
         reg_loss = ps.RIR_noise_regularization.loss
+        from ...utils.losses import NORM_MODE
         used = (ps.rec_loss, ps.rec_loss_params) + (() if reg_loss.name == "none" else (reg_loss,))
-        comps = {float(l.compression_factor) for l in used}
-        if any(l.name != "l2_comp_stft_summean" for l in used) or len(comps) != 1 or not (0.0 < min(comps) <= 1.0):
-            raise NotImplementedError("the HIP operator evaluates l2_comp_stft_summean with ONE compression factor in (0, 1] for the reconstruction, "
-                                      "parameter and regulariser terms (the shipped configs: 0.667 for all three)")
+        if any(hasattr(l, "loss_1") or l.name not in NORM_MODE for l in used):
+            raise NotImplementedError(f"the HIP operator's fused calls evaluate one member of {sorted(NORM_MODE)} (hybrids: through get_loss(...)(x, x_hat))")
+        comps, names = {float(l.compression_factor) for l in used}, {l.name for l in used}
+        if len(comps) != 1 or len(names) != 1 or not (0.0 < min(comps) <= 1.0):
+            raise NotImplementedError("the HIP operator's fused calls take ONE loss name and ONE compression factor in (0, 1] for the reconstruction, "
+                                      "parameter and regulariser terms (the shipped configs: l2_comp_stft_summean @ 0.667 for all three)")
+        self._loss_norm = NORM_MODE[names.pop()]
+        _lib.check(_lib.load().buddy_blindop_set_loss_norm(self._h, self._loss_norm))
         self.set_compression(comps.pop())
         self.w_rec = float(ps.rec_loss.get("weight", 1.0))
         self.w_rec_params = float(ps.rec_loss_params.get("weight", 1.0))

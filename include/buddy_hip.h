@@ -346,6 +346,9 @@ int buddy_blindop_stft_loss(void* handle, const float* a, const float* b, int le
 /* compression exponent of the spectral losses, (0, 1] (the handle is created with one; the shipped configs use 0.667); call buddy_blindop_set_y again
  * afterwards: the cached compressed observation depends on it */
 int buddy_blindop_set_compression(void* handle, float compression_factor);
+/* which member of the reference's compressed-spectrum family every loss entry of the handle evaluates (utils/losses.py:46-64):
+ * 0 = l2_comp_stft_summean (default, the shipped configs), 1 = l2_comp_stft_sum, 2 = l2_comp_stft_mean */
+int buddy_blindop_set_loss_norm(void* handle, int mode);
 int buddy_blindop_lengths(void* handle, int* L, int* L_rir, int* frames, int* frames_rir);
 int buddy_blindop_project(void* handle, void* stream);
 int buddy_blindop_get_adam(void* handle, float* m_decay, float* v_decay, float* m_weights, float* v_weights, float* m_phases, float* v_phases,

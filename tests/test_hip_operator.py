@@ -215,17 +215,26 @@ def test_autograd_surface_vs_torch_restatement():
         g2, = torch.autograd.grad((torch.view_as_real(Xh) * Wc).sum(), sh)
         assert rel(g2, g1) < 2e-5
     # (3) the callable loss, any compression factor, gradient w.r.t. either side
-    for c in (0.667, 0.5, 1.0):
-        la = AttrDict(name="l2_comp_stft_summean", weight=3.0, compression_factor=c)
+    hyb = AttrDict(name="hybrid", loss_1=AttrDict(name="l2_comp_stft_summean", weight=2.0, compression_factor=0.667),
+                   loss_2=AttrDict(name="l2_comp_stft_mean", weight=700.0, compression_factor=0.3))
+    for c, name in ((0.667, "l2_comp_stft_summean"), (0.5, "l2_comp_stft_summean"), (1.0, "l2_comp_stft_summean"), (0.667, "l2_comp_stft_sum"),
+                    (0.4, "l2_comp_stft_mean"), (None, "hybrid")):
+        la = hyb if name == "hybrid" else AttrDict(name=name, weight=3.0, compression_factor=c)
         lt, lh = get_loss(la, opt), get_loss_hip(la, oph)
         a1 = (0.8 * x).requires_grad_(True); b1 = (0.9 * y).requires_grad_(True)
         a2 = a1.detach().clone().requires_grad_(True); b2 = b1.detach().clone().requires_grad_(True)
         vt = lt(a1, b1); vh = lh(a2, b2)
-        assert abs(float(vh) - float(vt)) < 2e-4 * abs(float(vt)), (c, float(vh), float(vt))
+        assert abs(float(vh) - float(vt)) < 2e-4 * abs(float(vt)), (c, name, float(vh), float(vt))
         gta, gtb = torch.autograd.grad(vt, (a1, b1)); gha, ghb = torch.autograd.grad(vh, (a2, b2))
-        assert rel(gha, gta) < 2e-3 and rel(ghb, gtb) < 2e-3, (c, rel(gha, gta), rel(ghb, gtb))
-        assert rel(oph.last_loss_per_utt, lt(a1, b1, per_utt=True)) < 2e-4
-    oph.set_compression(0.667)
+        assert rel(gha, gta) < 2e-3 and rel(ghb, gtb) < 2e-3, (c, name, rel(gha, gta), rel(ghb, gtb))
+        if name != "hybrid":
+            assert rel(oph.last_loss_per_utt, lt(a1, b1, per_utt=True)) < 2e-4
+    # the callable leaves the handle as the fused calls were bound (exponent 0.667, summean): the likelihood still matches
+    oph.hip_bind(y, ps)
+    xd = (0.9 * x).requires_grad_(True)
+    assert abs(float(oph.hip_rec_loss(xd)) - float(get_loss(ps.rec_loss, opt)(y, opt.degradation(xd)))) < 2e-4 * abs(float(get_loss(ps.rec_loss, opt)(y, opt.degradation(xd))))
+    get_loss_hip(AttrDict(name="l2_comp_stft_sum", weight=1.0, compression_factor=0.3), oph)(x, y)
+    assert abs(float(oph.hip_rec_loss(xd)) - float(get_loss(ps.rec_loss, opt)(y, opt.degradation(xd)))) < 2e-4 * abs(float(get_loss(ps.rec_loss, opt)(y, opt.degradation(xd))))
     # (4) optimize_op's graph: parameters -> update_H -> degradation / get_time_RIR -> losses -> backward
     lp, lr = get_loss(ps.rec_loss_params, opt), get_loss(ps.RIR_noise_regularization.loss, opt)
     lph, lrh = get_loss_hip(ps.rec_loss_params, oph), get_loss_hip(ps.RIR_noise_regularization.loss, oph)
