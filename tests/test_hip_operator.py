@@ -220,7 +220,12 @@ def test_autograd_surface_vs_torch_restatement():
     for c, name in ((0.667, "l2_comp_stft_summean"), (0.5, "l2_comp_stft_summean"), (1.0, "l2_comp_stft_summean"), (0.667, "l2_comp_stft_sum"),
                     (0.4, "l2_comp_stft_mean"), (None, "hybrid")):
         la = hyb if name == "hybrid" else AttrDict(name=name, weight=3.0, compression_factor=c)
-        lt, lh = get_loss(la, opt), get_loss_hip(la, oph)
+        if name == "hybrid":     # the reference's own hybrid branch (utils/losses.py:22-23) iterates over the `name` key too and cannot run; the sum of the members is what it means
+            l1_, l2_ = get_loss(hyb.loss_1, opt), get_loss(hyb.loss_2, opt)
+            lt = lambda p, q, per_utt=False: l1_(p, q, per_utt) + l2_(p, q, per_utt)
+            lh = get_loss_hip(la, oph)
+        else:
+            lt, lh = get_loss(la, opt), get_loss_hip(la, oph)
         a1 = (0.8 * x).requires_grad_(True); b1 = (0.9 * y).requires_grad_(True)
         a2 = a1.detach().clone().requires_grad_(True); b2 = b1.detach().clone().requires_grad_(True)
         vt = lt(a1, b1); vh = lh(a2, b2)
