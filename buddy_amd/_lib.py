@@ -70,6 +70,10 @@ _SIGS = {
                                                       C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_gemm_bf16x3_gn_bwd": (C.c_int, [_f32p, C.c_int, C.c_void_p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_float,
                                            _f32p, _f32p, C.c_int, C.c_int, C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "buddy_gemm_f16x2": (C.c_int, [_f32p, C.c_int, _f32p, C.c_int, C.c_int, C.c_void_p, _f32p, C.c_int, C.c_longlong, C.c_int, C.c_int, _f32p, C.c_float,
+                                    C.c_int, C.c_void_p]),
+    "buddy_gemm_f16x2_gn_bwd": (C.c_int, [_f32p, C.c_int, C.c_void_p, _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_float,
+                                           _f32p, _f32p, C.c_int, C.c_int, C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_gn_upconv3x3_winograd6": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "buddy_gnbwd_upconv3x3_winograd6": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, C.c_void_p, _f32p,

@@ -212,6 +212,29 @@ int buddy_gemm_bf16x3(const float* A0, int ldA0, const float* A1, int ldA1, int 
   return finish();
 }
 
+// the same general form in f16x2 arithmetic (W2 = buddy_wgemm_f16x2_pack_weights(W, ., 1, N, K)); gn_bwd != 0 arguments as buddy_gemm_bf16x3_gn_bwd
+int buddy_gemm_f16x2(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W2, float* Cm, int ldC, long long M, int N, int K,
+                     const float* bias_n, float alpha, int accumulate, void* stream) {
+  if (!A0 || !W2 || !Cm || M < 1 || !wgemm_f16x2_general_supported(N, K, A1 ? C0 : 0, ldA0, A1 ? ldA1 : 0, ldC, A0, A1, Cm, bias_n)) {
+    set_error("bad arguments (N % 128, K % 64, C0 % 32, 16-byte aligned rows)"); return BUDDY_ERR_ARG;
+  }
+  launch_wgemm_f16x2_general(A0, ldA0, A1, ldA1, C0, W2, Cm, ldC, M, N, K, bias_n, alpha, accumulate, (hipStream_t)stream);
+  return finish();
+}
+int buddy_gemm_f16x2_gn_bwd(const float* A, int ldA, const void* W2, const float* x0, const float* x1, int C0, const float* da, const float* stats,
+                            const float* gamma, const float* beta, int G, int silu, float alpha, float* dx0, float* dx1, int acc0, int acc1,
+                            double* stat_scratch, float* red, int B, int HW, int N, int K, void* stream) {
+  if (!A || !W2 || !x0 || !da || !stats || !gamma || !beta || !dx0 || !stat_scratch || !red || B < 1 || HW < 1 || G < 1 || N % 4 || (N / G) % 4 || N > 1024 ||
+      (x1 && (C0 % 4 || C0 < 4 || C0 >= N)) || (x1 != nullptr) != (dx1 != nullptr)) { set_error("bad arguments"); return BUDDY_ERR_ARG; }
+  Src2 x; x.p0 = x0; x.p1 = x1; x.C0 = x1 ? C0 : N; x.ld0 = x1 ? C0 : N; x.ld1 = x1 ? N - C0 : 0;
+  Dst2 d; d.p0 = dx0; d.p1 = dx1; d.C0 = x.C0; d.ld0 = x.ld0; d.ld1 = x.ld1; d.acc0 = acc0; d.acc1 = acc1;
+  if (!wgemm_gnbwd_supported(N, K, ldA, x, d, A, da) || !wgemm_f16x2_supported(N, K)) { set_error("bad arguments (N % 128, K % 64, C0 % 128, 16-byte aligned rows)"); return BUDDY_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  launch_gn_bwd_sums(x, stats, gamma, beta, da, B, 1, HW, N, G, 0, silu, stat_scratch, red, st);
+  launch_wgemm_f16x2_gnbwd(A, ldA, W2, (long long)B * HW, N, K, alpha, x, da, stats, red, gamma, beta, G, silu, HW, d, st);
+  return finish();
+}
+
 int buddy_gemm_bf16x3_gn_bwd(const float* A, int ldA, const void* W3, const float* x0, const float* x1, int C0, const float* da, const float* stats,
                              const float* gamma, const float* beta, int G, int silu, float alpha, float* dx0, float* dx1, int acc0, int acc1,
                              double* stat_scratch, float* red, int B, int HW, int N, int K, void* stream) {

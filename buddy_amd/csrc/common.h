@@ -21,7 +21,7 @@ struct Options {
   int attn;            // attention core 0 .. 4 (net.hip)
   int gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr;                 // fusions of the network graph (A/B switches, default 1)
   int attn_split, attn_nw;                                                           // fp32 attention: forced loop-split count / forward tile height (0 = by shape)
-  int igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos, wgemm_epi, wgemm_rt, wgemm_nt;              // GEMM kernels
+  int igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos, wgemm_epi, wgemm_rt, wgemm_nt, gen_f16x2;              // GEMM kernels
   int wino_epi, wino_abl, wino_geo, w6_xcd, w6_nt;                                          // Winograd kernels
   int gn_fast, c2in4, c2out_tiled;                                                   // GroupNorm / 2-channel convolutions
   int fir_lds, op_graph;                                                             // blind operator
@@ -68,6 +68,9 @@ void launch_wgemm_f16x2(const float* V, const void* U2, float* M, long long Mt, 
 bool wgemm_general_supported(int N, int K, int C0, int ldA0, int ldA1, int ldC, const void* A0, const void* A1, const void* C, const void* bias);
 void launch_wgemm_bf16x3_general(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W3, float* C, int ldC, long long M, int N, int K,
                                  const float* bias_n, float alpha, int accumulate, hipStream_t st);
+bool wgemm_f16x2_general_supported(int N, int K, int C0, int ldA0, int ldA1, int ldC, const void* A0, const void* A1, const void* C, const void* bias);
+void launch_wgemm_f16x2_general(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W2, float* C, int ldC, long long M, int N, int K,
+                                const float* bias_n, float alpha, int accumulate, hipStream_t st);
 // Winograd F(2x2,3x3) variant of the 3x3 conv (wino.hip): same IgemmParams, pre-transformed weights U[Cin/16][16][Cout][16]
 bool wino_supported(const IgemmParams& p);
 void launch_wino(const IgemmParams& p, const float* Uw, hipStream_t st);
@@ -79,6 +82,8 @@ struct Dst2 { float* p0; float* p1; int C0; int ld0; int ld1; int acc0; int acc1
 bool wgemm_gnbwd_supported(int N, int K, int ldA, const Src2& x, const Dst2& d, const void* A, const void* da);
 void launch_wgemm_bf16x3_gnbwd(const float* A, int ldA, const void* W3, long long M, int N, int K, float alpha, Src2 x, const float* da, const float* stats,
                                const float* red, const float* gamma, const float* beta, int G, int silu, int HW, Dst2 d, hipStream_t st);
+void launch_wgemm_f16x2_gnbwd(const float* A, int ldA, const void* W2, long long M, int N, int K, float alpha, Src2 x, const float* da, const float* stats,
+                              const float* red, const float* gamma, const float* beta, int G, int silu, int HW, Dst2 d, hipStream_t st);
 // Winograd F(4x4,3x3) in three passes (wino4.hip): weights U4[36][Cout][Cin], scratch V (36*M/16*Cin floats) and Mb (36*M/16*N floats)
 // Fusions with the GroupNorms either side of the convolution (both optional):
 //   gn   -- the input is act(GroupNorm(gn->x)) of a same-resolution (concatenated) view, applied inside the input transform (p.A0 unused)

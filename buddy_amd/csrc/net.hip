@@ -119,7 +119,7 @@ struct GNW { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResW { GNW gn0, gn1; ConvW c0, c1, c2; bool has_c2 = false; int cin = 0, cout = 0, dense_off = 0; };
 struct AttnW { GNW gn; float* Wt[4]; float* Wn[4]; float* b[4]; int C = 0; };
 
-struct W3Img { const void* img; int N, K; };
+struct W3Img { const void* img; int N, K; const void* img2 = nullptr; };      // img: bf16x3 stage image; img2: f16x2 stage image (general f16x2 form), where the shape allows
 // Everything derived from the parameters: shared (read-only after preparation) by a handle and its replicas (net_replica)
 struct Weights {
   NetCfg cfg;
@@ -398,13 +398,24 @@ static int weights_create(const float* hp, long long n, const NetCfg& cfg, std::
     plain_off.push_back(pack3_bytes);
     if (wgemm_supported(j.second.first, j.second.second)) pack3_bytes += (wgemm_packed_bytes(1, j.second.first, j.second.second) + 255) / 256 * 256;
   }
-  if (pack3_bytes) {     // the 1x1 / NIN matrices once more, split into three bf16 planes in the GEMM's LDS stage order
-    HIPCHK(hipMalloc(&N->dpacked3, pack3_bytes));
+  std::vector<size_t> plain_off2;
+  size_t pack2_bytes = 0;
+  for (auto& j : plain3) {
+    plain_off2.push_back(pack2_bytes);
+    if (wgemm_f16x2_supported(j.second.first, j.second.second)) pack2_bytes += (wgemm_f16x2_packed_bytes(1, j.second.first, j.second.second) + 255) / 256 * 256;
+  }
+  if (pack3_bytes) {     // the 1x1 / NIN matrices once more, split into three bf16 planes in the GEMM's LDS stage order (+ the two-term f16 image of the f16x2 general form)
+    HIPCHK(hipMalloc(&N->dpacked3, pack3_bytes + pack2_bytes));
     for (size_t i = 0; i < plain3.size(); ++i) {
       const int n3 = plain3[i].second.first, k3 = plain3[i].second.second;
       if (!wgemm_supported(n3, k3) || *plain3[i].first == nullptr) continue;
       wgemm_pack_weights(*plain3[i].first, N->dpacked3 + plain_off[i], 1, n3, k3, nullptr);
-      N->w3[*plain3[i].first] = W3Img{N->dpacked3 + plain_off[i], n3, k3};
+      W3Img im{N->dpacked3 + plain_off[i], n3, k3};
+      if (wgemm_f16x2_supported(n3, k3)) {
+        wgemm_f16x2_pack_weights(*plain3[i].first, N->dpacked3 + pack3_bytes + plain_off2[i], 1, n3, k3, nullptr);
+        im.img2 = N->dpacked3 + pack3_bytes + plain_off2[i];
+      }
+      N->w3[*plain3[i].first] = im;
     }
   }
   HIPCHK(hipDeviceSynchronize());     // the host staging buffers go out of scope here
@@ -689,6 +700,12 @@ static int conv3(Net* N, const Conv3& c) {
   }
   return 0;
 }
+// The general GEMMs in f16x2 arithmetic (round 6; only with gemm = f16x2): option gen_f16x2 = 0 never, 1 every shape, 2 where the launch is matrix-bound -- the
+// level-0 launches (a million rows) stream 4-7 GB against 0.3-0.6 TFLOP and are HBM-bound in either arithmetic, and the f16x2 form reads A twice
+static bool gen_f16x2_on(const Net* N, long long M) {
+  if (N->opt.gemm != 2 || N->opt.gen_f16x2 == 0) return false;
+  return N->opt.gen_f16x2 == 1 || M <= 600000;
+}
 // a plain row-major GEMM against a registered [N][K] weight (1x1 convolution, NIN) in bf16x3 arithmetic when the handle's mode asks for it
 static bool try_wgemm(Net* N, const IgemmParams& p) {
   if (N->opt.gemm < 1 || p.bias_m || p.bias_bn || p.res_mode || p.out_scale != 1.f || p.sA || p.sC) return false;
@@ -696,7 +713,10 @@ static bool try_wgemm(Net* N, const IgemmParams& p) {
   if (it == N->W->w3.end() || p.ldB != p.Cin || it->second.N != p.N || it->second.K != p.Cin) return false;
   if (!wgemm_general_supported(p.N, p.Cin, p.A1 ? p.C0 : 0, p.ldA0, p.A1 ? p.ldA1 : 0, p.ldC, p.A0, p.A1, p.C, p.bias_n)) return false;
   igemm_prof_record(p, 1, 1, N->st, true, 1.0);
-  launch_wgemm_bf16x3_general(p.A0, p.ldA0, p.A1, p.ldA1, p.C0, it->second.img, p.C, p.ldC, p.M, p.N, p.Cin, p.bias_n, p.alpha, p.accumulate, N->st);
+  if (gen_f16x2_on(N, p.M) && it->second.img2 && wgemm_f16x2_supported(p.N, p.Cin))
+    launch_wgemm_f16x2_general(p.A0, p.ldA0, p.A1, p.ldA1, p.C0, it->second.img2, p.C, p.ldC, p.M, p.N, p.Cin, p.bias_n, p.alpha, p.accumulate, N->st);
+  else
+    launch_wgemm_bf16x3_general(p.A0, p.ldA0, p.A1, p.ldA1, p.C0, it->second.img, p.C, p.ldC, p.M, p.N, p.Cin, p.bias_n, p.alpha, p.accumulate, N->st);
   igemm_prof_record(p, 1, 1, N->st, false, 1.0);
   return true;
 }
@@ -851,6 +871,10 @@ static Tens* resblock(Net* N, const ResW& R, View x, int mode, const float* temb
           launch_gn_bwd_sums(src_of(x), stats0, Rp->gn0.gamma, Rp->gn0.beta, da0, B, H, W, Cin, G0, 0, 1, n->partial, n->red, s, s0);
           IgemmParams pr = ig_base(); pr.M = B * H * W; pr.N = Cin; pr.Cin = Cout;
           igemm_prof_record(pr, 1, 1, s, true, 1.0);
+          if (gen_f16x2_on(n, (long long)B * H * W) && c2i->img2 && wgemm_f16x2_supported(Cin, Cout))
+            launch_wgemm_f16x2_gnbwd(c2a, Cout, c2i->img2, (long long)B * H * W, Cin, Cout, INV_SQRT2, src_of(x), da0, stats0, n->red, Rp->gn0.gamma,
+                                     Rp->gn0.beta, G0, 1, H * W, d0, s);
+          else
           launch_wgemm_bf16x3_gnbwd(c2a, Cout, c2i->img, (long long)B * H * W, Cin, Cout, INV_SQRT2, src_of(x), da0, stats0, n->red, Rp->gn0.gamma,
                                     Rp->gn0.beta, G0, 1, H * W, d0, s);
           igemm_prof_record(pr, 1, 1, s, false, 1.0);

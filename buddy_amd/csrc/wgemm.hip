@@ -563,6 +563,202 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_f16x2_kernel(const WgemmArgs a) 
       *reinterpret_cast<float4*>(dst + cb * 32 + 8 * g) = make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
 }
 
+// ------------------------------------------------------------------------------------------------ f16x2 form of the GENERAL GEMM (round 6)
+// C (M x N) = alpha * [A0 | A1] (M x K) W^T + bias (+ C), or -- GNB -- the ResBlock skip path's data-gradient with the GroupNorm backward apply as its
+// epilogue: the 1x1 convolutions / NIN layers / DFT GEMMs in the arithmetic of the Winograd-domain GEMMs (three f16 MFMA products instead of bf16x3's six).
+// The A operand here is an activation nobody has measured: its power-of-two scale is taken PER ROW, from the row's own abs-max, in a pre-pass of the kernel
+// (the wave reads its 32 rows x K once more than the K loop does; that second read comes from L2 / the Infinity Cache) -- finer than the per-utterance scale
+// of the batched form, and a row's result depends on nothing but the row.  Structure = wgemm_f16x2_kernel<true> (32-row waves, LDS-DMA weight stages, two
+// K-stages of A in flight) with the two-source A of wgemm_bf16x3_kernel<true, ...> and its epilogues.
+template <bool GNB>
+__global__ __launch_bounds__(WNT, 3) void wgemm_f16x2_gen_kernel(const WgemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * STAGE2_BYTES > 4 * 32 * 68 * 4) ? 2 * STAGE2_BYTES : 4 * 32 * 68 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int lid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int nb = lid % a.NB, m0 = (lid / a.NB) * WBM;
+  const unsigned char* __restrict__ U2 = a.U3 + (long long)nb * a.S * STAGE2_BYTES;
+  const int S = a.S;
+  int row = m0 + wid * 32 + (lane & 31);
+  if (row >= a.Mt) row = a.Mt - 1;
+  const float* Ap0 = a.V + (long long)row * a.ldA0 + 16 * (lane >> 5);
+  const float* Ap1 = a.A1 ? a.A1 + (long long)row * a.ldA1 + 16 * (lane >> 5) - a.C0 : Ap0;       // channels >= C0 come from the second source
+  const int s1 = a.A1 ? a.C0 / WKS : S;                                                            // first K-stage of the second source
+  // pre-pass: the row's abs-max over all K (both lanes of a row), its power of two
+  float sv, inv;
+  {
+    float mx = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float* q = (s >= s1 ? Ap1 : Ap0) + s * WKS;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(q + 4 * j);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    pow2_scale(__float_as_uint(mx), sv, inv);
+  }
+  inv *= a.uinv[0];
+  const unsigned boff = (unsigned)tid * 16u;
+  const char* Ub = reinterpret_cast<const char*>(U2);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  float4 ra[2][4];
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem + wid * 1024);
+  auto loadA = [&](int s, float4 (&r)[4]) {
+    const float* q = (s >= s1 ? Ap1 : Ap0) + s * WKS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const float4*>(q + 4 * j);
+  };
+  auto dmaB = [&](int s) {
+    const void* base = uniform_ptr(Ub + (long long)s * STAGE2_BYTES);
+    const unsigned l = lds0 + (s & 1) * STAGE2_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16_asm(base, boff + j * (WNT * 16), l + j * (WNT * 16));
+  };
+  auto stage = [&](int s, float4 (&r)[4], auto nb_, auto na_) {
+    constexpr bool NB = decltype(nb_)::value, NA = decltype(na_)::value;
+    const Split2 av[2] = {split2(r[0], r[1], sv), split2(r[2], r[3], sv)};
+    if (NB) dmaB(s + 1);
+    if (NA) loadA(s + 2, r);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* Bcur = smem + (s & 1) * STAGE2_BYTES + lane * 16;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      f16x8 b[4][2];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[cb][q] = *reinterpret_cast<const f16x8*>(Bcur + ((kc * 4 + cb) * 2 + q) * FRAG);
+      constexpr int PB[3] = {1, 0, 0}, PA[3] = {0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[cb][PB[t]], av[kc].p[PA[t]], acc[cb], 0, 0, 0);
+    }
+    if (NB) { if (NA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __syncthreads();
+  };
+  dmaB(0);
+  loadA(0, ra[0]);
+  loadA(1, ra[1]);                                             // S is even (wgemm_f16x2_supported)
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  int s = 0;
+  for (; s + 2 < S; s += 2) {
+    stage(s, ra[0], std::true_type{}, std::true_type{});
+    stage(s + 1, ra[1], std::true_type{}, std::true_type{});
+  }
+  stage(s, ra[0], std::true_type{}, std::false_type{});
+  stage(s + 1, ra[1], std::false_type{}, std::false_type{});
+
+  // epilogues of wgemm_bf16x3_kernel<true, true, GNB>: the accumulator tile (x the row's inverse scale) through the wave-private LDS slab, 256-byte row pieces
+  constexpr int SP = 68;
+  float* St = reinterpret_cast<float*>(smem) + wid * (32 * SP);
+  const int rr = lane >> 4, c4 = (lane & 15) * 4;
+  const int rbase = m0 + wid * 32;
+  if constexpr (!GNB) {
+    const long long ldc = a.ldC;
+    float* Mrow = a.M + (long long)rbase * ldc + nb * WBN;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(St + (lane & 31) * SP + cl * 32 + 8 * g + 4 * (lane >> 5)) =
+              make_float4(acc[2 * hb + cl][4 * g] * inv, acc[2 * hb + cl][4 * g + 1] * inv, acc[2 * hb + cl][4 * g + 2] * inv, acc[2 * hb + cl][4 * g + 3] * inv);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias_n) bs = *reinterpret_cast<const float4*>(a.bias_n + nb * WBN + hb * 64 + c4);
+      float4 pv[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = min(4 * it + rr, a.Mt - 1 - rbase);
+        pv[it] = a.accumulate ? *reinterpret_cast<const float4*>(Mrow + (long long)r * ldc + hb * 64 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = 4 * it + rr;
+        float4 v = *reinterpret_cast<const float4*>(St + r * SP + c4);
+        v.x *= a.alpha; v.y *= a.alpha; v.z *= a.alpha; v.w *= a.alpha;
+        if (a.bias_n) { v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w; }
+        if (a.accumulate) { v.x += pv[it].x; v.y += pv[it].y; v.z += pv[it].z; v.w += pv[it].w; }
+        if (rbase + r < a.Mt) *reinterpret_cast<float4*>(Mrow + (long long)r * ldc + hb * 64 + c4) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    const int cpg = a.Cout / a.gG;
+    const bool second = a.gxv.p1 != nullptr && nb * WBN >= a.gxv.C0, dsecond = a.gd.p1 != nullptr && nb * WBN >= a.gd.C0;
+    const long long ldx = second ? a.gxv.ld1 : a.gxv.ld0, ldo = dsecond ? a.gd.ld1 : a.gd.ld0;
+    const bool accd = (dsecond ? a.gd.acc1 : a.gd.acc0) != 0;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      const int col = nb * WBN + hb * 64 + c4, grp = col / cpg;
+      const float* xs = (second ? a.gxv.p1 + (col - a.gxv.C0) : a.gxv.p0 + col);
+      float* o = (dsecond ? a.gd.p1 + (col - a.gd.C0) : a.gd.p0 + col);
+      const float* das = a.gda + col;
+      const float4 gm = *reinterpret_cast<const float4*>(a.ggamma + col), bt = *reinterpret_cast<const float4*>(a.gbeta + col);
+      const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(St + (lane & 31) * SP + cl * 32 + 8 * g + 4 * (lane >> 5)) =
+              make_float4(acc[2 * hb + cl][4 * g] * inv, acc[2 * hb + cl][4 * g + 1] * inv, acc[2 * hb + cl][4 * g + 2] * inv, acc[2 * hb + cl][4 * g + 3] * inv);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int bt4 = 0; bt4 < 2; ++bt4) {
+        float4 xv[4], dv[4], pv[4];
+        float mean[4], rstd[4], m1[4], m2[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int r = min(rbase + 16 * bt4 + 4 * it + rr, a.Mt - 1), bb = r / a.gHW;
+          xv[it] = *reinterpret_cast<const float4*>(xs + (long long)r * ldx);
+          dv[it] = *reinterpret_cast<const float4*>(das + (long long)r * a.Cout);
+          pv[it] = accd ? *reinterpret_cast<const float4*>(o + (long long)r * ldo) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float2 sm = *reinterpret_cast<const float2*>(a.gstats + ((long long)bb * a.gG + grp) * 2), rm = *reinterpret_cast<const float2*>(a.gred + ((long long)bb * a.gG + grp) * 2);
+          mean[it] = sm.x; rstd[it] = sm.y; m1[it] = rm.x; m2[it] = rm.y;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int rl = 16 * bt4 + 4 * it + rr;
+          const float4 cv = *reinterpret_cast<const float4*>(St + rl * SP + c4);
+          const float x4[4] = {xv[it].x, xv[it].y, xv[it].z, xv[it].w}, d4[4] = {dv[it].x, dv[it].y, dv[it].z, dv[it].w};
+          const float p4[4] = {pv[it].x, pv[it].y, pv[it].z, pv[it].w}, c4v[4] = {cv.x, cv.y, cv.z, cv.w};
+          float r[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xh = (x4[j] - mean[it]) * rstd[it];
+            const float z = xh * g4[j] + b4[j];
+            const float dxh = d4[j] * (a.gsilu ? dsilu_g(z) : 1.f) * g4[j];
+            r[j] = rstd[it] * (dxh - m1[it] - xh * m2[it]);
+            r[j] += a.alpha * c4v[j];
+            r[j] += p4[j];
+          }
+          if (rbase + rl < a.Mt) *reinterpret_cast<float4*>(o + (long long)(rbase + rl) * ldo) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // 64 rows per wave (two 32-row tiles; workgroup = 256 rows x 128 columns, 128 accumulators per lane, two workgroups per CU): every weight fragment read from LDS
 // feeds two MFMAs per product term instead of one (the 32-row form reads 0.67 fragments per MFMA) and a barrier separates 48 instead of 24 MFMAs per wave.  One K-stage of A in flight (a stage is 48 MFMAs per wave), reloaded in place after the split; the rest as wgemm_f16x2_kernel<true>.
 // NT (A/B switch wgemm_nt): bit 0 = the V rows are read with non-temporal loads (V is read exactly once: it should not displace the weight panels from
@@ -752,6 +948,30 @@ void launch_wgemm_bf16x3_gnbwd(const float* A, int ldA, const void* W3, long lon
   a.gxv = x; a.gd = d; a.gda = da; a.gstats = stats; a.gred = red; a.ggamma = gamma; a.gbeta = beta; a.gG = G; a.gsilu = silu; a.gHW = HW;
   const dim3 grid((unsigned)(cdiv((int)M, WBM) * a.NB), 1, 1);
   hipLaunchKernelGGL((wgemm_bf16x3_kernel<true, false, true>), grid, dim3(WNT), 0, st, a);
+}
+
+// f16x2 forms of the two general launches: W2 = wgemm_f16x2_pack_weights(W, ., 1, N, K) (one power of two for the whole matrix)
+bool wgemm_f16x2_general_supported(int N, int K, int C0, int ldA0, int ldA1, int ldC, const void* A0, const void* A1, const void* C, const void* bias) {
+  return wgemm_f16x2_supported(N, K) && wgemm_general_supported(N, K, C0, ldA0, ldA1, ldC, A0, A1, C, bias);
+}
+void launch_wgemm_f16x2_general(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W2, float* C, int ldC, long long M, int N, int K,
+                                const float* bias_n, float alpha, int accumulate, hipStream_t st) {
+  WgemmArgs a{};
+  a.V = A0; a.U3 = reinterpret_cast<const unsigned char*>(W2); a.M = C;
+  a.Mt = (int)M; a.Cin = K; a.Cout = N; a.S = K / WKS; a.NB = N / WBN;
+  a.A1 = A1; a.C0 = A1 ? C0 : K; a.ldA0 = ldA0; a.ldA1 = ldA1; a.ldC = ldC; a.bias_n = bias_n; a.alpha = alpha; a.accumulate = accumulate;
+  a.uinv = reinterpret_cast<const float*>(a.U3 + (size_t)N * K * 4);
+  hipLaunchKernelGGL((wgemm_f16x2_gen_kernel<false>), dim3((unsigned)(cdiv((int)M, WBM) * a.NB)), dim3(WNT), 0, st, a);
+}
+void launch_wgemm_f16x2_gnbwd(const float* A, int ldA, const void* W2, long long M, int N, int K, float alpha, Src2 x, const float* da, const float* stats,
+                              const float* red, const float* gamma, const float* beta, int G, int silu, int HW, Dst2 d, hipStream_t st) {
+  WgemmArgs a{};
+  a.V = A; a.U3 = reinterpret_cast<const unsigned char*>(W2); a.M = nullptr;
+  a.Mt = (int)M; a.Cin = K; a.Cout = N; a.S = K / WKS; a.NB = N / WBN;
+  a.A1 = nullptr; a.C0 = K; a.ldA0 = ldA; a.ldA1 = 0; a.ldC = N; a.alpha = alpha;
+  a.uinv = reinterpret_cast<const float*>(a.U3 + (size_t)N * K * 4);
+  a.gxv = x; a.gd = d; a.gda = da; a.gstats = stats; a.gred = red; a.ggamma = gamma; a.gbeta = beta; a.gG = G; a.gsilu = silu; a.gHW = HW;
+  hipLaunchKernelGGL((wgemm_f16x2_gen_kernel<true>), dim3((unsigned)(cdiv((int)M, WBM) * a.NB)), dim3(WNT), 0, st, a);
 }
 
 void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st) {

@@ -142,6 +142,14 @@ int buddy_gemm_bf16x3(const float* A0, int ldA0, const float* A1, int ldA1, int 
 int buddy_gemm_bf16x3_gn_bwd(const float* A, int ldA, const void* W3, const float* x0, const float* x1, int C0, const float* da, const float* stats,
                              const float* gamma, const float* beta, int G, int silu, float alpha, float* dx0, float* dx1, int acc0, int acc1,
                              double* stat_scratch, float* red, int B, int HW, int N, int K, void* stream);
+/* The two general forms above in f16x2 arithmetic (round 6; what a handle with gemm = f16x2 runs where option gen_f16x2 says so): W2 =
+ * buddy_wgemm_f16x2_pack_weights(W, ., 1, N, K) (one power of two for the matrix); the A operand's power of two is taken PER ROW from the row's own
+ * abs-max inside the kernel, so a row's result depends on nothing but the row.  K % 64 == 0; everything else as the bf16x3 entries. */
+int buddy_gemm_f16x2(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W2, float* C, int ldC, long long M, int N, int K,
+                     const float* bias_n, float alpha, int accumulate, void* stream);
+int buddy_gemm_f16x2_gn_bwd(const float* A, int ldA, const void* W2, const float* x0, const float* x1, int C0, const float* da, const float* stats,
+                            const float* gamma, const float* beta, int G, int silu, float alpha, float* dx0, float* dx1, int acc0, int acc1,
+                            double* stat_scratch, float* red, int B, int HW, int N, int K, void* stream);
 /* NHWC 3x3 stride-1 pad-1 conv, packed weights wt[Cout][9*Cin] (tap-major, channel-minor); replaces ddpm_conv3x3
  * (networks/ncsnpp_utils/layers.py:119-126). */
 int buddy_conv3x3(const float* x, const float* wt, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
@@ -217,7 +225,7 @@ int buddy_ncsnpp_set_fir(void* handle, int fir);
 /* Per-handle launcher options -- "no hidden global state" (SURVEY.md 8(b)): every switch a launcher consults (attention core, GEMM arithmetic, the
  * fusion / layout A/B switches) is a field of the handle's option struct; two handles in one process may differ.  Keys (csrc/options.hip): conv, gemm,
  * attention, gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr, attn_split, attn_nw, igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos,
- * wgemm_epi, wgemm_rt, wgemm_nt, wino_epi, wino_abl, wino_geo, w6_xcd, w6_nt, gn_fast, c2in4, c2out_tiled, fir_lds, op_graph.  An unknown key or a value out of range is
+ * wgemm_epi, wgemm_rt, wgemm_nt, gen_f16x2, wino_epi, wino_abl, wino_geo, w6_xcd, w6_nt, gn_fast, c2in4, c2out_tiled, fir_lds, op_graph.  An unknown key or a value out of range is
  * BUDDY_ERR_ARG.  A handle starts from the process defaults = the BUDDY_<KEY> environment variables, parsed and validated in ONE place at handle
  * creation: a bad value, or an unknown BUDDY_* name within edit distance 2 of a switch (a misspelling), makes buddy_ncsnpp_create fail with a message naming it;
  * BUDDY_* names that resemble no switch are not this library's and are left alone.  Set options before the first forward or between calls: the

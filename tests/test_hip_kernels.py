@@ -121,31 +121,55 @@ def test_winograd_domain_gemm_f16x2(lib, utts, tpu, Cout, Cin, P_):
     assert lib.buddy_wgemm_f16x2_packed_bytes(2, 96, 128) == 0 and lib.buddy_wgemm_f16x2_packed_bytes(65, 128, 128) == 0 and lib.buddy_wgemm_f16x2_packed_bytes(2, 128, 96) == 0
 
 
+def _packed_1x1(lib, W, arith):
+    """stage image of a [N][K] weight for the general GEMM forms: bf16x3 (three exact bf16 planes) or f16x2 (two f16 planes + the matrix's power of two)"""
+    from buddy_amd import _lib
+    N, K = W.shape
+    if arith == "f16x2":
+        W3 = torch.empty(lib.buddy_wgemm_f16x2_packed_bytes(1, N, K) // 4, dtype=torch.int32, device="cuda")
+        _lib.check(lib.buddy_wgemm_f16x2_pack_weights(P(W), W3.data_ptr(), 1, N, K, S()))
+    else:
+        W3 = torch.empty(N * K * 6 // 4, dtype=torch.int32, device="cuda")
+        _lib.check(lib.buddy_wgemm_pack_weights(P(W), W3.data_ptr(), 1, N, K, S()))
+    return W3
+
+
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("M,N,K,C0", [(1000, 128, 384, 256), (4097, 256, 256, 0), (300, 128, 64, 32)])
-def test_gemm_bf16x3_general_form(lib, M, N, K, C0):
-    """buddy_gemm_bf16x3 (the 1x1 convolutions / NINs on the bf16x3 kernel): two-source A (channel concatenation split at C0; 0 = one source), bias,
-    alpha, accumulate, ragged M -- against fp64, the fp32 GEMM's bound."""
+def test_gemm_bf16x3_general_form(lib, M, N, K, C0, arith):
+    """buddy_gemm_bf16x3 / buddy_gemm_f16x2 (the 1x1 convolutions / NINs on the split-arithmetic kernels): two-source A (channel concatenation split at C0;
+    0 = one source), bias, alpha, accumulate, ragged M -- against fp64, the fp32 GEMM's bound.  f16x2 (round 6): the A operand's power of two is taken per
+    row inside the kernel, so rows ten decades apart in one launch keep their relative accuracy."""
     from buddy_amd import _lib
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).cuda()
+    if arith == "f16x2":
+        A = A * torch.logspace(-6, 4, M).cuda()[:, None]
     W = torch.randn(N, K, generator=g).cuda()
     bias = torch.randn(N, generator=g).cuda()
-    W3 = torch.empty(N * K * 6 // 4, dtype=torch.int32, device="cuda")
-    _lib.check(lib.buddy_wgemm_pack_weights(P(W), W3.data_ptr(), 1, N, K, S()))
+    W3 = _packed_1x1(lib, W, arith)
+    gemm = lib.buddy_gemm_f16x2 if arith == "f16x2" else lib.buddy_gemm_bf16x3
     A0 = A[:, :C0].contiguous() if C0 else A
     A1 = A[:, C0:].contiguous() if C0 else None
     Cc = torch.full((M, N), 3.0, device="cuda")
     ref = 0.5 * (A.double() @ W.double().t()).float() + bias
-    _lib.check(lib.buddy_gemm_bf16x3(P(A0), A0.shape[1], P(A1), A1.shape[1] if C0 else 0, C0, W3.data_ptr(), P(Cc), N, M, N, K, P(bias), 0.5, 0, S()))
+    if arith == "f16x2":          # row by row, without the bias: every row against its own abs-max (the rows span ten decades)
+        _lib.check(gemm(P(A0), A0.shape[1], P(A1), A1.shape[1] if C0 else 0, C0, W3.data_ptr(), P(Cc), N, M, N, K, None, 0.5, 0, S()))
+        torch.cuda.synchronize()
+        ref0 = 0.5 * (A.double() @ W.double().t())
+        rowerr = ((Cc.double() - ref0).abs().amax(dim=1) / (ref0.abs().amax(dim=1) + 1e-300)).max()
+        assert float(rowerr) < 2e-5, float(rowerr)
+    _lib.check(gemm(P(A0), A0.shape[1], P(A1), A1.shape[1] if C0 else 0, C0, W3.data_ptr(), P(Cc), N, M, N, K, P(bias), 0.5, 0, S()))
     torch.cuda.synchronize()
     assert rel(Cc, ref) < 2e-5
-    _lib.check(lib.buddy_gemm_bf16x3(P(A0), A0.shape[1], P(A1), A1.shape[1] if C0 else 0, C0, W3.data_ptr(), P(Cc), N, M, N, K, None, 0.5, 1, S()))
+    _lib.check(gemm(P(A0), A0.shape[1], P(A1), A1.shape[1] if C0 else 0, C0, W3.data_ptr(), P(Cc), N, M, N, K, None, 0.5, 1, S()))
     torch.cuda.synchronize()
     assert rel(Cc, 2 * ref - bias) < 2e-5
 
 
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("B,HW,N,K,C0,silu,acc", [(2, 300, 128, 128, 0, 1, 0), (1, 1000, 384, 128, 256, 1, 1), (3, 77, 256, 64, 128, 0, 1), (1, 4096, 512, 256, 256, 1, 0)])
-def test_gemm_bf16x3_gn_bwd(lib, B, HW, N, K, C0, silu, acc):
+def test_gemm_bf16x3_gn_bwd(lib, B, HW, N, K, C0, silu, acc, arith):
     """buddy_gemm_bf16x3_gn_bwd: the skip path's 1x1 data-gradient GEMM with the GroupNorm_0 backward's apply pass as its epilogue (a ResBlock's input
     gradient, reference layerspp.py:242-274 backward) against fp64 autograd: dx = alpha * A W^T + d/dx [act(GroupNorm(x))] . da, two-source x,
     two-destination dx (the second accumulating), ragged M.  2e-5 for the GEMM term like the general form, 2e-4 of the abs-max overall (the
@@ -168,8 +192,7 @@ def test_gemm_bf16x3_gn_bwd(lib, B, HW, N, K, C0, silu, acc):
     xg = x.double().permute(0, 2, 1).reshape(B, G, N // G, HW)
     mean = xg.mean(dim=(2, 3)); rstd = 1.0 / torch.sqrt(xg.var(dim=(2, 3), unbiased=False) + 1e-6)
     stats = torch.stack([mean, rstd], dim=-1).float().contiguous()
-    W3 = torch.empty(N * K * 6 // 4, dtype=torch.int32, device="cuda")
-    _lib.check(lib.buddy_wgemm_pack_weights(P(W), W3.data_ptr(), 1, N, K, S()))
+    W3 = _packed_1x1(lib, W, arith)
     x0 = x[..., :C0].contiguous() if C0 else x
     x1 = x[..., C0:].contiguous() if C0 else None
     d0 = torch.full_like(x0, float("nan"))
@@ -178,7 +201,7 @@ def test_gemm_bf16x3_gn_bwd(lib, B, HW, N, K, C0, silu, acc):
         d1.fill_(float("nan"))
     stat_scratch = torch.empty(B * 256 * N * 2, dtype=torch.float64, device="cuda")
     red = torch.empty(B, G, 2, device="cuda")
-    _lib.check(lib.buddy_gemm_bf16x3_gn_bwd(P(A), K, W3.data_ptr(), P(x0), P(x1) if C0 else None, C0, P(da), P(stats), P(gamma), P(beta), G, silu, 0.70710678,
+    _lib.check((lib.buddy_gemm_f16x2_gn_bwd if arith == "f16x2" else lib.buddy_gemm_bf16x3_gn_bwd)(P(A), K, W3.data_ptr(), P(x0), P(x1) if C0 else None, C0, P(da), P(stats), P(gamma), P(beta), G, silu, 0.70710678,
                                             P(d0), P(d1) if C0 else None, 0, acc if C0 else 0, stat_scratch.data_ptr(), P(red), B, HW, N, K, S()))
     torch.cuda.synchronize()
     out = torch.cat([d0, d1], dim=-1) if C0 else d0
