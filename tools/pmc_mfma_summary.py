@@ -8,7 +8,7 @@ import csv, json, sys
 KEY = sys.argv[3] if len(sys.argv) > 3 else None     # kernel-name substring; default: the batched GEMM that ran (f16x2, else bf16x3; fp32 reference run: "2, 2, 36>")
 if KEY is None:
     names = {r["Kernel_Name"] for r in csv.DictReader(open(sys.argv[1]))}
-    KEY = "wgemm_f16x2_" if any("wgemm_f16x2_" in k for k in names) else "wgemm_bf16x3_kernel<false"
+    KEY = "wgemm_f16x2_rt2_kernel" if any("wgemm_f16x2_rt2_kernel" in k for k in names) else "wgemm_bf16x3_kernel<false"
 tot, n, dur = {}, {}, 0.0
 seen = set()
 for r in csv.DictReader(open(sys.argv[1])):

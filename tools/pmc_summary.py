@@ -7,7 +7,7 @@ import csv, hashlib, json, os, sys
 
 GROUP = ("input transform (w6_input_kernel, w4_input_kernel)", "batched GEMM (wgemm_f16x2_kernel / wgemm_bf16x3_kernel / igemm_kernel<...,36>)",
          "output transform (w6_output_kernel, w4_output_kernel)")
-MATCH = {GROUP[0]: ("w6_input_kernel", "w4_input_kernel"), GROUP[1]: ("2, 2, 36>", "wgemm_bf16x3_kernel<false", "wgemm_f16x2_"), GROUP[2]: ("w6_output_kernel", "w4_output_kernel")}   # not the <..., true, ...> instantiation: the 1x1 convolutions
+MATCH = {GROUP[0]: ("w6_input_kernel", "w4_input_kernel"), GROUP[1]: ("2, 2, 36>", "wgemm_bf16x3_kernel<false", "wgemm_f16x2_rt2_kernel", "wgemm_f16x2_kernel<"), GROUP[2]: ("w6_output_kernel", "w4_output_kernel")}   # not the <..., true, ...> instantiation: the 1x1 convolutions
 
 
 def per_kernel(path, counter):
