@@ -396,6 +396,14 @@ def gen_e2e_blind10():
          overrides=["tester.posterior_sampling.warm_initialization.mode=reverb_scaled"], utt=5)
 
 
+def gen_e2e_blind_full():
+    """The blind sampler at the FULL size, recorded from the reference itself (round 6; the other blind fixtures are nf = 32, L = 8 192): nf = 128,
+    L = 64 000 = BASELINE configs[1]'s utterance, the shipped 10 operator updates per step, order 1, a T = 3 schedule (three guided evaluations,
+    thirty Adam updates; the chain is chaotic beyond that)."""
+    _e2e("e2e_blind_full", "blind_dereverberation_BUDDy", blind=True, T=3, order=1,
+         overrides=["tester.posterior_sampling.warm_initialization.mode=reverb_scaled"], L=64000, nf=128, seed=0, utt=2)
+
+
 def gen_config1():
     """BASELINE config 1: audio_examples/clean/p226/p226_003.wav + its RIR, informed DPS, order 2, T=10 (reference testing/tester.py:123-153,
     conf/tester/informed_dereverberation_DPS.yaml), full-width network (nf=128) on seeded weights.  The clip (133 829 samples: not a
@@ -493,7 +501,7 @@ def gen_fir():
 
 GENS = dict(edm_sched=gen_edm_sched, net_small=gen_net_small, net_arch=gen_net_arch, net_full=gen_net_full, net_full_64000=gen_net_full_64000, ops=gen_ops,
             e2e_informed=gen_e2e_informed, e2e_blind=gen_e2e_blind, e2e_uncond=gen_uncond,
-            opt=gen_opt, e2e_blind_o2=gen_e2e_blind_o2, e2e_blind10=gen_e2e_blind10, config1=gen_config1, fir=gen_fir)
+            opt=gen_opt, e2e_blind_o2=gen_e2e_blind_o2, e2e_blind10=gen_e2e_blind10, e2e_blind_full=gen_e2e_blind_full, config1=gen_config1, fir=gen_fir)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
