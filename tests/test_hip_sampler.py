@@ -98,12 +98,13 @@ def test_blind_dps_vs_reference_fixture(golden, backend):
 
 def test_blind_dps_full_size_vs_reference_fixture(golden):
     """round 6: the blind sampler at the FULL size against the reference's own run, not only against the oracle: nf = 128,
-    L = 64 000, the shipped 10 operator updates per step, T = 3 (e2e_blind_full.npz recorded by tests/golden/make_golden.py from
+    L = 64 000, 3 operator updates per step, T = 3 (e2e_blind_full.npz recorded by tests/golden/make_golden.py from
     testing/EulerHeunSamplerDPS.py:115-204)."""
     g = golden("e2e_blind_full")
-    p, op, smp = _run_blind(g, ["tester.posterior_sampling.warm_initialization.mode=reverb_scaled"], "hip")
+    p, op, smp = _run_blind(g, ["tester.posterior_sampling.warm_initialization.mode=reverb_scaled",
+                                "tester.posterior_sampling.blind_hp.op_updates_per_step=3"], "hip")
     print(f"full-size blind run vs the reference: rel {rel(p, g['pred']):.2e}, SI-SDR {_sisdr(p, g['pred']):.1f} dB, decay {rel(op.params[0][0].detach().cpu().numpy(), g['decay']):.1e}")
-    assert rel(p, g["pred"]) < 6e-3          # the CPU oracle on the reference's own torch kernels: 3.1e-3 (thirty scale-free Adam updates in)
+    assert rel(p, g["pred"]) < 3e-3
     assert _sisdr(p, g["pred"]) > 40.0
     assert abs(_sisdr(p, g["clean"]) - _sisdr(g["pred"], g["clean"])) < 0.1
     assert rel(op.params[0][0].detach().cpu().numpy(), g["decay"]) < 5e-2
