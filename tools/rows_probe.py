@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, ".")
 from buddy_amd import _lib
 lib = _lib.require_gpu()
 n = 2 * 2 ** 30 // 4
