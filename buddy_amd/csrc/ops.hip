@@ -896,8 +896,10 @@ int gn_num_chunks(int HW) {
 
 static GnFast gn_fast(int HW, int C, int G) {
   GnFast a; a.HW = HW; a.C = C; a.G = G; a.q = C / 4; a.pl = 256 / a.q; if (a.pl < 1) a.pl = 1;
-  // ~2048 blocks over the batch at the big layers, at least 8 trips per thread
-  int chunks = HW / (a.pl * 32); if (chunks < 1) chunks = 1; if (chunks > 512) chunks = 512;
+  // pixels per thread = option gn_trips (default 4 since round 6: short-lived workgroups, like the one-shot copy of the streaming ubench: 4.34 -> 4.54 TB/s for the
+  // GroupNorm group; 32 = rounds 2-5: ~4096 workgroups over the batch at the big layers, 8 trips of 4 pixels per thread).  Elementwise kernels: results identical.
+  const int trips = cur_opt().gn_trips;
+  int chunks = HW / (a.pl * trips); if (chunks < 1) chunks = 1; if (chunks > (trips >= 32 ? 512 : 32768)) chunks = trips >= 32 ? 512 : 32768;
   a.ppc = (HW + chunks - 1) / chunks;
   a.ppc = (a.ppc + a.pl - 1) / a.pl * a.pl;
   return a;
