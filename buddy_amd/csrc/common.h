@@ -23,7 +23,7 @@ struct Options {
   int attn_split, attn_nw;                                                           // fp32 attention: forced loop-split count / forward tile height (0 = by shape)
   int igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos, wgemm_epi, wgemm_rt, wgemm_nt, gen_f16x2;              // GEMM kernels
   int wino_epi, wino_abl, wino_geo, w6_xcd, w6_nt;                                          // Winograd kernels
-  int gn_fast, gn_trips, c2in4, c2out_tiled;                                                   // GroupNorm / 2-channel convolutions
+  int gn_fast, gn_trips, ew_grid, c2in4, c2out_tiled;                                                   // GroupNorm / 2-channel convolutions
   int fir_lds, op_graph;                                                             // blind operator
 };
 const Options& default_options();           // process defaults (environment)

@@ -818,7 +818,8 @@ __global__ __launch_bounds__(256) void unpad_adj_kernel(const float* dframes, in
 
 inline int grid_for(long long total) {
   long long g = (total + 255) / 256;
-  if (g > 256 * 16) g = 256 * 16;
+  const long long cap = 1LL << cur_opt().ew_grid;            // option ew_grid (default 16: 58.2 -> 58.0 ms/step A/B, results identical): 12 = rounds 1-5 (4096 workgroups, long grid-stride loops)
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }

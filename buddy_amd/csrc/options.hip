@@ -57,6 +57,7 @@ const Entry kTable[] = {
     {"w6_xcd", "BUDDY_W6_XCD", &Options::w6_xcd, 0, 1, 1, nullptr},
     {"w6_nt", "BUDDY_W6_NT", &Options::w6_nt, 0, 1, 1, nullptr},
     {"gn_fast", "BUDDY_GN_FAST", &Options::gn_fast, 0, 1, 1, nullptr},
+    {"ew_grid", "BUDDY_EW_GRID", &Options::ew_grid, 8, 22, 16, nullptr},
     {"gn_trips", "BUDDY_GN_TRIPS", &Options::gn_trips, 1, 64, 4, nullptr},
     {"c2in4", "BUDDY_C2IN4", &Options::c2in4, 0, 1, 1, nullptr},
     {"c2out_tiled", "BUDDY_C2OUT_TILED", &Options::c2out_tiled, 0, 1, 1, nullptr},
