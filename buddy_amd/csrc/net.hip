@@ -700,10 +700,11 @@ static int conv3(Net* N, const Conv3& c) {
   }
   return 0;
 }
-// The general GEMMs in f16x2 arithmetic (round 6; only with gemm = f16x2): option gen_f16x2 = 0 never (DEFAULT), 1 every shape, 2 the smaller launches only.
-// Built because VERDICT r5 named it the largest untried lever (14 % of the step on six products where three suffice) and MEASURED not to be one: per launch
-// 331.8 vs 328.4 us (skip-path GroupNorm-backward form) and 129.0 vs 128.8 us (1x1 / NIN / DFT form) over a whole step (profiles/r06b_bench_kernel_stats.csv
-// against r06_...): these launches stream 1-7 GB against 0.1-0.6 TFLOP and wait for HBM in either arithmetic.  The exact bf16x3 split stays the default.
+// The general GEMMs in f16x2 arithmetic (round 6; only with gemm = f16x2): option gen_f16x2 = 1 every shape (DEFAULT), 0 never (the exact bf16x3 split),
+// 2 the smaller launches only.  The first version took each row's power of two in a pre-pass that re-read A from beyond L2 and measured equal to bf16x3
+// (331.8 vs 328.4 us, 129.0 vs 128.8 us per launch); with the scale found on the way (wgemm_f16x2_gen_kernel) every 1x1 / NIN / skip-path shape of the
+// network is faster, 6.83 -> 5.98 ms over one forward + VJP at B = 8 (tools/gemm_shapes.py, profiles/README.md round 6) and 1.2 - 1.5x per launch in
+// isolation (tools/gen_gemm_one.py).
 static bool gen_f16x2_on(const Net* N, long long M) {
   if (N->opt.gemm != 2 || N->opt.gen_f16x2 == 0) return false;
   return N->opt.gen_f16x2 == 1 || M <= 600000;

@@ -566,107 +566,19 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_f16x2_kernel(const WgemmArgs a) 
 // ------------------------------------------------------------------------------------------------ f16x2 form of the GENERAL GEMM (round 6)
 // C (M x N) = alpha * [A0 | A1] (M x K) W^T + bias (+ C), or -- GNB -- the ResBlock skip path's data-gradient with the GroupNorm backward apply as its
 // epilogue: the 1x1 convolutions / NIN layers / DFT GEMMs in the arithmetic of the Winograd-domain GEMMs (three f16 MFMA products instead of bf16x3's six).
-// The A operand here is an activation nobody has measured: its power-of-two scale is taken PER ROW, from the row's own abs-max, in a pre-pass of the kernel
-// (the wave reads its 32 rows x K once more than the K loop does; that second read comes from L2 / the Infinity Cache) -- finer than the per-utterance scale
-// of the batched form, and a row's result depends on nothing but the row.  Structure = wgemm_f16x2_kernel<true> (32-row waves, LDS-DMA weight stages, two
-// K-stages of A in flight) with the two-source A of wgemm_bf16x3_kernel<true, ...> and its epilogues.
+// The A operand here is an activation nobody has measured: its power-of-two scale is taken PER ROW and found ON THE WAY -- every K-stage takes the abs-max
+// of the row's 32 values it is about to split; while that stays below 2^15 under the current scale nothing happens, otherwise the row's accumulators are
+// multiplied by the (exact) power of two that takes them to the new scale, which puts the stage's abs-max into [2^12, 2^13).  A row's result depends on
+// nothing but the row, no pre-pass re-reads A (the first version's did, from beyond L2: it took away what the halved MFMA count gave), and the rescale is a
+// wave-uniform branch taken a few times per row.  Structure = wgemm_f16x2_kernel<true> (32-row waves, LDS-DMA weight stages, two K-stages of A in flight)
+// with the two-source A of wgemm_bf16x3_kernel<true, ...> and its epilogues.
+
+// epilogues of wgemm_bf16x3_kernel<true, true, GNB> for one 32-row x 128-column accumulator tile of a wave (rows rbase ..., x the rows' inverse scale)
+// through the wave-private LDS slab St, 256-byte row pieces
 template <bool GNB>
-__global__ __launch_bounds__(WNT, 3) void wgemm_f16x2_gen_kernel(const WgemmArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * STAGE2_BYTES > 4 * 32 * 68 * 4) ? 2 * STAGE2_BYTES : 4 * 32 * 68 * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  int lid;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
-  const int nb = lid % a.NB, m0 = (lid / a.NB) * WBM;
-  const unsigned char* __restrict__ U2 = a.U3 + (long long)nb * a.S * STAGE2_BYTES;
-  const int S = a.S;
-  int row = m0 + wid * 32 + (lane & 31);
-  if (row >= a.Mt) row = a.Mt - 1;
-  const float* Ap0 = a.V + (long long)row * a.ldA0 + 16 * (lane >> 5);
-  const float* Ap1 = a.A1 ? a.A1 + (long long)row * a.ldA1 + 16 * (lane >> 5) - a.C0 : Ap0;       // channels >= C0 come from the second source
-  const int s1 = a.A1 ? a.C0 / WKS : S;                                                            // first K-stage of the second source
-  // pre-pass: the row's abs-max over all K (both lanes of a row), its power of two
-  float sv, inv;
-  {
-    float mx = 0.f;
-    for (int s = 0; s < S; ++s) {
-      const float* q = (s >= s1 ? Ap1 : Ap0) + s * WKS;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 v = *reinterpret_cast<const float4*>(q + 4 * j);
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    pow2_scale(__float_as_uint(mx), sv, inv);
-  }
-  inv *= a.uinv[0];
-  const unsigned boff = (unsigned)tid * 16u;
-  const char* Ub = reinterpret_cast<const char*>(U2);
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-
-  float4 ra[2][4];
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem + wid * 1024);
-  auto loadA = [&](int s, float4 (&r)[4]) {
-    const float* q = (s >= s1 ? Ap1 : Ap0) + s * WKS;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const float4*>(q + 4 * j);
-  };
-  auto dmaB = [&](int s) {
-    const void* base = uniform_ptr(Ub + (long long)s * STAGE2_BYTES);
-    const unsigned l = lds0 + (s & 1) * STAGE2_BYTES;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16_asm(base, boff + j * (WNT * 16), l + j * (WNT * 16));
-  };
-  auto stage = [&](int s, float4 (&r)[4], auto nb_, auto na_) {
-    constexpr bool NB = decltype(nb_)::value, NA = decltype(na_)::value;
-    const Split2 av[2] = {split2(r[0], r[1], sv), split2(r[2], r[3], sv)};
-    if (NB) dmaB(s + 1);
-    if (NA) loadA(s + 2, r);
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned char* Bcur = smem + (s & 1) * STAGE2_BYTES + lane * 16;
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-      f16x8 b[4][2];
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) b[cb][q] = *reinterpret_cast<const f16x8*>(Bcur + ((kc * 4 + cb) * 2 + q) * FRAG);
-      constexpr int PB[3] = {1, 0, 0}, PA[3] = {0, 1, 0};
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[cb][PB[t]], av[kc].p[PA[t]], acc[cb], 0, 0, 0);
-    }
-    if (NB) { if (NA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    __syncthreads();
-  };
-  dmaB(0);
-  loadA(0, ra[0]);
-  loadA(1, ra[1]);                                             // S is even (wgemm_f16x2_supported)
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __syncthreads();
-  int s = 0;
-  for (; s + 2 < S; s += 2) {
-    stage(s, ra[0], std::true_type{}, std::true_type{});
-    stage(s + 1, ra[1], std::true_type{}, std::true_type{});
-  }
-  stage(s, ra[0], std::true_type{}, std::false_type{});
-  stage(s + 1, ra[1], std::false_type{}, std::false_type{});
-
-  // epilogues of wgemm_bf16x3_kernel<true, true, GNB>: the accumulator tile (x the row's inverse scale) through the wave-private LDS slab, 256-byte row pieces
+__device__ __forceinline__ void f16x2_gen_epilogue(const WgemmArgs& a, const f32x16 (&acc)[4], const float inv, const int rbase, const int nb, float* St, const int lane) {
   constexpr int SP = 68;
-  float* St = reinterpret_cast<float*>(smem) + wid * (32 * SP);
   const int rr = lane >> 4, c4 = (lane & 15) * 4;
-  const int rbase = m0 + wid * 32;
   if constexpr (!GNB) {
     const long long ldc = a.ldC;
     float* Mrow = a.M + (long long)rbase * ldc + nb * WBN;
@@ -756,6 +668,218 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_f16x2_gen_kernel(const WgemmArgs
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+  }
+}
+
+template <bool GNB>
+__global__ __launch_bounds__(WNT, 3) void wgemm_f16x2_gen_kernel(const WgemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * STAGE2_BYTES > 4 * 32 * 68 * 4) ? 2 * STAGE2_BYTES : 4 * 32 * 68 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int lid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int nb = lid % a.NB, m0 = (lid / a.NB) * WBM;
+  const unsigned char* __restrict__ U2 = a.U3 + (long long)nb * a.S * STAGE2_BYTES;
+  const int S = a.S;
+  int row = m0 + wid * 32 + (lane & 31);
+  if (row >= a.Mt) row = a.Mt - 1;
+  const float* Ap0 = a.V + (long long)row * a.ldA0 + 16 * (lane >> 5);
+  const float* Ap1 = a.A1 ? a.A1 + (long long)row * a.ldA1 + 16 * (lane >> 5) - a.C0 : Ap0;       // channels >= C0 come from the second source
+  const int s1 = a.A1 ? a.C0 / WKS : S;                                                            // first K-stage of the second source
+  // running per-row power of two (see the header comment): exponent field of the scale's reference magnitude, the scale itself
+  int ecur = 15;
+  float sv = __uint_as_float((unsigned)(266 - 15) << 23);
+  const unsigned boff = (unsigned)tid * 16u;
+  const char* Ub = reinterpret_cast<const char*>(U2);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  float4 ra[2][4];
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem + wid * 1024);
+  auto loadA = [&](int s, float4 (&r)[4]) {
+    const float* q = (s >= s1 ? Ap1 : Ap0) + s * WKS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const float4*>(q + 4 * j);
+  };
+  auto dmaB = [&](int s) {
+    const void* base = uniform_ptr(Ub + (long long)s * STAGE2_BYTES);
+    const unsigned l = lds0 + (s & 1) * STAGE2_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16_asm(base, boff + j * (WNT * 16), l + j * (WNT * 16));
+  };
+  auto stage = [&](int s, float4 (&r)[4], auto nb_, auto na_) {
+    constexpr bool NB = decltype(nb_)::value, NA = decltype(na_)::value;
+    {
+      float mx = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r[j].x), fabsf(r[j].y))), fmaxf(fabsf(r[j].z), fabsf(r[j].w)));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));                       // the row's other sixteen k of this stage
+      const int es = min((int)(__float_as_uint(mx) >> 23), 253);
+      const bool grow = es > ecur + 2;                          // the stage would leave [0, 2^15) under the current scale
+      if (__any(grow)) {
+        const int d = grow ? ecur - es : 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[c][q] = ldexpf(acc[c][q], d);
+        if (grow) { ecur = es; sv = __uint_as_float((unsigned)(266 - es) << 23); }
+      }
+    }
+    const Split2 av[2] = {split2(r[0], r[1], sv), split2(r[2], r[3], sv)};
+    if (NB) dmaB(s + 1);
+    if (NA) loadA(s + 2, r);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* Bcur = smem + (s & 1) * STAGE2_BYTES + lane * 16;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      f16x8 b[4][2];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[cb][q] = *reinterpret_cast<const f16x8*>(Bcur + ((kc * 4 + cb) * 2 + q) * FRAG);
+      constexpr int PB[3] = {1, 0, 0}, PA[3] = {0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[cb][PB[t]], av[kc].p[PA[t]], acc[cb], 0, 0, 0);
+    }
+    if (NB) { if (NA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __syncthreads();
+  };
+  dmaB(0);
+  loadA(0, ra[0]);
+  loadA(1, ra[1]);                                             // S is even (wgemm_f16x2_supported)
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  int s = 0;
+  for (; s + 2 < S; s += 2) {
+    stage(s, ra[0], std::true_type{}, std::true_type{});
+    stage(s + 1, ra[1], std::true_type{}, std::true_type{});
+  }
+  stage(s, ra[0], std::true_type{}, std::false_type{});
+  stage(s + 1, ra[1], std::false_type{}, std::false_type{});
+  const float inv = __uint_as_float((unsigned)(ecur - 12) << 23) * a.uinv[0];
+
+  f16x2_gen_epilogue<GNB>(a, acc, inv, m0 + wid * 32, nb, reinterpret_cast<float*>(smem) + wid * (32 * 68), lane);
+}
+
+// The same with 64 rows per wave (the tiling of wgemm_f16x2_rt2_kernel below: workgroup = 256 rows x 128 columns, 128 accumulators per lane, two workgroups
+// per CU, one K-stage of A in flight): a weight stage is fetched once per 256 rows instead of once per 128.
+template <bool GNB>
+__global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_gen2_kernel(const WgemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * STAGE2_BYTES > 4 * 32 * 68 * 4) ? 2 * STAGE2_BYTES : 4 * 32 * 68 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int lid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int nb = lid % a.NB, m0 = (lid / a.NB) * (2 * WBM);
+  const unsigned char* __restrict__ U2 = a.U3 + (long long)nb * a.S * STAGE2_BYTES;
+  const int S = a.S;
+  const float* Ap0[2];
+  const float* Ap1[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = min(m0 + wid * 64 + t * 32 + (lane & 31), a.Mt - 1);
+    Ap0[t] = a.V + (long long)row * a.ldA0 + 16 * (lane >> 5);
+    Ap1[t] = a.A1 ? a.A1 + (long long)row * a.ldA1 + 16 * (lane >> 5) - a.C0 : Ap0[t];
+  }
+  const int s1 = a.A1 ? a.C0 / WKS : S;
+  int ecur[2] = {15, 15};
+  float sv[2] = {__uint_as_float((unsigned)(266 - 15) << 23), __uint_as_float((unsigned)(266 - 15) << 23)};
+  const unsigned boff = (unsigned)tid * 16u;
+  const char* Ub = reinterpret_cast<const char*>(U2);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+  float4 ra[2][4];
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem + wid * 1024);
+  auto loadA = [&](int s) {
+    const bool snd = s >= s1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float* q = (snd ? Ap1[t] : Ap0[t]) + s * WKS;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ra[t][j] = *reinterpret_cast<const float4*>(q + 4 * j);
+    }
+  };
+  auto dmaB = [&](int s) {
+    const void* base = uniform_ptr(Ub + (long long)s * STAGE2_BYTES);
+    const unsigned l = lds0 + (s & 1) * STAGE2_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16_asm(base, boff + j * (WNT * 16), l + j * (WNT * 16));
+  };
+  auto stage = [&](int s, auto nx_) {
+    constexpr bool NX = decltype(nx_)::value;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float mx = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(ra[t][j].x), fabsf(ra[t][j].y))), fmaxf(fabsf(ra[t][j].z), fabsf(ra[t][j].w)));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const int es = min((int)(__float_as_uint(mx) >> 23), 253);
+      const bool grow = es > ecur[t] + 2;
+      if (__any(grow)) {
+        const int d = grow ? ecur[t] - es : 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[t][c][q] = ldexpf(acc[t][c][q], d);
+        if (grow) { ecur[t] = es; sv[t] = __uint_as_float((unsigned)(266 - es) << 23); }
+      }
+    }
+    Split2 av[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) av[t][kc] = split2(ra[t][2 * kc], ra[t][2 * kc + 1], sv[t]);
+    if (NX) { dmaB(s + 1); loadA(s + 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* Bcur = smem + (s & 1) * STAGE2_BYTES + lane * 16;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      f16x8 b[4][2];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) b[cb][q] = *reinterpret_cast<const f16x8*>(Bcur + ((kc * 4 + cb) * 2 + q) * FRAG);
+      constexpr int PB[3] = {1, 0, 0}, PA[3] = {0, 1, 0};
+#pragma unroll
+      for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) acc[t][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[cb][PB[tm]], av[t][kc].p[PA[tm]], acc[t][cb], 0, 0, 0);
+    }
+    if (NX) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();
+  };
+  dmaB(0);
+  loadA(0);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  int s = 0;
+  for (; s + 1 < S; ++s) stage(s, std::true_type{});
+  stage(s, std::false_type{});
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float inv = __uint_as_float((unsigned)(ecur[t] - 12) << 23) * a.uinv[0];
+    f16x2_gen_epilogue<GNB>(a, acc[t], inv, m0 + wid * 64 + t * 32, nb, reinterpret_cast<float*>(smem) + wid * (32 * 68), lane);
   }
 }
 
@@ -950,6 +1074,9 @@ void launch_wgemm_bf16x3_gnbwd(const float* A, int ldA, const void* W3, long lon
   hipLaunchKernelGGL((wgemm_bf16x3_kernel<true, false, true>), grid, dim3(WNT), 0, st, a);
 }
 
+// 64-row waves where option gen_rows says so; 0 = by size: from 32768 rows on (below that the halved workgroup count leaves CUs idle: 16384 x 256 x 256
+// runs 17 us in the 32-row form, 25 us in the 64-row form; 65536 x 256 x 256 50 / 42 us)
+static bool gen_rows64(long long M) { const int r = cur_opt().gen_rows; return r == 64 || (r == 0 && M >= 32768); }
 // f16x2 forms of the two general launches: W2 = wgemm_f16x2_pack_weights(W, ., 1, N, K) (one power of two for the whole matrix)
 bool wgemm_f16x2_general_supported(int N, int K, int C0, int ldA0, int ldA1, int ldC, const void* A0, const void* A1, const void* C, const void* bias) {
   return wgemm_f16x2_supported(N, K) && wgemm_general_supported(N, K, C0, ldA0, ldA1, ldC, A0, A1, C, bias);
@@ -961,7 +1088,8 @@ void launch_wgemm_f16x2_general(const float* A0, int ldA0, const float* A1, int 
   a.Mt = (int)M; a.Cin = K; a.Cout = N; a.S = K / WKS; a.NB = N / WBN;
   a.A1 = A1; a.C0 = A1 ? C0 : K; a.ldA0 = ldA0; a.ldA1 = ldA1; a.ldC = ldC; a.bias_n = bias_n; a.alpha = alpha; a.accumulate = accumulate;
   a.uinv = reinterpret_cast<const float*>(a.U3 + (size_t)N * K * 4);
-  hipLaunchKernelGGL((wgemm_f16x2_gen_kernel<false>), dim3((unsigned)(cdiv((int)M, WBM) * a.NB)), dim3(WNT), 0, st, a);
+  if (gen_rows64(M)) hipLaunchKernelGGL((wgemm_f16x2_gen2_kernel<false>), dim3((unsigned)(cdiv((int)M, 2 * WBM) * a.NB)), dim3(WNT), 0, st, a);
+  else hipLaunchKernelGGL((wgemm_f16x2_gen_kernel<false>), dim3((unsigned)(cdiv((int)M, WBM) * a.NB)), dim3(WNT), 0, st, a);
 }
 void launch_wgemm_f16x2_gnbwd(const float* A, int ldA, const void* W2, long long M, int N, int K, float alpha, Src2 x, const float* da, const float* stats,
                               const float* red, const float* gamma, const float* beta, int G, int silu, int HW, Dst2 d, hipStream_t st) {
@@ -971,7 +1099,8 @@ void launch_wgemm_f16x2_gnbwd(const float* A, int ldA, const void* W2, long long
   a.A1 = nullptr; a.C0 = K; a.ldA0 = ldA; a.ldA1 = 0; a.ldC = N; a.alpha = alpha;
   a.uinv = reinterpret_cast<const float*>(a.U3 + (size_t)N * K * 4);
   a.gxv = x; a.gd = d; a.gda = da; a.gstats = stats; a.gred = red; a.ggamma = gamma; a.gbeta = beta; a.gG = G; a.gsilu = silu; a.gHW = HW;
-  hipLaunchKernelGGL((wgemm_f16x2_gen_kernel<true>), dim3((unsigned)(cdiv((int)M, WBM) * a.NB)), dim3(WNT), 0, st, a);
+  if (gen_rows64(M)) hipLaunchKernelGGL((wgemm_f16x2_gen2_kernel<true>), dim3((unsigned)(cdiv((int)M, 2 * WBM) * a.NB)), dim3(WNT), 0, st, a);
+  else hipLaunchKernelGGL((wgemm_f16x2_gen_kernel<true>), dim3((unsigned)(cdiv((int)M, WBM) * a.NB)), dim3(WNT), 0, st, a);
 }
 
 void launch_wgemm_bf16x3(const float* V, const void* U3, float* M, long long Mt, int Cout, int Cin, int P, hipStream_t st) {
