@@ -337,8 +337,9 @@ int launch_hbm_ubench(const void* src, void* dst, long long bytes, int mode, int
     const unsigned g = (unsigned)(rows / 256);
     const char* sc = reinterpret_cast<const char*>(src); f32x4_t* dd = reinterpret_cast<f32x4_t*>(dst);
     if (g < 1) return BUDDY_ERR_ARG;
-#define BUDDY_ROWS(RB) do { if (mode == 3) hipLaunchKernelGGL((hbm_ubench_rows_kernel<RB, false>), dim3(g), dim3(256), 0, st, sc, dd, rows); \
-                            else hipLaunchKernelGGL((hbm_ubench_rows_kernel<RB, true>), dim3(g), dim3(256), 0, st, sc, dd, rows); } while (0)
+    const unsigned lds = blocks > 1 && blocks <= 64 ? (unsigned)blocks * 1024u : 0u;      // blocks = KB of (unused) dynamic LDS: bounds the workgroups per CU
+#define BUDDY_ROWS(RB) do { if (mode == 3) hipLaunchKernelGGL((hbm_ubench_rows_kernel<RB, false>), dim3(g), dim3(256), lds, st, sc, dd, rows); \
+                            else hipLaunchKernelGGL((hbm_ubench_rows_kernel<RB, true>), dim3(g), dim3(256), lds, st, sc, dd, rows); } while (0)
     if (nt == 512) BUDDY_ROWS(512); else if (nt == 1024) BUDDY_ROWS(1024); else if (nt == 2048) BUDDY_ROWS(2048); else return BUDDY_ERR_ARG;
 #undef BUDDY_ROWS
     return BUDDY_OK;

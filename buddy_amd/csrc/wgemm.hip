@@ -770,6 +770,118 @@ __global__ __launch_bounds__(WNT, 3) void wgemm_f16x2_gen_kernel(const WgemmArgs
   f16x2_gen_epilogue<GNB>(a, acc, inv, m0 + wid * 32, nb, reinterpret_cast<float*>(smem) + wid * (32 * 68), lane);
 }
 
+// The same with TWO column blocks per workgroup (128 rows x 256 columns, 32-row waves, 128 accumulators per lane, two workgroups per CU): with N = 256 the
+// two workgroups of a row block each read -- and split -- the same A rows; measured in isolation (tools/gen_gemm_one.py with the stores and the matrix work
+// taken out) that second read costs like a first one.  Here a row block's A is read and split once for both column blocks; the weight stage is 32 KB.
+template <bool GNB>
+__global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_gencp_kernel(const WgemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * STAGE2_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int lid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7, k = orig >> 3;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int NP = a.NB >> 1, np = lid % NP, m0 = (lid / NP) * WBM;
+  const unsigned char* __restrict__ U2 = a.U3 + (long long)(2 * np) * a.S * STAGE2_BYTES;       // column block 2 np; 2 np + 1 follows S stage images later
+  const int S = a.S;
+  int row = m0 + wid * 32 + (lane & 31);
+  if (row >= a.Mt) row = a.Mt - 1;
+  const float* Ap0 = a.V + (long long)row * a.ldA0 + 16 * (lane >> 5);
+  const float* Ap1 = a.A1 ? a.A1 + (long long)row * a.ldA1 + 16 * (lane >> 5) - a.C0 : Ap0;
+  const int s1 = a.A1 ? a.C0 / WKS : S;
+  int ecur = 15;
+  float sv = __uint_as_float((unsigned)(266 - 15) << 23);
+  const unsigned boff = (unsigned)tid * 16u;
+  const char* Ub = reinterpret_cast<const char*>(U2);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+  float4 ra[2][4];
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem + wid * 1024);
+  auto loadA = [&](int s, float4 (&r)[4]) {
+    const float* q = (s >= s1 ? Ap1 : Ap0) + s * WKS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const float4*>(q + 4 * j);
+  };
+  auto dmaB = [&](int s) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const void* base = uniform_ptr(Ub + ((long long)t * S + s) * STAGE2_BYTES);
+      const unsigned l = lds0 + ((s & 1) * 2 + t) * STAGE2_BYTES;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) glds16_asm(base, boff + j * (WNT * 16), l + j * (WNT * 16));
+    }
+  };
+  auto stage = [&](int s, float4 (&r)[4], auto nb_, auto na_) {
+    constexpr bool NB = decltype(nb_)::value, NA = decltype(na_)::value;
+    {
+      float mx = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r[j].x), fabsf(r[j].y))), fmaxf(fabsf(r[j].z), fabsf(r[j].w)));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const int es = min((int)(__float_as_uint(mx) >> 23), 253);
+      const bool grow = es > ecur + 2;
+      if (__any(grow)) {
+        const int d = grow ? ecur - es : 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][c][q] = ldexpf(acc[t][c][q], d);
+        if (grow) { ecur = es; sv = __uint_as_float((unsigned)(266 - es) << 23); }
+      }
+    }
+    const Split2 av[2] = {split2(r[0], r[1], sv), split2(r[2], r[3], sv)};
+    if (NB) dmaB(s + 1);
+    if (NA) loadA(s + 2, r);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const unsigned char* Bcur = smem + ((s & 1) * 2 + t) * STAGE2_BYTES + lane * 16;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        f16x8 b[4][2];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) b[cb][q] = *reinterpret_cast<const f16x8*>(Bcur + ((kc * 4 + cb) * 2 + q) * FRAG);
+        constexpr int PB[3] = {1, 0, 0}, PA[3] = {0, 1, 0};
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) acc[t][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[cb][PB[tm]], av[kc].p[PA[tm]], acc[t][cb], 0, 0, 0);
+      }
+    }
+    if (NB) { if (NA) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __syncthreads();
+  };
+  dmaB(0);
+  loadA(0, ra[0]);
+  loadA(1, ra[1]);                                             // S is even (wgemm_f16x2_supported)
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  int s = 0;
+  for (; s + 2 < S; s += 2) {
+    stage(s, ra[0], std::true_type{}, std::true_type{});
+    stage(s + 1, ra[1], std::true_type{}, std::true_type{});
+  }
+  stage(s, ra[0], std::true_type{}, std::false_type{});
+  stage(s + 1, ra[1], std::false_type{}, std::false_type{});
+  const float inv = __uint_as_float((unsigned)(ecur - 12) << 23) * a.uinv[0];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    f16x2_gen_epilogue<GNB>(a, acc[t], inv, m0 + wid * 32, 2 * np + t, reinterpret_cast<float*>(smem) + wid * (32 * 68), lane);
+}
+
 // The same with 64 rows per wave (the tiling of wgemm_f16x2_rt2_kernel below: workgroup = 256 rows x 128 columns, 128 accumulators per lane, two workgroups
 // per CU, one K-stage of A in flight): a weight stage is fetched once per 256 rows instead of once per 128.
 template <bool GNB>
@@ -887,6 +999,10 @@ __global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_gen2_kernel(const WgemmArg
 // feeds two MFMAs per product term instead of one (the 32-row form reads 0.67 fragments per MFMA) and a barrier separates 48 instead of 24 MFMAs per wave.  One K-stage of A in flight (a stage is 48 MFMAs per wave), reloaded in place after the split; the rest as wgemm_f16x2_kernel<true>.
 // NT (A/B switch wgemm_nt): bit 0 = the V rows are read with non-temporal loads (V is read exactly once: it should not displace the weight panels from
 // this XCD's L2), bit 1 = M leaves with non-temporal stores (its reader is the next launch, 0.4 - 1 GB later).
+// Measured and rejected (round 6, profiles/README.md): a PERSISTENT form -- 2 x CUs workgroups walking (position, row block, column block) items with the K-stage
+// pipeline running across items, so that an item's stores leave while the next item's first rows and weights are in flight: 422.8 us against 401.7 us per
+// launch (29584 x 128 x 128 x 64, rocprofv3), +-1.5 % on the other shapes.  Taken apart in isolation the kernel's time is close to the SUM of its parts (whole
+// 0.454 ms; V read + split only 0.176; + stores 0.16; + MFMAs 0.09; + weight DMA 0.07), but what fails to overlap is not one workgroup's phases.
 typedef float f32x4nt __attribute__((ext_vector_type(4)));
 template <int NT>
 __global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_rt2_kernel(const WgemmArgs a) {
@@ -1026,6 +1142,7 @@ __global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_rt2_kernel(const WgemmArgs
     }
   }
 }
+
 }  // namespace
 
 bool wgemm_supported(int Cout, int Cin) { return Cout % WBN == 0 && Cin % WKS == 0; }
@@ -1076,6 +1193,9 @@ void launch_wgemm_bf16x3_gnbwd(const float* A, int ldA, const void* W3, long lon
 
 // 64-row waves where option gen_rows says so; 0 = by size: from 32768 rows on (below that the halved workgroup count leaves CUs idle: 16384 x 256 x 256
 // runs 17 us in the 32-row form, 25 us in the 64-row form; 65536 x 256 x 256 50 / 42 us)
+// two column blocks per workgroup where N allows (option gen_cp: 0 never, 2 always, 1 = from 32768 rows on: 262144 x 256 x 512 279 -> 245 us, x 384 226 ->
+// 201 us, x 256 166 -> 158 us, 65536 x 256 x 512 71 -> 65 us in isolation; 16384 x 256 x 256 17 -> 23 us)
+static bool gen_colpair(long long M, int NB) { const int c = cur_opt().gen_cp; return NB % 2 == 0 && (c == 2 || (c == 1 && M >= 32768)); }
 static bool gen_rows64(long long M) { const int r = cur_opt().gen_rows; return r == 64 || (r == 0 && M >= 32768); }
 // f16x2 forms of the two general launches: W2 = wgemm_f16x2_pack_weights(W, ., 1, N, K) (one power of two for the whole matrix)
 bool wgemm_f16x2_general_supported(int N, int K, int C0, int ldA0, int ldA1, int ldC, const void* A0, const void* A1, const void* C, const void* bias) {
@@ -1088,7 +1208,8 @@ void launch_wgemm_f16x2_general(const float* A0, int ldA0, const float* A1, int 
   a.Mt = (int)M; a.Cin = K; a.Cout = N; a.S = K / WKS; a.NB = N / WBN;
   a.A1 = A1; a.C0 = A1 ? C0 : K; a.ldA0 = ldA0; a.ldA1 = ldA1; a.ldC = ldC; a.bias_n = bias_n; a.alpha = alpha; a.accumulate = accumulate;
   a.uinv = reinterpret_cast<const float*>(a.U3 + (size_t)N * K * 4);
-  if (gen_rows64(M)) hipLaunchKernelGGL((wgemm_f16x2_gen2_kernel<false>), dim3((unsigned)(cdiv((int)M, 2 * WBM) * a.NB)), dim3(WNT), 0, st, a);
+  if (gen_colpair(M, a.NB)) hipLaunchKernelGGL((wgemm_f16x2_gencp_kernel<false>), dim3((unsigned)(cdiv((int)M, WBM) * (a.NB / 2))), dim3(WNT), 0, st, a);
+  else if (gen_rows64(M)) hipLaunchKernelGGL((wgemm_f16x2_gen2_kernel<false>), dim3((unsigned)(cdiv((int)M, 2 * WBM) * a.NB)), dim3(WNT), 0, st, a);
   else hipLaunchKernelGGL((wgemm_f16x2_gen_kernel<false>), dim3((unsigned)(cdiv((int)M, WBM) * a.NB)), dim3(WNT), 0, st, a);
 }
 void launch_wgemm_f16x2_gnbwd(const float* A, int ldA, const void* W2, long long M, int N, int K, float alpha, Src2 x, const float* da, const float* stats,
@@ -1099,7 +1220,8 @@ void launch_wgemm_f16x2_gnbwd(const float* A, int ldA, const void* W2, long long
   a.A1 = nullptr; a.C0 = K; a.ldA0 = ldA; a.ldA1 = 0; a.ldC = N; a.alpha = alpha;
   a.uinv = reinterpret_cast<const float*>(a.U3 + (size_t)N * K * 4);
   a.gxv = x; a.gd = d; a.gda = da; a.gstats = stats; a.gred = red; a.ggamma = gamma; a.gbeta = beta; a.gG = G; a.gsilu = silu; a.gHW = HW;
-  if (gen_rows64(M)) hipLaunchKernelGGL((wgemm_f16x2_gen2_kernel<true>), dim3((unsigned)(cdiv((int)M, 2 * WBM) * a.NB)), dim3(WNT), 0, st, a);
+  if (gen_colpair(M, a.NB)) hipLaunchKernelGGL((wgemm_f16x2_gencp_kernel<true>), dim3((unsigned)(cdiv((int)M, WBM) * (a.NB / 2))), dim3(WNT), 0, st, a);
+  else if (gen_rows64(M)) hipLaunchKernelGGL((wgemm_f16x2_gen2_kernel<true>), dim3((unsigned)(cdiv((int)M, 2 * WBM) * a.NB)), dim3(WNT), 0, st, a);
   else hipLaunchKernelGGL((wgemm_f16x2_gen_kernel<true>), dim3((unsigned)(cdiv((int)M, WBM) * a.NB)), dim3(WNT), 0, st, a);
 }
 

@@ -14,8 +14,9 @@ def t(fn, reps=10):
     return e0.elapsed_time(e1) * 1e-3 / reps
 for rb in (512, 1024, 2048):
     for mode in (3, 4):
-        dt = t(lambda: _lib.check(lib.buddy_hbm_ubench(x.data_ptr(), y.data_ptr(), n * 4, mode, rb, 1, S)))
-        print(f"rows of {rb} B, {'all stages in flight' if mode == 3 else 'staged'}: {n * 4 / dt / 1e9:.0f} GB/s")
+        for lds in (1, 32, 48, 64):       # KB of dynamic LDS per workgroup: 1 = unbounded occupancy, 32 / 48 / 64 = at most 5 / 3 / 2 workgroups per CU
+            dt = t(lambda: _lib.check(lib.buddy_hbm_ubench(x.data_ptr(), y.data_ptr(), n * 4, mode, rb, lds, S)))
+            print(f"rows of {rb} B, {'all stages in flight' if mode == 3 else 'staged'}, lds {lds} KB: {n * 4 / dt / 1e9:.0f} GB/s")
 for nt in (0, 1):
     dt = t(lambda: _lib.check(lib.buddy_hbm_ubench(x.data_ptr(), y.data_ptr(), n * 4, 1, nt, -4, S)))
     print(f"contiguous read nt={nt}: {n * 4 / dt / 1e9:.0f} GB/s")
