@@ -429,9 +429,15 @@ void launch_wino6(const IgemmParams& p, const float* U6, float* V, float* Mb, hi
   if (prof || prof_gemm) (void)hipEventRecord(ev[2], st);
   const int TL = out_walk(go, up), per = go.TPB * TL, chunks = (go.TH * go.TW + per - 1) / per;
   const dim3 grid_out((unsigned)(go.B * chunks), (unsigned)((NG / 4 + go.QC - 1) / go.QC));
-  if (up == 1) {
+  if (up == 1 && cur_opt().w6_nt) {
+    if (stat) hipLaunchKernelGGL((w6_output_kernel<1, true, 7, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, W4Gn{});
+    else hipLaunchKernelGGL((w6_output_kernel<0, true, 7, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
+  } else if (up == 1) {
     if (stat) hipLaunchKernelGGL((w6_output_kernel<1, true, 7>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, W4Gn{});
     else hipLaunchKernelGGL((w6_output_kernel<0, true, 7>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
+  } else if (up == 2 && cur_opt().w6_nt) {
+    if (stat && bwd_gn) hipLaunchKernelGGL((w6_output_kernel<2, false, 7, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, *bwd_gn);
+    else hipLaunchKernelGGL((w6_output_kernel<0, false, 7, true>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});
   } else if (up == 2) {
     if (stat && bwd_gn) hipLaunchKernelGGL((w6_output_kernel<2, false, 7>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, stat, *bwd_gn);
     else hipLaunchKernelGGL((w6_output_kernel<0, false, 7>), grid_out, dim3(256), 0, st, (const float*)Mb, p, go, chunks, TL, (double*)nullptr, W4Gn{});

@@ -143,8 +143,10 @@ int buddy_gemm_bf16x3_gn_bwd(const float* A, int ldA, const void* W3, const floa
                              const float* gamma, const float* beta, int G, int silu, float alpha, float* dx0, float* dx1, int acc0, int acc1,
                              double* stat_scratch, float* red, int B, int HW, int N, int K, void* stream);
 /* The two general forms above in f16x2 arithmetic (round 6; what a handle with gemm = f16x2 runs where option gen_f16x2 says so): W2 =
- * buddy_wgemm_f16x2_pack_weights(W, ., 1, N, K) (one power of two for the matrix); the A operand's power of two is taken PER ROW from the row's own
- * abs-max inside the kernel, so a row's result depends on nothing but the row.  K % 64 == 0; everything else as the bf16x3 entries. */
+ * buddy_wgemm_f16x2_pack_weights(W, ., 1, N, K) (one power of two for the matrix); the A operand's power of two is taken PER ROW inside the kernel,
+ * found on the way along K (a stage that leaves the current scale's range rescales the row's accumulators by an exact power of two: no pre-pass), so a
+ * row's result depends on nothing but the row.  K % 64 == 0; everything else as the bf16x3 entries.  Options gen_f16x2 (1: the network's 1x1 / NIN /
+ * skip-path launches use these; 0: the exact bf16x3 split), gen_rows (0 by size | 32 | 64 rows per wave), gen_cp (two column blocks per workgroup). */
 int buddy_gemm_f16x2(const float* A0, int ldA0, const float* A1, int ldA1, int C0, const void* W2, float* C, int ldC, long long M, int N, int K,
                      const float* bias_n, float alpha, int accumulate, void* stream);
 int buddy_gemm_f16x2_gn_bwd(const float* A, int ldA, const void* W2, const float* x0, const float* x1, int C0, const float* da, const float* stats,

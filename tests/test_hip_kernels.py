@@ -167,6 +167,36 @@ def test_gemm_bf16x3_general_form(lib, M, N, K, C0, arith):
     assert rel(Cc, 2 * ref - bias) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(40000, 128, 256), (40000, 256, 512), (333, 256, 128)])
+def test_gemm_f16x2_running_row_scale(lib, M, N, K):
+    """The f16x2 general form finds a row's power of two ON THE WAY (wgemm_f16x2_gen_kernel: a K-stage whose abs-max leaves the current scale's range
+    rescales the row's accumulators by an exact power of two).  Rows whose magnitude climbs twelve decades along K (a rescale at almost every stage), rows
+    that fall as far (the first stage fixes the scale), zero rows, one huge element in the last stage, and a zero first half: every row within 2e-5 of its
+    own bound sum_k |a_k| |w_k| -- what a per-row scale known in advance would give.  The three shapes run the three kernel forms (64-row waves, two column
+    blocks per workgroup, 32-row waves: M and N select them, wgemm.hip gen_rows64 / gen_colpair)."""
+    from buddy_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(7 * M + N + K)
+    A = torch.randn(M, K, generator=g)
+    ramp = torch.logspace(-6, 6, K)
+    kind = torch.arange(M) % 6
+    A[kind == 0] *= ramp
+    A[kind == 1] *= ramp.flip(0)
+    A[kind == 2] = 0.0
+    A[kind == 3, -1] = 3.0e7
+    A[kind == 4, :K // 2] = 0.0
+    A = A.cuda()
+    W = torch.randn(N, K, generator=g).cuda()
+    W2 = _packed_1x1(lib, W, "f16x2")
+    Cc = torch.full((M, N), 3.0, device="cuda")
+    _lib.check(lib.buddy_gemm_f16x2(P(A), K, None, 0, 0, W2.data_ptr(), P(Cc), N, M, N, K, None, 1.0, 0, S()))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().t()
+    bound = A.double().abs() @ W.double().abs().t()
+    err = ((Cc.double() - ref).abs() / (bound + 1e-300)).max()
+    assert float(err) < 2e-6, float(err)
+    assert torch.equal(Cc[kind.cuda() == 2], torch.zeros_like(Cc[kind.cuda() == 2]))
+
+
 @pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("B,HW,N,K,C0,silu,acc", [(2, 300, 128, 128, 0, 1, 0), (1, 1000, 384, 128, 256, 1, 1), (3, 77, 256, 64, 128, 0, 1), (1, 4096, 512, 256, 256, 1, 0)])
 def test_gemm_bf16x3_gn_bwd(lib, B, HW, N, K, C0, silu, acc, arith):
