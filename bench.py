@@ -832,7 +832,7 @@ def main():
             "value": n_utt_steps / elapsed, "unit": "utterance-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16x3": "f32 (bf16x3 exact split in the Winograd-domain GEMMs)", "fp32": "f32",
-                      "f16x2": "f32 (Winograd-domain GEMM operands as two-term f16 splits, 2^-22, fp32 accumulation)"}[gemm_mode], "data": "synthetic (seeded clean/RIR/weights; random-init NCSN++ 27.7 M params)",
+                      "f16x2": "f32 (GEMM operands -- Winograd-domain and 1x1 / NIN -- as two-term f16 splits, 2^-22, fp32 accumulation)"}[gemm_mode], "data": "synthetic (seeded clean/RIR/weights; random-init NCSN++ 27.7 M params)",
             "config": {"workload": f"blind DPS sampler step, B={B} utterances/GPU x {a.length} samples ({a.length / 16000:g} s@16 kHz), T={a.T}-step schedule, "
                                    f"NCSN++ nf=128 STFT 510/128" + (" (BASELINE.json configs[1])" if (B == 8 and a.length == 64000) else ""),
                        "batch_per_gpu": B, "length": a.length, "T": a.T, "order": 1, "op_updates_per_step": 10,

@@ -21,7 +21,7 @@ struct Options {
   int attn;            // attention core 0 .. 4 (net.hip)
   int gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr;                 // fusions of the network graph (A/B switches, default 1)
   int attn_split, attn_nw;                                                           // fp32 attention: forced loop-split count / forward tile height (0 = by shape)
-  int igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos, wgemm_epi, wgemm_rt, wgemm_nt, gen_f16x2, gen_rows, gen_cp;              // GEMM kernels
+  int igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos, wgemm_epi, wgemm_rt, wgemm_nt, gen_f16x2, gen_rows, gen_cp, gnb_nt;              // GEMM kernels
   int wino_epi, wino_abl, wino_geo, w6_xcd, w6_nt;                                          // Winograd kernels
   int gn_fast, gn_trips, ew_grid, c2in4, c2out_tiled;                                                   // GroupNorm / 2-channel convolutions
   int fir_lds, op_graph;                                                             // blind operator

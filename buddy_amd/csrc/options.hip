@@ -53,6 +53,7 @@ const Entry kTable[] = {
     {"gen_f16x2", "BUDDY_GEN_F16X2", &Options::gen_f16x2, 0, 2, 1, nullptr},
     {"gen_rows", "BUDDY_GEN_ROWS", &Options::gen_rows, 0, 64, 0, nullptr},
     {"gen_cp", "BUDDY_GEN_CP", &Options::gen_cp, 0, 2, 1, nullptr},
+    {"gnb_nt", "BUDDY_GNB_NT", &Options::gnb_nt, 0, 1, 1, nullptr},
     {"wino_epi", "BUDDY_WINO_EPI", &Options::wino_epi, 0, 1, 1, nullptr},
     {"wino_abl", "BUDDY_WINO_ABL", &Options::wino_abl, 0, 3, 0, nullptr},
     {"wino_geo", "BUDDY_WINO_GEO", &Options::wino_geo, 42, 82, 42, nullptr},

@@ -91,7 +91,10 @@ struct WgemmArgs {
   Src2 gxv; Dst2 gd; const float* gda; const float* gstats; const float* gred; const float* ggamma; const float* gbeta; int gG, gsilu, gHW;
   // f16x2 form: per-utterance abs-max of V (float bits, written by the input transform), rows per utterance, per-position inverse weight scales
   const unsigned* vmax; int tpu; const float* uinv;
+  int gnt;                                                     // GNB epilogue of the f16x2 forms: x and da (each read once, whole lines per instruction) by non-temporal loads
 };
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4nt_g(const float* p) { const f32x4g v = __builtin_nontemporal_load(reinterpret_cast<const f32x4g*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
 
 __device__ __forceinline__ float dsilu_g(float z) {
   const float s = __builtin_amdgcn_rcpf(1.f + __expf(-z));
@@ -640,8 +643,8 @@ __device__ __forceinline__ void f16x2_gen_epilogue(const WgemmArgs& a, const f32
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int r = min(rbase + 16 * bt4 + 4 * it + rr, a.Mt - 1), bb = r / a.gHW;
-          xv[it] = *reinterpret_cast<const float4*>(xs + (long long)r * ldx);
-          dv[it] = *reinterpret_cast<const float4*>(das + (long long)r * a.Cout);
+          if (a.gnt) { xv[it] = ld4nt_g(xs + (long long)r * ldx); dv[it] = ld4nt_g(das + (long long)r * a.Cout); }
+          else { xv[it] = *reinterpret_cast<const float4*>(xs + (long long)r * ldx); dv[it] = *reinterpret_cast<const float4*>(das + (long long)r * a.Cout); }
           pv[it] = accd ? *reinterpret_cast<const float4*>(o + (long long)r * ldo) : make_float4(0.f, 0.f, 0.f, 0.f);
           const float2 sm = *reinterpret_cast<const float2*>(a.gstats + ((long long)bb * a.gG + grp) * 2), rm = *reinterpret_cast<const float2*>(a.gred + ((long long)bb * a.gG + grp) * 2);
           mean[it] = sm.x; rstd[it] = sm.y; m1[it] = rm.x; m2[it] = rm.y;
@@ -1003,6 +1006,8 @@ __global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_gen2_kernel(const WgemmArg
 // pipeline running across items, so that an item's stores leave while the next item's first rows and weights are in flight: 422.8 us against 401.7 us per
 // launch (29584 x 128 x 128 x 64, rocprofv3), +-1.5 % on the other shapes.  Taken apart in isolation the kernel's time is close to the SUM of its parts (whole
 // 0.454 ms; V read + split only 0.176; + stores 0.16; + MFMAs 0.09; + weight DMA 0.07), but what fails to overlap is not one workgroup's phases.
+// Also: 8 waves per workgroup (512 rows, one workgroup per CU: a weight stage fetched from L2 once per 512 rows, half the L2 -> LDS traffic): 2-15 % slower on six
+// shapes (0.451 vs 0.431, 1.293 vs 1.263, 0.358 vs 0.310, 0.640 vs 0.594, 0.078 vs 0.075, 0.787 vs 0.713 ms).
 typedef float f32x4nt __attribute__((ext_vector_type(4)));
 template <int NT>
 __global__ __launch_bounds__(WNT, 2) void wgemm_f16x2_rt2_kernel(const WgemmArgs a) {
@@ -1220,6 +1225,7 @@ void launch_wgemm_f16x2_gnbwd(const float* A, int ldA, const void* W2, long long
   a.A1 = nullptr; a.C0 = K; a.ldA0 = ldA; a.ldA1 = 0; a.ldC = N; a.alpha = alpha;
   a.uinv = reinterpret_cast<const float*>(a.U3 + (size_t)N * K * 4);
   a.gxv = x; a.gd = d; a.gda = da; a.gstats = stats; a.gred = red; a.ggamma = gamma; a.gbeta = beta; a.gG = G; a.gsilu = silu; a.gHW = HW;
+  a.gnt = cur_opt().gnb_nt;
   if (gen_colpair(M, a.NB)) hipLaunchKernelGGL((wgemm_f16x2_gencp_kernel<true>), dim3((unsigned)(cdiv((int)M, WBM) * (a.NB / 2))), dim3(WNT), 0, st, a);
   else if (gen_rows64(M)) hipLaunchKernelGGL((wgemm_f16x2_gen2_kernel<true>), dim3((unsigned)(cdiv((int)M, 2 * WBM) * a.NB)), dim3(WNT), 0, st, a);
   else hipLaunchKernelGGL((wgemm_f16x2_gen_kernel<true>), dim3((unsigned)(cdiv((int)M, WBM) * a.NB)), dim3(WNT), 0, st, a);

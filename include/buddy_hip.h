@@ -227,7 +227,7 @@ int buddy_ncsnpp_set_fir(void* handle, int fir);
 /* Per-handle launcher options -- "no hidden global state" (SURVEY.md 8(b)): every switch a launcher consults (attention core, GEMM arithmetic, the
  * fusion / layout A/B switches) is a field of the handle's option struct; two handles in one process may differ.  Keys (csrc/options.hip): conv, gemm,
  * attention, gn_fuse, gn_fuse_bwdin, gn_fuse_bwd, upconv, c2_fuse, attn_tr, attn_split, attn_nw, igemm_epi, igemm_variant, wgemm_gen_epi, wgemm_xcdpos,
- * wgemm_epi, wgemm_rt, wgemm_nt, gen_f16x2, gen_rows, gen_cp, wino_epi, wino_abl, wino_geo, w6_xcd, w6_nt, gn_fast, gn_trips, ew_grid, c2in4, c2out_tiled, fir_lds, op_graph.  An unknown key or a value out of range is
+ * wgemm_epi, wgemm_rt, wgemm_nt, gen_f16x2, gen_rows, gen_cp, gnb_nt, wino_epi, wino_abl, wino_geo, w6_xcd, w6_nt, gn_fast, gn_trips, ew_grid, c2in4, c2out_tiled, fir_lds, op_graph.  An unknown key or a value out of range is
  * BUDDY_ERR_ARG.  A handle starts from the process defaults = the BUDDY_<KEY> environment variables, parsed and validated in ONE place at handle
  * creation: a bad value, or an unknown BUDDY_* name within edit distance 2 of a switch (a misspelling), makes buddy_ncsnpp_create fail with a message naming it;
  * BUDDY_* names that resemble no switch are not this library's and are left alone.  Set options before the first forward or between calls: the
