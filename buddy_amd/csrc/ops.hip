@@ -742,6 +742,96 @@ __global__ __launch_bounds__(256) void conv_c2out_tiled_kernel(const float* __re
   }
 }
 
+// Strip form (round 6).  The kernel above is LDS-bound: every thread reads 9 taps x 8 quads of halo values AND the 18 weight quads per tap row -- 864 reads of
+// 16 bytes per pixel, 14.5 GB per level-0 launch against the LDS's 78 TB/s = 0.19 of the measured 0.22 ms (HBM: 0.71 GB).  Here a thread owns ONE channel quad
+// of the chunk and a strip of 8 pixels of one row: its 6 weight quads of a tap row sit in registers while the row's halo values pass (they were re-read per pixel), a halo value is read
+// once and feeds the up to three pixels it is a tap of (30 reads per strip instead of 72): 48 instead of 1728 reads of 16 bytes per thread and chunk for the same
+// multiply-adds.  The eight quads of a pixel live in eight neighbouring lanes: one butterfly (3 steps) at the end, lane q of the group stores pixel q of the strip.
+// Order of a pixel's sum: per quad (chunk, halo row, halo column, tap), then the butterfly over the quads.
+__global__ __launch_bounds__(256, 3) void conv_c2out_strip_kernel(const float* __restrict__ x, int ldX, const float* __restrict__ w, const float* bias,
+                                                               const float* up_add, float* y, int B, int H, int W, int Cin, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float tile[(C2O_TH + 2) * (C2O_TW + 2) * C2O_PITCH];
+  __shared__ __attribute__((aligned(16))) float wsh[9 * C2O_CK * 2];
+  const int tid = threadIdx.x;
+  const int q = tid & 7, strip = tid >> 3, ry = strip >> 2, sx = (strip & 3) * 8;
+  const int nbx = (W + C2O_TW - 1) / C2O_TW, nby = (H + C2O_TH - 1) / C2O_TH;
+  int blk = blockIdx.x;
+  const int bxi = blk % nbx; blk /= nbx;
+  const int byi = blk % nby; const int b = blk / nby;
+  const int h0 = byi * C2O_TH, w0 = bxi * C2O_TW;
+  float s[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s[i][0] = 0.f; s[i][1] = 0.f; }
+  constexpr int NPX = (C2O_TH + 2) * (C2O_TW + 2);
+  constexpr int NLD = (NPX * (C2O_CK / 4) + 255) / 256;
+  for (int c0 = 0; c0 < Cin; c0 += C2O_CK) {
+    float4 v[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i;
+      const int px = e >> 3, c4 = (e & 7) * 4;
+      const int hr = px / (C2O_TW + 2), wc = px - hr * (C2O_TW + 2);
+      const int gh = h0 - 1 + hr, gw = w0 - 1 + wc;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < NPX * (C2O_CK / 4) && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W) v[i] = ld4(x + (((long long)b * H + gh) * W + gw) * ldX + c0 + c4);
+    }
+    float wv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int e = tid + 256 * i; wv[i] = e < 9 * C2O_CK * 2 ? w[((long long)(e / (C2O_CK * 2)) * Cin + c0) * 2 + e % (C2O_CK * 2)] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i;
+      if (e < NPX * (C2O_CK / 4)) *reinterpret_cast<float4*>(tile + (e >> 3) * C2O_PITCH + (e & 7) * 4) = v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int e = tid + 256 * i; if (e < 9 * C2O_CK * 2) wsh[e] = wv[i]; }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < 3; ++r) {
+      float4 wa[3], wb[3];                                    // this quad's weights of tap row r: [dx] (4 channels x 2 outputs, interleaved)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        wa[dx] = *reinterpret_cast<const float4*>(wsh + (r * 3 + dx) * C2O_CK * 2 + q * 8);
+        wb[dx] = *reinterpret_cast<const float4*>(wsh + (r * 3 + dx) * C2O_CK * 2 + q * 8 + 4);
+      }
+      const float* row = tile + ((ry + r) * (C2O_TW + 2) + sx) * C2O_PITCH + q * 4;
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const float4 vv = *reinterpret_cast<const float4*>(row + j * C2O_PITCH);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int px = j - dx;
+          if (px >= 0 && px < 8) {
+            s[px][0] += vv.x * wa[dx].x + vv.y * wa[dx].z + vv.z * wb[dx].x + vv.w * wb[dx].z;
+            s[px][1] += vv.x * wa[dx].y + vv.y * wa[dx].w + vv.z * wb[dx].y + vv.w * wb[dx].w;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);                      // one tap row at a time: with all 30 halo reads hoisted the kernel needs 230 VGPRs
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i][0] += __shfl_xor(s[i][0], o); s[i][1] += __shfl_xor(s[i][1], o); }
+  float s0 = s[0][0], s1 = s[0][1];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) if (q == i) { s0 = s[i][0]; s1 = s[i][1]; }
+  const int h = h0 + ry, wq = w0 + sx + q;
+  if (h < H && wq < W) {
+    const long long p = ((long long)b * H + h) * W + wq;
+    if (bias) { s0 += bias[0]; s1 += bias[1]; }
+    if (up_add) {
+      const float2 u = reinterpret_cast<const float2*>(up_add)[(((long long)b * (H >> 1)) + (h >> 1)) * (W >> 1) + (wq >> 1)];
+      s0 += u.x; s1 += u.y;
+    }
+    float2* o = reinterpret_cast<float2*>(y) + p;
+    if (accumulate) { s0 += o->x; s1 += o->y; }
+    *o = make_float2(s0, s1);
+  }
+}
+
 // ------------------------------------------------------------------ STFT glue
 __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* x, float* xp, int B, int L, int pad, int Lp, float scale, const float* scale_b) {
   const long long total = (long long)B * Lp;
@@ -1073,7 +1163,10 @@ void launch_conv_c2out(const float* x, int ldX, const float* w, const float* bia
   long long groups = ((long long)B * H * W + ppb - 1) / ppb;
   int grid = (int)(groups < 256 * 8 ? groups : 256 * 8);
   const bool tiled = cur_opt().c2out_tiled != 0;
-  if (taps == 9 && tiled && Cin % C2O_CK == 0 && ldX % 4 == 0) {
+  if (taps == 9 && cur_opt().c2out_tiled == 2 && Cin % C2O_CK == 0 && ldX % 4 == 0) {
+    const int blocks = B * ((H + C2O_TH - 1) / C2O_TH) * ((W + C2O_TW - 1) / C2O_TW);
+    hipLaunchKernelGGL(conv_c2out_strip_kernel, dim3(blocks), dim3(256), 0, st, x, ldX, w, bias, up_add, y, B, H, W, Cin, accumulate);
+  } else if (taps == 9 && tiled && Cin % C2O_CK == 0 && ldX % 4 == 0) {
     const int blocks = B * ((H + C2O_TH - 1) / C2O_TH) * ((W + C2O_TW - 1) / C2O_TW);
     hipLaunchKernelGGL(conv_c2out_tiled_kernel, dim3(blocks), dim3(256), 0, st, x, ldX, w, bias, up_add, y, B, H, W, Cin, accumulate);
   } else if (taps == 9)

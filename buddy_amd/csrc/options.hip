@@ -63,7 +63,7 @@ const Entry kTable[] = {
     {"ew_grid", "BUDDY_EW_GRID", &Options::ew_grid, 8, 22, 16, nullptr},
     {"gn_trips", "BUDDY_GN_TRIPS", &Options::gn_trips, 1, 64, 4, nullptr},
     {"c2in4", "BUDDY_C2IN4", &Options::c2in4, 0, 1, 1, nullptr},
-    {"c2out_tiled", "BUDDY_C2OUT_TILED", &Options::c2out_tiled, 0, 1, 1, nullptr},
+    {"c2out_tiled", "BUDDY_C2OUT_TILED", &Options::c2out_tiled, 0, 2, 2, nullptr},
     {"fir_lds", "BUDDY_FIR_LDS", &Options::fir_lds, 0, 1, 1, nullptr},
     {"op_graph", "BUDDY_OP_GRAPH", &Options::op_graph, 0, 1, 1, nullptr},
 };
