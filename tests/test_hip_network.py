@@ -260,6 +260,35 @@ def test_cold_start_budget_and_shared_replica():
     print(f"cold start {cold * 1e3:.0f} ms, replica first forward {warm * 1e3:.0f} ms, weight store {wb2}")
 
 
+def test_round6_kernel_forms_equal_their_predecessors():
+    """Round 6's kernel forms against the ones they replaced, full-width network, forward and input-VJP, two handles of the same weights in one process:
+    the 1x1 / NIN / skip-path GEMMs in f16x2 with the running per-row scale (gen_f16x2, its 64-row and two-column-block forms gen_rows / gen_cp; predecessor:
+    the exact bf16x3 split), non-temporal loads in the skip-path epilogue (gnb_nt) and the strip form of the C -> 2 convolutions (c2out_tiled = 2;
+    predecessor 1).  Same function, other summation orders / a 2^-22 instead of a 2^-24 operand split in the 6 % of the FLOPs that are 1x1: 2e-5 of the
+    abs-max (each side holds 5e-4 against the reference fixtures); the 32-row-only f16x2 form against the size-selected forms: bit-identical."""
+    net = build(128, 510, 128, 0)
+    old = net.replica().set_option("gen_f16x2", 0).set_option("gnb_nt", 0).set_option("c2out_tiled", 1)
+    rows32 = net.replica().set_option("gen_rows", 32).set_option("gen_cp", 0)
+    rs = np.random.RandomState(12)
+    L, B = 32768, 2
+    cn = torch.tensor([-0.3, -1.2]).cuda()
+    cot = torch.from_numpy(rs.standard_normal((B, L)).astype(np.float32)).cuda()
+    x0 = torch.from_numpy((0.3 * rs.standard_normal((B, L))).astype(np.float32)).cuda()
+    outs = {}
+    for tag, n in (("new", net), ("old", old), ("rows32", rows32)):
+        x = x0.clone().requires_grad_(True)
+        y = n(x, cn)
+        g, = torch.autograd.grad(y, x, cot)
+        outs[tag] = (y.detach().cpu().numpy(), g.cpu().numpy())
+    ey, eg = rel(outs["new"][0], outs["old"][0]), rel(outs["new"][1], outs["old"][1])
+    print(f"round-6 forms vs their predecessors: forward {ey:.2e}, vjp {eg:.2e}")
+    assert not np.array_equal(outs["new"][1], outs["old"][1]), "the options did not change the path"
+    assert ey < 2e-5 and eg < 2e-5, (ey, eg)
+    # the three tilings of the f16x2 general form run the same per-row arithmetic in the same order (a row's scale depends on the row alone): bit-identical
+    assert rows32.get_option("gen_rows") == 32 and rows32.get_option("gen_cp") == 0 and net.get_option("gen_rows") == 0
+    assert np.array_equal(outs["new"][0], outs["rows32"][0]) and np.array_equal(outs["new"][1], outs["rows32"][1])
+
+
 def test_fused_round4_paths_equal_plain_paths():
     """The two structural fusions of round 4 -- the up blocks' Conv_0 in sub-pixel form (option upconv) and the skip path's 1x1 data-gradient GEMM with
     the GroupNorm_0 backward apply as its epilogue (option c2_fuse) -- against the plain paths (three-pass convolution on the materialised upsampled
